@@ -1,0 +1,206 @@
+/*
+ * maed_hip.h -- C-ABI of libmaed_hip.so: the MI355X (gfx950) kernels behind the MAED hot path.
+ *
+ * The reference (ziniuwan/maed) has no FFI layer: its hot path is a composition of ATen ops inside
+ * lib/models/*.py.  Each entry point below replaces one such composition; the comment on every
+ * function cites the reference lines (relative to the reference repo root) it stands in for.
+ * The host side (maed_amd/*.py) binds these with ctypes from torch.autograd.Functions that sit
+ * inside nn.Modules carrying the reference's class / attribute / state_dict names.
+ *
+ * Conventions
+ *  - plain pointers and extents only; no torch types.  All pointers are DEVICE pointers unless the
+ *    name ends in _host.  The caller owns every buffer (inputs, outputs, workspaces); nothing here
+ *    allocates, frees or synchronises.  Every launch goes to the hipStream_t passed as `stream`.
+ *  - return value: MAED_OK (0) or a negative maed_status.  Never throws, never aborts.
+ *    maed_last_error() returns a thread-local human readable message for the last failure.
+ *  - `dtype` selects the storage/compute type of activations and GEMM weights:
+ *    MAED_F32 (exact-f32 VALU kernels: the parity mode) or MAED_BF16 (MFMA kernels, fp32
+ *    accumulation: the throughput mode).  LayerNorm parameters, biases, the residual stream,
+ *    softmax statistics and all parameter gradients are always fp32.
+ *  - row-major everywhere; "ld" arguments are leading dimensions in ELEMENTS.
+ *  - token layout: tokens[(f*P + p)*C + c], f = n*T + t (frames of a clip are contiguous),
+ *    qkv[(f*P + p)*3C + s*C + h*64 + e]   (vision_transformer.py:147 channel order s, h, e).
+ *  - head dimension is 64 in every supported configuration (C = 64*H).
+ */
+#ifndef MAED_HIP_H
+#define MAED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MAED_F32 = 0, MAED_BF16 = 1 } maed_dtype;
+
+typedef enum {
+    MAED_OK = 0,
+    MAED_ERR_ARG = -1,         /* null pointer / bad enum */
+    MAED_ERR_SHAPE = -2,       /* unsupported extent */
+    MAED_ERR_ALIGN = -3,       /* pointer or leading dimension not aligned for vector access */
+    MAED_ERR_LAUNCH = -4,      /* hipLaunch failure (message holds hipGetErrorString) */
+    MAED_ERR_UNSUPPORTED = -5  /* combination not implemented */
+} maed_status;
+
+/* GEMM epilogues (out = epilogue(acc = A * B^T)) */
+typedef enum {
+    MAED_EPI_STORE = 0,      /* out[T]   = acc + bias                                              */
+    MAED_EPI_GELU = 1,       /* out2[T]  = acc + bias ; out[T] = gelu_erf(out2)  (nn.GELU)          */
+    MAED_EPI_RESID_F32 = 2,  /* out[f32] = aux[f32] + acc + bias   (residual add fused)             */
+    MAED_EPI_MUL_DGELU = 3,  /* out[T]   = acc * gelu_erf'(aux[T]) (backward through GELU)          */
+    MAED_EPI_ATOMIC_F32 = 4, /* out[f32] += acc  (atomic; weight gradients, split-K allowed)        */
+    MAED_EPI_STORE_F32 = 5,  /* out[f32] = acc + bias                                               */
+    MAED_EPI_TANH = 6        /* out[T]   = tanh(acc + bias)                                         */
+} maed_epilogue;
+
+/* kernel implementation selector for ops that have both */
+typedef enum { MAED_IMPL_AUTO = 0, MAED_IMPL_VALU = 1, MAED_IMPL_MFMA = 2 } maed_impl;
+
+const char* maed_last_error(void);
+int maed_version(void);
+
+/* ---- K1: nn.LayerNorm(eps=1e-6)  (vision_transformer.py:249,254,344,569) ---------------------- */
+/* y[T](rows,C) = LN(x[f32]) ; saves mean/rstd (fp32, rows) for backward.  x rows may be strided. */
+int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
+                       void* y, int dtype, float* mean, float* rstd,
+                       int64_t rows, int C, float eps, void* stream);
+/* dx_out[f32] = (dres_in ? dres_in : 0) + LN'(dy) ; dgamma/dbeta += (fp32, atomics). */
+int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int64_t x_row_stride,
+                       const float* gamma, const float* mean, const float* rstd,
+                       const float* dres_in, float* dx_out, float* dgamma, float* dbeta,
+                       int64_t rows, int C, void* stream);
+
+/* ---- K2/K6/K7/K9/K10: nn.Linear as out = epi(A[M,K] * B[N,K]^T)  (vision_transformer.py:98-111,
+ *      :124-128,:147,:154,:176; ktd.py:74-79)  B is the nn.Linear weight as stored (out,in). -------- */
+int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb,
+                 int64_t M, int64_t N, int64_t K, int dtype, int epilogue,
+                 const float* bias, void* out, int64_t ldo, void* out2,
+                 const void* aux, int64_t ldaux, int splitk, int impl, void* stream);
+
+/* transpose helper feeding the weight-gradient GEMMs (dW = dY^T X as an NT GEMM on transposed
+ * copies): out_t[T](N, ldt) = in(M,N)^T with columns [M, ldt) zero-filled; optional plain cast copy
+ * out_c[T](M,N); optional colsum[N] += sum over rows (bias gradient).  in_dtype may be MAED_F32
+ * while dtype (of the outputs) is MAED_BF16.  */
+int maed_transpose_cast(const void* in, int in_dtype, int64_t ldi, int64_t M, int64_t N,
+                        void* out_t, int64_t ldt, void* out_c, int64_t ldc, float* colsum,
+                        int dtype, void* stream);
+
+/* ---- K3: Attention.forward_spatial (vision_transformer.py:206-214) --------------------------- */
+/* per (frame, head): o = softmax(q k^T * scale) v over the P tokens of a frame.
+ * qkv (F,P,3C) as written by the qkv Linear; o (F,P,C) head-major channels; lse (F,H,P) fp32 =
+ * log-sum-exp of the scaled scores (saved for backward). */
+int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F, int P, int H, float scale,
+                          int dtype, int impl, void* stream);
+/* dqkv (F,P,3C): q/k/v gradients; accumulate!=0 adds into dqkv instead of overwriting. */
+int maed_attn_spatial_bwd(const void* qkv, const void* o, const void* d_o, const float* lse,
+                          void* dqkv, int accumulate, int F, int P, int H, float scale,
+                          int dtype, int impl, void* stream);
+
+/* ---- K4: Attention.forward_temporal (vision_transformer.py:216-228) -------------------------- */
+/* per (clip, head, token): attention across the T frames of the clip; no transposed copies. */
+int maed_attn_temporal_fwd(const void* qkv, void* o, float* lse, int F, int P, int H, int T,
+                           float scale, int dtype, void* stream);
+int maed_attn_temporal_bwd(const void* qkv, const void* o, const void* d_o, const float* lse,
+                           void* dqkv, int accumulate, int F, int P, int H, int T, float scale,
+                           int dtype, void* stream);
+
+/* ---- K5: attentive addition (vision_transformer.py:152-158) ----------------------------------- */
+/* means[T](F,2C) = mean over tokens of [x_s || x_t];  ws: caller-owned fp32 scratch of F*2C floats */
+int maed_st_colmean(const void* x_s, const void* x_t, void* means, float* ws, int F, int P, int C, int dtype, void* stream);
+/* mix[T](F,P,C) = x_t*a1 + x_s*a0, (a0,a1) = softmax(logits[f][2c], logits[f][2c+1]); logits fp32 (F,2C) */
+int maed_st_mix_fwd(const void* x_s, const void* x_t, const float* logits, void* mix,
+                    int F, int P, int C, int dtype, void* stream);
+/* dlogits[T](F,2C) from dmix: reduction over tokens + 2-way softmax backward; ws: F*2C fp32 scratch */
+int maed_st_mix_bwd_reduce(const void* dmix, const void* x_s, const void* x_t, const float* logits,
+                           void* dlogits, float* ws, int F, int P, int C, int dtype, void* stream);
+/* dx_s = dmix*a0 + dmeans[f][c]/P ; dx_t = dmix*a1 + dmeans[f][C+c]/P ; dmeans[T](F,2C) */
+int maed_st_mix_bwd_apply(const void* dmix, const float* logits, const void* dmeans, void* dx_s, void* dx_t,
+                          int F, int P, int C, int dtype, void* stream);
+
+/* ---- K8: cls / pos / temporal embeddings (vision_transformer.py:392-399) ---------------------- */
+/* tokens[f32](F,P,C): row 0 = cls, rows 1.. = patch[T](F,P-1,C); + pos_embed[p] + temp_embed[f % T] */
+int maed_embed_add_fwd(const void* patch, int dtype, const float* cls, const float* pos, const float* temp,
+                       float* tokens, int F, int P, int C, int T, void* stream);
+/* dpatch[T](F,P-1,C) = dtokens rows 1.. ; dpos[f32](P,C) += sum_f ; frame_colsum[f32](F,C) = sum_p */
+int maed_embed_add_bwd(const float* dtokens, void* dpatch, int dtype, float* dpos, float* frame_colsum,
+                       int F, int P, int C, void* stream);
+
+/* ---- whole STE Block (vision_transformer.py:244-261 with Attention 'parallel' :146-158,176 and
+ *      Mlp :106-112) as ONE host call that enqueues every kernel of the block -------------------- */
+typedef struct {
+    int F, P, C, H, T, hidden; /* frames, tokens/frame, embed dim, heads, clip length, MLP hidden */
+    int dtype;                 /* maed_dtype of activations + GEMM weights */
+    int impl;                  /* maed_impl for attention / GEMM */
+    float eps;                 /* LayerNorm eps (1e-6) */
+} maed_block_dims;
+
+typedef struct {              /* fp32 unless noted; w_* are [out,in] in compute dtype */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const void *w_qkv, *w_ts, *w_proj, *w_fc1, *w_fc2;
+    const float *b_qkv, *b_ts, *b_proj, *b_fc1, *b_fc2;
+    /* transposed weights [in,out] in compute dtype (backward only; may be NULL for forward) */
+    const void *wt_qkv, *wt_ts, *wt_proj, *wt_fc1, *wt_fc2;
+} maed_block_params;
+
+typedef struct {              /* fp32 gradient accumulators (+=) with the parameters' shapes */
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    float *w_qkv, *w_ts, *w_proj, *w_fc1, *w_fc2;
+    float *b_qkv, *b_ts, *b_proj, *b_fc1, *b_fc2;
+} maed_block_grads;
+
+/* bytes of activations the forward saves for the backward / of transient backward scratch */
+size_t maed_ste_block_saved_bytes(const maed_block_dims* d);
+size_t maed_ste_block_scratch_bytes(const maed_block_dims* d);
+/* x_out[f32](F,P,C) = Block(x_in[f32]).  `saved` (maed_ste_block_saved_bytes) is written and must be
+ * handed unchanged to maed_ste_block_bwd.  x_out may alias x_in only if no backward is wanted. */
+int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in,
+                       float* x_out, void* saved, void* stream);
+/* dx_in[f32] = dBlock/dx_in(dx_out); parameter gradients are accumulated into g. dx_in may alias dx_out. */
+int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, const maed_block_grads* g,
+                       const float* x_in, const float* dx_out, float* dx_in, void* saved, void* scratch,
+                       void* stream);
+
+/* ---- K10: KTD joint chain (ktd.py:81-86) ------------------------------------------------------- */
+/* base[f32](F,144) = x W_feat^T + b for the 1024-wide feature part of all 24 regressors has been
+ * computed by maed_gemm_nt; this adds the ancestor terms serially along ANCESTOR_INDEX (ktd.py:10-35):
+ * pose[f][6j..6j+5] = base[f][6j..] + sum_a W_anc[j][:, 6*slot(a)..] pose[f][6a..].
+ * w_anc: packed fp32, for joint j a (6, 6*n_anc(j)) row-major block at anc_offset[j]. */
+int maed_ktd_chain_fwd(const float* base, const float* w_anc, float* pose, int F, void* stream);
+
+/* ---- K11: rot6d_to_rotmat + rotation_matrix_to_angle_axis (geometry.py:320-334,58-87,143-223,90-140) */
+int maed_rot6d_pose_fwd(const float* pose6d, float* rotmat, float* angle_axis, int64_t n_joints, void* stream);
+
+/* ---- K12-K15: SMPL (smplx 0.1.13 lbs, pose2rot=False; smpl.py:94-106; ktd.py:108-114; spin.py:113-157) */
+typedef struct {
+    const float* v_template;  /* (6890,3)      */
+    const float* shapedirs;   /* (6890,3,10)   */
+    const float* posedirs;    /* (207,20670)   */
+    const float* J_template;  /* (24,3)  = J_regressor v_template   (precomputed by the host)  */
+    const float* J_shapedirs; /* (24,3,10) = J_regressor shapedirs  (precomputed by the host)  */
+    const float* lbs_weights; /* (6890,24)     */
+    const int32_t* parents;   /* (24) root -1  */
+} maed_smpl_params;
+/* verts (F,6890,3), posed joints (F,24,3); scratch: F*24*12 floats (skinning transforms A) */
+int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas, const float* rotmat,
+                      float* verts, float* joints24, float* scratch_A, int F, void* stream);
+/* out[f][j][:] = sum_v Jreg[j][v] verts[f][v][:]  (J <= 32 rows; MFMA f32 32x32x2) */
+int maed_joint_regress_fwd(const float* Jreg, int J, const float* verts, float* out, int F, void* stream);
+/* joints49 = gather(cat(joints24, verts[extra_vertex_ids(21)], extra9), joint_map(49 int64)) -- the
+ * integer index work is bit-exact (smpl.py:98-99); kp2d = projection(joints, cam) (spin.py:113-157).
+ * If joints_override (F,Jo,3) is non-NULL it replaces the 49 joints before projection (ktd.py:108-112). */
+int maed_smpl_joints_project_fwd(const float* joints24, const float* verts, const int64_t* extra_vertex_ids,
+                                 const float* extra9, const int64_t* joint_map, const float* cam,
+                                 const float* joints_override, int Jo, float* kp3d, float* kp2d, int F, void* stream);
+
+/* ---- optimizer: Adam (lib/utils/utils.py:127-132; torch.optim.Adam semantics, L2 weight decay) - */
+/* flat fp32 arenas p,g,m,v of n elements; grad is scaled by gscale first (1/world for DDP mean).
+ * Optionally refreshes the bf16 shadow copy of the parameters (shadow_bf16 may be NULL). */
+int maed_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_corr1, float bias_corr2, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAED_HIP_H */

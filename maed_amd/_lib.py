@@ -1,0 +1,102 @@
+"""ctypes binding of libmaed_hip.so (C-ABI declared in include/maed_hip.h).
+
+There is no fallback: if the library is missing the import of any op raises.  `lib()` loads it
+lazily so that CPU-only tooling (state_dict manipulation, gloo tests of the host logic) can import
+the package without a GPU; calling any kernel without the library is an error, never a silent
+PyTorch path.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmaed_hip.so")
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_GELU, EPI_RESID_F32, EPI_MUL_DGELU, EPI_ATOMIC_F32, EPI_STORE_F32, EPI_TANH = range(7)
+IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
+
+vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+
+class BlockDims(C.Structure):
+    _fields_ = [("F", i32), ("P", i32), ("C", i32), ("H", i32), ("T", i32), ("hidden", i32),
+                ("dtype", i32), ("impl", i32), ("eps", f32)]
+
+
+_PARAM_FIELDS = ["ln1_g", "ln1_b", "ln2_g", "ln2_b", "w_qkv", "w_ts", "w_proj", "w_fc1", "w_fc2",
+                 "b_qkv", "b_ts", "b_proj", "b_fc1", "b_fc2", "wt_qkv", "wt_ts", "wt_proj", "wt_fc1", "wt_fc2"]
+_GRAD_FIELDS = _PARAM_FIELDS[:14]
+
+
+class BlockParams(C.Structure):
+    _fields_ = [(n, vp) for n in _PARAM_FIELDS]
+
+
+class BlockGrads(C.Structure):
+    _fields_ = [(n, vp) for n in _GRAD_FIELDS]
+
+
+class SmplParams(C.Structure):
+    _fields_ = [(n, vp) for n in ["v_template", "shapedirs", "posedirs", "J_template", "J_shapedirs", "lbs_weights", "parents"]]
+
+
+# name -> (restype, argtypes): mirrors include/maed_hip.h one to one (tests/test_cabi.py checks it)
+SIGNATURES = {
+    "maed_last_error": (C.c_char_p, []),
+    "maed_version": (i32, []),
+    "maed_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i32, vp, vp, i64, i32, f32, vp]),
+    "maed_layernorm_bwd": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "maed_gemm_nt": (i32, [vp, i64, vp, i64, i64, i64, i64, i32, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp]),
+    "maed_transpose_cast": (i32, [vp, i32, i64, i64, i64, vp, i64, vp, i64, vp, i32, vp]),
+    "maed_attn_spatial_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),
+    "maed_attn_spatial_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
+    "maed_attn_temporal_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "maed_attn_temporal_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "maed_st_colmean": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "maed_st_mix_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "maed_st_mix_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "maed_st_mix_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "maed_embed_add_fwd": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "maed_embed_add_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp]),
+    "maed_ste_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
+    "maed_ste_block_scratch_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
+    "maed_ste_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
+    "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp]),
+    "maed_ktd_chain_fwd": (i32, [vp, vp, vp, i32, vp]),
+    "maed_rot6d_pose_fwd": (i32, [vp, vp, vp, i64, vp]),
+    "maed_smpl_lbs_fwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, i32, vp]),
+    "maed_joint_regress_fwd": (i32, [vp, i32, vp, vp, i32, vp]),
+    "maed_smpl_joints_project_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
+    "maed_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
+}
+
+_lib = None
+
+
+class MaedHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmaed_hip.so (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MaedHipError(f"{LIB_PATH} is missing: build it with `python -m maed_amd.build` "
+                               "(hipcc --offload-arch=gfx950).  maed_amd has no non-HIP fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().maed_last_error().decode("utf-8", "replace")
+        raise MaedHipError(f"{what or 'libmaed_hip'} failed with status {rc}: {msg}")
+
+
+def loaded_path():
+    return LIB_PATH if _lib is not None else None

@@ -1,0 +1,372 @@
+// K3: spatial attention of the STE (vision_transformer.py:206-214): per (frame, head)
+//     o = softmax(q k^T * scale) v  over the P tokens of one frame, d = 64.
+// The reference materialises the (F,H,P,P) score tensor twice in HBM; here scores never leave
+// registers, K/V of the head are staged once in LDS, and q/k/v are read straight out of the qkv
+// Linear's (F,P,3C) output (no permuted copies).
+//
+//  * bf16 forward (MFMA): one workgroup per (frame, head), one wave per 32-row q tile.
+//    S^T = K Q^T via v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q rows in registers), so a
+//    lane owns one q column and 16 keys of it: the softmax row reduction is in-register plus one
+//    cross-half shuffle.  O^T = V^T P^T uses the exponentiated scores directly as the B fragment
+//    (k-slot permutation shared with the V^T fragment read), so P never touches LDS and the
+//    online-softmax rescale of O^T is lane-local.  V is transposed once while staging.
+//  * generic-T VALU kernels (f32 parity mode, and the backward of both modes in this round):
+//    thread per row, the other side's matrices broadcast-read from LDS.
+#include "common.cuh"
+
+#define D HEAD_DIM
+
+// ==================================================================================================
+// VALU forward / backward (generic T)
+// ==================================================================================================
+template <typename T>
+__device__ __forceinline__ void stage_rows_f32(float* dst, int ldd, const T* src, int64_t row_stride, int P) {
+    // dst[p][0..63] (row stride ldd floats) <- src[p*row_stride + 0..63]
+    for (int idx = threadIdx.x; idx < P * (D / 4); idx += blockDim.x) {
+        const int p = idx / (D / 4), c = (idx % (D / 4)) * 4;
+        float v[4];
+        ld4(src + (int64_t)p * row_stride + c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[p * ldd + c + j] = v[j];
+    }
+}
+
+#define LDF 65  // padded LDS row (floats)
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_sp_fwd_valu(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+                                                        int P, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ks = sm; float* Vs = sm + (size_t)P * LDF;
+    const int f = blockIdx.x / H, h = blockIdx.x % H;
+    const int C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)f * P * ld + h * D;
+    stage_rows_f32(Ks, LDF, base + C, ld, P);
+    stage_rows_f32(Vs, LDF, base + 2 * C, ld, P);
+    __syncthreads();
+    for (int q = threadIdx.x; q < P; q += blockDim.x) {
+        float qv[D], acc[D];
+#pragma unroll
+        for (int c = 0; c < D; c += 4) { float v[4]; ld4(base + (int64_t)q * ld + c, v); qv[c] = v[0]; qv[c + 1] = v[1]; qv[c + 2] = v[2]; qv[c + 3] = v[3]; }
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        for (int k = 0; k < P; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) s = fmaf(qv[c], Ks[k * LDF + c], s);
+            s *= scale;
+            const float mn = fmaxf(m, s);
+            const float a = __expf(m - mn), p = __expf(s - mn);
+            l = l * a + p;
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] = fmaf(p, Vs[k * LDF + c], acc[c] * a);
+            m = mn;
+        }
+        const float inv = 1.f / l;
+        T* orow = o + ((int64_t)f * P + q) * C + h * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) { float v[4] = {acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv}; st4(orow + c, v); }
+        lse[((int64_t)f * H + h) * P + q] = m + __logf(l);
+    }
+}
+
+// dQ: thread per query row, K/V of the head in LDS
+template <typename T>
+__global__ __launch_bounds__(256) void attn_sp_bwd_dq_valu(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                           const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                           T* __restrict__ dqkv, int accumulate, int P, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ks = sm; float* Vs = sm + (size_t)P * LDF;
+    const int f = blockIdx.x / H, h = blockIdx.x % H;
+    const int C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)f * P * ld + h * D;
+    stage_rows_f32(Ks, LDF, base + C, ld, P);
+    stage_rows_f32(Vs, LDF, base + 2 * C, ld, P);
+    __syncthreads();
+    for (int q = threadIdx.x; q < P; q += blockDim.x) {
+        float qv[D], dov[D], dq[D];
+        const T* orow = o + ((int64_t)f * P + q) * C + h * D;
+        const T* dorow = d_o + ((int64_t)f * P + q) * C + h * D;
+        float Dq = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            float v[4], w[4], u[4];
+            ld4(base + (int64_t)q * ld + c, v); ld4(dorow + c, w); ld4(orow + c, u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { qv[c + j] = v[j]; dov[c + j] = w[j]; Dq = fmaf(w[j], u[j], Dq); dq[c + j] = 0.f; }
+        }
+        const float L = lse[((int64_t)f * H + h) * P + q];
+        for (int k = 0; k < P; ++k) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { s = fmaf(qv[c], Ks[k * LDF + c], s); dp = fmaf(dov[c], Vs[k * LDF + c], dp); }
+            const float p = __expf(s * scale - L);
+            const float ds = p * (dp - Dq) * scale;
+#pragma unroll
+            for (int c = 0; c < D; ++c) dq[c] = fmaf(ds, Ks[k * LDF + c], dq[c]);
+        }
+        T* dst = dqkv + ((int64_t)f * P + q) * ld + h * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            float v[4] = {dq[c], dq[c + 1], dq[c + 2], dq[c + 3]};
+            if (accumulate) { float old[4]; ld4(dst + c, old); v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3]; }
+            st4(dst + c, v);
+        }
+    }
+}
+
+// dK, dV: thread per key row, Q/dO of the head (+ lse, D) in LDS; two sweeps to stay in registers
+template <typename T>
+__global__ __launch_bounds__(256) void attn_sp_bwd_dkv_valu(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                            const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                            T* __restrict__ dqkv, int accumulate, int P, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm; float* dOs = sm + (size_t)P * LDF; float* Ls = dOs + (size_t)P * LDF; float* Ds = Ls + P;
+    const int f = blockIdx.x / H, h = blockIdx.x % H;
+    const int C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)f * P * ld + h * D;
+    const T* obase = o + (int64_t)f * P * C + h * D;
+    const T* dobase = d_o + (int64_t)f * P * C + h * D;
+    stage_rows_f32(Qs, LDF, base, ld, P);
+    stage_rows_f32(dOs, LDF, dobase, C, P);
+    __syncthreads();
+    for (int q = threadIdx.x; q < P; q += blockDim.x) {
+        float Dq = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) { float u[4]; ld4(obase + (int64_t)q * C + c, u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Dq = fmaf(dOs[q * LDF + c + j], u[j], Dq); }
+        Ds[q] = Dq;
+        Ls[q] = lse[((int64_t)f * H + h) * P + q];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+        float kv[D], acc[D];
+#pragma unroll
+        for (int c = 0; c < D; c += 4) { float v[4]; ld4(base + C + (int64_t)k * ld + c, v); kv[c] = v[0]; kv[c + 1] = v[1]; kv[c + 2] = v[2]; kv[c + 3] = v[3]; }
+        // sweep 1: dV[k] = sum_q p[q][k] dO[q]
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = 0.f;
+        for (int q = 0; q < P; ++q) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) s = fmaf(Qs[q * LDF + c], kv[c], s);
+            const float p = __expf(s * scale - Ls[q]);
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] = fmaf(p, dOs[q * LDF + c], acc[c]);
+        }
+        T* dv = dqkv + ((int64_t)f * P + k) * ld + 2 * C + h * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            float v[4] = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+            if (accumulate) { float old[4]; ld4(dv + c, old); v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3]; }
+            st4(dv + c, v);
+        }
+        // sweep 2: dK[k] = sum_q ds[q][k] Q[q]
+        float vv[D];
+#pragma unroll
+        for (int c = 0; c < D; c += 4) { float v[4]; ld4(base + 2 * C + (int64_t)k * ld + c, v); vv[c] = v[0]; vv[c + 1] = v[1]; vv[c + 2] = v[2]; vv[c + 3] = v[3]; }
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = 0.f;
+        for (int q = 0; q < P; ++q) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { s = fmaf(Qs[q * LDF + c], kv[c], s); dp = fmaf(dOs[q * LDF + c], vv[c], dp); }
+            const float p = __expf(s * scale - Ls[q]);
+            const float ds = p * (dp - Ds[q]) * scale;
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] = fmaf(ds, Qs[q * LDF + c], acc[c]);
+        }
+        T* dk = dqkv + ((int64_t)f * P + k) * ld + C + h * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            float v[4] = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+            if (accumulate) { float old[4]; ld4(dk + c, old); v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3]; }
+            st4(dk + c, v);
+        }
+    }
+}
+
+// ==================================================================================================
+// MFMA forward (bf16)
+// ==================================================================================================
+#define KLD 72  // K row stride in LDS (elements): 144 B, conflict-free ds_read_b128
+
+__global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                         float* __restrict__ lse, int P, int H, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int Pk = (P + 31) & ~31;
+    const int VLD = Pk + 4;                        // V^T row stride (elements): (Pk+4)/2 dwords = 2*odd -> conflict-free b64
+    unsigned short* Ks = smem;                     // [P][KLD]
+    unsigned short* Vt = smem + (size_t)P * KLD;   // [64][VLD]   (P*KLD*2 bytes is a multiple of 16)
+    const int f = blockIdx.x / H, h = blockIdx.x % H;
+    const int C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16* base = qkv + (int64_t)f * P * ld + h * D;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+
+    // ---- stage K (row-major, padded) and V^T (transposed while writing) -----------------------------
+    for (int idx = tid; idx < P * 8; idx += nthr) {
+        const int p = idx >> 3, c8 = (idx & 7) * 8;
+        const uint4 kv = *reinterpret_cast<const uint4*>(base + C + (int64_t)p * ld + c8);
+        *reinterpret_cast<uint4*>(Ks + p * KLD + c8) = kv;
+        const uint4 vv = *reinterpret_cast<const uint4*>(base + 2 * C + (int64_t)p * ld + c8);
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Vt[(c8 + 2 * j) * VLD + p] = (unsigned short)(w[j] & 0xffffu);
+            Vt[(c8 + 2 * j + 1) * VLD + p] = (unsigned short)(w[j] >> 16);
+        }
+    }
+    for (int idx = tid; idx < D * (VLD - P); idx += nthr) {  // zero the key padding of V^T
+        const int e = idx / (VLD - P), k = P + idx % (VLD - P);
+        Vt[e * VLD + k] = 0;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int q0 = wave * 32;
+    if (q0 >= P) return;
+    const int q = q0 + l31;
+    const int qc = q < P ? q : P - 1;
+
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8_t*>(base + (int64_t)qc * ld + t * 16 + hi * 8);
+
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+
+    const int nkt = Pk / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // S^T tile: rows = keys kt*32.., cols = this wave's 32 queries
+        f32x16_t s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        int krow = kt * 32 + l31;
+        if (krow > P - 1) krow = P - 1;
+        const unsigned short* kp = Ks + krow * KLD + hi * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + t * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s, 0, 0, 0);
+        }
+        // lane holds keys k(r) = kt*32 + (r&3) + 8*(r>>2) + 4*hi of query q
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            s[r] = (k < P) ? s[r] * scale_log2e : -INFINITY;
+            mt = fmaxf(mt, s[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mn = fmaxf(m, mt);
+        const float alpha = exp2f(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mn); ps += s[r]; }
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+        // O^T += V^T P^T : k-step st of 16 keys uses regs 8*st .. 8*st+7 (k = kt*32 + 16*st + 8*(j>>2) + 4*hi + (j&3))
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            union { bf16x8_t v; uint32_t u[4]; } pf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf2(s[8 * st + 2 * j], s[8 * st + 2 * j + 1]);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                const unsigned short* vp = Vt + (et * 32 + l31) * VLD + kt * 32 + 16 * st + 4 * hi;
+                union { bf16x8_t v; uint2 u[2]; } vf;
+                vf.u[0] = *reinterpret_cast<const uint2*>(vp);
+                vf.u[1] = *reinterpret_cast<const uint2*>(vp + 8);
+                oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[et], 0, 0, 0);
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (q < P) {
+        const float inv = 1.f / l;
+        bf16* orow = o + ((int64_t)f * P + q) * C + h * D;
+        // O^T tile et: lane holds e = et*32 + (r&3) + 8*(r>>2) + 4*hi for its query
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int e0 = et * 32 + 8 * g + 4 * hi;
+                const uint2 w = make_uint2(pack_bf2(oacc[et][4 * g] * inv, oacc[et][4 * g + 1] * inv),
+                                           pack_bf2(oacc[et][4 * g + 2] * inv, oacc[et][4 * g + 3] * inv));
+                *reinterpret_cast<uint2*>(orow + e0) = w;
+            }
+        if (hi == 0) lse[((int64_t)f * H + h) * P + q] = (m + log2f(l)) * 0.69314718055994530942f;
+    }
+}
+
+// ==================================================================================================
+static size_t valu_lds_bytes(int P, bool bwd_dkv) { return ((size_t)2 * P * LDF + (bwd_dkv ? 2 * P : 0)) * sizeof(float); }
+
+extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F, int P, int H, float scale, int dtype,
+                                     int impl, void* stream) {
+    MAED_CHECK_ARG(qkv && o && lse, MAED_ERR_ARG, "attn_spatial_fwd: null pointer");
+    MAED_CHECK_ARG(F >= 0 && P > 0 && H > 0, MAED_ERR_SHAPE, "attn_spatial_fwd: bad extents");
+    MAED_CHECK_ARG(is_aligned(qkv, 16) && is_aligned(o, 16), MAED_ERR_ALIGN, "attn_spatial_fwd: qkv/o must be 16-B aligned");
+    if (F == 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool use_mfma = (dtype == MAED_BF16) && (impl != MAED_IMPL_VALU);
+    MAED_CHECK_ARG(!(impl == MAED_IMPL_MFMA && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED, "attn_spatial_fwd: MFMA path is bf16 only");
+    if (use_mfma) {
+        const int Pk = (P + 31) & ~31;
+        MAED_CHECK_ARG(Pk / 32 <= 16, MAED_ERR_SHAPE, "attn_spatial_fwd(mfma): P=%d > 512 tokens per frame", P);
+        const size_t lds = ((size_t)P * KLD + (size_t)D * (Pk + 4)) * 2;
+        MAED_CHECK_ARG(lds <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_fwd(mfma): LDS %zu B", lds);
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void*)attn_sp_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(attn_sp_fwd_mfma, dim3(F * H), dim3(64 * (Pk / 32)), lds, s, (const bf16*)qkv, (bf16*)o, lse, P, H,
+                           scale * 1.44269504088896340736f);
+    } else {
+        const size_t lds = valu_lds_bytes(P, false);
+        MAED_CHECK_ARG(lds <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_fwd(valu): P=%d needs %zu B LDS", P, lds);
+        if (dtype == MAED_F32) {
+            hipFuncSetAttribute((const void*)attn_sp_fwd_valu<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((attn_sp_fwd_valu<float>), dim3(F * H), dim3(256), lds, s, (const float*)qkv, (float*)o, lse, P, H, scale);
+        } else if (dtype == MAED_BF16) {
+            hipFuncSetAttribute((const void*)attn_sp_fwd_valu<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((attn_sp_fwd_valu<bf16>), dim3(F * H), dim3(256), lds, s, (const bf16*)qkv, (bf16*)o, lse, P, H, scale);
+        } else { maed_set_error("attn_spatial_fwd: bad dtype"); return MAED_ERR_ARG; }
+    }
+    MAED_CHECK_LAUNCH("attn_spatial_fwd");
+    return MAED_OK;
+}
+
+template <typename T>
+static void launch_bwd_valu(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate,
+                            int F, int P, int H, float scale, hipStream_t s) {
+    hipFuncSetAttribute((const void*)attn_sp_bwd_dq_valu<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)attn_sp_bwd_dkv_valu<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((attn_sp_bwd_dq_valu<T>), dim3(F * H), dim3(256), valu_lds_bytes(P, false), s, (const T*)qkv, (const T*)o,
+                       (const T*)d_o, lse, (T*)dqkv, accumulate, P, H, scale);
+    hipLaunchKernelGGL((attn_sp_bwd_dkv_valu<T>), dim3(F * H), dim3(256), valu_lds_bytes(P, true), s, (const T*)qkv, (const T*)o,
+                       (const T*)d_o, lse, (T*)dqkv, accumulate, P, H, scale);
+}
+
+extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
+                                     int accumulate, int F, int P, int H, float scale, int dtype, int impl, void* stream) {
+    MAED_CHECK_ARG(qkv && o && d_o && lse && dqkv, MAED_ERR_ARG, "attn_spatial_bwd: null pointer");
+    MAED_CHECK_ARG(F >= 0 && P > 0 && H > 0, MAED_ERR_SHAPE, "attn_spatial_bwd: bad extents");
+    MAED_CHECK_ARG(valu_lds_bytes(P, true) <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_bwd: P=%d too large for LDS", P);
+    MAED_CHECK_ARG(impl != MAED_IMPL_MFMA, MAED_ERR_UNSUPPORTED, "attn_spatial_bwd: MFMA backward not implemented yet");
+    if (F == 0) return MAED_OK;
+    if (dtype == MAED_F32) launch_bwd_valu<float>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
+    else if (dtype == MAED_BF16) launch_bwd_valu<bf16>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
+    else { maed_set_error("attn_spatial_bwd: bad dtype"); return MAED_ERR_ARG; }
+    MAED_CHECK_LAUNCH("attn_spatial_bwd");
+    return MAED_OK;
+}

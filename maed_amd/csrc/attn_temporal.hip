@@ -1,0 +1,171 @@
+// K4: temporal attention of the STE (vision_transformer.py:216-228): per (clip n, head h, token p)
+//     attention across the T frames of the clip.  The reference makes three permuted copies of
+//     q/k/v and one of the output per block; here every thread gathers its rows straight from the
+//     (F,P,3C) qkv buffer (frame stride P*3C) and writes the (F,P,C) result in place.
+// HBM-bound (arithmetic intensity ~T/2 flop/B): thread per (n,h,p,t) query row, the T key/value rows
+// of the same (n,h,p) are shared by T neighbouring threads through L1.  fp32 math for both dtypes.
+#include "common.cuh"
+
+#define D HEAD_DIM
+
+template <typename T>
+__device__ __forceinline__ void load_row(const T* p, float (&v)[D]) {
+#pragma unroll
+    for (int c = 0; c < D; c += 8) {
+        float t[8];
+        ld8(p + c, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c + j] = t[j];
+    }
+}
+template <typename T>
+__device__ __forceinline__ float dot_row(const T* p, const float (&v)[D]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 8) {
+        float t[8];
+        ld8(p + c, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(v[c + j], t[j], s);
+    }
+    return s;
+}
+template <typename T>
+__device__ __forceinline__ void axpy_row(const T* p, float a, float (&acc)[D]) {
+#pragma unroll
+    for (int c = 0; c < D; c += 8) {
+        float t[8];
+        ld8(p + c, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[c + j] = fmaf(a, t[j], acc[c + j]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_row(T* p, const float (&v)[D], float mul, int accumulate) {
+#pragma unroll
+    for (int c = 0; c < D; c += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[c + j] * mul;
+        if (accumulate) { float o[8]; ld8(p + c, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] += o[j]; }
+        st8(p + c, t);
+    }
+}
+
+// gid = ((n*H + h)*P + p)*T + t
+template <typename T>
+__global__ __launch_bounds__(256) void attn_tm_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+                                                          int64_t total, int P, int H, int Tn, float scale) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int t = (int)(gid % Tn); int64_t r = gid / Tn;
+    const int p = (int)(r % P); r /= P;
+    const int h = (int)(r % H); const int64_t n = r / H;
+    const int C = H * D; const int64_t ld = 3 * (int64_t)C;
+    const int64_t f = n * Tn + t;
+    const T* qrow = qkv + (f * P + p) * ld + h * D;
+    float qv[D], acc[D];
+    load_row(qrow, qv);
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int t2 = 0; t2 < Tn; ++t2) {
+        const T* krow = qkv + ((n * Tn + t2) * P + p) * ld + C + h * D;
+        const float s = dot_row(krow, qv) * scale;
+        const float mn = fmaxf(m, s);
+        const float a = __expf(m - mn), pr = __expf(s - mn);
+        l = l * a + pr;
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] *= a;
+        axpy_row(krow + C, pr, acc);
+        m = mn;
+    }
+    store_row(o + (f * P + p) * C + h * D, acc, 1.f / l, 0);
+    lse[(f * H + h) * P + p] = m + __logf(l);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_tm_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
+                                                          const float* __restrict__ lse, T* __restrict__ dqkv, int accumulate,
+                                                          int64_t total, int P, int H, int Tn, float scale) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int t = (int)(gid % Tn); int64_t r = gid / Tn;
+    const int p = (int)(r % P); r /= P;
+    const int h = (int)(r % H); const int64_t n = r / H;
+    const int C = H * D; const int64_t ld = 3 * (int64_t)C;
+    const int64_t f = n * Tn + t;
+    const int64_t row = f * P + p;
+    float a[D], b[D], acc[D];
+    // ---- as query t: dQ = sum_t2 ds[t][t2] K[t2] ----
+    load_row(qkv + row * ld + h * D, a);          // q
+    load_row(d_o + row * C + h * D, b);           // dO
+    const float Dq = dot_row(o + row * C + h * D, b);
+    const float L = lse[(f * H + h) * P + p];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int t2 = 0; t2 < Tn; ++t2) {
+        const T* krow = qkv + ((n * Tn + t2) * P + p) * ld + C + h * D;
+        const float pr = __expf(dot_row(krow, a) * scale - L);
+        const float ds = pr * (dot_row(krow + C, b) - Dq) * scale;
+        axpy_row(krow, ds, acc);
+    }
+    store_row(dqkv + row * ld + h * D, acc, 1.f, accumulate);
+    // ---- as key t: dV = sum_t1 p[t1][t] dO[t1] ----
+    load_row(qkv + row * ld + C + h * D, a);      // k
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int t1 = 0; t1 < Tn; ++t1) {
+        const int64_t row1 = (n * Tn + t1) * P + p;
+        const float pr = __expf(dot_row(qkv + row1 * ld + h * D, a) * scale - lse[((n * Tn + t1) * H + h) * P + p]);
+        axpy_row(d_o + row1 * C + h * D, pr, acc);
+    }
+    store_row(dqkv + row * ld + 2 * C + h * D, acc, 1.f, accumulate);
+    // ---- as key t: dK = sum_t1 ds[t1][t] Q[t1] ----
+    const T* vrow = qkv + row * ld + 2 * C + h * D;  // v[t] stays in L1; registers hold k, dO[t1], acc
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int t1 = 0; t1 < Tn; ++t1) {
+        const int64_t row1 = (n * Tn + t1) * P + p;
+        const T* q1 = qkv + row1 * ld + h * D;
+        const T* do1 = d_o + row1 * C + h * D;
+        const float pr = __expf(dot_row(q1, a) * scale - lse[((n * Tn + t1) * H + h) * P + p]);
+        float d1[D];
+        load_row(do1, d1);
+        const float dp = dot_row(vrow, d1);  // dO[t1] . v[t]
+        const float D1 = dot_row(o + row1 * C + h * D, d1);
+        const float ds = pr * (dp - D1) * scale;
+        axpy_row(q1, ds, acc);
+    }
+    store_row(dqkv + row * ld + C + h * D, acc, 1.f, accumulate);
+}
+
+extern "C" int maed_attn_temporal_fwd(const void* qkv, void* o, float* lse, int F, int P, int H, int T, float scale, int dtype,
+                                      void* stream) {
+    MAED_CHECK_ARG(qkv && o && lse, MAED_ERR_ARG, "attn_temporal_fwd: null pointer");
+    MAED_CHECK_ARG(T > 0 && F % T == 0 && P > 0 && H > 0, MAED_ERR_SHAPE, "attn_temporal_fwd: F=%d must be a multiple of T=%d", F, T);
+    MAED_CHECK_ARG(is_aligned(qkv, 16) && is_aligned(o, 16), MAED_ERR_ALIGN, "attn_temporal_fwd: alignment");
+    const int64_t total = (int64_t)F * H * P;
+    if (total == 0) return MAED_OK;
+    dim3 grid((unsigned)((total + 255) / 256));
+    MAED_DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((attn_tm_fwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                       (const TT*)qkv, (TT*)o, lse, total, P, H, T, scale));
+    MAED_CHECK_LAUNCH("attn_temporal_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_attn_temporal_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv,
+                                      int accumulate, int F, int P, int H, int T, float scale, int dtype, void* stream) {
+    MAED_CHECK_ARG(qkv && o && d_o && lse && dqkv, MAED_ERR_ARG, "attn_temporal_bwd: null pointer");
+    MAED_CHECK_ARG(T > 0 && F % T == 0 && P > 0 && H > 0, MAED_ERR_SHAPE, "attn_temporal_bwd: F=%d must be a multiple of T=%d", F, T);
+    const int64_t total = (int64_t)F * H * P;
+    if (total == 0) return MAED_OK;
+    dim3 grid((unsigned)((total + 255) / 256));
+    MAED_DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((attn_tm_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                       (const TT*)qkv, (const TT*)o, (const TT*)d_o, lse, (TT*)dqkv, accumulate,
+                                                       total, P, H, T, scale));
+    MAED_CHECK_LAUNCH("attn_temporal_bwd");
+    return MAED_OK;
+}

@@ -1,0 +1,182 @@
+// One STE Block (vision_transformer.py:244-261, Attention st_mode='parallel' :146-158,176, Mlp :106-112)
+// as a single host call: the whole kernel sequence of the block is enqueued from C++ on the caller's
+// stream, so the Python autograd layer pays one ctypes call per block and direction instead of ~15-30
+// op dispatches.  The residual stream stays fp32; activations are in the compute dtype.
+//
+// forward : LN1 -> qkv GEMM -> temporal attn + spatial attn (both read qkv in place) -> token means ->
+//           ts_attn GEMM (F x 2C) -> attentive mix -> proj GEMM (+residual) -> LN2 -> fc1 GEMM (+GELU) ->
+//           fc2 GEMM (+residual)
+// backward: the mirror image; weight gradients are NT GEMMs on transposed copies (split-K, fp32 atomics
+//           into the caller's gradient arena), bias gradients fall out of the transposes.
+#include "common.cuh"
+#include <hip/hip_runtime.h>
+
+namespace {
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct SavedLayout {
+    size_t ln1, mean1, rstd1, qkv, xs, xt, lse_s, lse_t, means, logits, mix, xmid, mean2, rstd2, ln2, hpre, hact, total;
+};
+struct ScratchLayout {
+    size_t dyc, dyt, bigA, bigT, xT, act, dxs, dxt, dxmid, dlog, dmeans, dlogT, meansT, ws, total;
+    int64_t Mp, Fp;
+};
+
+SavedLayout saved_layout(const maed_block_dims& d) {
+    const size_t es = dtype_size(d.dtype);
+    const size_t M = (size_t)d.F * d.P, C = d.C, Hd = d.hidden;
+    SavedLayout s{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+    s.ln1 = take(M * C * es); s.mean1 = take(M * 4); s.rstd1 = take(M * 4);
+    s.qkv = take(M * 3 * C * es); s.xs = take(M * C * es); s.xt = take(M * C * es);
+    s.lse_s = take((size_t)d.F * d.H * d.P * 4); s.lse_t = take((size_t)d.F * d.H * d.P * 4);
+    s.means = take((size_t)d.F * 2 * C * es); s.logits = take((size_t)d.F * 2 * C * 4);
+    s.mix = take(M * C * es); s.xmid = take(M * C * 4);
+    s.mean2 = take(M * 4); s.rstd2 = take(M * 4); s.ln2 = take(M * C * es);
+    s.hpre = take(M * Hd * es); s.hact = take(M * Hd * es);
+    s.total = o;
+    return s;
+}
+
+ScratchLayout scratch_layout(const maed_block_dims& d) {
+    const size_t es = dtype_size(d.dtype);
+    const size_t M = (size_t)d.F * d.P, C = d.C, Hd = d.hidden;
+    ScratchLayout s{};
+    s.Mp = (int64_t)((M + 63) / 64 * 64);
+    s.Fp = (int64_t)(((size_t)d.F + 63) / 64 * 64);
+    const size_t big = Hd > 3 * C ? Hd : 3 * C;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += al(bytes); return r; };
+    s.dyc = take(M * C * es); s.dyt = take(C * (size_t)s.Mp * es);
+    s.bigA = take(M * big * es); s.bigT = take(big * (size_t)s.Mp * es);
+    s.xT = take(C * (size_t)s.Mp * es); s.act = take(M * C * es);
+    s.dxs = take(M * C * es); s.dxt = take(M * C * es); s.dxmid = take(M * C * 4);
+    s.dlog = take((size_t)d.F * 2 * C * es); s.dmeans = take((size_t)d.F * 2 * C * es);
+    s.dlogT = take(2 * C * (size_t)s.Fp * es); s.meansT = take(2 * C * (size_t)s.Fp * es);
+    s.ws = take((size_t)d.F * 2 * C * 4);
+    s.total = o;
+    return s;
+}
+
+int check_dims(const maed_block_dims* d, const char* who) {
+    MAED_CHECK_ARG(d, MAED_ERR_ARG, "%s: null dims", who);
+    MAED_CHECK_ARG(d->dtype == MAED_F32 || d->dtype == MAED_BF16, MAED_ERR_ARG, "%s: bad dtype %d", who, d->dtype);
+    MAED_CHECK_ARG(d->F > 0 && d->P > 0 && d->H > 0 && d->T > 0 && d->hidden > 0, MAED_ERR_SHAPE, "%s: non-positive extent", who);
+    MAED_CHECK_ARG(d->C == d->H * HEAD_DIM, MAED_ERR_SHAPE, "%s: C=%d must equal 64*H (H=%d)", who, d->C, d->H);
+    MAED_CHECK_ARG(d->F % d->T == 0, MAED_ERR_SHAPE, "%s: F=%d not a multiple of T=%d", who, d->F, d->T);
+    MAED_CHECK_ARG(d->hidden % 64 == 0, MAED_ERR_SHAPE, "%s: hidden=%d must be a multiple of 64", who, d->hidden);
+    return MAED_OK;
+}
+
+// split-K so that a weight-gradient GEMM (small output, huge K) still fills 256 CUs
+int pick_splitk(int64_t Mo, int64_t No, int64_t K, int dtype) {
+    const int64_t tile = (dtype == MAED_BF16) ? 128 : 64;
+    const int64_t kt = (dtype == MAED_BF16) ? 64 : 16;
+    const int64_t tiles = ((Mo + tile - 1) / tile) * ((No + tile - 1) / tile);
+    int64_t s = (1024 + tiles - 1) / tiles;
+    const int64_t maxs = K / (kt * 4) > 0 ? K / (kt * 4) : 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+// dW[No,Ko] += Yt[No,Mp] * Xt[Ko,Mp]^T
+int wgrad(const void* Yt, const void* Xt, int64_t No, int64_t Ko, int64_t Mp, float* dW, const maed_block_dims& d, void* st) {
+    return maed_gemm_nt(Yt, Mp, Xt, Mp, No, Ko, Mp, d.dtype, MAED_EPI_ATOMIC_F32, nullptr, dW, Ko, nullptr, nullptr, 0,
+                        pick_splitk(No, Ko, Mp, d.dtype), d.impl == MAED_IMPL_VALU ? MAED_IMPL_VALU : MAED_IMPL_AUTO, st);
+}
+
+}  // namespace
+
+extern "C" size_t maed_ste_block_saved_bytes(const maed_block_dims* d) { return d ? saved_layout(*d).total : 0; }
+extern "C" size_t maed_ste_block_scratch_bytes(const maed_block_dims* d) { return d ? scratch_layout(*d).total : 0; }
+
+extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out,
+                                  void* saved, void* stream) {
+    MAED_PROPAGATE(check_dims(d, "ste_block_fwd"));
+    MAED_CHECK_ARG(p && x_in && x_out && saved, MAED_ERR_ARG, "ste_block_fwd: null pointer");
+    MAED_CHECK_ARG(is_aligned(saved, 256), MAED_ERR_ALIGN, "ste_block_fwd: saved buffer must be 256-B aligned");
+    const SavedLayout L = saved_layout(*d);
+    char* sv = (char*)saved;
+    const int64_t M = (int64_t)d->F * d->P;
+    const int C = d->C, Hd = d->hidden, dt = d->dtype;
+    const int gi = d->impl == MAED_IMPL_VALU ? MAED_IMPL_VALU : MAED_IMPL_AUTO;
+    const float scale = 1.0f / sqrtf((float)HEAD_DIM);
+    float* logits = (float*)(sv + L.logits);
+
+    MAED_PROPAGATE(maed_layernorm_fwd(x_in, C, p->ln1_g, p->ln1_b, sv + L.ln1, dt, (float*)(sv + L.mean1), (float*)(sv + L.rstd1), M, C, d->eps, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sv + L.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, sv + L.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
+    MAED_PROPAGATE(maed_attn_temporal_fwd(sv + L.qkv, sv + L.xt, (float*)(sv + L.lse_t), d->F, d->P, d->H, d->T, scale, dt, stream));
+    MAED_PROPAGATE(maed_attn_spatial_fwd(sv + L.qkv, sv + L.xs, (float*)(sv + L.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
+    MAED_PROPAGATE(maed_st_colmean(sv + L.xs, sv + L.xt, sv + L.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sv + L.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
+    MAED_PROPAGATE(maed_st_mix_fwd(sv + L.xs, sv + L.xt, logits, sv + L.mix, d->F, d->P, C, dt, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sv + L.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, sv + L.xmid, C, nullptr, x_in, C, 1, gi, stream));
+    MAED_PROPAGATE(maed_layernorm_fwd((const float*)(sv + L.xmid), C, p->ln2_g, p->ln2_b, sv + L.ln2, dt, (float*)(sv + L.mean2), (float*)(sv + L.rstd2), M, C, d->eps, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sv + L.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, sv + L.hact, Hd, sv + L.hpre, nullptr, 0, 1, gi, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sv + L.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, sv + L.xmid, C, 1, gi, stream));
+    return MAED_OK;
+}
+
+extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, const maed_block_grads* g,
+                                  const float* x_in, const float* dx_out, float* dx_in, void* saved, void* scratch, void* stream) {
+    MAED_PROPAGATE(check_dims(d, "ste_block_bwd"));
+    MAED_CHECK_ARG(p && g && x_in && dx_out && dx_in && saved && scratch, MAED_ERR_ARG, "ste_block_bwd: null pointer");
+    MAED_CHECK_ARG(p->wt_qkv && p->wt_ts && p->wt_proj && p->wt_fc1 && p->wt_fc2, MAED_ERR_ARG, "ste_block_bwd: transposed weights missing");
+    MAED_CHECK_ARG(is_aligned(saved, 256) && is_aligned(scratch, 256), MAED_ERR_ALIGN, "ste_block_bwd: saved/scratch must be 256-B aligned");
+    const SavedLayout L = saved_layout(*d);
+    const ScratchLayout S = scratch_layout(*d);
+    char* sv = (char*)saved; char* sc = (char*)scratch;
+    const int64_t M = (int64_t)d->F * d->P, Mp = S.Mp, Fp = S.Fp;
+    const int C = d->C, Hd = d->hidden, dt = d->dtype;
+    const int gi = d->impl == MAED_IMPL_VALU ? MAED_IMPL_VALU : MAED_IMPL_AUTO;
+    const float scale = 1.0f / sqrtf((float)HEAD_DIM);
+    const float* logits = (const float*)(sv + L.logits);
+    float* dxmid = (float*)(sc + S.dxmid);
+
+    // ---- MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid)))) ------------------------------------------------
+    MAED_PROPAGATE(maed_transpose_cast(dx_out, MAED_F32, C, M, C, sc + S.dyt, Mp, sc + S.dyc, C, g->b_fc2, dt, stream));
+    MAED_PROPAGATE(maed_transpose_cast(sv + L.hact, dt, Hd, M, Hd, sc + S.bigT, Mp, nullptr, 0, nullptr, dt, stream));
+    MAED_PROPAGATE(wgrad(sc + S.dyt, sc + S.bigT, C, Hd, Mp, g->w_fc2, *d, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sc + S.dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
+    MAED_PROPAGATE(maed_transpose_cast(sc + S.bigA, dt, Hd, M, Hd, sc + S.bigT, Mp, nullptr, 0, g->b_fc1, dt, stream));
+    MAED_PROPAGATE(maed_transpose_cast(sv + L.ln2, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
+    MAED_PROPAGATE(wgrad(sc + S.bigT, sc + S.xT, Hd, C, Mp, g->w_fc1, *d, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
+    MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
+                                      dx_out, dxmid, g->ln2_g, g->ln2_b, M, C, stream));
+    // ---- attention: x_mid = x_in + proj(mix(x_s, x_t)) ---------------------------------------------------
+    MAED_PROPAGATE(maed_transpose_cast(dxmid, MAED_F32, C, M, C, sc + S.dyt, Mp, sc + S.dyc, C, g->b_proj, dt, stream));
+    MAED_PROPAGATE(maed_transpose_cast(sv + L.mix, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
+    MAED_PROPAGATE(wgrad(sc + S.dyt, sc + S.xT, C, C, Mp, g->w_proj, *d, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sc + S.dyc, C, p->wt_proj, C, M, C, C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
+    MAED_PROPAGATE(maed_st_mix_bwd_reduce(sc + S.act, sv + L.xs, sv + L.xt, logits, sc + S.dlog, (float*)(sc + S.ws), d->F, d->P, C, dt, stream));
+    MAED_PROPAGATE(maed_transpose_cast(sc + S.dlog, dt, 2 * C, d->F, 2 * C, sc + S.dlogT, Fp, nullptr, 0, g->b_ts, dt, stream));
+    MAED_PROPAGATE(maed_transpose_cast(sv + L.means, dt, 2 * C, d->F, 2 * C, sc + S.meansT, Fp, nullptr, 0, nullptr, dt, stream));
+    MAED_PROPAGATE(wgrad(sc + S.dlogT, sc + S.meansT, 2 * C, 2 * C, Fp, g->w_ts, *d, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
+    MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
+    MAED_PROPAGATE(maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
+    MAED_PROPAGATE(maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
+                                         MAED_IMPL_AUTO, stream));
+    MAED_PROPAGATE(maed_transpose_cast(sc + S.bigA, dt, 3 * C, M, 3 * C, sc + S.bigT, Mp, nullptr, 0, g->b_qkv, dt, stream));
+    MAED_PROPAGATE(maed_transpose_cast(sv + L.ln1, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
+    MAED_PROPAGATE(wgrad(sc + S.bigT, sc + S.xT, 3 * C, C, Mp, g->w_qkv, *d, stream));
+    MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
+    MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in,
+                                      g->ln1_g, g->ln1_b, M, C, stream));
+    return MAED_OK;
+}
+
+// ---- error plumbing / version ------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void maed_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* maed_last_error(void) { return g_err; }
+extern "C" int maed_version(void) { return 100; }

@@ -1,0 +1,107 @@
+// Shared device helpers for libmaed_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/maed_hip.h"
+
+#define HEAD_DIM 64
+
+struct bf16 { unsigned short v; };
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void maed_set_error(const char* fmt, ...);
+#define MAED_CHECK_ARG(cond, code, ...) do { if (!(cond)) { maed_set_error(__VA_ARGS__); return (code); } } while (0)
+#define MAED_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
+    maed_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return MAED_ERR_LAUNCH; } } while (0)
+#define MAED_PROPAGATE(expr) do { int rc__ = (expr); if (rc__ != MAED_OK) return rc__; } while (0)
+
+static inline bool is_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// ---- scalar conversions ----------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return bf2f(p->v); }
+__device__ __forceinline__ void stf(float* p, float x) { *p = x; }
+__device__ __forceinline__ void stf(bf16* p, float x) { p->v = f2bf(x); }
+
+// 4-element vector access (16 B for float, 8 B for bf16); pointers must be 4-element aligned
+__device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void ld4(const bf16* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void st4(bf16* p, const float (&o)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+}
+// 8 contiguous elements
+__device__ __forceinline__ void ld8(const float* p, float (&o)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16* p, float (&o)[8]) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ void st8(float* p, const float (&o)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+__device__ __forceinline__ void st8(bf16* p, const float (&o)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]),
+                                             pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+}
+
+// ---- wave (64 lanes) reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- math ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int value = MAED_F32; };
+template <> struct dtype_of<bf16> { static constexpr int value = MAED_BF16; };
+
+static inline size_t dtype_size(int dtype) { return dtype == MAED_BF16 ? 2 : 4; }
+
+// dispatch a templated launcher on the runtime dtype
+#define MAED_DISPATCH_DTYPE(dtype, T, ...) do { \
+    if ((dtype) == MAED_F32) { using T = float; __VA_ARGS__; } \
+    else if ((dtype) == MAED_BF16) { using T = bf16; __VA_ARGS__; } \
+    else { maed_set_error("bad dtype %d", (int)(dtype)); return MAED_ERR_ARG; } } while (0)

@@ -1,0 +1,344 @@
+// HBM-bound glue of the STE: attentive addition (K5), embeddings (K8), the transpose/cast feeding the
+// weight-gradient GEMMs, and the fused Adam step.  All kernels use 8/16-byte accesses and fp32 math.
+#include "common.cuh"
+
+// ---------------------------------------------------------------------------------------------------
+// K5 attentive addition (vision_transformer.py:152-158)
+// ---------------------------------------------------------------------------------------------------
+// means[f][c] = mean_p x_s[f][p][c], means[f][C + c] = mean_p x_t[f][p][c]; thread per 4 channels.
+// grid (ceil(C/4/64), F, 2); a wave reads 512/1024 contiguous bytes of a row per step.
+#define CM_SPLIT 8  // token-axis split per (f, channel group) so the grid fills the chip
+template <typename T>
+__global__ __launch_bounds__(64) void st_colmean_kernel(const T* __restrict__ x_s, const T* __restrict__ x_t, float* __restrict__ part,
+                                                        int P, int C) {
+    const int c4 = blockIdx.x * 64 + threadIdx.x;
+    if (c4 * 4 >= C) return;
+    const int f = blockIdx.y, which = blockIdx.z / CM_SPLIT, sp = blockIdx.z % CM_SPLIT;
+    const T* src = (which ? x_t : x_s) + (int64_t)f * P * C + c4 * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = sp; p < P; p += CM_SPLIT) {
+        float v[4];
+        ld4(src + (int64_t)p * C, v);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    float* dst = part + ((int64_t)f * 2 * C + which * C + c4 * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(dst + j, s[j]);
+}
+template <typename T>
+__global__ void st_colmean_finish(const float* __restrict__ part, T* __restrict__ means, int64_t n, float invP) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) stf(means + i, part[i] * invP);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void st_mix_fwd_kernel(const T* __restrict__ x_s, const T* __restrict__ x_t, const float* __restrict__ logits,
+                                                         T* __restrict__ mix, int64_t n4, int P, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t e = i * 4;
+    const int c = (int)(e % C); const int64_t f = e / ((int64_t)P * C);
+    float lg[8], a[4], b[4], o[4];
+    ld8(logits + f * 2 * C + 2 * c, lg);
+    ld4(x_s + e, a); ld4(x_t + e, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = 1.f / (1.f + __expf(lg[2 * j + 1] - lg[2 * j]));  // softmax over the pair, weight of x_s
+        o[j] = b[j] * (1.f - a0) + a[j] * a0;
+    }
+    st4(mix + e, o);
+}
+
+// dlogits: thread per 4 channels of one frame; reduction over tokens split CM_SPLIT ways through atomics
+template <typename T>
+__global__ __launch_bounds__(64) void st_mix_bwd_reduce_kernel(const T* __restrict__ dmix, const T* __restrict__ x_s, const T* __restrict__ x_t,
+                                                               float* __restrict__ part, int P, int C) {
+    const int c4 = blockIdx.x * 64 + threadIdx.x;
+    if (c4 * 4 >= C) return;
+    const int f = blockIdx.y, sp = blockIdx.z;
+    const int64_t base = (int64_t)f * P * C + c4 * 4;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = sp; p < P; p += CM_SPLIT) {
+        float d[4], a[4], b[4];
+        ld4(dmix + base + (int64_t)p * C, d); ld4(x_s + base + (int64_t)p * C, a); ld4(x_t + base + (int64_t)p * C, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s0[j] = fmaf(d[j], a[j], s0[j]); s1[j] = fmaf(d[j], b[j], s1[j]); }
+    }
+    float* dst = part + ((int64_t)f * 2 * C + 2 * c4 * 4);  // interleaved (da0, da1) per channel
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { atomicAdd(dst + 2 * j, s0[j]); atomicAdd(dst + 2 * j + 1, s1[j]); }
+}
+template <typename T>
+__global__ void st_mix_bwd_reduce_finish(const float* __restrict__ part, const float* __restrict__ logits, T* __restrict__ dlogits, int64_t npairs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const float l0 = logits[2 * i], l1 = logits[2 * i + 1];
+    const float a0 = 1.f / (1.f + __expf(l1 - l0)), a1 = 1.f - a0;
+    const float d0 = part[2 * i], d1 = part[2 * i + 1];
+    const float dot = a0 * d0 + a1 * d1;
+    stf(dlogits + 2 * i, a0 * (d0 - dot));
+    stf(dlogits + 2 * i + 1, a1 * (d1 - dot));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void st_mix_bwd_apply_kernel(const T* __restrict__ dmix, const float* __restrict__ logits, const T* __restrict__ dmeans,
+                                                               T* __restrict__ dx_s, T* __restrict__ dx_t, int64_t n4, int P, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t e = i * 4;
+    const int c = (int)(e % C); const int64_t f = e / ((int64_t)P * C);
+    float lg[8], d[4], ms[4], mt[4], os[4], ot[4];
+    ld8(logits + f * 2 * C + 2 * c, lg);
+    ld4(dmix + e, d);
+    ld4(dmeans + f * 2 * C + c, ms); ld4(dmeans + f * 2 * C + C + c, mt);
+    const float invP = 1.f / (float)P;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = 1.f / (1.f + __expf(lg[2 * j + 1] - lg[2 * j]));
+        os[j] = d[j] * a0 + ms[j] * invP;
+        ot[j] = d[j] * (1.f - a0) + mt[j] * invP;
+    }
+    st4(dx_s + e, os); st4(dx_t + e, ot);
+}
+
+// the token-axis reductions are split CM_SPLIT ways; partial sums meet in a caller-owned fp32 scratch `ws`
+extern "C" int maed_st_colmean(const void* x_s, const void* x_t, void* means, float* ws /* F*2C fp32 */, int F, int P, int C,
+                                  int dtype, void* stream) {
+    MAED_CHECK_ARG(x_s && x_t && means && ws, MAED_ERR_ARG, "st_colmean: null pointer");
+    MAED_CHECK_ARG(C % 4 == 0 && P > 0, MAED_ERR_SHAPE, "st_colmean: C %% 4");
+    if (F == 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)F * 2 * C;
+    hipMemsetAsync(ws, 0, n * sizeof(float), s);
+    dim3 grid((C / 4 + 63) / 64, F, 2 * CM_SPLIT);
+    MAED_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((st_colmean_kernel<T>), grid, dim3(64), 0, s, (const T*)x_s, (const T*)x_t, ws, P, C);
+        hipLaunchKernelGGL((st_colmean_finish<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, (T*)means, n, 1.f / (float)P);
+    });
+    MAED_CHECK_LAUNCH("st_colmean");
+    return MAED_OK;
+}
+
+extern "C" int maed_st_mix_fwd(const void* x_s, const void* x_t, const float* logits, void* mix, int F, int P, int C, int dtype,
+                               void* stream) {
+    MAED_CHECK_ARG(x_s && x_t && logits && mix, MAED_ERR_ARG, "st_mix_fwd: null pointer");
+    MAED_CHECK_ARG(C % 4 == 0, MAED_ERR_SHAPE, "st_mix_fwd: C %% 4");
+    const int64_t n4 = (int64_t)F * P * C / 4;
+    if (n4 == 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((st_mix_fwd_kernel<T>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                                      (const T*)x_s, (const T*)x_t, logits, (T*)mix, n4, P, C));
+    MAED_CHECK_LAUNCH("st_mix_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_st_mix_bwd_reduce(const void* dmix, const void* x_s, const void* x_t, const float* logits, void* dlogits,
+                                         float* ws /* F*2C fp32 */, int F, int P, int C, int dtype, void* stream) {
+    MAED_CHECK_ARG(dmix && x_s && x_t && logits && dlogits && ws, MAED_ERR_ARG, "st_mix_bwd_reduce: null pointer");
+    MAED_CHECK_ARG(C % 4 == 0, MAED_ERR_SHAPE, "st_mix_bwd_reduce: C %% 4");
+    if (F == 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)F * 2 * C;
+    hipMemsetAsync(ws, 0, n * sizeof(float), s);
+    dim3 grid((C / 4 + 63) / 64, F, CM_SPLIT);
+    MAED_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((st_mix_bwd_reduce_kernel<T>), grid, dim3(64), 0, s, (const T*)dmix, (const T*)x_s, (const T*)x_t, ws, P, C);
+        hipLaunchKernelGGL((st_mix_bwd_reduce_finish<T>), dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, ws, logits, (T*)dlogits, n / 2);
+    });
+    MAED_CHECK_LAUNCH("st_mix_bwd_reduce");
+    return MAED_OK;
+}
+
+extern "C" int maed_st_mix_bwd_apply(const void* dmix, const float* logits, const void* dmeans, void* dx_s, void* dx_t, int F, int P,
+                                     int C, int dtype, void* stream) {
+    MAED_CHECK_ARG(dmix && logits && dmeans && dx_s && dx_t, MAED_ERR_ARG, "st_mix_bwd_apply: null pointer");
+    MAED_CHECK_ARG(C % 4 == 0, MAED_ERR_SHAPE, "st_mix_bwd_apply: C %% 4");
+    const int64_t n4 = (int64_t)F * P * C / 4;
+    if (n4 == 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((st_mix_bwd_apply_kernel<T>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                                      (const T*)dmix, logits, (const T*)dmeans, (T*)dx_s, (T*)dx_t, n4, P, C));
+    MAED_CHECK_LAUNCH("st_mix_bwd_apply");
+    return MAED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K8 embeddings (vision_transformer.py:392-399)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const T* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                        const float* __restrict__ temp, float* __restrict__ tok, int64_t n4, int P, int C, int Tn) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t e = i * 4;
+    const int c = (int)(e % C); const int64_t r = e / C;
+    const int p = (int)(r % P); const int64_t f = r / P;
+    float a[4], b[4], t[4], o[4];
+    if (p == 0) ld4(cls + c, a); else ld4(patch + (f * (P - 1) + (p - 1)) * C + c, a);
+    ld4(pos + (int64_t)p * C + c, b);
+    ld4(temp + (f % Tn) * C + c, t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (a[j] + b[j]) + t[j];  // same association as the reference: (x + pos) + temp
+    st4(tok + e, o);
+}
+
+// thread per (p, 4 channels): dpatch rows copied/cast, dpos[p] += sum_f dtok[f][p]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restrict__ dtok, T* __restrict__ dpatch, float* __restrict__ dpos,
+                                                            int F, int P, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n4 = (int64_t)P * C / 4;
+    if (i >= n4) return;
+    const int64_t e = i * 4;
+    const int c = (int)(e % C); const int p = (int)(e / C);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < F; ++f) {
+        float v[4];
+        ld4(dtok + ((int64_t)f * P + p) * C + c, v);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        if (p > 0 && dpatch) st4(dpatch + ((int64_t)f * (P - 1) + (p - 1)) * C + c, v);
+    }
+    float o[4];
+    ld4(dpos + e, o);
+    o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3];
+    st4(dpos + e, o);
+}
+// thread per (f, 4 channels): frame_colsum[f] = sum_p dtok[f][p]
+__global__ __launch_bounds__(256) void embed_bwd_frame_kernel(const float* __restrict__ dtok, float* __restrict__ fsum, int F, int P, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n4 = (int64_t)F * C / 4;
+    if (i >= n4) return;
+    const int64_t e = i * 4;
+    const int c = (int)(e % C); const int64_t f = e / C;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < P; ++p) {
+        float v[4];
+        ld4(dtok + (f * P + p) * C + c, v);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    st4(fsum + e, s);
+}
+
+extern "C" int maed_embed_add_fwd(const void* patch, int dtype, const float* cls, const float* pos, const float* temp, float* tokens,
+                                  int F, int P, int C, int T, void* stream) {
+    MAED_CHECK_ARG(patch && cls && pos && temp && tokens, MAED_ERR_ARG, "embed_add_fwd: null pointer");
+    MAED_CHECK_ARG(C % 4 == 0 && T > 0 && P > 1, MAED_ERR_SHAPE, "embed_add_fwd: bad extents");
+    const int64_t n4 = (int64_t)F * P * C / 4;
+    if (n4 == 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((embed_fwd_kernel<TT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                                       (const TT*)patch, cls, pos, temp, tokens, n4, P, C, T));
+    MAED_CHECK_LAUNCH("embed_add_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_embed_add_bwd(const float* dtokens, void* dpatch, int dtype, float* dpos, float* frame_colsum, int F, int P, int C,
+                                  void* stream) {
+    MAED_CHECK_ARG(dtokens && dpos && frame_colsum, MAED_ERR_ARG, "embed_add_bwd: null pointer");
+    MAED_CHECK_ARG(C % 4 == 0 && P > 1, MAED_ERR_SHAPE, "embed_add_bwd: bad extents");
+    if (F == 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n4 = (int64_t)P * C / 4, m4 = (int64_t)F * C / 4;
+    MAED_DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((embed_bwd_pos_kernel<TT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                                                       dtokens, (TT*)dpatch, dpos, F, P, C));
+    hipLaunchKernelGGL(embed_bwd_frame_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, s, dtokens, frame_colsum, F, P, C);
+    MAED_CHECK_LAUNCH("embed_add_bwd");
+    return MAED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transpose + cast (+ column sums): out_t[n][m] = in[m][n]
+// ---------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const TI* __restrict__ in, int64_t ldi, int64_t M, int64_t N, TO* __restrict__ out_t,
+                                                             int64_t ldt, TO* __restrict__ out_c, int64_t ldc, float* __restrict__ colsum) {
+    __shared__ float tile[64][65];
+    const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 rows of 64 per pass
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t m = m0 + r, n = n0 + tx;
+        float v = 0.f;
+        if (m < M && n < N) {
+            v = ldf(in + m * ldi + n);
+            if (out_c) stf(out_c + m * ldc + n, v);
+        }
+        tile[r][tx] = v;
+    }
+    if (colsum) {  // combine the 4 partial sums of each column through LDS after the tile is complete
+        __syncthreads();
+        if (ty == 0) {
+            float s = 0.f;
+            for (int r = 0; r < 64; ++r) s += tile[r][tx];
+            if (n0 + tx < N) atomicAdd(colsum + n0 + tx, s);
+        }
+    } else {
+        __syncthreads();
+    }
+    if (out_t) {
+        for (int r = ty; r < 64; r += 4) {  // r indexes n, tx indexes m
+            const int64_t n = n0 + r, m = m0 + tx;
+            if (n < N && m < ldt) stf(out_t + n * ldt + m, tile[tx][r]);  // rows m >= M were zero-filled
+        }
+    }
+}
+
+extern "C" int maed_transpose_cast(const void* in, int in_dtype, int64_t ldi, int64_t M, int64_t N, void* out_t, int64_t ldt,
+                                   void* out_c, int64_t ldc, float* colsum, int dtype, void* stream) {
+    MAED_CHECK_ARG(in, MAED_ERR_ARG, "transpose_cast: null input");
+    MAED_CHECK_ARG(M > 0 && N > 0 && ldi >= N && (!out_t || ldt >= M) && (!out_c || ldc >= N), MAED_ERR_SHAPE, "transpose_cast: bad extents");
+    const int64_t rows = out_t ? ldt : M;  // cover the zero-filled padding columns of out_t
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == MAED_F32 && dtype == MAED_F32)
+        hipLaunchKernelGGL((transpose_cast_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, ldi, M, N, (float*)out_t, ldt, (float*)out_c, ldc, colsum);
+    else if (in_dtype == MAED_F32 && dtype == MAED_BF16)
+        hipLaunchKernelGGL((transpose_cast_kernel<float, bf16>), grid, dim3(256), 0, s, (const float*)in, ldi, M, N, (bf16*)out_t, ldt, (bf16*)out_c, ldc, colsum);
+    else if (in_dtype == MAED_BF16 && dtype == MAED_BF16)
+        hipLaunchKernelGGL((transpose_cast_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)in, ldi, M, N, (bf16*)out_t, ldt, (bf16*)out_c, ldc, colsum);
+    else { maed_set_error("transpose_cast: unsupported dtype pair %d -> %d", in_dtype, dtype); return MAED_ERR_UNSUPPORTED; }
+    MAED_CHECK_LAUNCH("transpose_cast");
+    return MAED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics: L2 weight decay folded into the gradient)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   bf16* __restrict__ shadow, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                                   float bc1, float bc2, float gscale) {
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    const float step = lr / bc1, rbc2 = rsqrtf(bc2);
+    if (i4 + 4 <= n) {
+        float pp[4], gg[4], mm[4], vv[4];
+        ld4(p + i4, pp); ld4(g + i4, gg); ld4(m + i4, mm); ld4(v + i4, vv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = fmaf(wd, pp[j], gg[j] * gscale);
+            mm[j] = b1 * mm[j] + (1.f - b1) * gr;
+            vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
+            pp[j] -= step * mm[j] / (sqrtf(vv[j]) * rbc2 + eps);
+        }
+        st4(p + i4, pp); st4(m + i4, mm); st4(v + i4, vv);
+        if (shadow) st4(shadow + i4, pp);
+    } else {
+        for (int64_t i = i4; i < n; ++i) {
+            const float gr = fmaf(wd, p[i], g[i] * gscale);
+            m[i] = b1 * m[i] + (1.f - b1) * gr;
+            v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+            p[i] -= step * m[i] / (sqrtf(v[i]) * rbc2 + eps);
+            if (shadow) shadow[i].v = f2bf(p[i]);
+        }
+    }
+}
+
+extern "C" int maed_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float gscale,
+                              void* stream) {
+    MAED_CHECK_ARG(p && g && m && v, MAED_ERR_ARG, "adam_step: null pointer");
+    MAED_CHECK_ARG(is_aligned(p, 16) && is_aligned(g, 16) && is_aligned(m, 16) && is_aligned(v, 16) && (!shadow_bf16 || is_aligned(shadow_bf16, 8)),
+                   MAED_ERR_ALIGN, "adam_step: arenas must be 16-B aligned");
+    if (n == 0) return MAED_OK;
+    const int64_t nthr = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n, lr,
+                       beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, gscale);
+    MAED_CHECK_LAUNCH("adam_step");
+    return MAED_OK;
+}

@@ -1,0 +1,277 @@
+// nn.Linear family: out = epilogue(A[M,K] * B[N,K]^T).  Both operands are K-contiguous (activations
+// are row-major, nn.Linear weights are stored (out,in)), which is exactly the MFMA A/B fragment order.
+//
+//  * bf16: 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles,
+//    fp32 accumulation.  Global -> VGPR -> LDS staging (16-byte accesses, full 128-B lines per row),
+//    LDS rows padded to 144 B so ds_read_b128 fragment reads are bank-conflict free, double-buffered
+//    LDS with the next tile's global loads in flight under the current tile's MFMAs (one barrier per
+//    K tile).  Workgroup ids are remapped so the N-tiles of one M-panel run on one XCD (A panel is
+//    fetched once per XCD L2; the weight matrix is small and L2/MALL resident).
+//  * f32 (parity mode): 64x64x16 LDS-tiled VALU kernel, exact fp32 FMA chains.
+// Split-K (grid.z) is available for the atomic weight-gradient epilogue.
+#include "common.cuh"
+
+struct EpiArgs {
+    const float* bias;
+    void* out; int64_t ldo;
+    void* out2;
+    const void* aux; int64_t ldaux;
+};
+
+template <int EPI, typename T>
+__device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int64_t c, float acc) {
+    if constexpr (EPI == MAED_EPI_STORE) {
+        stf((T*)e.out + r * e.ldo + c, acc + (e.bias ? e.bias[c] : 0.f));
+    } else if constexpr (EPI == MAED_EPI_GELU) {
+        const float pre = acc + (e.bias ? e.bias[c] : 0.f);
+        T* p2 = (T*)e.out2 + r * e.ldo + c;
+        stf(p2, pre);
+        stf((T*)e.out + r * e.ldo + c, gelu_erf(ldf(p2)));  // activation of the STORED (rounded) pre-activation
+    } else if constexpr (EPI == MAED_EPI_RESID_F32) {
+        ((float*)e.out)[r * e.ldo + c] = ((const float*)e.aux)[r * e.ldaux + c] + (acc + (e.bias ? e.bias[c] : 0.f));
+    } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
+        stf((T*)e.out + r * e.ldo + c, acc * dgelu_erf(ldf((const T*)e.aux + r * e.ldaux + c)));
+    } else if constexpr (EPI == MAED_EPI_ATOMIC_F32) {
+        atomicAdd((float*)e.out + r * e.ldo + c, acc);
+    } else if constexpr (EPI == MAED_EPI_STORE_F32) {
+        ((float*)e.out)[r * e.ldo + c] = acc + (e.bias ? e.bias[c] : 0.f);
+    } else if constexpr (EPI == MAED_EPI_TANH) {
+        stf((T*)e.out + r * e.ldo + c, tanhf(acc + (e.bias ? e.bias[c] : 0.f)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// VALU kernel (any T; used for f32 and as the cross-check for the MFMA kernel)
+// ------------------------------------------------------------------------------------------------
+template <int EPI, typename T>
+__global__ __launch_bounds__(256) void gemm_nt_valu_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                                           int64_t ldb, int64_t M, int64_t N, int64_t K, int64_t k_per_split,
+                                                           EpiArgs e) {
+    __shared__ float As[16][64 + 1];
+    __shared__ float Bs[16][64 + 1];
+    const int tid = threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+    const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    const int ty = tid >> 4, tx = tid & 15;
+    const int lr = tid >> 2, lk = (tid & 3) * 4;  // staging: row lr, k offset lk..lk+3
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int64_t ar = (m0 + lr < M) ? m0 + lr : M - 1;
+    const int64_t br = (n0 + lr < N) ? n0 + lr : N - 1;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t k = k0 + lk + i;
+            As[lk + i][lr] = (k < kend) ? ldf(A + ar * lda + k) : 0.f;
+            Bs[lk + i][lr] = (k < kend) ? ldf(B + br * ldb + k) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = m0 + ty * 4 + i, c = n0 + tx * 4 + j;
+            if (r < M && c < N) epilogue_store<EPI, T>(e, r, c, acc[i][j]);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA bf16 kernel
+// ------------------------------------------------------------------------------------------------
+#define GM_BM 128
+#define GM_BN 128
+#define GM_BK 64
+#define GM_LD 72  // padded LDS row (elements): 144 B = 9 x 16-B slots, 9 coprime with 16 -> conflict-free b128
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // bijective remap: blocks that the dispatcher places on XCD x (bid % 8 == x) get a contiguous id range
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                                const bf16* __restrict__ B, int64_t ldb, int64_t M,
+                                                                int64_t N, int64_t K, int tiles_n, int ktiles_per_split,
+                                                                EpiArgs e) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][GM_BM * GM_LD];  // [buf][A|B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = gridDim.x;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int64_t m0 = (int64_t)(id / tiles_n) * GM_BM, n0 = (int64_t)(id % tiles_n) * GM_BN;
+    const int nkt_total = (int)(K / GM_BK);
+    const int kt_beg = blockIdx.z * ktiles_per_split;
+    int kt_end = kt_beg + ktiles_per_split;
+    if (kt_end > nkt_total) kt_end = nkt_total;
+    if (kt_beg >= kt_end) return;
+
+    // staging map: 128 rows x 64 cols = 1024 16-byte chunks per operand, 4 per thread
+    // chunk c = tid + 256*i : row = c >> 3, col chunk = c & 7  (8 lanes cover one 128-B row segment)
+    const bf16* ap[4]; const bf16* bp[4]; int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, cc = (c & 7) * 8;
+        const int64_t ar = (m0 + row < M) ? m0 + row : M - 1;
+        const int64_t br = (n0 + row < N) ? n0 + row : N - 1;
+        ap[i] = A + ar * lda + cc;
+        bp[i] = B + br * ldb + cc;
+        soff[i] = row * GM_LD + cc;
+    }
+    uint4 ra[4], rb[4];
+#define GM_LOAD_TILE(kt_)                                                         \
+    {                                                                             \
+        const int64_t k0__ = (int64_t)(kt_) * GM_BK;                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                           \
+            ra[i] = *reinterpret_cast<const uint4*>(ap[i] + k0__);                \
+            rb[i] = *reinterpret_cast<const uint4*>(bp[i] + k0__);                \
+        }                                                                         \
+    }
+#define GM_STORE_TILE(buf_)                                                       \
+    {                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                           \
+            *reinterpret_cast<uint4*>(&lds[buf_][0][soff[i]]) = ra[i];            \
+            *reinterpret_cast<uint4*>(&lds[buf_][1][soff[i]]) = rb[i];            \
+        }                                                                         \
+    }
+
+    f32x16_t acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+#define GM_COMPUTE_TILE(buf_)                                                                              \
+    {                                                                                                      \
+        const unsigned short* As = &lds[buf_][0][(wr * 64 + l31) * GM_LD + hi * 8];                        \
+        const unsigned short* Bs = &lds[buf_][1][(wc * 64 + l31) * GM_LD + hi * 8];                        \
+        _Pragma("unroll") for (int kk = 0; kk < GM_BK / 16; ++kk) {                                        \
+            bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(As + kk * 16);                                \
+            bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(As + 32 * GM_LD + kk * 16);                   \
+            bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(Bs + kk * 16);                                \
+            bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(Bs + 32 * GM_LD + kk * 16);                   \
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);                       \
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);                       \
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);                       \
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);                       \
+        }                                                                                                  \
+    }
+    GM_LOAD_TILE(kt_beg);
+    GM_STORE_TILE(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_beg; kt < kt_end - 1; ++kt) {
+        GM_LOAD_TILE(kt + 1);       // global loads of the next tile fly under this tile's MFMAs
+        GM_COMPUTE_TILE(buf);
+        GM_STORE_TILE(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    GM_COMPUTE_TILE(buf);
+    // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#define GM_EPILOGUE(acc_, i_, j_)                                                                     \
+    {                                                                                                 \
+        const int64_t c = n0 + wc * 64 + (j_) * 32 + l31;                                             \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+            const int64_t row = m0 + wr * 64 + (i_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;           \
+            if (row < M && c < N) epilogue_store<EPI, bf16>(e, row, c, acc_[r]);                      \
+        }                                                                                             \
+    }
+    GM_EPILOGUE(acc00, 0, 0);
+    GM_EPILOGUE(acc01, 0, 1);
+    GM_EPILOGUE(acc10, 1, 0);
+    GM_EPILOGUE(acc11, 1, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int EPI, typename T>
+static int launch_valu(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                       const EpiArgs& e, int splitk, hipStream_t s) {
+    int64_t kps = (K + splitk - 1) / splitk;
+    kps = (kps + 15) / 16 * 16;
+    const int z = (int)((K + kps - 1) / kps);
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)z);
+    hipLaunchKernelGGL((gemm_nt_valu_kernel<EPI, T>), grid, dim3(256), 0, s, (const T*)A, lda, (const T*)B, ldb, M, N, K, kps, e);
+    return MAED_OK;
+}
+
+template <int EPI>
+static int launch_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                       const EpiArgs& e, int splitk, hipStream_t s) {
+    const int tm = (int)((M + GM_BM - 1) / GM_BM), tn = (int)((N + GM_BN - 1) / GM_BN);
+    const int nkt = (int)(K / GM_BK);
+    int kps = (nkt + splitk - 1) / splitk;
+    if (kps < 1) kps = 1;
+    const int z = (nkt + kps - 1) / kps;
+    dim3 grid((unsigned)(tm * tn), 1, (unsigned)z);
+    hipLaunchKernelGGL((gemm_nt_mfma_bf16_kernel<EPI>), grid, dim3(256), 0, s, (const bf16*)A, lda, (const bf16*)B, ldb,
+                       M, N, K, tn, kps, e);
+    return MAED_OK;
+}
+
+template <int EPI>
+static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype,
+                    const EpiArgs& e, int splitk, int impl, hipStream_t s) {
+    if (dtype == MAED_F32) {
+        MAED_CHECK_ARG(impl != MAED_IMPL_MFMA, MAED_ERR_UNSUPPORTED, "gemm_nt: f32 has no MFMA path (exact-f32 VALU kernel)");
+        return launch_valu<EPI, float>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    }
+    const bool mfma_ok = (K % GM_BK == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && is_aligned(A, 16) && is_aligned(B, 16);
+    if (impl == MAED_IMPL_VALU) return launch_valu<EPI, bf16>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    if (impl == MAED_IMPL_MFMA) {
+        MAED_CHECK_ARG(mfma_ok, MAED_ERR_ALIGN, "gemm_nt(mfma): need K%%64==0 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B", (long long)K);
+        return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    }
+    return mfma_ok ? launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s)
+                   : launch_valu<EPI, bf16>(A, lda, B, ldb, M, N, K, e, splitk, s);
+}
+
+extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                            int dtype, int epilogue, const float* bias, void* out, int64_t ldo, void* out2,
+                            const void* aux, int64_t ldaux, int splitk, int impl, void* stream) {
+    MAED_CHECK_ARG(A && B && out, MAED_ERR_ARG, "gemm_nt: null pointer");
+    MAED_CHECK_ARG(dtype == MAED_F32 || dtype == MAED_BF16, MAED_ERR_ARG, "gemm_nt: bad dtype %d", dtype);
+    MAED_CHECK_ARG(M >= 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldo >= N, MAED_ERR_SHAPE, "gemm_nt: bad extents M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    if (splitk < 1) splitk = 1;
+    MAED_CHECK_ARG(splitk == 1 || epilogue == MAED_EPI_ATOMIC_F32, MAED_ERR_ARG, "gemm_nt: split-K needs the atomic epilogue");
+    if (M == 0) return MAED_OK;
+    EpiArgs e{bias, out, ldo, out2, aux, ldaux};
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (epilogue) {
+        case MAED_EPI_STORE: rc = dispatch<MAED_EPI_STORE>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
+        case MAED_EPI_GELU:
+            MAED_CHECK_ARG(out2, MAED_ERR_ARG, "gemm_nt: GELU epilogue needs out2");
+            rc = dispatch<MAED_EPI_GELU>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
+        case MAED_EPI_RESID_F32:
+            MAED_CHECK_ARG(aux, MAED_ERR_ARG, "gemm_nt: RESID epilogue needs aux");
+            rc = dispatch<MAED_EPI_RESID_F32>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
+        case MAED_EPI_MUL_DGELU:
+            MAED_CHECK_ARG(aux, MAED_ERR_ARG, "gemm_nt: MUL_DGELU epilogue needs aux");
+            rc = dispatch<MAED_EPI_MUL_DGELU>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
+        case MAED_EPI_ATOMIC_F32: rc = dispatch<MAED_EPI_ATOMIC_F32>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
+        case MAED_EPI_STORE_F32: rc = dispatch<MAED_EPI_STORE_F32>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
+        case MAED_EPI_TANH: rc = dispatch<MAED_EPI_TANH>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
+        default: maed_set_error("gemm_nt: bad epilogue %d", epilogue); return MAED_ERR_ARG;
+    }
+    if (rc != MAED_OK) return rc;
+    MAED_CHECK_LAUNCH("gemm_nt");
+    return MAED_OK;
+}

@@ -1,0 +1,154 @@
+// K1: LayerNorm forward / backward.  HBM-bound: one wave per row, 16-byte accesses, the row stays in
+// registers between the statistics passes (two-pass variance like ATen, vision_transformer.py:569).
+#include "common.cuh"
+
+#define LN_MAXV 8  // float4 chunks per lane: C <= 64*4*8 = 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t xs,
+                                                     const float* __restrict__ g, const float* __restrict__ b,
+                                                     T* __restrict__ y, float* __restrict__ mean_o,
+                                                     float* __restrict__ rstd_o, int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * xs;
+    float v[LN_MAXV][4];
+    float s = 0.f;
+    const int nv = C / 4;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < nv) { ld4(xr + c4 * 4, v[i]); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
+    T* yr = y + row * (int64_t)C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < nv) {
+            float gg[4], bb[4], o[4];
+            ld4(g + c4 * 4, gg); ld4(b + c4 * 4, bb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+            st4(yr + c4 * 4, o);
+        }
+    }
+}
+
+// Each workgroup (4 waves) walks LN_ROWS_PER_WG rows; per-lane partial dgamma/dbeta stay in registers,
+// are combined across the 4 waves through LDS and leave the workgroup as one atomicAdd per column.
+#define LN_ROWS_PER_WG 32
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, int64_t xs,
+                                                     const float* __restrict__ g, const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ dg, float* __restrict__ db,
+                                                     int64_t rows, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][4 waves][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C / 4;
+    float gg[LN_MAXV][4], pg[LN_MAXV][4], pb[LN_MAXV][4];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + i * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; gg[i][j] = 0.f; }
+        if (c4 < nv) ld4(g + c4 * 4, gg[i]);
+    }
+    const int64_t row0 = (int64_t)blockIdx.x * LN_ROWS_PER_WG;
+    for (int r = wave; r < LN_ROWS_PER_WG; r += 4) {
+        const int64_t row = row0 + r;
+        if (row >= rows) break;
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        const float* xr = x + row * xs;
+        const T* dyr = dy + row * (int64_t)C;
+        float xh[LN_MAXV][4], gy[LN_MAXV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv) {
+                float xv[4], dv[4];
+                ld4(xr + c4 * 4, xv); ld4(dyr + c4 * 4, dv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (xv[j] - mean) * rstd;
+                    gy[i][j] = dv[j] * gg[i][j];
+                    s1 += gy[i][j]; s2 += gy[i][j] * xh[i][j];
+                    pg[i][j] += dv[j] * xh[i][j]; pb[i][j] += dv[j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+        float* dxr = dx + row * (int64_t)C;
+        const float* drr = dres ? dres + row * (int64_t)C : nullptr;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv) {
+                float o[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
+                if (drr) ld4(drr + c4 * 4, rr);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rr[j] + rstd * (gy[i][j] - s1 - xh[i][j] * s2);
+                st4(dxr + c4 * 4, o);
+            }
+        }
+    }
+    float* lg = lds + (size_t)wave * C;
+    float* lb = lds + (size_t)(4 + wave) * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < nv) { st4(lg + c4 * 4, pg[i]); st4(lb + c4 * 4, pb[i]); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float sg = (lds[c] + lds[C + c]) + (lds[2 * C + c] + lds[3 * C + c]);
+        const float sb = (lds[4 * C + c] + lds[5 * C + c]) + (lds[6 * C + c] + lds[7 * C + c]);
+        atomicAdd(dg + c, sg);
+        atomicAdd(db + c, sb);
+    }
+}
+
+extern "C" int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
+                                  void* y, int dtype, float* mean, float* rstd, int64_t rows, int C, float eps,
+                                  void* stream) {
+    MAED_CHECK_ARG(x && gamma && beta && y, MAED_ERR_ARG, "layernorm_fwd: null pointer");
+    MAED_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXV, MAED_ERR_SHAPE, "layernorm_fwd: C=%d must be a multiple of 4, <= %d", C, 64 * 4 * LN_MAXV);
+    MAED_CHECK_ARG(x_row_stride % 4 == 0 && is_aligned(x, 16) && is_aligned(y, 8), MAED_ERR_ALIGN, "layernorm_fwd: x/y/stride alignment");
+    if (rows == 0) return MAED_OK;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ln_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                      x, x_row_stride, gamma, beta, (T*)y, mean, rstd, rows, C, eps));
+    MAED_CHECK_LAUNCH("layernorm_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma,
+                                  const float* mean, const float* rstd, const float* dres_in, float* dx_out,
+                                  float* dgamma, float* dbeta, int64_t rows, int C, void* stream) {
+    MAED_CHECK_ARG(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta, MAED_ERR_ARG, "layernorm_bwd: null pointer");
+    MAED_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXV, MAED_ERR_SHAPE, "layernorm_bwd: C=%d unsupported", C);
+    MAED_CHECK_ARG(x_row_stride % 4 == 0 && is_aligned(x, 16) && is_aligned(dy, 8) && is_aligned(dx_out, 16), MAED_ERR_ALIGN, "layernorm_bwd: alignment");
+    if (rows == 0) return MAED_OK;
+    dim3 grid((unsigned)((rows + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG));
+    const size_t lds = (size_t)8 * C * sizeof(float);
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ln_bwd_kernel<T>), grid, dim3(256), lds, (hipStream_t)stream,
+                                                      (const T*)dy, x, x_row_stride, gamma, mean, rstd, dres_in, dx_out,
+                                                      dgamma, dbeta, rows, C));
+    MAED_CHECK_LAUNCH("layernorm_bwd");
+    return MAED_OK;
+}

@@ -1,0 +1,317 @@
+// Kinematic Topology Decoder tail: joint chain (K10), 6D->rotmat->axis-angle (K11), SMPL linear blend
+// skinning (K12), joint regressor GEMM on f32 MFMA (K13), integer joint gather (K14, bit-exact) and
+// weak-perspective projection (K15).  Everything here is fp32: these are SMPL parameters (1e-3 bar).
+#include "common.cuh"
+
+#define NJ 24
+#define NV 6890
+
+// lib/models/ktd.py:10-35 ANCESTOR_INDEX, flattened
+__constant__ int c_anc_cnt[NJ] = {0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7, 7, 8, 8};
+__constant__ int c_anc_start[NJ] = {0, 0, 1, 2, 3, 5, 7, 9, 12, 15, 18, 22, 26, 30, 34, 38, 43, 48, 53, 59, 65, 72, 79, 87};
+__constant__ int c_anc[95] = {
+    0, 0, 0, 0, 1, 0, 2, 0, 3, 0, 1, 4, 0, 2, 5, 0, 3, 6, 0, 1, 4, 7, 0, 2, 5, 8, 0, 3, 6, 9, 0, 3, 6, 9, 0, 3, 6, 9,
+    0, 3, 6, 9, 12, 0, 3, 6, 9, 13, 0, 3, 6, 9, 14, 0, 3, 6, 9, 13, 16, 0, 3, 6, 9, 14, 17,
+    0, 3, 6, 9, 13, 16, 18, 0, 3, 6, 9, 14, 17, 19, 0, 3, 6, 9, 13, 16, 18, 20, 0, 3, 6, 9, 14, 17, 19, 21};
+
+// ---- K10: pose[f][6j+o] = base[f][6j+o] + sum_{slot,i} W_j[o][6*slot+i] * pose[f][6*anc(j,slot)+i] ------------
+__global__ void ktd_chain_kernel(const float* __restrict__ base, const float* __restrict__ w_anc, float* __restrict__ pose, int F) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float ps[NJ * 6];
+    for (int i = 0; i < NJ * 6; ++i) ps[i] = base[(int64_t)f * NJ * 6 + i];
+    for (int j = 1; j < NJ; ++j) {
+        const int na = c_anc_cnt[j];
+        const float* W = w_anc + 36 * c_anc_start[j];  // (6, 6*na) row-major
+        float out[6];
+        for (int o = 0; o < 6; ++o) {
+            float s = ps[j * 6 + o];
+            for (int sl = 0; sl < na; ++sl) {
+                const int a = c_anc[c_anc_start[j] + sl];
+                for (int i = 0; i < 6; ++i) s = fmaf(W[o * 6 * na + sl * 6 + i], ps[a * 6 + i], s);
+            }
+            out[o] = s;
+        }
+        for (int o = 0; o < 6; ++o) ps[j * 6 + o] = out[o];
+    }
+    for (int i = 0; i < NJ * 6; ++i) pose[(int64_t)f * NJ * 6 + i] = ps[i];
+}
+
+extern "C" int maed_ktd_chain_fwd(const float* base, const float* w_anc, float* pose, int F, void* stream) {
+    MAED_CHECK_ARG(base && w_anc && pose, MAED_ERR_ARG, "ktd_chain_fwd: null pointer");
+    if (F <= 0) return MAED_OK;
+    hipLaunchKernelGGL(ktd_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, base, w_anc, pose, F);
+    MAED_CHECK_LAUNCH("ktd_chain_fwd");
+    return MAED_OK;
+}
+
+// ---- K11 --------------------------------------------------------------------------------------------------
+__global__ void rot6d_pose_kernel(const float* __restrict__ x6, float* __restrict__ rotmat, float* __restrict__ aa, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* x = x6 + i * 6;
+    // geometry.py:320-334: x.view(-1,3,2): a1 = x[:, :, 0] = (x0,x2,x4), a2 = x[:, :, 1] = (x1,x3,x5)
+    float a1[3] = {x[0], x[2], x[4]}, a2[3] = {x[1], x[3], x[5]};
+    float n1 = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    n1 = fmaxf(n1, 1e-6f);
+    float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const float dot = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    float u[3] = {a2[0] - dot * b1[0], a2[1] - dot * b1[1], a2[2] - dot * b1[2]};
+    float n2 = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    n2 = fmaxf(n2, 1e-6f);
+    float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+    float R[3][3];
+    for (int r = 0; r < 3; ++r) { R[r][0] = b1[r]; R[r][1] = b2[r]; R[r][2] = b3[r]; }
+    if (rotmat) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rotmat[i * 9 + r * 3 + c] = R[r][c];
+    if (!aa) return;
+    // geometry.py:143-223 with rmat_t = R^T: t(a,b) = R[b][a]
+#define RT(a, b) R[b][a]
+    const bool d2 = RT(2, 2) < 1e-6f, d0d1 = RT(0, 0) > RT(1, 1), d0nd1 = RT(0, 0) < -RT(1, 1);
+    float q[4], t;
+    if (d2 && d0d1) {
+        t = 1 + RT(0, 0) - RT(1, 1) - RT(2, 2);
+        q[0] = RT(1, 2) - RT(2, 1); q[1] = t; q[2] = RT(0, 1) + RT(1, 0); q[3] = RT(2, 0) + RT(0, 2);
+    } else if (d2 && !d0d1) {
+        t = 1 - RT(0, 0) + RT(1, 1) - RT(2, 2);
+        q[0] = RT(2, 0) - RT(0, 2); q[1] = RT(0, 1) + RT(1, 0); q[2] = t; q[3] = RT(1, 2) + RT(2, 1);
+    } else if (!d2 && d0nd1) {
+        t = 1 - RT(0, 0) - RT(1, 1) + RT(2, 2);
+        q[0] = RT(0, 1) - RT(1, 0); q[1] = RT(2, 0) + RT(0, 2); q[2] = RT(1, 2) + RT(2, 1); q[3] = t;
+    } else {
+        t = 1 + RT(0, 0) + RT(1, 1) + RT(2, 2);
+        q[0] = t; q[1] = RT(1, 2) - RT(2, 1); q[2] = RT(2, 0) - RT(0, 2); q[3] = RT(0, 1) - RT(1, 0);
+    }
+#undef RT
+    const float st = sqrtf(t);
+    for (int k = 0; k < 4; ++k) q[k] = (q[k] / st) * 0.5f;
+    // geometry.py:90-140
+    const float ss = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const float sn = sqrtf(ss), cs = q[0];
+    const float two_theta = 2.0f * (cs < 0.0f ? atan2f(-sn, -cs) : atan2f(sn, cs));
+    const float k = ss > 0.0f ? two_theta / sn : 2.0f;
+    for (int c = 0; c < 3; ++c) {
+        float v = q[1 + c] * k;
+        if (v != v) v = 0.0f;  // geometry.py:86 aa[isnan(aa)] = 0
+        aa[i * 3 + c] = v;
+    }
+}
+
+extern "C" int maed_rot6d_pose_fwd(const float* pose6d, float* rotmat, float* angle_axis, int64_t n_joints, void* stream) {
+    MAED_CHECK_ARG(pose6d && (rotmat || angle_axis), MAED_ERR_ARG, "rot6d_pose_fwd: null pointer");
+    if (n_joints <= 0) return MAED_OK;
+    hipLaunchKernelGGL(rot6d_pose_kernel, dim3((unsigned)((n_joints + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pose6d, rotmat, angle_axis, n_joints);
+    MAED_CHECK_LAUNCH("rot6d_pose_fwd");
+    return MAED_OK;
+}
+
+// ---- K12: SMPL LBS (smplx.lbs.lbs, pose2rot=False) ---------------------------------------
+// kernel A: one thread per frame walks the kinematic chain -> A (24 x 3x4 skinning transforms) + posed joints
+__global__ void lbs_chain_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
+                                 float* __restrict__ joints24, float* __restrict__ A, int F) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float J[NJ][3], Rw[NJ][9], tw[NJ][3];
+    const float* b = betas + (int64_t)f * 10;
+    for (int j = 0; j < NJ; ++j)
+        for (int c = 0; c < 3; ++c) {
+            float s = sp.J_template[j * 3 + c];
+            for (int l = 0; l < 10; ++l) s = fmaf(sp.J_shapedirs[(j * 3 + c) * 10 + l], b[l], s);
+            J[j][c] = s;
+        }
+    const float* R = rotmat + (int64_t)f * NJ * 9;
+    for (int j = 0; j < NJ; ++j) {
+        const int p = sp.parents[j];
+        const float* Rj = R + j * 9;
+        if (p < 0) {
+            for (int k = 0; k < 9; ++k) Rw[j][k] = Rj[k];
+            for (int c = 0; c < 3; ++c) tw[j][c] = J[j][c];
+        } else {
+            float rel[3] = {J[j][0] - J[p][0], J[j][1] - J[p][1], J[j][2] - J[p][2]};
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c)
+                    Rw[j][r * 3 + c] = Rw[p][r * 3 + 0] * Rj[0 * 3 + c] + Rw[p][r * 3 + 1] * Rj[1 * 3 + c] + Rw[p][r * 3 + 2] * Rj[2 * 3 + c];
+                tw[j][r] = Rw[p][r * 3 + 0] * rel[0] + Rw[p][r * 3 + 1] * rel[1] + Rw[p][r * 3 + 2] * rel[2] + tw[p][r];
+            }
+        }
+    }
+    for (int j = 0; j < NJ; ++j) {
+        float* Aj = A + ((int64_t)f * NJ + j) * 12;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) Aj[r * 4 + c] = Rw[j][r * 3 + c];
+            Aj[r * 4 + 3] = tw[j][r] - (Rw[j][r * 3 + 0] * J[j][0] + Rw[j][r * 3 + 1] * J[j][1] + Rw[j][r * 3 + 2] * J[j][2]);
+            joints24[((int64_t)f * NJ + j) * 3 + r] = tw[j][r];
+        }
+    }
+}
+
+// kernel B: thread per vertex, LBS_FB frames per workgroup so posedirs (17 MB) is streamed once per LBS_FB frames
+#define LBS_FB 4
+__global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
+                                                       const float* __restrict__ A, float* __restrict__ verts, int F) {
+    __shared__ float s_pf[LBS_FB][208];
+    __shared__ float s_A[LBS_FB][NJ * 12];
+    __shared__ float s_b[LBS_FB][10];
+    const int f0 = blockIdx.y * LBS_FB;
+    for (int i = threadIdx.x; i < LBS_FB * 207; i += 256) {
+        const int fb = i / 207, k = i % 207;
+        const int f = min(f0 + fb, F - 1);
+        const int j = 1 + k / 9, rc = k % 9;
+        s_pf[fb][k] = rotmat[((int64_t)f * NJ + j) * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.f : 0.f);
+    }
+    for (int i = threadIdx.x; i < LBS_FB * NJ * 12; i += 256) {
+        const int fb = i / (NJ * 12), k = i % (NJ * 12);
+        s_A[fb][k] = A[(int64_t)min(f0 + fb, F - 1) * NJ * 12 + k];
+    }
+    if (threadIdx.x < LBS_FB * 10) s_b[threadIdx.x / 10][threadIdx.x % 10] = betas[(int64_t)min(f0 + threadIdx.x / 10, F - 1) * 10 + threadIdx.x % 10];
+    __syncthreads();
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= NV) return;
+    float vp[LBS_FB][3];
+    for (int c = 0; c < 3; ++c) {
+        const float vt = sp.v_template[v * 3 + c];
+        float sd[10];
+        for (int l = 0; l < 10; ++l) sd[l] = sp.shapedirs[(v * 3 + c) * 10 + l];
+#pragma unroll
+        for (int fb = 0; fb < LBS_FB; ++fb) {
+            float s = vt;
+            for (int l = 0; l < 10; ++l) s = fmaf(sd[l], s_b[fb][l], s);
+            vp[fb][c] = s;
+        }
+    }
+    float po[LBS_FB][3];
+#pragma unroll
+    for (int fb = 0; fb < LBS_FB; ++fb) { po[fb][0] = 0.f; po[fb][1] = 0.f; po[fb][2] = 0.f; }
+    for (int k = 0; k < 207; ++k) {
+        const float* pd = sp.posedirs + (int64_t)k * (NV * 3) + v * 3;
+        const float p0 = pd[0], p1 = pd[1], p2 = pd[2];
+#pragma unroll
+        for (int fb = 0; fb < LBS_FB; ++fb) {
+            const float w = s_pf[fb][k];
+            po[fb][0] = fmaf(w, p0, po[fb][0]); po[fb][1] = fmaf(w, p1, po[fb][1]); po[fb][2] = fmaf(w, p2, po[fb][2]);
+        }
+    }
+    float w[NJ];
+    for (int j = 0; j < NJ; ++j) w[j] = sp.lbs_weights[v * NJ + j];
+#pragma unroll
+    for (int fb = 0; fb < LBS_FB; ++fb) {
+        if (f0 + fb >= F) break;
+        const float x = vp[fb][0] + po[fb][0], y = vp[fb][1] + po[fb][1], z = vp[fb][2] + po[fb][2];
+        float T[12];
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < NJ; ++j)
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], s_A[fb][j * 12 + e], T[e]);
+        float* o = verts + ((int64_t)(f0 + fb) * NV + v) * 3;
+        o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+        o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+        o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    }
+}
+
+extern "C" int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas, const float* rotmat, float* verts,
+                                 float* joints24, float* scratch_A, int F, void* stream) {
+    MAED_CHECK_ARG(sp && betas && rotmat && verts && joints24 && scratch_A, MAED_ERR_ARG, "smpl_lbs_fwd: null pointer");
+    MAED_CHECK_ARG(sp->v_template && sp->shapedirs && sp->posedirs && sp->J_template && sp->J_shapedirs && sp->lbs_weights && sp->parents,
+                   MAED_ERR_ARG, "smpl_lbs_fwd: null SMPL parameter");
+    if (F <= 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lbs_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
+    hipLaunchKernelGGL(lbs_skin_kernel, dim3((NV + 255) / 256, (F + LBS_FB - 1) / LBS_FB), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, F);
+    MAED_CHECK_LAUNCH("smpl_lbs_fwd");
+    return MAED_OK;
+}
+
+// ---- K13: joint regressor  out[f][j][c] = sum_v Jreg[j][v] verts[f][v][c]  on v_mfma_f32_32x32x2_f32 ---------------
+// GEMM view: A = Jreg (J<=32 rows x 6890), B[k=v][n = 3*fl + c] for a group of 10 frames (30 of 32 columns),
+// K split into 256-vertex chunks, one wave per (chunk, frame group); both operands staged through LDS with
+// coalesced loads; exact-f32 fma chains (MI355X_MICROARCH: f32-input MFMA == fmaf chain, bitwise).
+#define JR_KC 256
+#define JR_FG 10
+__global__ __launch_bounds__(64) void joint_regress_kernel(const float* __restrict__ Jreg, int J, const float* __restrict__ verts,
+                                                           float* __restrict__ out, int F) {
+    __shared__ float Js[32][JR_KC + 1];
+    __shared__ float Bs[JR_FG][JR_KC * 3];
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int v0 = blockIdx.x * JR_KC, f0 = blockIdx.y * JR_FG;
+    const int kc = min(JR_KC, NV - v0);
+    for (int i = lane; i < 32 * JR_KC; i += 64) {
+        const int j = i / JR_KC, k = i % JR_KC;
+        Js[j][k] = (j < J && k < kc) ? Jreg[(int64_t)j * NV + v0 + k] : 0.f;
+    }
+    for (int fl = 0; fl < JR_FG; ++fl) {
+        const int f = f0 + fl;
+        for (int i = lane; i < JR_KC * 3; i += 64)
+            Bs[fl][i] = (f < F && i < kc * 3) ? verts[((int64_t)f * NV + v0) * 3 + i] : 0.f;
+    }
+    __syncthreads();
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int fl = l31 / 3, c = l31 % 3;  // column n = l31 -> (frame, coord); n = 30, 31 idle
+    for (int s = 0; s < JR_KC / 2; ++s) {
+        const int k = 2 * s + hi;
+        const float a = Js[l31][k];
+        const float b = (l31 < 30) ? Bs[fl][k * 3 + c] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    // D: col n = l31, row j = (r&3) + 8*(r>>2) + 4*hi
+    if (l31 < 30 && f0 + fl < F) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (j < J) atomicAdd(out + ((int64_t)(f0 + fl) * J + j) * 3 + c, acc[r]);
+        }
+    }
+}
+
+extern "C" int maed_joint_regress_fwd(const float* Jreg, int J, const float* verts, float* out, int F, void* stream) {
+    MAED_CHECK_ARG(Jreg && verts && out, MAED_ERR_ARG, "joint_regress_fwd: null pointer");
+    MAED_CHECK_ARG(J > 0 && J <= 32, MAED_ERR_SHAPE, "joint_regress_fwd: J=%d must be in 1..32", J);
+    if (F <= 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipMemsetAsync(out, 0, (size_t)F * J * 3 * sizeof(float), s);
+    hipLaunchKernelGGL(joint_regress_kernel, dim3((NV + JR_KC - 1) / JR_KC, (F + JR_FG - 1) / JR_FG), dim3(64), 0, s, Jreg, J, verts, out, F);
+    MAED_CHECK_LAUNCH("joint_regress_fwd");
+    return MAED_OK;
+}
+
+// ---- K14 + K15 -------------------------------------------------------------------------------------------------
+__global__ void joints_project_kernel(const float* __restrict__ joints24, const float* __restrict__ verts, const int64_t* __restrict__ extra_ids,
+                                      const float* __restrict__ extra9, const int64_t* __restrict__ joint_map, const float* __restrict__ cam,
+                                      const float* __restrict__ jover, int Jo, float* __restrict__ kp3d, float* __restrict__ kp2d, int F) {
+    const int Jn = jover ? Jo : 49;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)F * Jn) return;
+    const int64_t f = i / Jn; const int jj = (int)(i % Jn);
+    float p[3];
+    if (jover) {
+        for (int c = 0; c < 3; ++c) p[c] = jover[i * 3 + c];
+    } else {
+        const int64_t idx = joint_map[jj];  // smpl.py:98-99: cat(45 smplx joints, 9 extra)[joint_map]
+        const float* src;
+        if (idx < 24) src = joints24 + (f * 24 + idx) * 3;
+        else if (idx < 45) src = verts + (f * NV + extra_ids[idx - 24]) * 3;
+        else src = extra9 + (f * 9 + (idx - 45)) * 3;
+        for (int c = 0; c < 3; ++c) p[c] = src[c];
+    }
+    for (int c = 0; c < 3; ++c) kp3d[i * 3 + c] = p[c];
+    // spin.py:113-157
+    const float* cm = cam + f * 3;
+    const float tz = 2.0f * 5000.0f / (224.0f * cm[0] + 1e-9f);
+    const float X = p[0] + cm[1], Y = p[1] + cm[2], Z = p[2] + tz;
+    kp2d[i * 2 + 0] = (5000.0f * (X / Z)) / 112.0f;
+    kp2d[i * 2 + 1] = (5000.0f * (Y / Z)) / 112.0f;
+}
+
+extern "C" int maed_smpl_joints_project_fwd(const float* joints24, const float* verts, const int64_t* extra_vertex_ids, const float* extra9,
+                                            const int64_t* joint_map, const float* cam, const float* joints_override, int Jo, float* kp3d,
+                                            float* kp2d, int F, void* stream) {
+    MAED_CHECK_ARG(cam && kp3d && kp2d, MAED_ERR_ARG, "smpl_joints_project_fwd: null pointer");
+    MAED_CHECK_ARG(joints_override || (joints24 && verts && extra_vertex_ids && extra9 && joint_map), MAED_ERR_ARG, "smpl_joints_project_fwd: null joint source");
+    if (F <= 0) return MAED_OK;
+    const int64_t n = (int64_t)F * (joints_override ? Jo : 49);
+    hipLaunchKernelGGL(joints_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, joints24, verts, extra_vertex_ids, extra9,
+                       joint_map, cam, joints_override, Jo, kp3d, kp2d, F);
+    MAED_CHECK_LAUNCH("smpl_joints_project_fwd");
+    return MAED_OK;
+}

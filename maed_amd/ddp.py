@@ -1,0 +1,177 @@
+"""Data-parallel training runtime for one node of MI355X (reference: train.py:113,182 DDP over NCCL;
+lib/utils/utils.py:127-132 Adam; lib/core/trainer.py:240-248 backward/step).
+
+MI355X-first layout instead of torch DDP + per-tensor Adam:
+  * every trainable parameter lives in ONE flat fp32 arena (params are views), gradients in a second
+    arena with the same offsets, Adam moments in two more -> the optimizer step is one kernel
+    (maed_adam_step) over 288 GB-class HBM-resident arenas, and a gradient bucket is a contiguous slice.
+  * arena order follows the forward pass, so backward completes buckets from the END of the arena;
+    as soon as every gradient of a bucket is final (autograd post-accumulate hooks for ATen-managed
+    parameters, the fused Block backward's `grads_ready` callback for the STE) the bucket's
+    all-reduce is launched asynchronously: RCCL runs it on its own HIP stream, fenced by events against
+    the backward stream, i.e. overlapped with the remaining backward kernels.  xGMI is a
+    point-to-point mesh (7 links/GPU), so buckets are large (32 MiB default) -- few, big collectives.
+  * the division by world size is folded into the Adam kernel (gscale).
+One process per GPU; rank/world come from torch.distributed (backend "nccl" == RCCL on ROCm).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .vision_transformer import Block
+
+ALIGN = 64  # elements: every view starts 256-B aligned
+
+
+def _forward_order_key(name):
+    """backbone -> proj -> embeddings -> blocks 0..n -> norm -> pre_logits -> decoder"""
+    if name.startswith("encoder.patch_embed.backbone."):
+        return (0, 0)
+    if name.startswith("encoder.patch_embed."):
+        return (1, 0)
+    if name in ("encoder.cls_token", "encoder.pos_embed", "encoder.temp_embed"):
+        return (2, 0)
+    if name.startswith("encoder.blocks."):
+        return (3, int(name.split(".")[2]))
+    if name.startswith("encoder."):
+        return (4, 0)
+    return (5, 0)
+
+
+class ParamArena:
+    """Re-homes a model's trainable parameters (and their .grad) into flat fp32 arenas."""
+
+    def __init__(self, model, device=None):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        named.sort(key=lambda np_: _forward_order_key(np_[0]))  # stable: keeps definition order inside a group
+        device = device or named[0][1].device
+        self.names, self.params, self.offsets = [], [], []
+        off = 0
+        for n, p in named:
+            self.names.append(n)
+            self.params.append(p)
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):  # re-attach if someone set .grad = None
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class GradBucketer:
+    """Bucketed, overlapped gradient all-reduce over the gradient arena."""
+
+    def __init__(self, arena, model, bucket_bytes=32 << 20, process_group=None):
+        self.arena = arena
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        cap = max(1, bucket_bytes // 4)
+        # buckets are built from the END of the arena (first to complete in backward)
+        self.buckets = []  # [start, end, n_params]
+        self.bucket_of = [0] * len(arena.params)
+        end = arena.numel
+        cur_start, cur_n = end, 0
+        for i in range(len(arena.params) - 1, -1, -1):
+            o = arena.offsets[i]
+            if cur_n > 0 and end - o > cap:
+                self.buckets.append([cur_start, end, cur_n])
+                end, cur_n = cur_start, 0
+            cur_start = o
+            cur_n += 1
+            self.bucket_of[i] = len(self.buckets)
+        if cur_n:
+            self.buckets.append([cur_start, end, cur_n])
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._fused = set()
+        for m in model.modules():
+            if isinstance(m, Block):
+                m.grads_ready = self._block_ready
+                self._fused.update(id(p) for p in m.fused_parameters())
+        for p in arena.params:
+            if id(p) not in self._fused:
+                p.register_post_accumulate_grad_hook(self._param_ready)
+
+    # ---- readiness -------------------------------------------------------------------------------
+    def _mark(self, p):
+        i = self.arena.index.get(id(p))
+        if i is None:
+            return
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _param_ready(self, p):
+        self._mark(p)
+
+    def _block_ready(self, block):
+        for p in block.fused_parameters():
+            self._mark(p)
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        if self.world > 1:
+            s, e, _ = self.buckets[b]
+            self._works.append(dist.all_reduce(self.arena.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        """Launch whatever has not fired (parameters without a gradient this step), then make the
+        current stream wait for every bucket.  Call once per step, before the optimizer."""
+        for b in range(len(self.buckets)):
+            self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
+    def broadcast_parameters(self, src=0):
+        """train.py:113 DDP construction broadcasts rank 0's parameters once."""
+        if self.world > 1:
+            dist.broadcast(self.arena.flat, src=src, group=self.pg)
+            ops.bump_weight_epoch()
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (L2 weight decay) as one kernel over the arena; refreshes nothing
+    else: compute-dtype weight copies are rebuilt lazily by the modules (ops.WEIGHT_EPOCH)."""
+
+    def __init__(self, arena, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucketer=None):
+        self.arena, self.bucketer = arena, bucketer
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(arena.flat)
+        self.exp_avg_sq = torch.zeros_like(arena.flat)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def step(self):
+        world = 1
+        if self.bucketer is not None:
+            self.bucketer.finish()
+            world = self.bucketer.world
+        self.step_count += 1
+        ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, None, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.weight_decay, self.step_count, gscale=1.0 / world)
+        ops.bump_weight_epoch()
+
+    def state_dict(self):
+        return dict(step=self.step_count, lr=self.lr, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, names=self.arena.names,
+                    offsets=self.arena.offsets)

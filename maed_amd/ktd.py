@@ -1,0 +1,123 @@
+"""Kinematic Topology Decoder (reference: lib/models/ktd.py).
+
+Same module/parameter names (`fc1, drop1, fc2, drop2, joint_regs.{0..23}, decshape, deccam, smpl`).
+Inference (eval mode, no grad) runs on libmaed_hip.so: two f32 GEMMs, ONE GEMM for the 1024-wide
+feature part of all 24 joint regressors + shape + cam, the serial ancestor chain in one kernel
+(maed_ktd_chain_fwd, replaces 24 cat+Linear launches, ktd.py:81-84), fused 6D->rotmat->axis-angle,
+SMPL LBS, the joint-regressor GEMM on f32 MFMA, the int64 joint_map gather and the projection.
+Training keeps the decoder tail ((F, .) rows; <1% of the step) on ATen ops so autograd carries it.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from .geometry import rot6d_to_rotmat, rotation_matrix_to_angle_axis
+from .smpl import SMPL
+from .spin import projection
+
+# lib/models/ktd.py:10-35
+ANCESTOR_INDEX = [
+    [], [0], [0], [0], [0, 1], [0, 2], [0, 3], [0, 1, 4], [0, 2, 5], [0, 3, 6],
+    [0, 1, 4, 7], [0, 2, 5, 8], [0, 3, 6, 9], [0, 3, 6, 9], [0, 3, 6, 9],
+    [0, 3, 6, 9, 12], [0, 3, 6, 9, 13], [0, 3, 6, 9, 14],
+    [0, 3, 6, 9, 13, 16], [0, 3, 6, 9, 14, 17],
+    [0, 3, 6, 9, 13, 16, 18], [0, 3, 6, 9, 14, 17, 19],
+    [0, 3, 6, 9, 13, 16, 18, 20], [0, 3, 6, 9, 14, 17, 19, 21],
+]
+
+
+class KTD(nn.Module):
+    def __init__(self, feat_dim=2048, hidden_dim=1024, smpl_arrays=None, **kwargs):
+        super().__init__()
+        self.feat_dim, self.hidden_dim = feat_dim, hidden_dim
+        self.smpl = SMPL(smpl_arrays)
+        self.fc1 = nn.Linear(feat_dim, hidden_dim)
+        self.drop1 = nn.Dropout()
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.drop2 = nn.Dropout()
+        self.joint_regs = nn.ModuleList()
+        for anc in ANCESTOR_INDEX:
+            reg = nn.Linear(hidden_dim + 6 * len(anc), 6)
+            nn.init.xavier_uniform_(reg.weight, gain=0.01)
+            self.joint_regs.append(reg)
+        self.decshape = nn.Linear(hidden_dim, 10)
+        self.deccam = nn.Linear(hidden_dim, 3)
+        nn.init.xavier_uniform_(self.decshape.weight, gain=0.01)
+        nn.init.xavier_uniform_(self.deccam.weight, gain=0.01)
+        self._packed_key, self._packed = None, None
+
+    # ---- ATen path (training) -------------------------------------------------------------------
+    def _head_torch(self, x):
+        x = self.drop1(self.fc1(x))
+        x = self.drop2(self.fc2(x))
+        shape, cam = self.decshape(x), self.deccam(x)
+        pose = []
+        for anc, reg in zip(ANCESTOR_INDEX, self.joint_regs):
+            pose.append(reg(torch.cat([x] + [pose[i] for i in anc], dim=1)))
+        return torch.cat(pose, dim=1), shape, cam
+
+    # ---- HIP path (inference) ---------------------------------------------------------------------
+    def _pack(self):
+        key = (ops.WEIGHT_EPOCH, tuple(p._version for p in self.parameters()), self.fc1.weight.data_ptr())
+        if key != self._packed_key:
+            h = self.hidden_dim
+            with torch.no_grad():
+                w_feat = torch.cat([r.weight[:, :h] for r in self.joint_regs] + [self.decshape.weight, self.deccam.weight], 0).contiguous()
+                b_feat = torch.cat([r.bias for r in self.joint_regs] + [self.decshape.bias, self.deccam.bias], 0).contiguous()
+                w_anc = torch.cat([r.weight[:, h:].reshape(-1) for r in self.joint_regs[1:]], 0).contiguous()
+            self._packed_key, self._packed = key, (w_feat, b_feat, w_anc)
+        return self._packed
+
+    def _head_hip(self, x):
+        w_feat, b_feat, w_anc = self._pack()
+        x = x.float().contiguous()
+        h1 = ops.gemm_nt(x, self.fc1.weight.detach(), L.EPI_STORE, bias=self.fc1.bias)
+        h2 = ops.gemm_nt(h1, self.fc2.weight.detach(), L.EPI_STORE, bias=self.fc2.bias)
+        out = ops.gemm_nt(h2, w_feat, L.EPI_STORE, bias=b_feat)                      # (F, 144 + 10 + 3)
+        base = out[:, :144].contiguous()
+        pose = torch.empty_like(base)
+        ops.check(L.lib().maed_ktd_chain_fwd(ops._p(base), ops._p(w_anc), ops._p(pose), x.shape[0], ops._stream()), "ktd_chain_fwd")
+        return pose, out[:, 144:154].contiguous(), out[:, 154:157].contiguous()
+
+    def _use_hip(self, x):
+        return x.is_cuda and not self.training and not (torch.is_grad_enabled() and (x.requires_grad or self.fc1.weight.requires_grad))
+
+    def forward(self, x, seqlen, J_regressor=None, return_shape_cam=False, **kwargs):
+        hip = self._use_hip(x)
+        pred_pose, pred_shape, pred_cam = self._head_hip(x) if hip else self._head_torch(x.float())
+        if return_shape_cam:
+            return pred_shape, pred_cam
+        return self.get_output(pred_pose, pred_shape, pred_cam, J_regressor, hip)
+
+    def get_output(self, pred_pose, pred_shape, pred_cam, J_regressor, hip=None):
+        """ktd.py:94-124"""
+        nt = pred_pose.shape[0]
+        hip = self._use_hip(pred_pose) if hip is None else hip
+        if hip:
+            rotmat = torch.empty(nt, 24, 3, 3, dtype=torch.float32, device=pred_pose.device)
+            aa = torch.empty(nt, 72, dtype=torch.float32, device=pred_pose.device)
+            ops.check(L.lib().maed_rot6d_pose_fwd(ops._p(pred_pose.contiguous()), ops._p(rotmat), ops._p(aa), nt * 24, ops._stream()), "rot6d_pose_fwd")
+            verts, j24 = self.smpl.lbs_hip(pred_shape, rotmat)
+            extra9 = self.smpl.joint_regress_hip(self.smpl.J_regressor_extra, verts)
+            jover, Jo = None, 0
+            if J_regressor is not None:
+                jover = self.smpl.joint_regress_hip(J_regressor.to(verts.device, torch.float32), verts)
+                Jo = jover.shape[1]
+            nj = Jo if jover is not None else 49
+            kp3d = torch.empty(nt, nj, 3, dtype=torch.float32, device=verts.device)
+            kp2d = torch.empty(nt, nj, 2, dtype=torch.float32, device=verts.device)
+            ops.check(L.lib().maed_smpl_joints_project_fwd(ops._p(j24), ops._p(verts), ops._p(self.smpl.extra_vertex_ids), ops._p(extra9),
+                                                           ops._p(self.smpl.joint_map), ops._p(pred_cam.contiguous()), ops._p(jover), Jo,
+                                                           ops._p(kp3d), ops._p(kp2d), nt, ops._stream()), "smpl_joints_project_fwd")
+            theta = torch.cat([pred_cam, aa, pred_shape], dim=1)
+            return dict(theta=theta, verts=verts, kp_2d=kp2d, kp_3d=kp3d, rotmat=rotmat)
+        rotmat = rot6d_to_rotmat(pred_pose).reshape(nt, -1, 3, 3)
+        out = self.smpl(betas=pred_shape, body_pose=rotmat[:, 1:], global_orient=rotmat[:, 0].unsqueeze(1), pose2rot=False)
+        verts, joints = out.vertices[:nt], out.joints[:nt]
+        if J_regressor is not None:
+            joints = torch.matmul(J_regressor[None].expand(nt, -1, -1).to(verts.device), verts)
+        kp2d = projection(joints, pred_cam)
+        aa = rotation_matrix_to_angle_axis(rotmat.reshape(-1, 3, 3)).reshape(nt, -1)
+        return dict(theta=torch.cat([pred_cam, aa, pred_shape], dim=1), verts=verts, kp_2d=kp2d, kp_3d=joints, rotmat=rotmat)

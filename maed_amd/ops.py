@@ -1,0 +1,307 @@
+"""Host-side operators: thin typed wrappers over the C-ABI (for tests and composition) and the
+torch.autograd.Functions the nn.Modules in this package are made of.
+
+Every function here enqueues HIP kernels on torch's CURRENT stream through libmaed_hip.so; there
+is no PyTorch/CPU fallback (a CPU tensor or a missing library is an error).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import BF16, F32, check
+
+# bumped by optimizers that update parameters through raw pointers (FusedAdam) so that cached
+# compute-dtype / transposed weight copies are rebuilt
+WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"maed_amd: unsupported compute dtype {dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.MaedHipError("maed_amd kernels need CUDA/HIP tensors (no CPU path)")
+    return t.data_ptr()
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# primitive wrappers (no autograd)
+# ----------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-6, row_stride=None, rows=None):
+    C_ = x.shape[-1]
+    if rows is None:
+        x = _c(x)
+        rows = x.numel() // C_
+        row_stride = C_
+    y = torch.empty(rows, C_, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(L.lib().maed_layernorm_fwd(_p(x), row_stride, _p(gamma), _p(beta), _p(y), dt_code(out_dtype), _p(mean), _p(rstd),
+                                     rows, C_, eps, _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None):
+    C_ = x.shape[-1]
+    x, dy = _c(x), _c(dy)
+    rows = x.numel() // C_
+    dx = torch.empty(rows, C_, dtype=torch.float32, device=x.device)
+    dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
+    dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
+    check(L.lib().maed_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), C_, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+                                     _p(dgamma), _p(dbeta), rows, C_, _stream()), "layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def gemm_nt(A, B, epilogue=L.EPI_STORE, bias=None, out=None, out2=None, aux=None, splitk=1, impl=L.IMPL_AUTO, M=None, K=None):
+    """out = epilogue(A[M,K] @ B[N,K]^T).  A/B in the compute dtype (f32 or bf16); bias fp32."""
+    assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = B.shape[0]
+    assert A.stride(1) == 1 and B.stride(1) == 1
+    if out is None:
+        odt = torch.float32 if epilogue in (L.EPI_RESID_F32, L.EPI_ATOMIC_F32, L.EPI_STORE_F32) else A.dtype
+        out = (torch.zeros if epilogue == L.EPI_ATOMIC_F32 else torch.empty)(M, N, dtype=odt, device=A.device)
+    if epilogue == L.EPI_GELU and out2 is None:
+        out2 = torch.empty_like(out)
+    check(L.lib().maed_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, dt_code(A.dtype), epilogue, _p(bias),
+                               _p(out), out.stride(0), _p(out2), _p(aux), aux.stride(0) if aux is not None else 0,
+                               splitk, impl, _stream()), "gemm_nt")
+    return (out, out2) if epilogue == L.EPI_GELU else out
+
+
+def transpose_cast(x, out_dtype, want_t=True, want_c=False, colsum=None, pad_to=64):
+    """x (M,N) f32/bf16 -> (x^T (N, Mp) zero-padded, cast copy (M,N)) in out_dtype; colsum[N] += sum_m."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    Mp = (M + pad_to - 1) // pad_to * pad_to
+    out_t = torch.empty(N, Mp, dtype=out_dtype, device=x.device) if want_t else None
+    out_c = torch.empty(M, N, dtype=out_dtype, device=x.device) if want_c else None
+    check(L.lib().maed_transpose_cast(_p(x), dt_code(x.dtype), x.stride(0), M, N, _p(out_t), Mp, _p(out_c), N, _p(colsum),
+                                      dt_code(out_dtype), _stream()), "transpose_cast")
+    return out_t, out_c
+
+
+def attn_spatial_fwd(qkv, H, impl=L.IMPL_AUTO):
+    F_, P, C3 = qkv.shape
+    C_ = C3 // 3
+    qkv = _c(qkv)
+    o = torch.empty(F_, P, C_, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(F_, H, P, dtype=torch.float32, device=qkv.device)
+    check(L.lib().maed_attn_spatial_fwd(_p(qkv), _p(o), _p(lse), F_, P, H, 1.0 / math.sqrt(C_ // H), dt_code(qkv.dtype), impl, _stream()),
+          "attn_spatial_fwd")
+    return o, lse
+
+
+def attn_spatial_bwd(qkv, o, d_o, lse, H, dqkv=None, accumulate=False, impl=L.IMPL_AUTO):
+    F_, P, C3 = qkv.shape
+    dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
+    check(L.lib().maed_attn_spatial_bwd(_p(_c(qkv)), _p(_c(o)), _p(_c(d_o)), _p(lse), _p(dqkv), int(accumulate), F_, P, H,
+                                        1.0 / math.sqrt(C3 // 3 // H), dt_code(qkv.dtype), impl, _stream()), "attn_spatial_bwd")
+    return dqkv
+
+
+def attn_temporal_fwd(qkv, H, T):
+    F_, P, C3 = qkv.shape
+    C_ = C3 // 3
+    qkv = _c(qkv)
+    o = torch.empty(F_, P, C_, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(F_, H, P, dtype=torch.float32, device=qkv.device)
+    check(L.lib().maed_attn_temporal_fwd(_p(qkv), _p(o), _p(lse), F_, P, H, T, 1.0 / math.sqrt(C_ // H), dt_code(qkv.dtype), _stream()),
+          "attn_temporal_fwd")
+    return o, lse
+
+
+def attn_temporal_bwd(qkv, o, d_o, lse, H, T, dqkv=None, accumulate=False):
+    F_, P, C3 = qkv.shape
+    dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
+    check(L.lib().maed_attn_temporal_bwd(_p(_c(qkv)), _p(_c(o)), _p(_c(d_o)), _p(lse), _p(dqkv), int(accumulate), F_, P, H, T,
+                                         1.0 / math.sqrt(C3 // 3 // H), dt_code(qkv.dtype), _stream()), "attn_temporal_bwd")
+    return dqkv
+
+
+def st_colmean(x_s, x_t):
+    F_, P, C_ = x_s.shape
+    means = torch.empty(F_, 2 * C_, dtype=x_s.dtype, device=x_s.device)
+    ws = torch.empty(F_, 2 * C_, dtype=torch.float32, device=x_s.device)
+    check(L.lib().maed_st_colmean(_p(_c(x_s)), _p(_c(x_t)), _p(means), _p(ws), F_, P, C_, dt_code(x_s.dtype), _stream()), "st_colmean")
+    return means
+
+
+def st_mix_fwd(x_s, x_t, logits):
+    F_, P, C_ = x_s.shape
+    mix = torch.empty_like(x_s)
+    check(L.lib().maed_st_mix_fwd(_p(_c(x_s)), _p(_c(x_t)), _p(_c(logits)), _p(mix), F_, P, C_, dt_code(x_s.dtype), _stream()), "st_mix_fwd")
+    return mix
+
+
+def st_mix_bwd(dmix, x_s, x_t, logits, dmeans_fn):
+    """dmeans_fn(dlogits) -> dmeans (both (F,2C) in the compute dtype): the ts_attn backward GEMM."""
+    F_, P, C_ = x_s.shape
+    dlogits = torch.empty(F_, 2 * C_, dtype=x_s.dtype, device=x_s.device)
+    ws = torch.empty(F_, 2 * C_, dtype=torch.float32, device=x_s.device)
+    check(L.lib().maed_st_mix_bwd_reduce(_p(_c(dmix)), _p(_c(x_s)), _p(_c(x_t)), _p(logits), _p(dlogits), _p(ws), F_, P, C_,
+                                         dt_code(x_s.dtype), _stream()), "st_mix_bwd_reduce")
+    dmeans = dmeans_fn(dlogits)
+    dx_s, dx_t = torch.empty_like(x_s), torch.empty_like(x_t)
+    check(L.lib().maed_st_mix_bwd_apply(_p(_c(dmix)), _p(logits), _p(_c(dmeans)), _p(dx_s), _p(dx_t), F_, P, C_, dt_code(x_s.dtype), _stream()),
+          "st_mix_bwd_apply")
+    return dx_s, dx_t, dlogits
+
+
+def adam_step(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, gscale=1.0):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(L.lib().maed_adam_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2, gscale, _stream()),
+          "adam_step")
+
+
+# ----------------------------------------------------------------------------------------------
+# compute-dtype weight cache
+# ----------------------------------------------------------------------------------------------
+class WeightCache:
+    """(cast copy [out,in], transposed cast copy [in,out]) of nn.Linear weights in the compute dtype,
+    rebuilt when the fp32 master changes (tensor version counter or FusedAdam's epoch)."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, weights, dtype):
+        key = (WEIGHT_EPOCH, dtype, tuple((w.data_ptr(), w._version) for w in weights))
+        if key != self._key:
+            val = []
+            with torch.no_grad():
+                for w in weights:
+                    w2 = _c(w.detach())
+                    wt, wc = transpose_cast(w2, dtype, want_t=True, want_c=(dtype != torch.float32), pad_to=1)
+                    val.append((w2 if dtype == torch.float32 else wc, wt))
+            self._key, self._val = key, val
+        return self._val
+
+
+_SCRATCH = {}
+
+
+def _scratch(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd Functions
+# ----------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b through maed_gemm_nt (nn.Linear / 1x1 conv semantics); x (M,K) in the compute dtype,
+    W, b fp32 masters.  Returns y in the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        (wc, wt), = cache.get([weight], x.dtype)
+        ctx.save_for_backward(x, weight, bias)
+        ctx.wt = wt
+        return gemm_nt(_c(x), wc, L.EPI_STORE, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        dy = _c(dy)
+        db = torch.zeros_like(bias) if bias is not None else None
+        dyt, _ = transpose_cast(dy, dy.dtype, colsum=db)
+        xt, _ = transpose_cast(x, x.dtype)
+        tiles = max(1, (weight.shape[0] // 128) * (weight.shape[1] // 128))
+        dW = gemm_nt(dyt, xt, L.EPI_ATOMIC_F32, splitk=max(1, min(dyt.shape[1] // 256, 1024 // tiles)))
+        dx = gemm_nt(dy, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
+        return dx, dW, db, None
+
+
+class EmbedAddFn(torch.autograd.Function):
+    """tokens = cat(cls, patch) + pos_embed + temp_embed[:, :T]  (vision_transformer.py:392-399)"""
+
+    @staticmethod
+    def forward(ctx, patch, cls, pos, temp, T):
+        F_, Pm1, C_ = patch.shape
+        tok = torch.empty(F_, Pm1 + 1, C_, dtype=torch.float32, device=patch.device)
+        check(L.lib().maed_embed_add_fwd(_p(_c(patch)), dt_code(patch.dtype), _p(_c(cls)), _p(_c(pos)), _p(_c(temp)), _p(tok),
+                                         F_, Pm1 + 1, C_, T, _stream()), "embed_add_fwd")
+        ctx.T, ctx.pdtype = T, patch.dtype
+        ctx.temp_shape = temp.shape
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        dtok = _c(dtok)
+        F_, P, C_ = dtok.shape
+        dpatch = torch.empty(F_, P - 1, C_, dtype=ctx.pdtype, device=dtok.device)
+        dpos = torch.zeros(1, P, C_, dtype=torch.float32, device=dtok.device)
+        fsum = torch.empty(F_, C_, dtype=torch.float32, device=dtok.device)
+        check(L.lib().maed_embed_add_bwd(_p(dtok), _p(dpatch), dt_code(ctx.pdtype), _p(dpos), _p(fsum), F_, P, C_, _stream()), "embed_add_bwd")
+        dtemp = torch.zeros(ctx.temp_shape, dtype=torch.float32, device=dtok.device)
+        dtemp[0, :ctx.T, 0] = fsum.view(-1, ctx.T, C_).sum(0)
+        dcls = dtok[:, 0].sum(0).view(1, 1, C_)
+        return dpatch, dcls, dpos, dtemp, None
+
+
+class STEBlockFn(torch.autograd.Function):
+    """One STE Block through maed_ste_block_{fwd,bwd}.  Parameter gradients are accumulated by the
+    kernels directly into p.grad (fp32, allocated on demand); autograd sees None for them, and the
+    module's `grads_ready` hook tells the data-parallel bucketer when they are final."""
+
+    @staticmethod
+    def forward(ctx, x, block, dims, H, T, *params):
+        lib = L.lib()
+        x = _c(x)
+        d = L.BlockDims(*dims)
+        pr = block._c_params(x.dtype if False else block.compute_dtype)
+        saved = torch.empty(lib.maed_ste_block_saved_bytes(C.byref(d)), dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        check(lib.maed_ste_block_fwd(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _stream()), "ste_block_fwd")
+        ctx.block, ctx.dims = block, dims
+        ctx.save_for_backward(x, saved)
+        block._pending_backwards += 1
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        x, saved = ctx.saved_tensors
+        block = ctx.block
+        d = L.BlockDims(*ctx.dims)
+        pr = block._c_params(block.compute_dtype)
+        gr = block._c_grads()
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        scratch = _scratch(lib.maed_ste_block_scratch_bytes(C.byref(d)), dy.device)
+        check(lib.maed_ste_block_bwd(C.byref(d), C.byref(pr), C.byref(gr), _p(x), _p(dy), _p(dx), _p(saved), _p(scratch), _stream()),
+              "ste_block_bwd")
+        block._pending_backwards -= 1
+        if block._pending_backwards == 0 and block.grads_ready is not None:
+            block.grads_ready(block)
+        return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)

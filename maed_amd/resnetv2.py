@@ -1,0 +1,155 @@
+"""Hybrid R50 backbone of the STE (reference: lib/models/resnetv2.py).
+
+Not torchvision's ResNet-50: the ViT-hybrid ResNetV2 with 3 stages (3,4,9), weight-standardised
+convolutions with TF 'SAME' padding, GroupNorm(32) and non-pre-activation bottlenecks, output
+stride 16 (resnetv2.py:74-93,159-204,277-335; vision_transformer.py:564-566).
+
+Per BASELINE.json's north_star the convolutions ride on MIOpen through PyTorch-ROCm; what this
+module decides is the MI355X-side data layout: activations are channels_last in the compute dtype
+(bf16 for throughput), the weight standardisation is done once per forward in fp32 (the reference
+recomputes it twice per conv call, resnetv2.py:92-93) and the output is handed to the 1x1
+projection GEMM as a (F*H*W, C) row-major matrix without a transpose copy.
+
+Module / parameter names match the reference so its checkpoints load unchanged.
+"""
+import math
+from collections import OrderedDict
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _same_pad(x, k, s, value=0.0):
+    """TF 'SAME' padding computed from the input size (resnetv2.py:51-59): left = pad//2."""
+    ih, iw = x.shape[-2:]
+    ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
+    pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
+    if ph > 0 or pw > 0:
+        x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2], value=value)
+    return x
+
+
+class StdConv2dSame(nn.Conv2d):
+    """resnetv2.py:74-93: biased std, eps added to the std, no bias."""
+
+    def __init__(self, in_channel, out_channels, kernel_size, stride=1, dilation=1, groups=1, bias=False, eps=1e-5):
+        super().__init__(in_channel, out_channels, kernel_size, stride=stride, padding=0, dilation=dilation, groups=groups, bias=bias)
+        self.eps = eps
+
+    def get_weight(self):
+        std, mean = torch.std_mean(self.weight, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        return (self.weight - mean) / (std + self.eps)
+
+    def forward(self, x):
+        w = self.get_weight().to(x.dtype)
+        if x.is_cuda:
+            w = w.contiguous(memory_format=torch.channels_last)
+        x = _same_pad(x, self.kernel_size[0], self.stride[0])
+        return F.conv2d(x, w, None, self.stride, 0, self.dilation, self.groups)
+
+
+class GroupNormAct(nn.GroupNorm):
+    """resnetv2.py:35-49"""
+
+    def __init__(self, num_channels, num_groups=32, eps=1e-5, affine=True, apply_act=True):
+        super().__init__(num_groups, num_channels, eps=eps, affine=affine)
+        self.apply_act = apply_act
+
+    def forward(self, x):
+        x = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
+        return F.relu(x, inplace=True) if self.apply_act else x
+
+
+class MaxPool2dSame(nn.Module):
+    """resnetv2.py:61-72: pads with -inf"""
+
+    def __init__(self, kernel_size=3, stride=2):
+        super().__init__()
+        self.kernel_size, self.stride = kernel_size, stride
+
+    def forward(self, x):
+        return F.max_pool2d(_same_pad(x, self.kernel_size, self.stride, value=-float("inf")), self.kernel_size, self.stride, 0)
+
+
+class DownsampleConv(nn.Module):
+    """resnetv2.py:207-216 (preact=False: conv + norm without activation)"""
+
+    def __init__(self, in_chs, out_chs, stride=1):
+        super().__init__()
+        self.conv = StdConv2dSame(in_chs, out_chs, 1, stride=stride)
+        self.norm = GroupNormAct(out_chs, apply_act=False)
+
+    def forward(self, x):
+        return self.norm(self.conv(x))
+
+
+class Bottleneck(nn.Module):
+    """resnetv2.py:159-204 non-pre-activation bottleneck; mid = out/4"""
+
+    def __init__(self, in_chs, out_chs, stride=1, downsample=False):
+        super().__init__()
+        mid = out_chs // 4
+        self.downsample = DownsampleConv(in_chs, out_chs, stride) if downsample else None
+        self.conv1 = StdConv2dSame(in_chs, mid, 1)
+        self.norm1 = GroupNormAct(mid)
+        self.conv2 = StdConv2dSame(mid, mid, 3, stride=stride)
+        self.norm2 = GroupNormAct(mid)
+        self.conv3 = StdConv2dSame(mid, out_chs, 1)
+        self.norm3 = GroupNormAct(out_chs, apply_act=False)
+        self.drop_path = nn.Identity()
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        x = self.norm1(self.conv1(x))
+        x = self.norm2(self.conv2(x))
+        x = self.norm3(self.conv3(x))
+        return F.relu(x + shortcut, inplace=True)
+
+
+class ResNetStage(nn.Module):
+    """resnetv2.py:218-242"""
+
+    def __init__(self, in_chs, out_chs, stride, depth):
+        super().__init__()
+        blocks = OrderedDict()
+        for b in range(depth):
+            blocks[str(b)] = Bottleneck(in_chs if b == 0 else out_chs, out_chs, stride=stride if b == 0 else 1, downsample=(b == 0))
+        self.blocks = nn.Sequential(blocks)
+
+    def forward(self, x):
+        return self.blocks(x)
+
+
+class ResNetV2(nn.Module):
+    """resnetv2.py:277-348 restricted to what the STE uses: preact=False, stem_type='same', no head."""
+
+    def __init__(self, layers=(3, 4, 9), channels=(256, 512, 1024), in_chans=3, stem_chs=64, compute_dtype=torch.float32, **_):
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        self.stem = nn.Sequential(OrderedDict([
+            ("conv", StdConv2dSame(in_chans, stem_chs, 7, stride=2)),
+            ("norm", GroupNormAct(stem_chs)),
+            ("pool", MaxPool2dSame(3, 2)),
+        ]))
+        stages = OrderedDict()
+        prev = stem_chs
+        for i, (d, c) in enumerate(zip(layers, channels)):
+            stages[str(i)] = ResNetStage(prev, c, stride=1 if i == 0 else 2, depth=d)
+            prev = c
+        self.stages = nn.Sequential(stages)
+        self.num_features = prev
+        self.norm = nn.Identity()
+        self.head = nn.Identity()
+        for m in self.modules():  # resnetv2.py:330-335
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward_features(self, x):
+        if x.is_cuda:
+            x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
+        return self.stages(self.stem(x))
+
+    def forward(self, x, seqlen=8):
+        return self.forward_features(x)

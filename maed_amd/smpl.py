@@ -1,0 +1,168 @@
+"""SMPL body model wrapper (reference: lib/models/smpl.py on top of third-party smplx==0.1.13).
+
+The reference subclasses smplx.SMPL and needs the licensed SMPL model file; neither exists here
+(parity of the LBS arithmetic is UNPINNED).  This module restates the published
+formulation and takes the model arrays from a dict / .npz / .pkl-derived
+dict with the smplx field names; `SMPL.synthetic()` builds deterministic SMPL-shaped stand-in
+parameters so the path can run and be timed without licensed data.
+
+forward(betas, body_pose, global_orient, pose2rot=False) keeps smplx's call signature used at
+lib/models/ktd.py:100-105 and returns an object with .vertices and .joints (49 joints through
+joint_map, smpl.py:97-99).
+"""
+import ctypes as C
+from collections import namedtuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+# lib/models/smpl.py:16-53,89
+JOINT_MAP = {
+    'OP Nose': 24, 'OP Neck': 12, 'OP RShoulder': 17, 'OP RElbow': 19, 'OP RWrist': 21, 'OP LShoulder': 16,
+    'OP LElbow': 18, 'OP LWrist': 20, 'OP MidHip': 0, 'OP RHip': 2, 'OP RKnee': 5, 'OP RAnkle': 8,
+    'OP LHip': 1, 'OP LKnee': 4, 'OP LAnkle': 7, 'OP REye': 25, 'OP LEye': 26, 'OP REar': 27,
+    'OP LEar': 28, 'OP LBigToe': 29, 'OP LSmallToe': 30, 'OP LHeel': 31, 'OP RBigToe': 32, 'OP RSmallToe': 33,
+    'OP RHeel': 34, 'Right Ankle': 8, 'Right Knee': 5, 'Right Hip': 45, 'Left Hip': 46, 'Left Knee': 4,
+    'Left Ankle': 7, 'Right Wrist': 21, 'Right Elbow': 19, 'Right Shoulder': 17, 'Left Shoulder': 16,
+    'Left Elbow': 18, 'Left Wrist': 20, 'Neck (LSP)': 47, 'Top of Head (LSP)': 48, 'Pelvis (MPII)': 49,
+    'Thorax (MPII)': 50, 'Spine (H36M)': 51, 'Jaw (H36M)': 52, 'Head (H36M)': 53, 'Nose': 24, 'Left Eye': 26,
+    'Right Eye': 25, 'Left Ear': 28, 'Right Ear': 27,
+}
+JOINT_NAMES = [
+    'OP Nose', 'OP Neck', 'OP RShoulder', 'OP RElbow', 'OP RWrist', 'OP LShoulder', 'OP LElbow', 'OP LWrist',
+    'OP MidHip', 'OP RHip', 'OP RKnee', 'OP RAnkle', 'OP LHip', 'OP LKnee', 'OP LAnkle', 'OP REye', 'OP LEye',
+    'OP REar', 'OP LEar', 'OP LBigToe', 'OP LSmallToe', 'OP LHeel', 'OP RBigToe', 'OP RSmallToe', 'OP RHeel',
+    'Right Ankle', 'Right Knee', 'Right Hip', 'Left Hip', 'Left Knee', 'Left Ankle', 'Right Wrist', 'Right Elbow',
+    'Right Shoulder', 'Left Shoulder', 'Left Elbow', 'Left Wrist', 'Neck (LSP)', 'Top of Head (LSP)',
+    'Pelvis (MPII)', 'Thorax (MPII)', 'Spine (H36M)', 'Jaw (H36M)', 'Head (H36M)', 'Nose', 'Left Eye',
+    'Right Eye', 'Left Ear', 'Right Ear',
+]
+JOINT_IDS = {JOINT_NAMES[i]: i for i in range(len(JOINT_NAMES))}
+H36M_TO_J17 = [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 0, 7, 9, 10]
+H36M_TO_J14 = [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10]
+
+SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+# smplx vertex_ids['smpl'] in VertexJointSelector order (face, feet, finger tips)
+SMPL_EXTRA_VERTEX_IDS = [332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
+                         2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133]
+N_VERTS = 6890
+
+ModelOutput = namedtuple('ModelOutput', ['vertices', 'joints', 'full_pose', 'betas', 'global_orient', 'body_pose'])
+
+
+def synthetic_smpl_arrays(seed=0):
+    """Deterministic SMPL-shaped arrays (same generator as the test oracle's stand-in model)."""
+    g = torch.Generator().manual_seed(seed)
+    V = N_VERTS
+    out = dict(v_template=torch.randn(V, 3, generator=g) * 0.3, shapedirs=torch.randn(V, 3, 10, generator=g) * 0.01,
+               posedirs=torch.randn(207, V * 3, generator=g) * 0.001)
+
+    def sparse_rows(rows, nnz):
+        m = torch.zeros(rows, V)
+        for r in range(rows):
+            idx = torch.randperm(V, generator=g)[:nnz]
+            w = torch.rand(nnz, generator=g) + 0.1
+            m[r, idx] = w / w.sum()
+        return m
+
+    out['J_regressor'] = sparse_rows(24, 40)
+    out['J_regressor_extra'] = sparse_rows(9, 30)
+    out['J_regressor_h36m'] = sparse_rows(17, 50)
+    wj = torch.randint(0, 24, (V, 4), generator=g)
+    ww = torch.rand(V, 4, generator=g) + 0.05
+    lw = torch.zeros(V, 24)
+    lw.scatter_add_(1, wj, ww)
+    out['lbs_weights'] = lw / lw.sum(1, keepdim=True)
+    return out
+
+
+class SMPL(nn.Module):
+    """Buffers use smplx's names so `decoder.smpl.*` state_dict entries line up (they are filtered
+    out on load by the reference anyway: eval.py:29, train.py:101)."""
+
+    def __init__(self, model_arrays=None, **kwargs):
+        super().__init__()
+        a = model_arrays if model_arrays is not None else synthetic_smpl_arrays(0)
+        self.synthetic = model_arrays is None
+        f = lambda k: torch.as_tensor(a[k], dtype=torch.float32).contiguous()
+        self.register_buffer('v_template', f('v_template'))
+        self.register_buffer('shapedirs', f('shapedirs')[:, :, :10].contiguous())
+        self.register_buffer('posedirs', f('posedirs').reshape(207, N_VERTS * 3).contiguous())
+        self.register_buffer('J_regressor', f('J_regressor'))
+        self.register_buffer('lbs_weights', f('lbs_weights'))
+        self.register_buffer('J_regressor_extra', f('J_regressor_extra'))
+        self.register_buffer('parents', torch.tensor(SMPL_PARENTS, dtype=torch.int32), persistent=False)
+        self.register_buffer('extra_vertex_ids', torch.tensor(SMPL_EXTRA_VERTEX_IDS, dtype=torch.long), persistent=False)
+        self.register_buffer('joint_map', torch.tensor([JOINT_MAP[n] for n in JOINT_NAMES], dtype=torch.long), persistent=False)
+        # rest-pose joint regression folded once: J = J_regressor (v_template + shapedirs beta)
+        self.register_buffer('J_template', self.J_regressor @ self.v_template, persistent=False)
+        self.register_buffer('J_shapedirs', torch.einsum('jv,vcl->jcl', self.J_regressor, self.shapedirs).contiguous(), persistent=False)
+        self.faces = None
+
+    # ---- ATen path (training graph; differentiable) ------------------------------------------------
+    def lbs_torch(self, betas, rotmat):
+        Fr = betas.shape[0]
+        v_shaped = self.v_template[None] + torch.einsum('bl,mkl->bmk', betas, self.shapedirs)
+        J = self.J_template[None] + torch.einsum('bl,jcl->bjc', betas, self.J_shapedirs)
+        ident = torch.eye(3, dtype=betas.dtype, device=betas.device)
+        pose_feature = (rotmat[:, 1:] - ident).reshape(Fr, 207)
+        v_posed = v_shaped + (pose_feature @ self.posedirs).reshape(Fr, -1, 3)
+        parents = SMPL_PARENTS
+        Rw, tw = [rotmat[:, 0]], [J[:, 0]]
+        for i in range(1, 24):
+            p = parents[i]
+            Rw.append(Rw[p] @ rotmat[:, i])
+            tw.append((Rw[p] @ (J[:, i] - J[:, p]).unsqueeze(-1)).squeeze(-1) + tw[p])
+        Rw, tw = torch.stack(Rw, 1), torch.stack(tw, 1)
+        trel = tw - (Rw @ J.unsqueeze(-1)).squeeze(-1)
+        A = torch.cat([Rw, trel.unsqueeze(-1)], dim=-1).reshape(Fr, 24, 12)
+        Tv = (self.lbs_weights @ A).reshape(Fr, -1, 3, 4)
+        verts = (Tv[..., :3] @ v_posed.unsqueeze(-1)).squeeze(-1) + Tv[..., 3]
+        return verts, tw
+
+    def joints49_torch(self, verts, joints24):
+        j45 = torch.cat([joints24, verts[:, self.extra_vertex_ids]], dim=1)
+        extra = torch.einsum('bik,ji->bjk', verts, self.J_regressor_extra)
+        return torch.cat([j45, extra], dim=1)[:, self.joint_map]
+
+    # ---- HIP path (inference) ----------------------------------------------------------------------------
+    def _c_params(self):
+        sp = L.SmplParams()
+        for k in ['v_template', 'shapedirs', 'posedirs', 'J_template', 'J_shapedirs', 'lbs_weights', 'parents']:
+            setattr(sp, k, getattr(self, k).data_ptr())
+        return sp
+
+    def lbs_hip(self, betas, rotmat):
+        Fr = betas.shape[0]
+        dev = betas.device
+        verts = torch.empty(Fr, N_VERTS, 3, dtype=torch.float32, device=dev)
+        j24 = torch.empty(Fr, 24, 3, dtype=torch.float32, device=dev)
+        A = torch.empty(Fr, 24, 12, dtype=torch.float32, device=dev)
+        sp = self._c_params()
+        ops.check(L.lib().maed_smpl_lbs_fwd(C.byref(sp), ops._p(betas.contiguous()), ops._p(rotmat.contiguous()), ops._p(verts),
+                                            ops._p(j24), ops._p(A), Fr, ops._stream()), 'smpl_lbs_fwd')
+        return verts, j24
+
+    def joint_regress_hip(self, Jreg, verts):
+        Fr, J = verts.shape[0], Jreg.shape[0]
+        out = torch.empty(Fr, J, 3, dtype=torch.float32, device=verts.device)
+        ops.check(L.lib().maed_joint_regress_fwd(ops._p(Jreg.contiguous()), J, ops._p(verts), ops._p(out), Fr, ops._stream()), 'joint_regress_fwd')
+        return out
+
+    def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=False, **kwargs):
+        if pose2rot:
+            raise NotImplementedError('pose2rot=True is not used on the MAED path (ktd.py:104)')
+        rot = torch.cat([global_orient, body_pose], dim=1)
+        needs_grad = torch.is_grad_enabled() and (betas.requires_grad or rot.requires_grad)
+        if needs_grad or not betas.is_cuda:  # ATen composition = the training graph (device-agnostic)
+            verts, j24 = self.lbs_torch(betas, rot)
+            joints = self.joints49_torch(verts, j24)
+        else:
+            verts, j24 = self.lbs_hip(betas.float(), rot.float())
+            extra = self.joint_regress_hip(self.J_regressor_extra, verts)
+            j54 = torch.cat([j24, verts[:, self.extra_vertex_ids], extra], dim=1)
+            joints = j54[:, self.joint_map]
+        return ModelOutput(vertices=verts, joints=joints, full_pose=rot, betas=betas, global_orient=global_orient, body_pose=body_pose)

@@ -1,0 +1,319 @@
+"""GPU parity tests, kernel level: every libmaed_hip entry point against the CPU oracle
+(oracle/maed_ref.py, pinned to the reference by tests/golden) on the same seeded inputs.
+
+Tolerances: f32 kernels 2e-5 (exact-f32 arithmetic, different summation order); bf16 kernels are
+compared with the oracle evaluated in fp32 on the SAME bf16-rounded inputs, so what remains is the
+bf16 rounding of outputs / probabilities (2^-8 relative).  Integer/index work is bit-exact.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import maed_ref as R
+
+pytestmark = pytest.mark.gpu
+
+from _util import DEV, q, report, rnd, tol  # noqa: E402
+
+
+def _ops():
+    from maed_amd import ops, _lib
+    return ops, _lib
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(37, 128), (197 * 3, 512), (64, 768)])
+def test_layernorm_fwd_bwd(dtype, rows, C):
+    ops, _ = _ops()
+    x = rnd(rows, C, seed=1) * 2 + 0.3
+    g, b = 1 + 0.2 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), dtype)
+    ref = R.layer_norm(x, g, b)
+    report(f"layernorm_fwd[{dtype},{rows}x{C}]", y.float(), ref, **tol(dtype, 4))
+    dy = q(rnd(rows, C, seed=4), dtype)
+    dres = rnd(rows, C, seed=5)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    R.layer_norm(xr, gr, br).backward(dy.double())
+    dx, dg, db = ops.layernorm_bwd(dy.to(DEV).to(dtype), x.to(DEV), g.to(DEV), mean, rstd, dres=dres.to(DEV))
+    report(f"layernorm_bwd.dx[{dtype},{rows}x{C}]", dx, xr.grad + dres.double(), rtol=2e-5, atol=1e-4)
+    report(f"layernorm_bwd.dgamma[{dtype}]", dg, gr.grad, rtol=1e-4, atol=1e-3)
+    report(f"layernorm_bwd.dbeta[{dtype}]", db, br.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_layernorm_strided_rows():
+    ops, _ = _ops()
+    x = rnd(6, 5, 128, seed=7)
+    g, b = 1 + 0.2 * rnd(128, seed=2), 0.1 * rnd(128, seed=3)
+    y, _, _ = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), torch.float32, row_stride=5 * 128, rows=6)
+    report("layernorm_fwd[cls rows, stride P*C]", y, R.layer_norm(x[:, 0], g, b), **tol(torch.float32, 4))
+
+
+# ---------------------------------------------------------------------------------------------
+GEMM_CASES = [("f32-valu", torch.float32, 1), ("bf16-valu", torch.bfloat16, 1), ("bf16-mfma", torch.bfloat16, 2)]
+
+
+@pytest.mark.parametrize("name,dtype,impl", GEMM_CASES)
+@pytest.mark.parametrize("M,N,K", [(300, 100, 64), (197 * 4, 384, 128), (130, 512, 2048), (128, 128, 64)])
+def test_gemm_epilogues(name, dtype, impl, M, N, K):
+    ops, L = _ops()
+    A, B = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2, scale=K ** -0.5), dtype)
+    bias = rnd(N, seed=3)
+    Ad, Bd, bd = A.to(DEV).to(dtype), B.to(DEV).to(dtype), bias.to(DEV)
+    ref = A.double() @ B.double().t()
+    t = tol(dtype, 2)
+    out = ops.gemm_nt(Ad, Bd, L.EPI_STORE, bias=bd, impl=impl)
+    report(f"gemm[{name},STORE,{M}x{N}x{K}]", out.float(), ref + bias.double(), **t)
+    out = ops.gemm_nt(Ad, Bd, L.EPI_STORE_F32, bias=bd, impl=impl)
+    report(f"gemm[{name},STORE_F32]", out, ref + bias.double(), rtol=2e-5, atol=1e-4)
+    act, pre = ops.gemm_nt(Ad, Bd, L.EPI_GELU, bias=bd, impl=impl)
+    report(f"gemm[{name},GELU.pre]", pre.float(), ref + bias.double(), **t)
+    report(f"gemm[{name},GELU.act]", act.float(), R.gelu(pre.float().cpu().double()), **t)
+    res = rnd(M, N, seed=4)
+    out = ops.gemm_nt(Ad, Bd, L.EPI_RESID_F32, bias=bd, aux=res.to(DEV), impl=impl)
+    report(f"gemm[{name},RESID_F32]", out, ref + bias.double() + res.double(), rtol=2e-5, atol=1e-4)
+    pre_in = q(rnd(M, N, seed=5), dtype)
+    out = ops.gemm_nt(Ad, Bd, L.EPI_MUL_DGELU, aux=pre_in.to(DEV).to(dtype), impl=impl)
+    xg = pre_in.double().requires_grad_(True)
+    R.gelu(xg).sum().backward()
+    report(f"gemm[{name},MUL_DGELU]", out.float(), ref * xg.grad, **t)
+    out = ops.gemm_nt(Ad, Bd, L.EPI_TANH, bias=bd, impl=impl)
+    report(f"gemm[{name},TANH]", out.float(), torch.tanh(ref + bias.double()), **t)
+    acc = rnd(M, N, seed=6).to(DEV)
+    acc0 = acc.clone()
+    splitk = 4 if K >= 256 else 1
+    ops.gemm_nt(Ad, Bd, L.EPI_ATOMIC_F32, out=acc, splitk=splitk, impl=impl)
+    report(f"gemm[{name},ATOMIC_F32,splitk={splitk}]", acc, acc0.cpu().double() + ref, rtol=2e-5, atol=2e-4)
+
+
+def test_gemm_mfma_rejects_bad_k():
+    ops, L = _ops()
+    A = torch.zeros(64, 48, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(L.MaedHipError):
+        ops.gemm_nt(A, A, L.EPI_STORE, impl=L.IMPL_MFMA)
+
+
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+def test_transpose_cast(din, dout):
+    ops, _ = _ops()
+    x = q(rnd(197 * 3 + 1, 200, seed=1), din)
+    cs = torch.zeros(200, device=DEV)
+    xt, xc = ops.transpose_cast(x.to(DEV).to(din), dout, want_c=True, colsum=cs)
+    M = x.shape[0]
+    assert xt.shape == (200, (M + 63) // 64 * 64)
+    assert torch.equal(xt[:, :M].float().cpu(), x.to(dout).float().t()), "transpose must be exact"
+    assert torch.count_nonzero(xt[:, M:]) == 0, "padding must be zero"
+    assert torch.equal(xc.float().cpu(), x.to(dout).float())
+    report(f"transpose_cast.colsum[{din}->{dout}]", cs, x.double().sum(0), rtol=1e-5, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+def _qkv(Fr, P, H, dtype, seed=0):
+    return q(rnd(Fr, P, 3 * 64 * H, seed=seed), dtype)
+
+
+ATTN_CASES = [("f32-valu", torch.float32, 1), ("bf16-valu", torch.bfloat16, 1), ("bf16-mfma", torch.bfloat16, 2)]
+
+
+@pytest.mark.parametrize("name,dtype,impl", ATTN_CASES)
+@pytest.mark.parametrize("Fr,P,H", [(4, 5, 2), (3, 197, 2), (2, 257, 3), (2, 32, 1), (2, 33, 1)])
+def test_attn_spatial_fwd(name, dtype, impl, Fr, P, H):
+    ops, _ = _ops()
+    qkv = _qkv(Fr, P, H, dtype, seed=P)
+    qq, kk, vv = R.split_qkv(qkv.double(), H)
+    ref = R.attention_spatial(qq, kk, vv, 64 ** -0.5)
+    lse_ref = torch.logsumexp((qq @ kk.transpose(-2, -1)) * 64 ** -0.5, dim=-1)
+    o, lse = ops.attn_spatial_fwd(qkv.to(DEV).to(dtype), H, impl)
+    report(f"attn_spatial_fwd[{name},F{Fr} P{P} H{H}]", o.float(), ref, **tol(dtype))
+    report(f"attn_spatial_fwd.lse[{name},P{P}]", lse, lse_ref, rtol=1e-4, atol=1e-3 if dtype == torch.float32 else 2e-2)
+
+
+def test_attn_spatial_fwd_mfma_spiked_scores():
+    """online-softmax rescale path: one key dominates late in the sequence (large running-max jump)."""
+    ops, _ = _ops()
+    Fr, P, H = 2, 197, 1
+    qkv = rnd(Fr, P, 192, seed=11)
+    qkv[:, 150, 64:128] = qkv[:, 3, 0:64] * 6.0   # key 150 aligned with query 3
+    qkv[:, 40, 64:128] = qkv[:, 100, 0:64] * 4.0
+    qkv = q(qkv, torch.bfloat16)
+    qq, kk, vv = R.split_qkv(qkv.double(), H)
+    ref = R.attention_spatial(qq, kk, vv, 64 ** -0.5)
+    o, _ = ops.attn_spatial_fwd(qkv.to(DEV).bfloat16(), H, 2)
+    report("attn_spatial_fwd[bf16-mfma, spiked]", o.float(), ref, **tol(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Fr,P,H", [(2, 5, 2), (2, 197, 2)])
+def test_attn_spatial_bwd(dtype, Fr, P, H):
+    ops, _ = _ops()
+    qkv = _qkv(Fr, P, H, dtype, seed=3)
+    do = q(rnd(Fr, P, 64 * H, seed=4), dtype)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_spatial(qq, kk, vv, 64 ** -0.5)
+    oref.backward(do.double())
+    qd = qkv.to(DEV).to(dtype)
+    o, lse = ops.attn_spatial_fwd(qd, H, 1)
+    dqkv = ops.attn_spatial_bwd(qd, o, do.to(DEV).to(dtype), lse, H)
+    report(f"attn_spatial_bwd[{dtype},P{P}]", dqkv.float(), x.grad, **tol(dtype, 0.5))
+    base = torch.ones_like(dqkv)
+    dq2 = ops.attn_spatial_bwd(qd, o, do.to(DEV).to(dtype), lse, H, dqkv=base.clone(), accumulate=True)
+    report(f"attn_spatial_bwd.accumulate[{dtype}]", dq2.float(), x.grad + 1.0, **tol(dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,T,P,H", [(2, 3, 5, 2), (2, 16, 50, 2), (1, 1, 7, 1), (1, 64, 9, 1)])
+def test_attn_temporal_fwd_bwd(dtype, N, T, P, H):
+    ops, _ = _ops()
+    Fr = N * T
+    qkv = _qkv(Fr, P, H, dtype, seed=5)
+    do = q(rnd(Fr, P, 64 * H, seed=6), dtype)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_temporal(qq, kk, vv, T, 64 ** -0.5)
+    oref.backward(do.double())
+    qd = qkv.to(DEV).to(dtype)
+    o, lse = ops.attn_temporal_fwd(qd, H, T)
+    report(f"attn_temporal_fwd[{dtype},N{N} T{T} P{P}]", o.float(), oref, **tol(dtype))
+    dqkv = ops.attn_temporal_bwd(qd, o, do.to(DEV).to(dtype), lse, H, T)
+    report(f"attn_temporal_bwd[{dtype},T{T}]", dqkv.float(), x.grad, **tol(dtype, 0.5))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_st_mix_fwd_bwd(dtype):
+    ops, _ = _ops()
+    Fr, P, C = 6, 37, 128
+    xs, xt = q(rnd(Fr, P, C, seed=1), dtype), q(rnd(Fr, P, C, seed=2), dtype)
+    logits = rnd(Fr, 2 * C, seed=3)
+    means = ops.st_colmean(xs.to(DEV).to(dtype), xt.to(DEV).to(dtype))
+    report(f"st_colmean[{dtype}]", means.float(), torch.cat([xs, xt], -1).double().mean(1), **tol(dtype))
+    a = xs.double().requires_grad_(True)
+    b = xt.double().requires_grad_(True)
+    lg = logits.double().requires_grad_(True)
+    alpha = lg.reshape(Fr, 1, C, 2).softmax(-1)
+    ref = b * alpha[:, :, :, 1] + a * alpha[:, :, :, 0]
+    mix = ops.st_mix_fwd(xs.to(DEV).to(dtype), xt.to(DEV).to(dtype), logits.to(DEV))
+    report(f"st_mix_fwd[{dtype}]", mix.float(), ref, **tol(dtype))
+    dmix = q(rnd(Fr, P, C, seed=4), dtype)
+    ref.backward(dmix.double())
+    W = rnd(2 * C, 2 * C, seed=5, scale=0.05)  # stands in for the ts_attn weight: dmeans = dlogits @ W
+    dmeans_ref = lg.grad @ W.double()
+    dxs, dxt, dlog = ops.st_mix_bwd(dmix.to(DEV).to(dtype), xs.to(DEV).to(dtype), xt.to(DEV).to(dtype), logits.to(DEV),
+                                    lambda dl: (dl.float() @ W.to(DEV)).to(dtype))
+    report(f"st_mix_bwd.dlogits[{dtype}]", dlog.float(), lg.grad, **tol(dtype, 2))
+    report(f"st_mix_bwd.dx_s[{dtype}]", dxs.float(), a.grad + dmeans_ref[:, None, :C] / P, **tol(dtype))
+    report(f"st_mix_bwd.dx_t[{dtype}]", dxt.float(), b.grad + dmeans_ref[:, None, C:] / P, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_add_fwd_bwd(dtype):
+    ops, _ = _ops()
+    N, T, P, C = 2, 3, 5, 128
+    patch = q(rnd(N * T, P - 1, C, seed=1), dtype)
+    prm = {"cls_token": rnd(1, 1, C, seed=2), "pos_embed": rnd(1, P, C, seed=3), "temp_embed": rnd(1, 16, 1, C, seed=4)}
+    leaves = {k: v.double().requires_grad_(True) for k, v in prm.items()}
+    pt = patch.double().requires_grad_(True)
+    ref = R.embed_tokens(pt, leaves, "", T)
+    dtok = rnd(N * T, P, C, seed=5)
+    ref.backward(dtok.double())
+    args = [t.to(DEV).requires_grad_(True) for t in (patch.to(dtype), prm["cls_token"], prm["pos_embed"], prm["temp_embed"])]
+    tok = ops.EmbedAddFn.apply(*args, T)
+    report(f"embed_add_fwd[{dtype}]", tok, ref, rtol=1e-6, atol=1e-6)
+    tok.backward(dtok.to(DEV))
+    report(f"embed_add_bwd.dpatch[{dtype}]", args[0].grad.float(), pt.grad, **tol(dtype))
+    report(f"embed_add_bwd.dcls[{dtype}]", args[1].grad, leaves["cls_token"].grad, rtol=1e-5, atol=1e-5)
+    report(f"embed_add_bwd.dpos[{dtype}]", args[2].grad, leaves["pos_embed"].grad, rtol=1e-5, atol=1e-5)
+    report(f"embed_add_bwd.dtemp[{dtype}]", args[3].grad, leaves["temp_embed"].grad, rtol=1e-5, atol=1e-5)
+
+
+def test_adam_matches_torch():
+    ops, _ = _ops()
+    n = 1000 * 4 + 3
+    p0, g = rnd(n, seed=1), rnd(n, seed=2)
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5)
+    p = p0.to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in range(1, 4):
+        gs = g * step
+        ref.grad = (gs / 2).double()
+        opt.step()
+        ops.adam_step(p, gs.to(DEV), m, v, shadow, 1e-3, 0.9, 0.999, 1e-8, 1e-5, step, gscale=0.5)
+    report("adam_step[3 steps, gscale=0.5]", p, ref.data, rtol=1e-5, atol=1e-6)
+    assert torch.equal(shadow.float(), p.bfloat16().float())
+
+
+# ---------------------------------------------------------------------------------------------
+def test_ktd_chain_and_rot6d(golden):
+    ops, L = _ops()
+    fx = golden("g6_ktd")
+    from maed_amd.ktd import KTD
+    dec = KTD(feat_dim=128, hidden_dim=64).eval()
+    sd = {k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd.")}
+    missing, unexpected = dec.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("smpl.") for k in missing)
+    dec = dec.to(DEV)
+    with torch.no_grad():
+        pose, shape, cam = dec._head_hip(torch.from_numpy(fx["x"]).to(DEV))
+    report("ktd_head.pose6d (golden g6)", pose, torch.from_numpy(fx["pose6d"]), rtol=1e-4, atol=1e-5)
+    report("ktd_head.shape (golden g6)", shape, torch.from_numpy(fx["shape"]), rtol=1e-4, atol=1e-5)
+    report("ktd_head.cam (golden g6)", cam, torch.from_numpy(fx["cam"]), rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        o = dec(torch.from_numpy(fx["x"]).to(DEV), seqlen=3)
+        o17 = dec(torch.from_numpy(fx["x"]).to(DEV), seqlen=3, J_regressor=R.make_synthetic_smpl(0)["J_regressor_h36m"].to(DEV))
+    for k in ("theta", "rotmat", "kp_3d"):
+        report(f"KTD.forward.{k} (golden g6)", o[k], torch.from_numpy(fx[k]), rtol=1e-3, atol=1e-5)
+    report("KTD.forward.kp_2d (golden g6)", o["kp_2d"], torch.from_numpy(fx["kp_2d"]), rtol=1e-3, atol=1e-4)
+    report("KTD.forward.verts (golden g6)", o["verts"][:, ::53], torch.from_numpy(fx["verts_sub"]), rtol=1e-3, atol=1e-5)
+    report("KTD.forward.kp_3d_h36m (golden g6)", o17["kp_3d"], torch.from_numpy(fx["kp_3d_h36m"]), rtol=1e-3, atol=1e-5)
+    report("KTD.forward.kp_2d_h36m (golden g6)", o17["kp_2d"], torch.from_numpy(fx["kp_2d_h36m"]), rtol=1e-3, atol=1e-4)
+
+
+def test_rot6d_pose_golden(golden):
+    ops, L = _ops()
+    fx = golden("g7_geometry")
+    r6 = torch.from_numpy(fx["rot6d"]).to(DEV)
+    n = r6.shape[0]
+    rot = torch.empty(n, 3, 3, device=DEV)
+    aa = torch.empty(n, 3, device=DEV)
+    ops.check(L.lib().maed_rot6d_pose_fwd(r6.data_ptr(), rot.data_ptr(), aa.data_ptr(), n, torch.cuda.current_stream().cuda_stream))
+    report("rot6d_to_rotmat (golden g7)", rot, torch.from_numpy(fx["rotmat"]), rtol=1e-5, atol=1e-6)
+    report("rotmat_to_angle_axis (golden g7)", aa, torch.from_numpy(fx["angle_axis"][:n]), rtol=1e-4, atol=1e-5)
+
+
+def test_smpl_lbs_and_joint_gather_bit_exact():
+    ops, L = _ops()
+    from maed_amd.smpl import SMPL
+    sp = R.make_synthetic_smpl(0)
+    smpl = SMPL().to(DEV)
+    Fr = 7
+    betas = rnd(Fr, 10, seed=1)
+    rot = R.rot6d_to_rotmat(rnd(Fr * 24, 6, seed=2)).reshape(Fr, 24, 3, 3)
+    verts_ref, j24_ref = R.smpl_lbs(betas.double(), rot.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in sp.items()})
+    verts, j24 = smpl.lbs_hip(betas.to(DEV), rot.to(DEV))
+    report("smpl_lbs.verts", verts, verts_ref, rtol=1e-4, atol=1e-5)
+    report("smpl_lbs.joints24", j24, j24_ref, rtol=1e-4, atol=1e-5)
+    extra = smpl.joint_regress_hip(smpl.J_regressor_extra, verts)
+    report("joint_regress[J=9, f32 MFMA]", extra, torch.einsum("bik,ji->bjk", verts.cpu().double(), sp["J_regressor_extra"].double()), rtol=1e-4, atol=1e-5)
+    h36m = smpl.joint_regress_hip(sp["J_regressor_h36m"].to(DEV), verts)
+    report("joint_regress[J=17, f32 MFMA]", h36m, torch.einsum("bik,ji->bjk", verts.cpu().double(), sp["J_regressor_h36m"].double()), rtol=1e-4, atol=1e-5)
+    cam = torch.tensor([[0.9, 0.1, -0.2]]).repeat(Fr, 1).to(DEV)
+    kp3d = torch.empty(Fr, 49, 3, device=DEV)
+    kp2d = torch.empty(Fr, 49, 2, device=DEV)
+    ops.check(L.lib().maed_smpl_joints_project_fwd(j24.data_ptr(), verts.data_ptr(), smpl.extra_vertex_ids.data_ptr(), extra.data_ptr(),
+                                                   smpl.joint_map.data_ptr(), cam.data_ptr(), None, 0, kp3d.data_ptr(), kp2d.data_ptr(), Fr,
+                                                   torch.cuda.current_stream().cuda_stream))
+    j54 = torch.cat([j24, verts[:, sp["extra_vertex_ids"].to(DEV)], extra], 1)
+    expect = j54[:, torch.tensor(R.JOINT_MAP_49, device=DEV)]
+    assert torch.equal(kp3d, expect), "joint_map gather must be bit-exact"
+    report("projection", kp2d, R.projection(expect.cpu(), cam.cpu()), rtol=1e-5, atol=1e-5)

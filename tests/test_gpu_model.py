@@ -1,0 +1,223 @@
+"""GPU parity tests, module level: the nn.Modules of maed_amd (HIP path) against the golden fixtures
+produced by the reference and against the CPU oracle, forward and backward.
+
+north_star bar: outputs within 1e-3 relative on SMPL parameters (theta) in the f32 parity mode,
+bit-exact joint index gathers; the bf16 throughput mode is held to the bf16 tolerance stated in
+each test.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maed_ref as R
+from _util import DEV, q, report, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def sd(fx, prefix):
+    return {k[len(prefix):]: t(fx[k]) for k in fx.files if k.startswith(prefix)}
+
+
+def make_block(dim, heads, dtype, state=None, impl=0):
+    from functools import partial
+    import torch.nn as nn
+    from maed_amd.vision_transformer import Block
+    blk = Block(dim, heads, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel",
+                compute_dtype=dtype, impl=impl)
+    if state is not None:
+        blk.load_state_dict(state)
+    return blk.to(DEV)
+
+
+def test_block_forward_golden_f32(golden):
+    fx = golden("g2_block")
+    blk = make_block(128, int(fx["heads"]), torch.float32, sd(fx, "sd."))
+    with torch.no_grad():
+        y = blk(t(fx["x"]).to(DEV), int(fx["seqlen"]))
+    report("Block.forward f32 (golden g2, reference output)", y, t(fx["out"]), rtol=1e-4, atol=1e-4)
+
+
+def test_attention_mlp_forward_golden_f32(golden):
+    from maed_amd.vision_transformer import Attention, Mlp
+    fx = golden("g1_attention")
+    att = Attention(128, num_heads=2, qkv_bias=True, st_mode="parallel")
+    att.load_state_dict(sd(fx, "sd."))
+    att = att.to(DEV)
+    with torch.no_grad():
+        out, parts = att(t(fx["x"]).to(DEV), int(fx["seqlen"]), compute_dtype=torch.float32, return_parts=True)
+    report("Attention.x_s f32 (golden g1)", parts["x_s"], t(fx["x_s"]), rtol=1e-4, atol=1e-5)
+    report("Attention.x_t f32 (golden g1)", parts["x_t"], t(fx["x_t"]), rtol=1e-4, atol=1e-5)
+    report("Attention.forward f32 (golden g1)", out, t(fx["out"]), rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        out, parts = att(t(fx["x"]).to(DEV), int(fx["seqlen"]), compute_dtype=torch.bfloat16, return_parts=True)
+    report("Attention.forward bf16 (golden g1)", out, t(fx["out"]), rtol=3e-2, atol=3e-2)
+    fx = golden("g3_mlp_ln")
+    m = Mlp(128, 512)
+    m.load_state_dict(sd(fx, "mlp."))
+    m = m.to(DEV)
+    with torch.no_grad():
+        report("Mlp.forward f32 (golden g3)", m(t(fx["x"]).to(DEV)), t(fx["mlp_out"]), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,impl", [(torch.float32, 0), (torch.bfloat16, 1), (torch.bfloat16, 0)])
+@pytest.mark.parametrize("N,T,P,H", [(2, 3, 5, 2), (1, 4, 197, 2)])
+def test_block_forward_backward_vs_oracle(dtype, impl, N, T, P, H):
+    """forward + every gradient of one Block against fp64 autograd through the oracle."""
+    C = 64 * H
+    Fr = N * T
+    p = {k[len("encoder.blocks.0."):]: v for k, v in R.make_params(embed_dim=C, depth=1, hidden_dim=64, layers=(1, 1, 1), n_tokens=P, seed=3).items()
+         if k.startswith("encoder.blocks.0.")}
+    p = {k: v * (3.0 if k.endswith("weight") and v.dim() == 2 else 1.0) for k, v in p.items()}
+    blk = make_block(C, H, dtype, p, impl)
+    x = rnd(Fr, P, C, seed=1)
+    dy = rnd(Fr, P, C, seed=2)
+    pd = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    xr = x.double().requires_grad_(True)
+    yref = R.block(xr, pd, "", H, T)
+    yref.backward(dy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    y = blk(xg, T)
+    y.backward(dy.to(DEV))
+    f32 = dtype == torch.float32
+    tl = dict(rtol=1e-4, atol=1e-4) if f32 else dict(rtol=3e-2, atol=3e-2)
+    tag = f"[{dtype},impl{impl},F{Fr} P{P}]"
+    report(f"Block.forward{tag}", y, yref, **tl)
+    report(f"Block.backward.dx{tag}", xg.grad, xr.grad, **tl)
+    for name, prm in blk.named_parameters():
+        ref = pd[name].grad
+        scale = ref.abs().max().item()
+        report(f"Block.backward.d[{name}]{tag}", prm.grad, ref, rtol=1e-3 if f32 else 5e-2, atol=(1e-4 if f32 else 3e-2) * max(scale, 1e-3))
+
+
+def test_vit_tiny_golden_f32(golden):
+    """tiny hybrid ViT (backbone on MIOpen/ATen + STE kernels) against the reference's output."""
+    from functools import partial
+    import torch.nn as nn
+    from maed_amd.resnetv2 import ResNetV2
+    from maed_amd.vision_transformer import VisionTransformer
+    fx = golden("g4_vit_tiny")
+    bb = ResNetV2(layers=(1, 1, 1), channels=(128, 256, 512), compute_dtype=torch.float32)
+    vit = VisionTransformer(img_size=32, embed_dim=128, depth=2, num_heads=2, hybrid_backbone=bb, mlp_ratio=4, qkv_bias=True,
+                            representation_size=128, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", num_classes=-1,
+                            compute_dtype=torch.float32)
+    vit.load_state_dict(sd(fx, "sd."))
+    vit = vit.to(DEV).eval()
+    img = t(fx["img"]).to(DEV)
+    with torch.no_grad():
+        report("ResNetV2.forward_features f32 (golden g4)", vit.patch_embed.backbone(img).float(), t(fx["backbone_out"]), rtol=1e-3, atol=1e-3)
+        report("HybridEmbed.forward f32 (golden g4)", vit.patch_embed(img).float(), t(fx["tokens"]), rtol=1e-3, atol=1e-3)
+        report("VisionTransformer.forward f32 (golden g4)", vit(img, seqlen=int(fx["seqlen"])), t(fx["out"]), rtol=1e-3, atol=1e-3)
+
+
+def _small_maed(dtype, depth=2, H=2, img=64, hidden=64, seed=5):
+    import maed_amd
+    C = 64 * H
+    P = (img // 16) ** 2 + 1
+    params = R.make_params(embed_dim=C, depth=depth, hidden_dim=hidden, n_tokens=P, seed=seed)
+    m = maed_amd.MAED(num_blocks=depth, num_heads=H, embed_dim=C, hidden_dim=hidden, img_size=img, compute_dtype=dtype)
+    missing, unexpected = m.load_state_dict(params, strict=False)
+    assert not unexpected and all(".smpl." in k for k in missing), (missing, unexpected)
+    return m.to(DEV), params
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maed_forward_small_vs_oracle(dtype):
+    m, params = _small_maed(dtype)
+    m.eval()
+    sp = R.make_synthetic_smpl(0)
+    clip = rnd(2, 4, 3, 64, 64, seed=9)
+    with torch.no_grad():
+        ref = R.maed_forward(clip, params, sp, depth=2, H=2)
+        ref17 = R.maed_forward(clip, params, sp, depth=2, H=2, J_regressor=sp["J_regressor_h36m"])
+        out = m(clip.to(DEV))
+        out17 = m(clip.to(DEV), J_regressor=sp["J_regressor_h36m"].to(DEV))
+    f32 = dtype == torch.float32
+    for k in ("theta", "rotmat", "kp_3d", "verts", "kp_2d"):
+        report(f"MAED.forward.{k} [{dtype}, 2x4x64^2] (HIP inference path)", out[k], ref[k], rtol=1e-3 if f32 else 5e-2, atol=1e-4 if f32 else 5e-2)
+    report(f"MAED.forward.kp_3d(J_regressor) [{dtype}]", out17["kp_3d"], ref17["kp_3d"], rtol=1e-3 if f32 else 5e-2, atol=1e-4 if f32 else 5e-2)
+
+
+def test_maed_cfg1_golden_f32(golden):
+    """cfg1 (2x8x224^2, C=768, H=12, 6 blocks): output of the REFERENCE model stored in g10."""
+    import maed_amd
+    fx = golden("g10_cfg1_full")
+    params = R.make_params(embed_dim=768, depth=6, hidden_dim=1024, seed=int(fx["param_seed"]))
+    m = maed_amd.MAED(num_blocks=6, num_heads=12, compute_dtype=torch.float32)
+    assert {k for k in m.state_dict() if ".smpl." not in k} == {k for k in fx["state_dict_keys"].tolist() if ".smpl." not in k}
+    m.load_state_dict(params, strict=False)
+    m = m.to(DEV).eval()
+    clip = torch.randn(2, 8, 3, 224, 224, generator=torch.Generator().manual_seed(int(fx["clip_seed"])))
+    sp = R.make_synthetic_smpl(int(fx["smpl_seed"]))
+    with torch.no_grad():
+        o = m(clip.to(DEV))
+        o17 = m(clip.to(DEV), J_regressor=sp["J_regressor_h36m"].to(DEV))
+    report("MAED cfg1 theta f32 vs REFERENCE (g10)", o["theta"], t(fx["theta"]), rtol=1e-3, atol=1e-4)
+    report("MAED cfg1 rotmat f32 vs REFERENCE (g10)", o["rotmat"], t(fx["rotmat"]), rtol=1e-3, atol=1e-4)
+    report("MAED cfg1 kp_3d f32 vs REFERENCE (g10)", o["kp_3d"], t(fx["kp_3d"]), rtol=1e-3, atol=1e-4)
+    report("MAED cfg1 kp_2d f32 vs REFERENCE (g10)", o["kp_2d"], t(fx["kp_2d"]), rtol=1e-3, atol=1e-3)
+    report("MAED cfg1 verts f32 vs REFERENCE (g10)", o["verts"][:, :, ::53], t(fx["verts_sub"]), rtol=1e-3, atol=1e-4)
+    report("MAED cfg1 kp_3d(h36m) f32 vs REFERENCE (g10)", o17["kp_3d"], t(fx["kp_3d_h36m"]), rtol=1e-3, atol=1e-4)
+    m2 = maed_amd.MAED(num_blocks=6, num_heads=12, compute_dtype=torch.bfloat16)
+    m2.load_state_dict(params, strict=False)
+    m2 = m2.to(DEV).eval()
+    with torch.no_grad():
+        ob = m2(clip.to(DEV))
+    report("MAED cfg1 theta bf16 vs REFERENCE (g10) [throughput mode]", ob["theta"], t(fx["theta"]), rtol=5e-2, atol=2e-2)
+
+
+def test_maed_train_gradients_small_vs_oracle_f32():
+    """whole-model gradients (backbone via ATen/MIOpen, STE via HIP kernels, decoder tail via ATen)
+    against CPU autograd through the oracle (dropout disabled for comparability)."""
+    m, params = _small_maed(torch.float32, depth=1, img=32, seed=6)
+    m.train()
+    m.decoder.drop1.p = 0.0
+    m.decoder.drop2.p = 0.0
+    sp = R.make_synthetic_smpl(0)
+    clip = rnd(2, 2, 3, 32, 32, seed=10)
+    pd = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = R.maed_forward(clip, pd, sp, depth=1, H=2)
+    wts = {"theta": 1.0, "kp_3d": 1.0, "kp_2d": 0.01}
+    loss_ref = sum(w * (ref[k] ** 2).mean() for k, w in wts.items())
+    loss_ref.backward()
+    out = m(clip.to(DEV))
+    loss = sum(w * (out[k] ** 2).mean() for k, w in wts.items())
+    loss.backward()
+    report("train loss f32 (small)", loss.detach().reshape(1), loss_ref.detach().reshape(1), rtol=1e-4, atol=1e-6)
+    worst = 0.0
+    for name, prm in m.named_parameters():
+        g, gr = prm.grad, pd[name].grad
+        assert g is not None, name
+        scale = gr.abs().max().item() + 1e-12
+        err = (g.cpu() - gr).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 5e-3, f"grad {name}: rel-to-max err {err:.3e} (scale {scale:.3e})"
+    report("max relative gradient error over all params f32", torch.tensor([worst]), torch.zeros(1), rtol=0, atol=5e-3)
+
+
+def test_train_step_arena_adam_bf16_runs_and_learns():
+    from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+    m, _ = _small_maed(torch.bfloat16, depth=2, img=64, seed=7)
+    m.train()
+    arena = ParamArena(m)
+    bucketer = GradBucketer(arena, m, bucket_bytes=1 << 20)
+    opt = FusedAdam(arena, lr=1e-3, weight_decay=1e-5, bucketer=bucketer)
+    clip = rnd(2, 4, 3, 64, 64, seed=11).to(DEV)
+    tgt = rnd(2, 4, 49, 3, seed=12).to(DEV) * 0.1
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        out = m(clip)
+        loss = ((out["kp_3d"] - tgt) ** 2).mean() + 1e-3 * (out["theta"] ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    assert all(p.grad.data_ptr() >= arena.grad.data_ptr() for p in arena.params)

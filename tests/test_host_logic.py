@@ -1,0 +1,200 @@
+"""CPU tests of the host side: module API / state_dict names against the reference, the ATen parts of
+the package (backbone, decoder training tail) against the golden fixtures, and the data-parallel
+runtime (flat arenas, bucketed all-reduce) on 2 gloo ranks."""
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import maed_ref as R
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def sd(fx, prefix):
+    return {k[len(prefix):]: t(fx[k]) for k in fx.files if k.startswith(prefix)}
+
+
+def test_state_dict_names_match_reference(golden):
+    import maed_amd
+    fx = golden("g10_cfg1_full")
+    m = maed_amd.MAED()  # reference defaults: ste / 6 blocks / 12 heads / parallel / ktd / 1024
+    ours = {k for k in m.state_dict() if ".smpl." not in k}
+    ref = {k for k in fx["state_dict_keys"].tolist() if ".smpl." not in k}
+    assert ours == ref
+    assert sum(p.numel() for p in m.parameters()) == int(fx["n_params"])
+    assert m.encoder_type == "ste" and m.decoder_type == "ktd"
+    # DDP checkpoints carry a 'module.' prefix; smpl buffers are dropped on load (eval.py:29)
+    params = R.make_params(seed=1)
+    missing, unexpected = m.load_state_dict(params, strict=False)
+    assert not unexpected and all(".smpl." in k for k in missing)
+
+
+def test_unsupported_variants_raise_like_reference():
+    import maed_amd
+    with pytest.raises(NotImplementedError):
+        maed_amd.MAED(encoder="foo")
+    with pytest.raises(NotImplementedError):
+        maed_amd.MAED(decoder="foo")
+    with pytest.raises(NotImplementedError):
+        maed_amd.Attention(128, 2, st_mode="bogus")
+
+
+@pytest.mark.parametrize("tag", ["odd", "even"])
+def test_backbone_pieces_golden(golden, tag):
+    from maed_amd import resnetv2 as rn
+    fx = golden("g5_backbone_pieces")
+    x = t(fx[f"{tag}.x"])
+    c3 = rn.StdConv2dSame(32, 64, 3, stride=2)
+    c3.weight.data = t(fx[f"{tag}.w3"])
+    c7 = rn.StdConv2dSame(32, 64, 7, stride=2)
+    c7.weight.data = t(fx[f"{tag}.w7"])
+    gn = rn.GroupNormAct(64)
+    gn.weight.data, gn.bias.data = t(fx[f"{tag}.gn.weight"]), t(fx[f"{tag}.gn.bias"])
+    with torch.no_grad():
+        y3 = c3(x)
+        np.testing.assert_allclose(y3.numpy(), fx[f"{tag}.conv3s2"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(c7(x).numpy(), fx[f"{tag}.conv7s2"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(gn(y3).numpy(), fx[f"{tag}.gn_relu"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_array_equal(rn.MaxPool2dSame(3, 2)(x).numpy(), fx[f"{tag}.maxpool"])
+        bt = rn.Bottleneck(32, 128, stride=2, downsample=True)
+        bt.load_state_dict(sd(fx, f"{tag}.bt."))
+        np.testing.assert_allclose(bt(x).numpy(), fx[f"{tag}.bottleneck"], rtol=1e-4, atol=1e-4)
+
+
+def test_backbone_tiny_golden(golden):
+    from maed_amd.resnetv2 import ResNetV2
+    fx = golden("g4_vit_tiny")
+    bb = ResNetV2(layers=(1, 1, 1), channels=(128, 256, 512))
+    bb.load_state_dict(sd(fx, "sd.patch_embed.backbone."))
+    with torch.no_grad():
+        np.testing.assert_allclose(bb(t(fx["img"])).numpy(), fx["backbone_out"], rtol=1e-4, atol=1e-4)
+
+
+def test_ktd_training_tail_golden(golden):
+    """the ATen (training) path of the decoder against the reference's outputs (eval mode: dropout off)"""
+    from maed_amd.ktd import KTD
+    fx = golden("g6_ktd")
+    dec = KTD(feat_dim=128, hidden_dim=64).eval()
+    dec.load_state_dict(sd(fx, "sd."), strict=False)
+    with torch.no_grad():
+        pose, shape, cam = dec._head_torch(t(fx["x"]))
+        o = dec(t(fx["x"]), seqlen=3)
+        o17 = dec(t(fx["x"]), seqlen=3, J_regressor=R.make_synthetic_smpl(0)["J_regressor_h36m"])
+    np.testing.assert_allclose(pose.numpy(), fx["pose6d"], rtol=2e-5, atol=2e-5)
+    for k in ("theta", "rotmat", "kp_3d"):
+        np.testing.assert_allclose(o[k].numpy(), fx[k], rtol=1e-4, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(o["kp_2d"].numpy(), fx["kp_2d"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(o["verts"][:, ::53].numpy(), fx["verts_sub"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(o17["kp_3d"].numpy(), fx["kp_3d_h36m"], rtol=1e-4, atol=2e-5)
+    assert np.array_equal(dec.smpl.joint_map.numpy(), fx["joint_map"])  # integer table: bit-exact
+
+
+def test_geometry_golden(golden):
+    from maed_amd import geometry, spin
+    fx = golden("g7_geometry")
+    np.testing.assert_allclose(geometry.rot6d_to_rotmat(t(fx["rot6d"])).numpy(), fx["rotmat"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(geometry.rotation_matrix_to_angle_axis(t(fx["rotmat_all"])).numpy(), fx["angle_axis"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(spin.projection(t(fx["joints"]), t(fx["cam"])).numpy(), fx["kp_2d"], rtol=1e-5, atol=1e-5)
+
+
+def test_synthetic_smpl_matches_oracle_stand_in():
+    from maed_amd.smpl import SMPL, synthetic_smpl_arrays
+    a, b = synthetic_smpl_arrays(0), R.make_synthetic_smpl(0)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    s = SMPL()
+    assert s.joint_map.tolist() == R.JOINT_MAP_49
+    assert s.parents.tolist() == R.SMPL_PARENTS
+
+
+# ---------------------------------------------------------------------------------------------------
+# data-parallel runtime on 2 gloo ranks (CPU)
+# ---------------------------------------------------------------------------------------------------
+class _Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = nn.Linear(16, 32)
+        self.b = nn.Linear(32, 32)
+        self.c = nn.Linear(32, 4)
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from maed_amd.ddp import GradBucketer, ParamArena
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _Toy()
+        if rank == 1:  # rank 1 starts from different weights: broadcast_parameters must fix that
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)
+        arena = ParamArena(model, device=torch.device("cpu"))
+        bucketer = GradBucketer(arena, model, bucket_bytes=2048)  # several small buckets
+        bucketer.broadcast_parameters(0)
+        assert len(bucketer.buckets) > 1
+        x = torch.randn(8, 16, generator=torch.Generator().manual_seed(42))
+        y = torch.randn(8, 4, generator=torch.Generator().manual_seed(43))
+        shard = slice(rank * 4, rank * 4 + 4)
+        for _ in range(2):  # two steps: counters must reset
+            arena.zero_grad()
+            # two forwards, one backward (lib/core/trainer.py:188-202)
+            loss = ((model(x[shard]) - y[shard]) ** 2).mean() + 0.5 * ((model(x[shard] * 2) - y[shard]) ** 2).mean()
+            loss.backward()
+            bucketer.finish()
+        out[rank] = (arena.grad / world).clone(), arena.flat.clone()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_bucketing_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+    world, port = 2, 29533 + os.getpid() % 1000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(world, port, out), nprocs=world, join=True)
+    g0, p0 = out[0]
+    g1, p1 = out[1]
+    assert torch.equal(p0, p1), "parameters must be identical after broadcast"
+    assert torch.equal(g0, g1), "every rank must hold the same reduced gradient"
+    # single-process reference on the concatenated batch
+    from maed_amd.ddp import ParamArena
+    model = _Toy()
+    arena = ParamArena(model, device=torch.device("cpu"))
+    x = torch.randn(8, 16, generator=torch.Generator().manual_seed(42))
+    y = torch.randn(8, 4, generator=torch.Generator().manual_seed(43))
+    loss = ((model(x) - y) ** 2).mean() + 0.5 * ((model(x * 2) - y) ** 2).mean()
+    loss.backward()
+    torch.testing.assert_close(g0, arena.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_param_arena_views_and_order():
+    import maed_amd
+    from maed_amd.ddp import GradBucketer, ParamArena
+    m = maed_amd.MAED(num_blocks=2, num_heads=2, embed_dim=128, hidden_dim=64, img_size=32, compute_dtype=torch.float32)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    arena = ParamArena(m, device=torch.device("cpu"))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for p, o in zip(arena.params, arena.offsets):
+        assert p.data_ptr() == arena.flat.data_ptr() + 4 * o and o % 64 == 0
+        assert p.grad.data_ptr() == arena.grad.data_ptr() + 4 * o
+    groups = [0 if n.startswith("encoder.patch_embed.backbone") else 1 if n.startswith("encoder.patch_embed") else
+              3 if n.startswith("encoder.blocks") else 5 if n.startswith("decoder") else 2 for n in arena.names]
+    first_block, last_backbone = groups.index(3), max(i for i, g in enumerate(groups) if g == 0)
+    assert last_backbone < first_block < groups.index(5)
+    b = GradBucketer(arena, m, bucket_bytes=1 << 20)
+    covered = sorted((s, e) for s, e, _ in b.buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == arena.numel
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+    assert sum(n for _, _, n in b.buckets) == len(arena.params)
