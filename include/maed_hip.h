@@ -161,6 +161,13 @@ int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, con
                        const float* x_in, const float* dx_out, float* dx_in, void* saved, void* scratch,
                        void* stream);
 
+/* measurement only: bracket selected launches inside the composite block calls with hipEvents on the
+ * launch stream.  Tags: 0 attn_spatial_fwd, 1 attn_temporal_fwd, 2 qkv GEMM, 3 fc1 GEMM, 4 fc2 GEMM,
+ * 5 attn_spatial_bwd, 6 attn_temporal_bwd, 7 weight-gradient GEMMs.  collect() synchronises the events and
+ * fills ms_total[8] / count[8] (host pointers), then clears the records. */
+int maed_prof_enable(int on);
+int maed_prof_collect(double* ms_total_host, int* count_host);
+
 /* ---- K10: KTD joint chain (ktd.py:81-86) ------------------------------------------------------- */
 /* base[f32](F,144) = x W_feat^T + b for the 1024-wide feature part of all 24 regressors has been
  * computed by maed_gemm_nt; this adds the ancestor terms serially along ANCESTOR_INDEX (ktd.py:10-35):

@@ -10,6 +10,41 @@
 //           into the caller's gradient arena), bias gradients fall out of the transposes.
 #include "common.cuh"
 #include <hip/hip_runtime.h>
+#include <utility>
+#include <vector>
+
+// ---- in-situ kernel timing (measurement only; off by default) -----------------------------------------
+// When enabled, the composite block calls bracket selected launches with hipEvents recorded on the SAME
+// stream the kernel is launched on; maed_prof_collect() synchronises the events and returns total ms and
+// launch counts per tag.  bench.py uses this for the roofline numbers.
+enum { PROF_ATTN_SP_FWD = 0, PROF_ATTN_TM_FWD, PROF_GEMM_QKV, PROF_GEMM_FC1, PROF_GEMM_FC2, PROF_ATTN_SP_BWD, PROF_ATTN_TM_BWD, PROF_GEMM_WGRAD, PROF_NTAGS };
+static bool g_prof = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_NTAGS];
+struct ProfScope {
+    int tag; hipStream_t s; hipEvent_t a, b; bool on;
+    ProfScope(int tag_, void* stream) : tag(tag_), s((hipStream_t)stream), on(g_prof) {
+        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    }
+    ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof_ev[tag].emplace_back(a, b); } }
+};
+extern "C" int maed_prof_enable(int on) { g_prof = on != 0; return MAED_OK; }
+extern "C" int maed_prof_collect(double* ms_total, int* count) {
+    for (int t = 0; t < PROF_NTAGS; ++t) {
+        double tot = 0.0;
+        for (auto& ev : g_prof_ev[t]) {
+            hipEventSynchronize(ev.second);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, ev.first, ev.second);
+            tot += ms;
+            hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+        }
+        if (ms_total) ms_total[t] = tot;
+        if (count) count[t] = (int)g_prof_ev[t].size();
+        g_prof_ev[t].clear();
+    }
+    return MAED_OK;
+}
+#define PROF(tag, expr) do { ProfScope ps__(tag, stream); MAED_PROPAGATE(expr); } while (0)
 
 namespace {
 
@@ -107,16 +142,16 @@ extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_par
     float* logits = (float*)(sv + L.logits);
 
     MAED_PROPAGATE(maed_layernorm_fwd(x_in, C, p->ln1_g, p->ln1_b, sv + L.ln1, dt, (float*)(sv + L.mean1), (float*)(sv + L.rstd1), M, C, d->eps, stream));
-    MAED_PROPAGATE(maed_gemm_nt(sv + L.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, sv + L.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
-    MAED_PROPAGATE(maed_attn_temporal_fwd(sv + L.qkv, sv + L.xt, (float*)(sv + L.lse_t), d->F, d->P, d->H, d->T, scale, dt, stream));
-    MAED_PROPAGATE(maed_attn_spatial_fwd(sv + L.qkv, sv + L.xs, (float*)(sv + L.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
+    PROF(PROF_GEMM_QKV, maed_gemm_nt(sv + L.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, sv + L.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
+    PROF(PROF_ATTN_TM_FWD, maed_attn_temporal_fwd(sv + L.qkv, sv + L.xt, (float*)(sv + L.lse_t), d->F, d->P, d->H, d->T, scale, dt, stream));
+    PROF(PROF_ATTN_SP_FWD, maed_attn_spatial_fwd(sv + L.qkv, sv + L.xs, (float*)(sv + L.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
     MAED_PROPAGATE(maed_st_colmean(sv + L.xs, sv + L.xt, sv + L.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
     MAED_PROPAGATE(maed_gemm_nt(sv + L.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
     MAED_PROPAGATE(maed_st_mix_fwd(sv + L.xs, sv + L.xt, logits, sv + L.mix, d->F, d->P, C, dt, stream));
     MAED_PROPAGATE(maed_gemm_nt(sv + L.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, sv + L.xmid, C, nullptr, x_in, C, 1, gi, stream));
     MAED_PROPAGATE(maed_layernorm_fwd((const float*)(sv + L.xmid), C, p->ln2_g, p->ln2_b, sv + L.ln2, dt, (float*)(sv + L.mean2), (float*)(sv + L.rstd2), M, C, d->eps, stream));
-    MAED_PROPAGATE(maed_gemm_nt(sv + L.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, sv + L.hact, Hd, sv + L.hpre, nullptr, 0, 1, gi, stream));
-    MAED_PROPAGATE(maed_gemm_nt(sv + L.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, sv + L.xmid, C, 1, gi, stream));
+    PROF(PROF_GEMM_FC1, maed_gemm_nt(sv + L.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, sv + L.hact, Hd, sv + L.hpre, nullptr, 0, 1, gi, stream));
+    PROF(PROF_GEMM_FC2, maed_gemm_nt(sv + L.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, sv + L.xmid, C, 1, gi, stream));
     return MAED_OK;
 }
 
@@ -139,31 +174,31 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
     // ---- MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid)))) ------------------------------------------------
     MAED_PROPAGATE(maed_transpose_cast(dx_out, MAED_F32, C, M, C, sc + S.dyt, Mp, sc + S.dyc, C, g->b_fc2, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sv + L.hact, dt, Hd, M, Hd, sc + S.bigT, Mp, nullptr, 0, nullptr, dt, stream));
-    MAED_PROPAGATE(wgrad(sc + S.dyt, sc + S.bigT, C, Hd, Mp, g->w_fc2, *d, stream));
+    PROF(PROF_GEMM_WGRAD, wgrad(sc + S.dyt, sc + S.bigT, C, Hd, Mp, g->w_fc2, *d, stream));
     MAED_PROPAGATE(maed_gemm_nt(sc + S.dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
     MAED_PROPAGATE(maed_transpose_cast(sc + S.bigA, dt, Hd, M, Hd, sc + S.bigT, Mp, nullptr, 0, g->b_fc1, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sv + L.ln2, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
-    MAED_PROPAGATE(wgrad(sc + S.bigT, sc + S.xT, Hd, C, Mp, g->w_fc1, *d, stream));
+    PROF(PROF_GEMM_WGRAD, wgrad(sc + S.bigT, sc + S.xT, Hd, C, Mp, g->w_fc1, *d, stream));
     MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
     MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
                                       dx_out, dxmid, g->ln2_g, g->ln2_b, M, C, stream));
     // ---- attention: x_mid = x_in + proj(mix(x_s, x_t)) ---------------------------------------------------
     MAED_PROPAGATE(maed_transpose_cast(dxmid, MAED_F32, C, M, C, sc + S.dyt, Mp, sc + S.dyc, C, g->b_proj, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sv + L.mix, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
-    MAED_PROPAGATE(wgrad(sc + S.dyt, sc + S.xT, C, C, Mp, g->w_proj, *d, stream));
+    PROF(PROF_GEMM_WGRAD, wgrad(sc + S.dyt, sc + S.xT, C, C, Mp, g->w_proj, *d, stream));
     MAED_PROPAGATE(maed_gemm_nt(sc + S.dyc, C, p->wt_proj, C, M, C, C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
     MAED_PROPAGATE(maed_st_mix_bwd_reduce(sc + S.act, sv + L.xs, sv + L.xt, logits, sc + S.dlog, (float*)(sc + S.ws), d->F, d->P, C, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sc + S.dlog, dt, 2 * C, d->F, 2 * C, sc + S.dlogT, Fp, nullptr, 0, g->b_ts, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sv + L.means, dt, 2 * C, d->F, 2 * C, sc + S.meansT, Fp, nullptr, 0, nullptr, dt, stream));
-    MAED_PROPAGATE(wgrad(sc + S.dlogT, sc + S.meansT, 2 * C, 2 * C, Fp, g->w_ts, *d, stream));
+    PROF(PROF_GEMM_WGRAD, wgrad(sc + S.dlogT, sc + S.meansT, 2 * C, 2 * C, Fp, g->w_ts, *d, stream));
     MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
     MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
-    MAED_PROPAGATE(maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
-    MAED_PROPAGATE(maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
+    PROF(PROF_ATTN_TM_BWD, maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
+    PROF(PROF_ATTN_SP_BWD, maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
                                          MAED_IMPL_AUTO, stream));
     MAED_PROPAGATE(maed_transpose_cast(sc + S.bigA, dt, 3 * C, M, 3 * C, sc + S.bigT, Mp, nullptr, 0, g->b_qkv, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sv + L.ln1, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
-    MAED_PROPAGATE(wgrad(sc + S.bigT, sc + S.xT, 3 * C, C, Mp, g->w_qkv, *d, stream));
+    PROF(PROF_GEMM_WGRAD, wgrad(sc + S.bigT, sc + S.xT, 3 * C, C, Mp, g->w_qkv, *d, stream));
     MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
     MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in,
                                       g->ln1_g, g->ln1_b, M, C, stream));
