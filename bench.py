@@ -29,6 +29,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CFG = dict(clips=8, T=16, img=224, depth=6, heads=8, dim=512, hidden=1024)
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
@@ -77,6 +84,7 @@ def cpu_baseline(budget_s=25.0):
     t0 = time.perf_counter()
     step()  # warm-up (also bounds the sample: if one step is slow we time fewer)
     warm = time.perf_counter() - t0
+    log(f"cpu_baseline: warm-up step {warm:.1f}s on {cores} threads")
     n = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
     t0 = time.perf_counter()
     for _ in range(n):
@@ -112,6 +120,7 @@ def main():
     from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
     lib = L.lib()  # raises if libmaed_hip.so is missing: no fallback
 
+    log(f"building model ({args.dtype}) on {dev}")
     model = build_model(dtype, dev)
     gen = torch.Generator().manual_seed(1000 + rank)
     clip = torch.randn(CFG["clips"], CFG["T"], 3, CFG["img"], CFG["img"], generator=gen).to(dev)
@@ -142,8 +151,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        t1 = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {time.perf_counter() - t1:.3f}s")
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -155,6 +167,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
     ms_per_step = 1e3 * dt / args.steps
+    log(f"timed {args.steps} steps: {ms_per_step:.2f} ms/step")
 
     # ---- in-situ kernel timing for the roofline (extra steps, events on the launch stream) ----------------
     kernels = {}
@@ -201,6 +214,7 @@ def main():
                             note="algorithmic bytes = q,k,v read + o written once (8*P*C*F B bf16) + lse; in-situ hipEvent timing over "
                                  f"{cnt[0]} launches inside {nprof} extra steps")
 
+    log(f"kernel timing done: {json.dumps(kernels)}")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -311,6 +311,217 @@ __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict_
 }
 
 // ==================================================================================================
+// MFMA backward (bf16): flash-style recompute from the saved log-sum-exp, two kernels, whole head in LDS.
+//   dQ pass : wave per 32 queries.  S^T = K Q^T and dP^T = V dO^T (lane = query, 16 keys per tile in
+//             registers) -> dS in registers -> dQ^T += K^T dS^T with dS as the MFMA B fragment (no LDS
+//             round trip, same k-slot trick as the forward) and K^T read from a transposed LDS image.
+//   dK/dV   : wave per 32 keys.  S = Q K^T and dP = dO V^T (lane = key, 16 queries per tile) ->
+//             dV^T += dO^T P, dK^T += Q^T dS with P / dS as B fragments, Q^T / dO^T transposed in LDS.
+// ==================================================================================================
+__device__ __forceinline__ void stage_rowmajor_and_transposed(unsigned short* rows, unsigned short* tr, int VLD,
+                                                              const bf16* src, int64_t ld, int P, int tid, int nthr) {
+    for (int idx = tid; idx < P * 8; idx += nthr) {
+        const int p = idx >> 3, c8 = (idx & 7) * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)p * ld + c8);
+        if (rows) *reinterpret_cast<uint4*>(rows + p * KLD + c8) = v;
+        if (tr) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tr[(c8 + 2 * j) * VLD + p] = (unsigned short)(w[j] & 0xffffu);
+                tr[(c8 + 2 * j + 1) * VLD + p] = (unsigned short)(w[j] >> 16);
+            }
+        }
+    }
+    if (tr)
+        for (int idx = tid; idx < D * (VLD - P); idx += nthr) tr[(idx / (VLD - P)) * VLD + P + idx % (VLD - P)] = 0;
+}
+
+__device__ __forceinline__ bf16x8_t lds_frag_tr(const unsigned short* base) {  // 4 + 4 elements, 8 apart
+    union { bf16x8_t v; uint2 u[2]; } f;
+    f.u[0] = *reinterpret_cast<const uint2*>(base);
+    f.u[1] = *reinterpret_cast<const uint2*>(base + 8);
+    return f.v;
+}
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& x, int st) {
+    union { bf16x8_t v; uint32_t u[4]; } f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.u[j] = pack_bf2(x[8 * st + 2 * j], x[8 * st + 2 * j + 1]);
+    return f.v;
+}
+__device__ __forceinline__ void store_rowT(bf16* row, const f32x16_t (&acc)[2], int hi, int accumulate) {
+    // acc[et][4g+i] = value at e = et*32 + 8g + 4hi + i of this lane's row
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int e0 = et * 32 + 8 * g + 4 * hi;
+            float v[4] = {acc[et][4 * g], acc[et][4 * g + 1], acc[et][4 * g + 2], acc[et][4 * g + 3]};
+            if (accumulate) { float o[4]; ld4(row + e0, o); v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+            st4(row + e0, v);
+        }
+}
+
+__global__ __launch_bounds__(640) void attn_sp_bwd_dq_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                            const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                            bf16* __restrict__ dqkv, int accumulate, int P, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int Pk = (P + 31) & ~31, VLD = Pk + 4;
+    unsigned short* Ks = smem;
+    unsigned short* Vs = Ks + (size_t)P * KLD;
+    unsigned short* Kt = Vs + (size_t)P * KLD;
+    const int f = blockIdx.x / H, h = blockIdx.x % H, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16* base = qkv + (int64_t)f * P * ld + h * D;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    stage_rowmajor_and_transposed(Ks, Kt, VLD, base + C, ld, P, tid, nthr);
+    stage_rowmajor_and_transposed(Vs, nullptr, VLD, base + 2 * C, ld, P, tid, nthr);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int q = wave * 32 + l31;
+    if (wave * 32 >= P) return;
+    const int qc = q < P ? q : P - 1;
+    const bf16* orow = o + ((int64_t)f * P + qc) * C + h * D;
+    const bf16* dorow = d_o + ((int64_t)f * P + qc) * C + h * D;
+    bf16x8_t qf[4], dof[4];
+    float Dq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        qf[t] = *reinterpret_cast<const bf16x8_t*>(base + (int64_t)qc * ld + t * 16 + hi * 8);
+        dof[t] = *reinterpret_cast<const bf16x8_t*>(dorow + t * 16 + hi * 8);
+        float a[8], b[8];
+        ld8(dorow + t * 16 + hi * 8, a); ld8(orow + t * 16 + hi * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Dq = fmaf(a[j], b[j], Dq);
+    }
+    Dq += __shfl_xor(Dq, 32, 64);
+    const float l2e = 1.44269504088896340736f;
+    const float L2 = lse[((int64_t)f * H + h) * P + qc] * l2e, sl2e = scale * l2e;
+    f32x16_t dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    const int nkt = Pk / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        int krow = kt * 32 + l31;
+        if (krow > P - 1) krow = P - 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + krow * KLD + t * 16 + hi * 8);
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + krow * KLD + t * 16 + hi * 8);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[t], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float p = (k < P) ? exp2f(s[r] * sl2e - L2) : 0.f;
+            s[r] = p * (dp[r] - Dq) * scale;  // dS
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8_t dsf = pack_frag(s, st);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                const bf16x8_t ktf = lds_frag_tr(Kt + (et * 32 + l31) * VLD + kt * 32 + 16 * st + 4 * hi);
+                dq[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[et], 0, 0, 0);
+            }
+        }
+    }
+    if (q < P) store_rowT(dqkv + ((int64_t)f * P + q) * ld + h * D, dq, hi, accumulate);
+}
+
+__global__ __launch_bounds__(640) void attn_sp_bwd_dkv_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                             const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                             bf16* __restrict__ dqkv, int accumulate, int P, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int Pk = (P + 31) & ~31, VLD = Pk + 4;
+    unsigned short* Qs = smem;
+    unsigned short* dOs = Qs + (size_t)P * KLD;
+    unsigned short* Qt = dOs + (size_t)P * KLD;
+    unsigned short* dOt = Qt + (size_t)D * VLD;
+    float* Ls = reinterpret_cast<float*>(dOt + (size_t)D * VLD);
+    float* Ds = Ls + Pk;
+    const int f = blockIdx.x / H, h = blockIdx.x % H, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16* base = qkv + (int64_t)f * P * ld + h * D;
+    const bf16* obase = o + (int64_t)f * P * C + h * D;
+    const bf16* dobase = d_o + (int64_t)f * P * C + h * D;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    stage_rowmajor_and_transposed(Qs, Qt, VLD, base, ld, P, tid, nthr);
+    stage_rowmajor_and_transposed(dOs, dOt, VLD, dobase, C, P, tid, nthr);
+    const float l2e = 1.44269504088896340736f;
+    for (int qi = tid; qi < Pk; qi += nthr) {
+        float dsum = 0.f, L = 0.f;
+        if (qi < P) {
+#pragma unroll
+            for (int c = 0; c < D; c += 8) {
+                float a[8], b[8];
+                ld8(dobase + (int64_t)qi * C + c, a); ld8(obase + (int64_t)qi * C + c, b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum = fmaf(a[j], b[j], dsum);
+            }
+            L = lse[((int64_t)f * H + h) * P + qi] * l2e;
+        }
+        Ds[qi] = dsum; Ls[qi] = L;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    if (wave * 32 >= P) return;
+    const int k = wave * 32 + l31;
+    const int kc = k < P ? k : P - 1;
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        kf[t] = *reinterpret_cast<const bf16x8_t*>(base + C + (int64_t)kc * ld + t * 16 + hi * 8);
+        vf[t] = *reinterpret_cast<const bf16x8_t*>(base + 2 * C + (int64_t)kc * ld + t * 16 + hi * 8);
+    }
+    const float sl2e = scale * l2e;
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+    const int nqt = Pk / 32;
+    for (int qt = 0; qt < nqt; ++qt) {
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        int qrow = qt * 32 + l31;
+        if (qrow > P - 1) qrow = P - 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8_t qfr = *reinterpret_cast<const bf16x8_t*>(Qs + qrow * KLD + t * 16 + hi * 8);
+            const bf16x8_t dofr = *reinterpret_cast<const bf16x8_t*>(dOs + qrow * KLD + t * 16 + hi * 8);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[t], s, 0, 0, 0);     // D[q][k]: lane = key
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[t], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float p = (qq < P) ? exp2f(s[r] * sl2e - Ls[qq]) : 0.f;
+            dp[r] = p * (dp[r] - Ds[qq]) * scale;  // dS
+            s[r] = p;                              // P
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8_t pf = pack_frag(s, st), dsf = pack_frag(dp, st);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                const int off = (et * 32 + l31) * VLD + qt * 32 + 16 * st + 4 * hi;
+                dv[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(dOt + off), pf, dv[et], 0, 0, 0);
+                dk[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Qt + off), dsf, dk[et], 0, 0, 0);
+            }
+        }
+    }
+    if (k < P) {
+        bf16* drow = dqkv + ((int64_t)f * P + k) * ld + h * D;
+        store_rowT(drow + C, dk, hi, accumulate);
+        store_rowT(drow + 2 * C, dv, hi, accumulate);
+    }
+}
+
+// ==================================================================================================
 static size_t valu_lds_bytes(int P, bool bwd_dkv) { return ((size_t)2 * P * LDF + (bwd_dkv ? 2 * P : 0)) * sizeof(float); }
 
 extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F, int P, int H, float scale, int dtype,
@@ -362,8 +573,29 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
     MAED_CHECK_ARG(qkv && o && d_o && lse && dqkv, MAED_ERR_ARG, "attn_spatial_bwd: null pointer");
     MAED_CHECK_ARG(F >= 0 && P > 0 && H > 0, MAED_ERR_SHAPE, "attn_spatial_bwd: bad extents");
     MAED_CHECK_ARG(valu_lds_bytes(P, true) <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_bwd: P=%d too large for LDS", P);
-    MAED_CHECK_ARG(impl != MAED_IMPL_MFMA, MAED_ERR_UNSUPPORTED, "attn_spatial_bwd: MFMA backward not implemented yet");
+    MAED_CHECK_ARG(!(impl == MAED_IMPL_MFMA && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED, "attn_spatial_bwd: MFMA path is bf16 only");
     if (F == 0) return MAED_OK;
+    const bool mfma_fits = ((P + 31) / 32) <= 10;  // 640-thread workgroups (register budget 168/lane)
+    MAED_CHECK_ARG(!(impl == MAED_IMPL_MFMA && !mfma_fits), MAED_ERR_SHAPE, "attn_spatial_bwd(mfma): P=%d > 320", P);
+    if (dtype == MAED_BF16 && impl != MAED_IMPL_VALU && mfma_fits) {
+        const int Pk = (P + 31) & ~31;
+        const size_t lds_dq = ((size_t)2 * P * KLD + (size_t)D * (Pk + 4)) * 2;
+        const size_t lds_dkv = ((size_t)2 * P * KLD + (size_t)2 * D * (Pk + 4)) * 2 + (size_t)2 * Pk * sizeof(float);
+        MAED_CHECK_ARG(lds_dkv <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_bwd(mfma): P=%d needs %zu B LDS", P, lds_dkv);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)attn_sp_bwd_dq_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)attn_sp_bwd_dkv_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipStream_t s = (hipStream_t)stream;
+        hipLaunchKernelGGL(attn_sp_bwd_dq_mfma, dim3(F * H), dim3(64 * (Pk / 32)), lds_dq, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse,
+                           (bf16*)dqkv, accumulate, P, H, scale);
+        hipLaunchKernelGGL(attn_sp_bwd_dkv_mfma, dim3(F * H), dim3(64 * (Pk / 32)), lds_dkv, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse,
+                           (bf16*)dqkv, accumulate, P, H, scale);
+        MAED_CHECK_LAUNCH("attn_spatial_bwd(mfma)");
+        return MAED_OK;
+    }
     if (dtype == MAED_F32) launch_bwd_valu<float>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     else if (dtype == MAED_BF16) launch_bwd_valu<bf16>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     else { maed_set_error("attn_spatial_bwd: bad dtype"); return MAED_ERR_ARG; }

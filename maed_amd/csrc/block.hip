@@ -195,7 +195,7 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
     MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
     PROF(PROF_ATTN_TM_BWD, maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
     PROF(PROF_ATTN_SP_BWD, maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
-                                         MAED_IMPL_AUTO, stream));
+                                         d->impl == MAED_IMPL_VALU ? MAED_IMPL_VALU : MAED_IMPL_AUTO, stream));
     MAED_PROPAGATE(maed_transpose_cast(sc + S.bigA, dt, 3 * C, M, 3 * C, sc + S.bigT, Mp, nullptr, 0, g->b_qkv, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sv + L.ln1, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
     PROF(PROF_GEMM_WGRAD, wgrad(sc + S.bigT, sc + S.xT, 3 * C, C, Mp, g->w_qkv, *d, stream));

@@ -1,0 +1,53 @@
+"""Where does a cfg3 train step spend its time?  Phase timings (wall, synchronised) + in-situ kernel events.
+Diagnostic only: python scripts/diag_step.py [--dtype bf16]"""
+import argparse, ctypes, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from maed_amd import _lib as L
+from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+
+ap = argparse.ArgumentParser(); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--clips", type=int, default=8)
+args = ap.parse_args()
+dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+dev = torch.device("cuda", 0)
+bench.CFG["clips"] = args.clips
+T0 = time.perf_counter()
+def P(msg): print(f"[diag +{time.perf_counter()-T0:7.1f}s] {msg}", flush=True)
+def timed(name, fn, n=3):
+    for i in range(n):
+        torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        P(f"{name} #{i}: {1e3*(time.perf_counter()-t):9.2f} ms")
+    return r
+P("build model"); model = bench.build_model(dtype, dev).train()
+arena = ParamArena(model); buck = GradBucketer(arena, model); opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=buck)
+gen = torch.Generator().manual_seed(0)
+clip = torch.randn(bench.CFG["clips"], 16, 3, 224, 224, generator=gen).to(dev)
+img = clip.reshape(-1, 3, 224, 224)
+tgt = bench.make_targets(bench.CFG["clips"], 16, dev, gen)
+bb = model.encoder.patch_embed.backbone
+with torch.no_grad():
+    timed("backbone fwd (no grad)", lambda: bb(img))
+    timed("patch_embed fwd (no grad)", lambda: model.encoder.patch_embed(img))
+    tok = timed("encoder.forward_tokens (no grad)", lambda: model.encoder.forward_tokens(img, 16))
+    timed("6 blocks fwd (no grad)", lambda: [blk(tok, 16) for blk in model.encoder.blocks][-1])
+def bb_train():
+    arena.zero_grad(); y = bb(img); y.float().square().mean().backward(); return y
+timed("backbone fwd+bwd", bb_train)
+tokg = tok.detach().clone().requires_grad_(True)
+def ste_train():
+    arena.zero_grad(); x = tokg
+    for blk in model.encoder.blocks: x = blk(x, 16)
+    x.square().mean().backward()
+timed("6 blocks fwd+bwd", ste_train)
+def step():
+    opt.zero_grad(); loss = bench.proxy_loss(model(clip), tgt); loss.backward(); opt.step(); return loss
+timed("full train step", step, n=4)
+lib = L.lib(); lib.maed_prof_enable(1); step(); torch.cuda.synchronize()
+ms = (ctypes.c_double * 8)(); cnt = (ctypes.c_int * 8)(); lib.maed_prof_collect(ms, cnt); lib.maed_prof_enable(0)
+names = ["attn_sp_fwd", "attn_tm_fwd", "gemm_qkv", "gemm_fc1", "gemm_fc2", "attn_sp_bwd", "attn_tm_bwd", "gemm_wgrad"]
+P("in-situ per-launch us: " + json.dumps({n: round(1e3 * ms[i] / max(cnt[i], 1), 1) for i, n in enumerate(names)}))
+P("in-situ total ms/step: " + json.dumps({n: round(ms[i], 2) for i, n in enumerate(names)}))
+model.eval()
+with torch.no_grad():
+    timed("inference forward (cfg2)", lambda: model(clip))

@@ -150,9 +150,9 @@ def test_attn_spatial_fwd_mfma_spiked_scores():
     report("attn_spatial_fwd[bf16-mfma, spiked]", o.float(), ref, **tol(torch.bfloat16))
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("Fr,P,H", [(2, 5, 2), (2, 197, 2)])
-def test_attn_spatial_bwd(dtype, Fr, P, H):
+@pytest.mark.parametrize("name,dtype,impl", ATTN_CASES)
+@pytest.mark.parametrize("Fr,P,H", [(2, 5, 2), (2, 197, 2), (1, 257, 1), (1, 64, 1)])
+def test_attn_spatial_bwd(name, dtype, impl, Fr, P, H):
     ops, _ = _ops()
     qkv = _qkv(Fr, P, H, dtype, seed=3)
     do = q(rnd(Fr, P, 64 * H, seed=4), dtype)
@@ -162,11 +162,13 @@ def test_attn_spatial_bwd(dtype, Fr, P, H):
     oref.backward(do.double())
     qd = qkv.to(DEV).to(dtype)
     o, lse = ops.attn_spatial_fwd(qd, H, 1)
-    dqkv = ops.attn_spatial_bwd(qd, o, do.to(DEV).to(dtype), lse, H)
-    report(f"attn_spatial_bwd[{dtype},P{P}]", dqkv.float(), x.grad, **tol(dtype, 0.5))
+    dqkv = ops.attn_spatial_bwd(qd, o, do.to(DEV).to(dtype), lse, H, impl=impl)
+    C = 64 * H
+    for nm, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        report(f"attn_spatial_bwd.{nm}[{name},P{P}]", dqkv[..., sl].float(), x.grad[..., sl], **tol(dtype, 0.5))
     base = torch.ones_like(dqkv)
-    dq2 = ops.attn_spatial_bwd(qd, o, do.to(DEV).to(dtype), lse, H, dqkv=base.clone(), accumulate=True)
-    report(f"attn_spatial_bwd.accumulate[{dtype}]", dq2.float(), x.grad + 1.0, **tol(dtype, 0.5))
+    dq2 = ops.attn_spatial_bwd(qd, o, do.to(DEV).to(dtype), lse, H, dqkv=base.clone(), accumulate=True, impl=impl)
+    report(f"attn_spatial_bwd.accumulate[{name}]", dq2.float(), x.grad + 1.0, **tol(dtype, 0.5))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
