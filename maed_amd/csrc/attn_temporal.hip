@@ -142,6 +142,158 @@ __global__ __launch_bounds__(256) void attn_tm_bwd_kernel(const T* __restrict__ 
     store_row(dqkv + row * ld + C + h * D, acc, 1.f, accumulate);
 }
 
+// ==================================================================================================
+// LDS-staged variants (used when T divides the workgroup): a workgroup owns GP token positions x T frames
+// of one (clip, head); the K/V (and for the backward Q/dO) rows of those GP*T (frame, token) pairs are
+// staged ONCE in LDS with fully coalesced 128-B line loads, then every thread (gp, t) walks the T rows of
+// its group from LDS (broadcast reads; a 16-B skew per group keeps the groups of a wave on distinct banks).
+// HBM traffic = the algorithmic minimum (qkv read once, o written once).
+// ==================================================================================================
+template <typename T> struct RowGeom { static constexpr int RS = D * (int)sizeof(T); };  // row bytes
+
+template <typename T>
+__device__ __forceinline__ T* lds_row(char* base, int r, int gp) { return reinterpret_cast<T*>(base + (size_t)r * RowGeom<T>::RS + gp * 16); }
+
+// cooperative stage: rows r = gp*Tn + t  <-  src(frame n*Tn+t, token p0+gp) ; 16-B chunks, 8|16 per row
+template <typename T>
+__device__ __forceinline__ void stage_group_rows(char* dst, const T* src_base, int64_t ld, int64_t n, int Tn, int P, int p0, int GP, int nthr) {
+    constexpr int CH = RowGeom<T>::RS / 16;         // chunks per row
+    constexpr int EPC = 16 / (int)sizeof(T);        // elements per chunk
+    for (int idx = threadIdx.x; idx < GP * Tn * CH; idx += nthr) {
+        const int r = idx / CH, c = idx % CH, gp = r / Tn, t = r % Tn;
+        int p = p0 + gp; if (p > P - 1) p = P - 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(src_base + ((n * Tn + t) * P + p) * ld + c * EPC);
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds_row<T>(dst, r, gp)) + c * 16) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_tm_fwd_lds(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+                                                       int P, int H, int Tn, int GP, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int C = H * D; const int64_t ld = 3 * (int64_t)C;
+    const int chunks = (P + GP - 1) / GP;
+    const int pc = blockIdx.x % chunks; int r0 = blockIdx.x / chunks;
+    const int h = r0 % H; const int64_t n = r0 / H;
+    const int p0 = pc * GP, nthr = GP * Tn;
+    const size_t arr = (size_t)GP * Tn * RowGeom<T>::RS + GP * 16;
+    char* Ks = sm; char* Vs = sm + arr;
+    stage_group_rows<T>(Ks, qkv + C + h * D, ld, n, Tn, P, p0, GP, nthr);
+    stage_group_rows<T>(Vs, qkv + 2 * C + h * D, ld, n, Tn, P, p0, GP, nthr);
+    __syncthreads();
+    const int gp = threadIdx.x / Tn, t = threadIdx.x % Tn;
+    const int p = p0 + gp;
+    if (p >= P) return;
+    const int64_t f = n * Tn + t;
+    float qv[D], acc[D];
+    load_row(qkv + (f * P + p) * ld + h * D, qv);
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int t2 = 0; t2 < Tn; ++t2) {
+        const float s = dot_row(lds_row<T>(Ks, gp * Tn + t2, gp), qv) * scale;
+        const float mn = fmaxf(m, s);
+        const float a = __expf(m - mn), pr = __expf(s - mn);
+        l = l * a + pr;
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] *= a;
+        axpy_row(lds_row<T>(Vs, gp * Tn + t2, gp), pr, acc);
+        m = mn;
+    }
+    store_row(o + (f * P + p) * C + h * D, acc, 1.f / l, 0);
+    lse[(f * H + h) * P + p] = m + __logf(l);
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void attn_tm_bwd_lds(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
+                                                       const float* __restrict__ lse, T* __restrict__ dqkv, int accumulate,
+                                                       int P, int H, int Tn, int GP, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int C = H * D; const int64_t ld = 3 * (int64_t)C;
+    const int chunks = (P + GP - 1) / GP;
+    const int pc = blockIdx.x % chunks; int r0 = blockIdx.x / chunks;
+    const int h = r0 % H; const int64_t n = r0 / H;
+    const int p0 = pc * GP, nthr = GP * Tn;
+    const size_t arr = (size_t)GP * Tn * RowGeom<T>::RS + GP * 16;
+    char* Qs = sm; char* Ks = sm + arr; char* Vs = sm + 2 * arr; char* dOs = sm + 3 * arr;
+    float* Ls = reinterpret_cast<float*>(sm + 4 * arr); float* Ds = Ls + nthr;
+    stage_group_rows<T>(Qs, qkv + h * D, ld, n, Tn, P, p0, GP, nthr);
+    stage_group_rows<T>(Ks, qkv + C + h * D, ld, n, Tn, P, p0, GP, nthr);
+    stage_group_rows<T>(Vs, qkv + 2 * C + h * D, ld, n, Tn, P, p0, GP, nthr);
+    stage_group_rows<T>(dOs, d_o + h * D, (int64_t)C, n, Tn, P, p0, GP, nthr);
+    const int gp = threadIdx.x / Tn, t = threadIdx.x % Tn;
+    const int p = p0 + gp;
+    const int pcl = p < P ? p : P - 1;
+    const int64_t f = n * Tn + t;
+    const int64_t row = f * P + pcl;
+    const int g0 = gp * Tn;
+    float a[D], b[D], acc[D];
+    load_row(d_o + row * C + h * D, b);                       // dO (own row)
+    const float Dq = dot_row(o + row * C + h * D, b);
+    const float L = lse[(f * H + h) * P + pcl];
+    Ds[threadIdx.x] = Dq; Ls[threadIdx.x] = L;
+    __syncthreads();
+    if (p >= P) return;
+    // ---- as query t: dQ = sum_t2 ds[t][t2] K[t2] ----
+    load_row(lds_row<T>(Qs, g0 + t, gp), a);
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int t2 = 0; t2 < Tn; ++t2) {
+        const T* kr = lds_row<T>(Ks, g0 + t2, gp);
+        const float pr = __expf(dot_row(kr, a) * scale - L);
+        const float ds = pr * (dot_row(lds_row<T>(Vs, g0 + t2, gp), b) - Dq) * scale;
+        axpy_row(kr, ds, acc);
+    }
+    store_row(dqkv + row * ld + h * D, acc, 1.f, accumulate);
+    // ---- as key t: dV = sum_t1 p[t1][t] dO[t1] ----
+    load_row(lds_row<T>(Ks, g0 + t, gp), a);                   // k (own row)
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int t1 = 0; t1 < Tn; ++t1) {
+        const float pr = __expf(dot_row(lds_row<T>(Qs, g0 + t1, gp), a) * scale - Ls[g0 + t1]);
+        axpy_row(lds_row<T>(dOs, g0 + t1, gp), pr, acc);
+    }
+    store_row(dqkv + row * ld + 2 * C + h * D, acc, 1.f, accumulate);
+    // ---- as key t: dK = sum_t1 ds[t1][t] Q[t1] ----
+    load_row(lds_row<T>(Vs, g0 + t, gp), b);                   // v (own row)
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int t1 = 0; t1 < Tn; ++t1) {
+        const T* q1 = lds_row<T>(Qs, g0 + t1, gp);
+        const float pr = __expf(dot_row(q1, a) * scale - Ls[g0 + t1]);
+        const float ds = pr * (dot_row(lds_row<T>(dOs, g0 + t1, gp), b) - Ds[g0 + t1]) * scale;
+        axpy_row(q1, ds, acc);
+    }
+    store_row(dqkv + row * ld + C + h * D, acc, 1.f, accumulate);
+}
+
+template <typename T>
+static bool launch_tm_fwd_lds(const void* qkv, void* o, float* lse, int F, int P, int H, int Tn, float scale, hipStream_t s) {
+    if (Tn > 256 || 256 % Tn != 0) return false;
+    const int GP = 256 / Tn;
+    const size_t lds = 2 * ((size_t)256 * RowGeom<T>::RS + GP * 16);
+    if (lds > 160 * 1024) return false;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)attn_tm_fwd_lds<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const int chunks = (P + GP - 1) / GP;
+    hipLaunchKernelGGL((attn_tm_fwd_lds<T>), dim3((unsigned)((F / Tn) * H * chunks)), dim3(256), lds, s, (const T*)qkv, (T*)o, lse, P, H, Tn, GP, scale);
+    return true;
+}
+template <typename T>
+static bool launch_tm_bwd_lds(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int P,
+                              int H, int Tn, float scale, hipStream_t s) {
+    if (Tn > 128 || 128 % Tn != 0) return false;
+    const int GP = 128 / Tn;
+    const size_t lds = 4 * ((size_t)128 * RowGeom<T>::RS + GP * 16) + 2 * 128 * sizeof(float);
+    if (lds > 160 * 1024) return false;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)attn_tm_bwd_lds<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const int chunks = (P + GP - 1) / GP;
+    hipLaunchKernelGGL((attn_tm_bwd_lds<T>), dim3((unsigned)((F / Tn) * H * chunks)), dim3(128), lds, s, (const T*)qkv, (const T*)o, (const T*)d_o,
+                       lse, (T*)dqkv, accumulate, P, H, Tn, GP, scale);
+    return true;
+}
+
 extern "C" int maed_attn_temporal_fwd(const void* qkv, void* o, float* lse, int F, int P, int H, int T, float scale, int dtype,
                                       void* stream) {
     MAED_CHECK_ARG(qkv && o && lse, MAED_ERR_ARG, "attn_temporal_fwd: null pointer");
@@ -150,8 +302,10 @@ extern "C" int maed_attn_temporal_fwd(const void* qkv, void* o, float* lse, int 
     const int64_t total = (int64_t)F * H * P;
     if (total == 0) return MAED_OK;
     dim3 grid((unsigned)((total + 255) / 256));
-    MAED_DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((attn_tm_fwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                       (const TT*)qkv, (TT*)o, lse, total, P, H, T, scale));
+    MAED_DISPATCH_DTYPE(dtype, TT, {
+        if (!launch_tm_fwd_lds<TT>(qkv, o, lse, F, P, H, T, scale, (hipStream_t)stream))
+            hipLaunchKernelGGL((attn_tm_fwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, (TT*)o, lse, total, P, H, T, scale);
+    });
     MAED_CHECK_LAUNCH("attn_temporal_fwd");
     return MAED_OK;
 }
@@ -163,9 +317,11 @@ extern "C" int maed_attn_temporal_bwd(const void* qkv, const void* o, const void
     const int64_t total = (int64_t)F * H * P;
     if (total == 0) return MAED_OK;
     dim3 grid((unsigned)((total + 255) / 256));
-    MAED_DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((attn_tm_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                       (const TT*)qkv, (const TT*)o, (const TT*)d_o, lse, (TT*)dqkv, accumulate,
-                                                       total, P, H, T, scale));
+    MAED_DISPATCH_DTYPE(dtype, TT, {
+        if (!launch_tm_bwd_lds<TT>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, T, scale, (hipStream_t)stream))
+            hipLaunchKernelGGL((attn_tm_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, (const TT*)o, (const TT*)d_o, lse,
+                               (TT*)dqkv, accumulate, total, P, H, T, scale);
+    });
     MAED_CHECK_LAUNCH("attn_temporal_bwd");
     return MAED_OK;
 }

@@ -117,7 +117,7 @@ class KTD(nn.Module):
         out = self.smpl(betas=pred_shape, body_pose=rotmat[:, 1:], global_orient=rotmat[:, 0].unsqueeze(1), pose2rot=False)
         verts, joints = out.vertices[:nt], out.joints[:nt]
         if J_regressor is not None:
-            joints = torch.matmul(J_regressor[None].expand(nt, -1, -1).to(verts.device), verts)
+            joints = self.smpl.regress_joints(J_regressor.to(verts.device, verts.dtype), verts)
         kp2d = projection(joints, pred_cam)
         aa = rotation_matrix_to_angle_axis(rotmat.reshape(-1, 3, 3)).reshape(nt, -1)
         return dict(theta=torch.cat([pred_cam, aa, pred_shape], dim=1), verts=verts, kp_2d=kp2d, kp_3d=joints, rotmat=rotmat)

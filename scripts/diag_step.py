@@ -8,7 +8,10 @@ from maed_amd import _lib as L
 from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
 
 ap = argparse.ArgumentParser(); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--clips", type=int, default=8)
+ap.add_argument("--miopen-benchmark", action="store_true")
 args = ap.parse_args()
+if args.miopen_benchmark:
+    torch.backends.cudnn.benchmark = True
 dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = torch.device("cuda", 0)
 bench.CFG["clips"] = args.clips
