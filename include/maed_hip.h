@@ -2,9 +2,9 @@
  * maed_hip.h -- C-ABI of libmaed_hip.so: the MI355X (gfx950) kernels behind the MAED hot path.
  *
  * The reference (ziniuwan/maed) has no FFI layer: its hot path is a composition of ATen ops inside
- * lib/models/*.py.  Each entry point below replaces one such composition; the comment on every
+ * lib/models (Python).  Each entry point below replaces one such composition; the comment on every
  * function cites the reference lines (relative to the reference repo root) it stands in for.
- * The host side (maed_amd/*.py) binds these with ctypes from torch.autograd.Functions that sit
+ * The host side (the maed_amd Python package) binds these with ctypes from torch.autograd.Functions that sit
  * inside nn.Modules carrying the reference's class / attribute / state_dict names.
  *
  * Conventions
@@ -199,6 +199,28 @@ int maed_joint_regress_fwd(const float* Jreg, int J, const float* verts, float* 
 int maed_smpl_joints_project_fwd(const float* joints24, const float* verts, const int64_t* extra_vertex_ids,
                                  const float* extra9, const int64_t* joint_map, const float* cam,
                                  const float* joints_override, int Jo, float* kp3d, float* kp2d, int F, void* stream);
+
+/* ---- backbone helpers (the convolutions themselves ride on MIOpen) ---------------------------------- */
+/* StdConv2dSame weight standardisation (resnetv2.py:74-93) for ALL convolutions in one launch.
+ * conv_table: device array of n_convs maed_ws_conv; filters are numbered globally (fstart).  Forward writes
+ * (w - mean)/(std + eps) in the compute dtype, laid out (O, kh, kw, I) = channels_last, at dst_off of `out`,
+ * and stats[2*f] = mean, stats[2*f+1] = 1/(std+eps).  Backward accumulates (+=) into each gw from gout. */
+typedef struct {
+    const float* w;     /* fp32 master weight (O, I, kh, kw) contiguous                      */
+    float* gw;          /* fp32 gradient of w, same layout (backward; NULL in forward)       */
+    const void* gout;   /* grad w.r.t. the standardised weight, (O, kh, kw, I); NULL = skip  */
+    int64_t dst_off;    /* element offset of this convolution inside `out`                   */
+    int32_t O, I, KHW, fstart;
+} maed_ws_conv;
+int maed_weight_std_fwd(const void* conv_table, int n_convs, int n_filters, void* out, int dtype, float* stats, float eps, void* stream);
+int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int dtype, const float* stats, float eps, void* stream);
+/* GroupNorm(32 groups)(+ residual)(+ ReLU) on channels_last activations x (N, HW, C) (resnetv2.py:35-49,189-204):
+ * y = act(GN(x) * gamma + beta [+ residual]).  sums: (N,32,2) doubles written by forward, read by backward. */
+int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
+                       int N, int HW, int C, float eps, int relu, int dtype, void* stream);
+/* dx (and dres = masked dy when dres != NULL); dgamma/dbeta += ; ab_scratch: N*C*2 floats; y needed iff relu */
+int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, void* dx, void* dres,
+                       float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps, int relu, int dtype, void* stream);
 
 /* ---- optimizer: Adam (lib/utils/utils.py:127-132; torch.optim.Adam semantics, L2 weight decay) - */
 /* flat fp32 arenas p,g,m,v of n elements; grad is scaled by gscale first (1/world for DDP mean).

@@ -209,17 +209,42 @@ __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict_
     const bf16* base = qkv + (int64_t)f * P * ld + h * D;
     const int tid = threadIdx.x, nthr = blockDim.x;
 
-    // ---- stage K (row-major, padded) and V^T (transposed while writing) -----------------------------
-    for (int idx = tid; idx < P * 8; idx += nthr) {
-        const int p = idx >> 3, c8 = (idx & 7) * 8;
-        const uint4 kv = *reinterpret_cast<const uint4*>(base + C + (int64_t)p * ld + c8);
-        *reinterpret_cast<uint4*>(Ks + p * KLD + c8) = kv;
-        const uint4 vv = *reinterpret_cast<const uint4*>(base + 2 * C + (int64_t)p * ld + c8);
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+    // this wave's 32 query rows: fragment loads issued first so they fly together with the K/V staging loads
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int q0 = wave * 32;
+    const int q = q0 + l31;
+    const int qc = q < P ? q : P - 1;
+    bf16x8_t qf[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Vt[(c8 + 2 * j) * VLD + p] = (unsigned short)(w[j] & 0xffffu);
-            Vt[(c8 + 2 * j + 1) * VLD + p] = (unsigned short)(w[j] >> 16);
+    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8_t*>(base + (int64_t)qc * ld + t * 16 + hi * 8);
+
+    // ---- stage K (row-major, padded) and V^T (transposed while writing) -----------------------------
+    // blockDim = 64*ceil(P/32) >= 2P threads and P*8 chunks => at most 4 chunks per thread: issue ALL global
+    // loads first (8 x 16 B in flight per lane), then write LDS -- one memory latency instead of four.
+    {
+        uint4 kreg[4], vreg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + i * nthr;
+            if (idx > P * 8 - 1) idx = P * 8 - 1;
+            const int p = idx >> 3, c8 = (idx & 7) * 8;
+            kreg[i] = *reinterpret_cast<const uint4*>(base + C + (int64_t)p * ld + c8);
+            vreg[i] = *reinterpret_cast<const uint4*>(base + 2 * C + (int64_t)p * ld + c8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * nthr;
+            if (idx < P * 8) {
+                const int p = idx >> 3, c8 = (idx & 7) * 8;
+                *reinterpret_cast<uint4*>(Ks + p * KLD + c8) = kreg[i];
+                const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Vt[(c8 + 2 * j) * VLD + p] = (unsigned short)(w[j] & 0xffffu);
+                    Vt[(c8 + 2 * j + 1) * VLD + p] = (unsigned short)(w[j] >> 16);
+                }
+            }
         }
     }
     for (int idx = tid; idx < D * (VLD - P); idx += nthr) {  // zero the key padding of V^T
@@ -228,16 +253,7 @@ __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict_
     }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int q0 = wave * 32;
     if (q0 >= P) return;
-    const int q = q0 + l31;
-    const int qc = q < P ? q : P - 1;
-
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8_t*>(base + (int64_t)qc * ld + t * 16 + hi * 8);
 
     f32x16_t oacc[2];
 #pragma unroll
@@ -320,16 +336,27 @@ __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict_
 // ==================================================================================================
 __device__ __forceinline__ void stage_rowmajor_and_transposed(unsigned short* rows, unsigned short* tr, int VLD,
                                                               const bf16* src, int64_t ld, int P, int tid, int nthr) {
-    for (int idx = tid; idx < P * 8; idx += nthr) {
-        const int p = idx >> 3, c8 = (idx & 7) * 8;
-        const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)p * ld + c8);
-        if (rows) *reinterpret_cast<uint4*>(rows + p * KLD + c8) = v;
-        if (tr) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    // <= 4 chunks of 16 B per thread (blockDim >= 2P): all loads in flight first, then the LDS writes
+    uint4 reg[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tr[(c8 + 2 * j) * VLD + p] = (unsigned short)(w[j] & 0xffffu);
-                tr[(c8 + 2 * j + 1) * VLD + p] = (unsigned short)(w[j] >> 16);
+    for (int i = 0; i < 4; ++i) {
+        int idx = tid + i * nthr;
+        if (idx > P * 8 - 1) idx = P * 8 - 1;
+        reg[i] = *reinterpret_cast<const uint4*>(src + (int64_t)(idx >> 3) * ld + (idx & 7) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * nthr;
+        if (idx < P * 8) {
+            const int p = idx >> 3, c8 = (idx & 7) * 8;
+            if (rows) *reinterpret_cast<uint4*>(rows + p * KLD + c8) = reg[i];
+            if (tr) {
+                const uint32_t w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tr[(c8 + 2 * j) * VLD + p] = (unsigned short)(w[j] & 0xffffu);
+                    tr[(c8 + 2 * j + 1) * VLD + p] = (unsigned short)(w[j] >> 16);
+                }
             }
         }
     }

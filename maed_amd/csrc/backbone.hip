@@ -1,0 +1,341 @@
+// Backbone-side HBM-bound helpers.  The convolutions of the hybrid R50 ride on MIOpen (north_star); what
+// MIOpen does not give us is fused here:
+//   * weight standardisation of ALL StdConv2dSame filters (resnetv2.py:74-93) in ONE launch forward and ONE
+//     launch backward (the reference recomputes it twice per conv call through ~6 ATen ops each; per step
+//     that was ~1000 tiny launches), writing the compute-dtype weights directly in MIOpen's channels_last
+//     (O, kh, kw, I) order;
+//   * GroupNorm(32) + ReLU (resnetv2.py:35-49) on channels_last activations: statistics pass + fused
+//     normalise/affine/ReLU pass forward; backward as one reduction pass + one apply pass with the ReLU
+//     mask recomputed (ATen: three passes plus separate ReLU forward/backward passes).
+#include "common.cuh"
+
+// ---------------------------------------------------------------------------------------------------------
+// weight standardisation, batched over all convolutions of the backbone
+// ---------------------------------------------------------------------------------------------------------
+struct WsConv {           // one per convolution (host builds the table; <= 64 entries)
+    const float* w;       // fp32 master weight (O, I, kh, kw) contiguous
+    float* gw;            // fp32 gradient of w (same layout), += target            (backward only)
+    const void* gout;     // gradient w.r.t. the standardised weight, (O, kh, kw, I) (backward only)
+    int64_t dst_off;      // element offset of this conv in the standardised-weight arena, (O, kh, kw, I)
+    int32_t O, I, KHW, fstart;  // fstart = index of this conv's first filter in the global filter numbering
+};
+#define WS_MAX_CONVS 64
+
+__device__ __forceinline__ int ws_find_conv(const WsConv* __restrict__ tab, int n_convs, int fi) {
+    int c = 0;
+    for (int i = 1; i < n_convs; ++i) c = (fi >= tab[i].fstart) ? i : c;   // wave-uniform, table is tiny
+    return c;
+}
+
+// one wave per filter
+template <typename T>
+__global__ __launch_bounds__(256) void ws_fwd_kernel(const WsConv* __restrict__ tab, int n_convs, int n_filters, T* __restrict__ out,
+                                                     float* __restrict__ stats /* [n_filters][2]: mean, 1/(std+eps) */, float eps) {
+    const int fi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (fi >= n_filters) return;
+    const WsConv d = tab[ws_find_conv(tab, n_convs, fi)];
+    const int K = d.I * d.KHW, o = fi - d.fstart;
+    const float* src = d.w + (int64_t)o * K;
+    float s = 0.f;
+    for (int i = lane; i < K; i += 64) s += src[i];
+    const float mean = wave_sum(s) / (float)K;
+    float q = 0.f;
+    for (int i = lane; i < K; i += 64) { const float c = src[i] - mean; q += c * c; }
+    const float inv = 1.f / (sqrtf(wave_sum(q) / (float)K) + eps);   // biased std, eps added to the std (resnetv2.py:87-88)
+    if (lane == 0) { stats[2 * fi] = mean; stats[2 * fi + 1] = inv; }
+    T* dst = out + d.dst_off + (int64_t)o * K;
+    for (int i = lane; i < K; i += 64) {           // i = ci*KHW + r in the source; destination is (r, ci)
+        const int ci = i / d.KHW, r = i % d.KHW;
+        stf(dst + (int64_t)r * d.I + ci, (src[i] - mean) * inv);
+    }
+}
+
+// dw_i += inv*(g_i - mean(g)) - (w_i - mu) * inv^2 / (K*sigma) * sum_j g_j (w_j - mu),   sigma = 1/inv - eps
+template <typename T>
+__global__ __launch_bounds__(256) void ws_bwd_kernel(const WsConv* __restrict__ tab, int n_convs, int n_filters,
+                                                     const float* __restrict__ stats, float eps) {
+    const int fi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (fi >= n_filters) return;
+    const WsConv d = tab[ws_find_conv(tab, n_convs, fi)];
+    if (!d.gout || !d.gw) return;   // this convolution received no gradient
+    const int K = d.I * d.KHW, o = fi - d.fstart;
+    const float* src = d.w + (int64_t)o * K;
+    const T* g = (const T*)d.gout + (int64_t)o * K;
+    const float mean = stats[2 * fi], inv = stats[2 * fi + 1];
+    float sg = 0.f, sgw = 0.f;
+    for (int i = lane; i < K; i += 64) {
+        const int ci = i / d.KHW, r = i % d.KHW;
+        const float gi = ldf(g + (int64_t)r * d.I + ci);
+        sg += gi; sgw += gi * (src[i] - mean);
+    }
+    sg = wave_sum(sg); sgw = wave_sum(sgw);
+    const float sigma = 1.f / inv - eps;
+    const float c2 = (sigma > 0.f) ? sgw * inv * inv / ((float)K * sigma) : 0.f;
+    const float gm = sg / (float)K;
+    float* dst = d.gw + (int64_t)o * K;
+    for (int i = lane; i < K; i += 64) {
+        const int ci = i / d.KHW, r = i % d.KHW;
+        const float gi = ldf(g + (int64_t)r * d.I + ci);
+        dst[i] += inv * (gi - gm) - (src[i] - mean) * c2;
+    }
+}
+
+extern "C" int maed_weight_std_fwd(const void* conv_table, int n_convs, int n_filters, void* out, int dtype, float* stats, float eps,
+                                   void* stream) {
+    MAED_CHECK_ARG(conv_table && out && stats, MAED_ERR_ARG, "weight_std_fwd: null pointer");
+    MAED_CHECK_ARG(n_convs > 0 && n_convs <= WS_MAX_CONVS, MAED_ERR_SHAPE, "weight_std_fwd: n_convs=%d out of range", n_convs);
+    if (n_filters <= 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ws_fwd_kernel<T>), dim3((n_filters + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                                                      (const WsConv*)conv_table, n_convs, n_filters, (T*)out, stats, eps));
+    MAED_CHECK_LAUNCH("weight_std_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int dtype, const float* stats, float eps, void* stream) {
+    MAED_CHECK_ARG(conv_table && stats, MAED_ERR_ARG, "weight_std_bwd: null pointer");
+    MAED_CHECK_ARG(n_convs > 0 && n_convs <= WS_MAX_CONVS, MAED_ERR_SHAPE, "weight_std_bwd: n_convs=%d out of range", n_convs);
+    if (n_filters <= 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ws_bwd_kernel<T>), dim3((n_filters + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                                                      (const WsConv*)conv_table, n_convs, n_filters, stats, eps));
+    MAED_CHECK_LAUNCH("weight_std_bwd");
+    return MAED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GroupNorm(32 groups) [+ residual add] [+ ReLU] on channels_last activations x[n][hw][c]
+// ---------------------------------------------------------------------------------------------------------
+#define GN_G 32
+
+// a thread owns 8 consecutive channels (16 B of bf16); threads of a workgroup tile (rows x channel blocks)
+template <typename T>
+__device__ __forceinline__ void gn_load8(const T* p, float (&v)[8]) { ld8(p, v); }
+
+// ---- forward pass 1: per (n, group) sums in double (fp32 partials per thread, double across threads) -------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ sums /* [N][32][2] */, int HW, int C,
+                                                       int rows_per_wg) {
+    __shared__ double ls[GN_G][2];
+    const int n = blockIdx.y, cbn = C / 8, cb = threadIdx.x % cbn, rsub = threadIdx.x / cbn, rstep = 256 / cbn;
+    if (threadIdx.x < GN_G * 2) (&ls[0][0])[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_wg;
+    const int r1 = min(HW, r0 + rows_per_wg);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    const T* base = x + ((int64_t)n * HW) * C + cb * 8;
+    for (int r = r0 + rsub; r < r1; r += rstep) {
+        float v[8];
+        gn_load8(base + (int64_t)r * C, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] = fmaf(v[j], v[j], q[j]); }
+    }
+    const int cpg = C / GN_G;
+    if (cpg >= 8) {
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ss += s[j]; qq += q[j]; }
+        const int g = cb * 8 / cpg;
+        atomicAdd(&ls[g][0], (double)ss); atomicAdd(&ls[g][1], (double)qq);
+    } else {
+        for (int j0 = 0; j0 < 8; j0 += cpg) {
+            float ss = 0.f, qq = 0.f;
+            for (int j = j0; j < j0 + cpg; ++j) { ss += s[j]; qq += q[j]; }
+            const int g = (cb * 8 + j0) / cpg;
+            atomicAdd(&ls[g][0], (double)ss); atomicAdd(&ls[g][1], (double)qq);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < GN_G * 2) atomicAdd(sums + (int64_t)n * GN_G * 2 + threadIdx.x, (&ls[0][0])[threadIdx.x]);
+}
+
+
+// ---- forward pass 2: y = act((x - mu) * rstd * gamma + beta [+ residual]) ------------------------------------
+template <typename T, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const double* __restrict__ sums,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                                       int HW, int C, float eps, int rows_per_wg) {
+    __shared__ float lmu[GN_G], lrs[GN_G];
+    const int n = blockIdx.y;
+    if (threadIdx.x < GN_G) {
+        const double cnt = (double)HW * (C / GN_G);
+        const double m = sums[((int64_t)n * GN_G + threadIdx.x) * 2] / cnt;
+        double var = sums[((int64_t)n * GN_G + threadIdx.x) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        lmu[threadIdx.x] = (float)m; lrs[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cbn = C / 8, cb = threadIdx.x % cbn, rsub = threadIdx.x / cbn, rstep = 256 / cbn, cpg = C / GN_G;
+    float a[8], b[8];   // y = x*a + b
+    {
+        float gg[8], bb[8];
+        ld8(gamma + cb * 8, gg); ld8(beta + cb * 8, bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (cb * 8 + j) / cpg;
+            a[j] = lrs[g] * gg[j]; b[j] = bb[j] - lmu[g] * a[j];
+        }
+    }
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
+    const int64_t base = ((int64_t)n * HW) * C + cb * 8;
+    for (int r = r0 + rsub; r < r1; r += rstep) {
+        float v[8], o[8];
+        gn_load8(x + base + (int64_t)r * C, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(v[j], a[j], b[j]);
+        if (RES) { float rr[8]; gn_load8(res + base + (int64_t)r * C, rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += rr[j]; }
+        if (RELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f); }
+        st8(y + base + (int64_t)r * C, o);
+    }
+}
+
+// ---- backward pass 1: ab[n][c] = (sum_hw dy_eff, sum_hw dy_eff * xhat), dy_eff = dy * (y > 0) if RELU ----------
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                                            const double* __restrict__ sums, float* __restrict__ ab /* [N][C][2] */,
+                                                            int HW, int C, float eps, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float lab[];   // [C][2]
+    __shared__ float lmu[GN_G], lrs[GN_G];
+    const int n = blockIdx.y;
+    if (threadIdx.x < GN_G) {
+        const double cnt = (double)HW * (C / GN_G);
+        const double m = sums[((int64_t)n * GN_G + threadIdx.x) * 2] / cnt;
+        double var = sums[((int64_t)n * GN_G + threadIdx.x) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        lmu[threadIdx.x] = (float)m; lrs[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lab[i] = 0.f;
+    __syncthreads();
+    const int cbn = C / 8, cb = threadIdx.x % cbn, rsub = threadIdx.x / cbn, rstep = 256 / cbn, cpg = C / GN_G;
+    float mu[8], rs[8], sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int g = (cb * 8 + j) / cpg; mu[j] = lmu[g]; rs[j] = lrs[g]; sa[j] = 0.f; sb[j] = 0.f; }
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
+    const int64_t base = ((int64_t)n * HW) * C + cb * 8;
+    for (int r = r0 + rsub; r < r1; r += rstep) {
+        float v[8], d[8];
+        gn_load8(x + base + (int64_t)r * C, v); gn_load8(dy + base + (int64_t)r * C, d);
+        if (RELU) { float o[8]; gn_load8(y + base + (int64_t)r * C, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sa[j] += d[j]; sb[j] = fmaf(d[j], (v[j] - mu[j]) * rs[j], sb[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { atomicAdd(&lab[(cb * 8 + j) * 2], sa[j]); atomicAdd(&lab[(cb * 8 + j) * 2 + 1], sb[j]); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(ab + (int64_t)n * C * 2 + i, lab[i]);
+}
+
+// ---- backward pass 2: dx = rstd * (gamma*dy_eff - m1 - xhat*m2); optional d_res = dy_eff ------------------------
+template <typename T, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                                           const double* __restrict__ sums, const float* __restrict__ ab,
+                                                           const float* __restrict__ gamma, T* __restrict__ dx, T* __restrict__ dres,
+                                                           int HW, int C, float eps, int rows_per_wg) {
+    __shared__ float lmu[GN_G], lrs[GN_G], lm1[GN_G], lm2[GN_G];
+    const int n = blockIdx.y, cpg = C / GN_G;
+    if (threadIdx.x < GN_G) {
+        const double cnt = (double)HW * cpg;
+        const double m = sums[((int64_t)n * GN_G + threadIdx.x) * 2] / cnt;
+        double var = sums[((int64_t)n * GN_G + threadIdx.x) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        lmu[threadIdx.x] = (float)m; lrs[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+        float m1 = 0.f, m2 = 0.f;
+        for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
+            m1 = fmaf(gamma[c], ab[((int64_t)n * C + c) * 2], m1);
+            m2 = fmaf(gamma[c], ab[((int64_t)n * C + c) * 2 + 1], m2);
+        }
+        lm1[threadIdx.x] = m1 / (float)cnt; lm2[threadIdx.x] = m2 / (float)cnt;
+    }
+    __syncthreads();
+    const int cbn = C / 8, cb = threadIdx.x % cbn, rsub = threadIdx.x / cbn, rstep = 256 / cbn;
+    float mu[8], rs[8], gg[8], m1[8], m2[8];
+    ld8(gamma + cb * 8, gg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int g = (cb * 8 + j) / cpg; mu[j] = lmu[g]; rs[j] = lrs[g]; m1[j] = lm1[g]; m2[j] = lm2[g]; }
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
+    const int64_t base = ((int64_t)n * HW) * C + cb * 8;
+    for (int r = r0 + rsub; r < r1; r += rstep) {
+        float v[8], d[8], o[8];
+        gn_load8(x + base + (int64_t)r * C, v); gn_load8(dy + base + (int64_t)r * C, d);
+        if (RELU) { float yy[8]; gn_load8(y + base + (int64_t)r * C, yy);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = yy[j] > 0.f ? d[j] : 0.f; }
+        if (RES) st8(dres + base + (int64_t)r * C, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs[j] * (gg[j] * d[j] - m1[j] - (v[j] - mu[j]) * rs[j] * m2[j]);
+        st8(dx + base + (int64_t)r * C, o);
+    }
+}
+
+// dgamma[c] += sum_n ab[n][c][1], dbeta[c] += sum_n ab[n][c][0]
+__global__ void gn_bwd_param_kernel(const float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int n = 0; n < N; ++n) { a += ab[((int64_t)n * C + c) * 2]; b += ab[((int64_t)n * C + c) * 2 + 1]; }
+    dbeta[c] += a; dgamma[c] += b;
+}
+
+static int gn_check(int C, int HW, const char* who) {
+    MAED_CHECK_ARG(C % GN_G == 0 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, MAED_ERR_SHAPE, "%s: C=%d unsupported (need C%%32==0, C/8 a power of two <= 256)", who, C);
+    MAED_CHECK_ARG(HW > 0, MAED_ERR_SHAPE, "%s: HW=%d", who, HW);
+    return MAED_OK;
+}
+static int gn_rows_per_wg(int N, int HW, int C) {
+    // aim for ~2048 workgroups overall; at least one pass of the row tile (256 / (C/8) rows)
+    const int tile = 256 / (C / 8);
+    int chunks = (2048 + N - 1) / N;
+    int rows = (HW + chunks - 1) / chunks;
+    rows = (rows + tile - 1) / tile * tile;
+    return rows < tile ? tile : rows;
+}
+
+extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
+                                  int N, int HW, int C, float eps, int relu, int dtype, void* stream) {
+    MAED_CHECK_ARG(x && gamma && beta && y && sums, MAED_ERR_ARG, "groupnorm_fwd: null pointer");
+    MAED_PROPAGATE(gn_check(C, HW, "groupnorm_fwd"));
+    if (N <= 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = gn_rows_per_wg(N, HW, C);
+    dim3 grid((HW + rows - 1) / rows, N);
+    hipMemsetAsync(sums, 0, (size_t)N * GN_G * 2 * sizeof(double), s);
+    MAED_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)x, sums, HW, C, rows);
+        if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows);
+        else if (residual) hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows);
+        else if (relu) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, HW, C, eps, rows);
+        else hipLaunchKernelGGL((gn_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, HW, C, eps, rows);
+    });
+    MAED_CHECK_LAUNCH("groupnorm_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, void* dx, void* dres,
+                                  float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps, int relu, int dtype,
+                                  void* stream) {
+    MAED_CHECK_ARG(x && dy && sums && gamma && dx && dgamma && dbeta && ab_scratch && (!relu || y), MAED_ERR_ARG, "groupnorm_bwd: null pointer");
+    MAED_PROPAGATE(gn_check(C, HW, "groupnorm_bwd"));
+    if (N <= 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = gn_rows_per_wg(N, HW, C);
+    dim3 grid((HW + rows - 1) / rows, N);
+    hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
+    const size_t lds = (size_t)2 * C * sizeof(float);
+    MAED_DISPATCH_DTYPE(dtype, T, {
+        if (relu) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, true>), grid, dim3(256), lds, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, HW, C, eps, rows);
+        else hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, false>), grid, dim3(256), lds, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, HW, C, eps, rows);
+        if (dres && relu) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, gamma, (T*)dx, (T*)dres, HW, C, eps, rows);
+        else if (dres) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, gamma, (T*)dx, (T*)dres, HW, C, eps, rows);
+        else if (relu) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, gamma, (T*)dx, (T*)nullptr, HW, C, eps, rows);
+        else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, gamma, (T*)dx, (T*)nullptr, HW, C, eps, rows);
+    });
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ab_scratch, dgamma, dbeta, N, C);
+    MAED_CHECK_LAUNCH("groupnorm_bwd");
+    return MAED_OK;
+}

@@ -97,8 +97,8 @@ class GradBucketer:
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._fused = set()
-        for m in model.modules():
-            if isinstance(m, Block):
+        for m in model.modules():  # modules whose kernels write parameter gradients directly (STE Block, ResNetV2)
+            if hasattr(m, "fused_parameters") and hasattr(m, "grads_ready"):
                 m.grads_ready = self._block_ready
                 self._fused.update(id(p) for p in m.fused_parameters())
         for p in arena.params:

@@ -305,3 +305,104 @@ class STEBlockFn(torch.autograd.Function):
         if block._pending_backwards == 0 and block.grads_ready is not None:
             block.grads_ready(block)
         return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+# ----------------------------------------------------------------------------------------------
+# backbone helpers: batched weight standardisation, fused GroupNorm(+residual)(+ReLU)
+# ----------------------------------------------------------------------------------------------
+import numpy as _np
+
+_WS_DTYPE = _np.dtype([("w", "u8"), ("gw", "u8"), ("gout", "u8"), ("dst_off", "i8"), ("O", "i4"), ("I", "i4"), ("KHW", "i4"), ("fstart", "i4")])
+
+
+def _ws_table(weights, grads=None, gouts=None):
+    tab = _np.zeros(len(weights), dtype=_WS_DTYPE)
+    off = fstart = 0
+    for i, w in enumerate(weights):
+        O, I, kh, kw = w.shape
+        tab[i] = (w.data_ptr(), 0 if grads is None else grads[i], 0 if gouts is None else gouts[i], off, O, I, kh * kw, fstart)
+        off += w.numel()
+        fstart += O
+    return tab, off, fstart
+
+
+class WeightStdFn(torch.autograd.Function):
+    """All StdConv2dSame weights of a backbone standardised in ONE launch (forward) / ONE launch (backward).
+    Outputs are channels_last-strided (O,I,kh,kw) views of one arena in the compute dtype.  Like STEBlockFn
+    the backward accumulates straight into p.grad and reports through owner.grads_ready."""
+
+    @staticmethod
+    def forward(ctx, owner, dtype, eps, *weights):
+        weights = [_c(w) for w in weights]
+        tab, total, nf = _ws_table(weights)
+        dev = weights[0].device
+        out = torch.empty(total, dtype=dtype, device=dev)
+        stats = torch.empty(nf * 2, dtype=torch.float32, device=dev)
+        tab_dev = torch.from_numpy(tab.view(_np.uint8)).to(dev)
+        check(L.lib().maed_weight_std_fwd(_p(tab_dev), len(weights), nf, _p(out), dt_code(dtype), _p(stats), eps, _stream()), "weight_std_fwd")
+        ctx.owner, ctx.dtype, ctx.eps, ctx.stats, ctx.nf = owner, dtype, eps, stats, nf
+        ctx.weights = weights
+        owner._pending_backwards += 1
+        views, off = [], 0
+        for w in weights:
+            O, I, kh, kw = w.shape
+            views.append(out[off:off + w.numel()].view(O, kh, kw, I).permute(0, 3, 1, 2))
+            off += w.numel()
+        return tuple(views)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        weights, owner = ctx.weights, ctx.owner
+        params = owner.fused_parameters()
+        keep, gptr, optr = [], [], []
+        for w, p, g in zip(weights, params, gouts):
+            if g is None:
+                gptr.append(0); optr.append(0)
+                continue
+            g = g.to(ctx.dtype)
+            g = g.contiguous(memory_format=torch.channels_last) if w.shape[2] * w.shape[3] > 1 else g.contiguous()
+            keep.append(g)
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            gptr.append(p.grad.data_ptr()); optr.append(g.data_ptr())
+        tab, _, nf = _ws_table(weights, gptr, optr)
+        tab_dev = torch.from_numpy(tab.view(_np.uint8)).to(weights[0].device)
+        check(L.lib().maed_weight_std_bwd(_p(tab_dev), len(weights), nf, dt_code(ctx.dtype), _p(ctx.stats), ctx.eps, _stream()), "weight_std_bwd")
+        owner._pending_backwards -= 1
+        if owner._pending_backwards == 0 and owner.grads_ready is not None:
+            owner.grads_ready(owner)
+        return (None, None, None) + (None,) * len(weights)
+
+
+class GroupNormFn(torch.autograd.Function):
+    """y = act(GroupNorm32(x) * gamma + beta [+ residual]) on channels_last tensors (maed_groupnorm_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps, relu):
+        N, C_, H, W = x.shape
+        x = x.contiguous(memory_format=torch.channels_last)
+        if residual is not None:
+            residual = residual.contiguous(memory_format=torch.channels_last).to(x.dtype)
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        sums = torch.empty(N, 32, 2, dtype=torch.float64, device=x.device)
+        check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), N, H * W, C_, eps, int(relu),
+                                         dt_code(x.dtype), _stream()), "groupnorm_fwd")
+        ctx.save_for_backward(x, y if relu else None, gamma, sums)
+        ctx.eps, ctx.relu, ctx.has_res = eps, relu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, sums = ctx.saved_tensors
+        N, C_, H, W = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dres = torch.empty_like(x, memory_format=torch.channels_last) if ctx.has_res else None
+        dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device)
+        ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
+        check(L.lib().maed_groupnorm_bwd(_p(x), _p(y), _p(dy), _p(sums), _p(gamma), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
+                                         N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), _stream()), "groupnorm_bwd")
+        if ctx.has_res and not ctx.relu:
+            dres = dy
+        return dx, dres, dgamma, dbeta, None, None

@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 
 def _same_pad(x, k, s, value=0.0):
     """TF 'SAME' padding computed from the input size (resnetv2.py:51-59): left = pad//2."""
@@ -42,11 +44,21 @@ class StdConv2dSame(nn.Conv2d):
         std, mean = torch.std_mean(self.weight, dim=[1, 2, 3], keepdim=True, unbiased=False)
         return (self.weight - mean) / (std + self.eps)
 
+    _w_std = None  # set by ResNetV2 for the duration of a forward: weight standardised by the batched HIP kernel
+
     def forward(self, x):
-        w = self.get_weight().to(x.dtype)
-        if x.is_cuda:
-            w = w.contiguous(memory_format=torch.channels_last)
-        x = _same_pad(x, self.kernel_size[0], self.stride[0])
+        w = self._w_std
+        if w is None:  # stand-alone use / CPU: per-conv ATen composition
+            w = self.get_weight().to(x.dtype)
+            if x.is_cuda:
+                w = w.contiguous(memory_format=torch.channels_last)
+        k, s = self.kernel_size[0], self.stride[0]
+        ih, iw = x.shape[-2:]
+        ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
+        pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
+        if ph % 2 == 0 and pw % 2 == 0:   # symmetric SAME padding: let the convolution pad (no padded copy)
+            return F.conv2d(x, w, None, self.stride, (ph // 2, pw // 2), self.dilation, self.groups)
+        x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
         return F.conv2d(x, w, None, self.stride, 0, self.dilation, self.groups)
 
 
@@ -57,9 +69,15 @@ class GroupNormAct(nn.GroupNorm):
         super().__init__(num_groups, num_channels, eps=eps, affine=affine)
         self.apply_act = apply_act
 
-    def forward(self, x):
+    def forward(self, x, residual=None, relu=None):
+        """y = act(GN(x) [+ residual]); relu defaults to the layer's own activation flag"""
+        relu = self.apply_act if relu is None else relu
+        if x.is_cuda and self.num_groups == 32:
+            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu)
         x = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
-        return F.relu(x, inplace=True) if self.apply_act else x
+        if residual is not None:
+            x = x + residual
+        return F.relu(x) if relu else x
 
 
 class MaxPool2dSame(nn.Module):
@@ -104,8 +122,7 @@ class Bottleneck(nn.Module):
         shortcut = x if self.downsample is None else self.downsample(x)
         x = self.norm1(self.conv1(x))
         x = self.norm2(self.conv2(x))
-        x = self.norm3(self.conv3(x))
-        return F.relu(x + shortcut, inplace=True)
+        return self.norm3(self.conv3(x), residual=shortcut, relu=True)   # GN + shortcut add + ReLU in one pass
 
 
 class ResNetStage(nn.Module):
@@ -145,11 +162,26 @@ class ResNetV2(nn.Module):
         for m in self.modules():  # resnetv2.py:330-335
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._convs = [m for m in self.modules() if isinstance(m, StdConv2dSame)]
+        self._pending_backwards = 0
+        self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
+
+    def fused_parameters(self):
+        """conv weights whose gradients are written by the batched weight-standardisation backward"""
+        return [c.weight for c in self._convs]
 
     def forward_features(self, x):
-        if x.is_cuda:
-            x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
-        return self.stages(self.stem(x))
+        if not x.is_cuda:
+            return self.stages(self.stem(x))
+        x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
+        ws = ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.fused_parameters())
+        try:
+            for c, w in zip(self._convs, ws):
+                c._w_std = w
+            return self.stages(self.stem(x))
+        finally:
+            for c in self._convs:
+                c._w_std = None
 
     def forward(self, x, seqlen=8):
         return self.forward_features(x)

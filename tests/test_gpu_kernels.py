@@ -319,3 +319,72 @@ def test_smpl_lbs_and_joint_gather_bit_exact():
     expect = j54[:, torch.tensor(R.JOINT_MAP_49, device=DEV)]
     assert torch.equal(kp3d, expect), "joint_map gather must be bit-exact"
     report("projection", kp2d, R.projection(expect.cpu(), cam.cpu()), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# backbone helpers
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,C,H,W", [(3, 64, 9, 7), (2, 256, 14, 14), (2, 1024, 5, 5), (2, 128, 28, 28)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False), (True, False)])
+def test_groupnorm_fused(dtype, N, C, H, W, res, relu):
+    ops, _ = _ops()
+    x = q(rnd(N, C, H, W, seed=1) * 1.5 + 0.2, dtype)
+    r = q(rnd(N, C, H, W, seed=2), dtype) if res else None
+    g, b = 1 + 0.2 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    dy = q(rnd(N, C, H, W, seed=5), dtype)
+    xd = x.double().requires_grad_(True)
+    rd = r.double().requires_grad_(True) if res else None
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.group_norm(xd, 32, gd, bd, 1e-5)
+    if res:
+        ref = ref + rd
+    if relu:
+        ref = F.relu(ref)
+    ref.backward(dy.double())
+    cl = lambda t: t.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    xg = cl(x).requires_grad_(True)
+    rg = cl(r).requires_grad_(True) if res else None
+    gg, bg = g.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.GroupNormFn.apply(xg, rg, gg, bg, 1e-5, relu)
+    y.backward(cl(dy))
+    tag = f"[{dtype},{N}x{C}x{H}x{W},res={res},relu={relu}]"
+    t = tol(dtype, 4)
+    report(f"groupnorm_fwd{tag}", y.float(), ref, **t)
+    report(f"groupnorm_bwd.dx{tag}", xg.grad.float(), xd.grad, **tol(dtype, 2))
+    if res:
+        report(f"groupnorm_bwd.dres{tag}", rg.grad.float(), rd.grad, **tol(dtype, 2))
+    scale = max(1.0, gd.grad.abs().max().item())
+    report(f"groupnorm_bwd.dgamma{tag}", gg.grad, gd.grad, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=(1e-4 if dtype == torch.float32 else 3e-2) * scale)
+    report(f"groupnorm_bwd.dbeta{tag}", bg.grad, bd.grad, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=(1e-4 if dtype == torch.float32 else 3e-2) * scale)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_weight_std_batched(dtype):
+    ops, _ = _ops()
+
+    class Owner:
+        _pending_backwards = 0
+        grads_ready = None
+
+        def __init__(self, ws):
+            self.ws = ws
+
+        def fused_parameters(self):
+            return self.ws
+
+    shapes = [(64, 3, 7, 7), (16, 32, 1, 1), (40, 24, 3, 3), (8, 256, 1, 1)]
+    ws = [torch.nn.Parameter((rnd(*s, seed=i) * 0.3 + 0.05).to(DEV)) for i, s in enumerate(shapes)]
+    owner = Owner(ws)
+    outs = ops.WeightStdFn.apply(owner, dtype, 1e-5, *ws)
+    gs = [q(rnd(*s, seed=10 + i), dtype) for i, s in enumerate(shapes)]
+    torch.autograd.backward(outs, [g.to(DEV).to(dtype) for g in gs])
+    for i, (w, o, g) in enumerate(zip(ws, outs, gs)):
+        wd = w.detach().cpu().double().requires_grad_(True)
+        std, mean = torch.std_mean(wd, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        ref = (wd - mean) / (std + 1e-5)
+        ref.backward(g.double())
+        assert o.shape == w.shape and o.is_contiguous(memory_format=torch.channels_last) or w.shape[2] == 1
+        report(f"weight_std_fwd[{dtype},{shapes[i]}]", o.float(), ref, **tol(dtype, 2))
+        report(f"weight_std_bwd[{dtype},{shapes[i]}]", w.grad, wd.grad, rtol=1e-4 if dtype == torch.float32 else 2e-2,
+               atol=(1e-4 if dtype == torch.float32 else 2e-2) * wd.grad.abs().max().item())
