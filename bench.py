@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="cfg2: inference forward instead of the train step")
+    ap.add_argument("--graph-tail", type=int, default=int(os.environ.get("MAED_GRAPH_TAIL", "0")), help="capture the decoder tail fwd+bwd into hipGraphs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,6 +155,9 @@ def main():
         bucketer = GradBucketer(arena, model)
         bucketer.broadcast_parameters(0)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=bucketer)  # configs/config_stage2.yaml:63-66
+        if args.graph_tail:
+            model.graph_training_tail(CFG["clips"] * CFG["T"])
+            log("decoder tail captured into hipGraphs")
 
         def step():
             opt.zero_grad()
@@ -222,13 +226,21 @@ def main():
                 ent.update(tflops=round(fl / us / 1e6, 2), frac_mfma_peak=round(fl / us / 1e6 / MFMA_BF16_PEAK_TF, 4),
                            algorithmic_gbs=round(by / us / 1e3, 1), frac_hbm_peak=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
             kernels[nm] = ent
+        traffic, traffic_note = None, ""
+        try:  # HBM bytes per launch from the committed PMC passes (scripts/gpu_pmc.sh), same kernel and shape
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "attn_traffic.json")))
+            if dtype == torch.bfloat16:
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_note = "; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B from separate rocprofv3 --pmc passes (profiles/r01_pmc/attn_traffic.json)"
+        except Exception:
+            pass
         if "attn_spatial_fwd" in kernels:
             k = kernels["attn_spatial_fwd"]
             roofline = dict(kernel="attn_sp_fwd_mfma (STE spatial attention forward)", bound="hbm", achieved=k["algorithmic_gbs"], peak=HBM_PEAK_GBS,
-                            unit="GB/s", frac=round(k["algorithmic_gbs"] / HBM_PEAK_GBS, 4), traffic=None, avg_us=k["avg_us"],
+                            unit="GB/s", frac=round(k["algorithmic_gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, avg_us=k["avg_us"],
                             mfma_view=dict(achieved=k["tflops"], peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"]),
                             note="algorithmic bytes = q,k,v read + o written once (8*P*C*F B bf16) + lse; in-situ hipEvent timing over "
-                                 f"{cnt[0]} launches inside {nprof} extra steps")
+                                 f"{cnt[0]} launches inside {nprof} extra steps" + traffic_note)
 
     log(f"kernel timing done: {json.dumps(kernels)}")
     cpu = None

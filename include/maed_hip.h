@@ -218,9 +218,11 @@ int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int 
  * y = act(GN(x) * gamma + beta [+ residual]).  sums: (N,32,2) doubles written by forward, read by backward. */
 int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
                        int N, int HW, int C, float eps, int relu, int dtype, void* stream);
-/* dx (and dres = masked dy when dres != NULL); dgamma/dbeta += ; ab_scratch: N*C*2 floats; y needed iff relu */
-int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, void* dx, void* dres,
-                       float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps, int relu, int dtype, void* stream);
+/* dx (and dres = masked dy when dres != NULL); dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats;
+ * y (the saved forward output) is needed only for relu with a residual, otherwise the mask is recomputed from x */
+int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, const float* beta,
+                       void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
+                       int relu, int dtype, void* stream);
 
 /* ---- optimizer: Adam (lib/utils/utils.py:127-132; torch.optim.Adam semantics, L2 weight decay) - */
 /* flat fp32 arenas p,g,m,v of n elements; grad is scaled by gscale first (1/world for DDP mean).

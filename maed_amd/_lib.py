@@ -72,7 +72,7 @@ SIGNATURES = {
     "maed_weight_std_fwd": (i32, [vp, i32, i32, vp, i32, vp, f32, vp]),
     "maed_weight_std_bwd": (i32, [vp, i32, i32, i32, vp, f32, vp]),
     "maed_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),
-    "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),
+    "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),
     "maed_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
 }
 

@@ -191,6 +191,15 @@ __global__ __launch_bounds__(256) void attn_sp_bwd_dkv_valu(const T* __restrict_
     }
 }
 
+// blocks b, b+8, b+16, ... share an XCD (observed dispatch: XCD = b % 8).  Remap so that one XCD walks CONTIGUOUS
+// (frame, head) pairs: the 8 heads of a frame (adjacent 128-B lines of every qkv row) then meet in ONE L2 close in time
+// instead of being fetched piecemeal by 8 different XCDs.  Pure speed heuristic; any placement is correct.
+__device__ __forceinline__ int attn_xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
 // ==================================================================================================
 // MFMA forward (bf16)
 // ==================================================================================================
@@ -201,9 +210,13 @@ __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int Pk = (P + 31) & ~31;
     const int VLD = Pk + 4;                        // V^T row stride (elements): (Pk+4)/2 dwords = 2*odd -> conflict-free b64
-    unsigned short* Ks = smem;                     // [P][KLD]
-    unsigned short* Vt = smem + (size_t)P * KLD;   // [64][VLD]   (P*KLD*2 bytes is a multiple of 16)
-    const int f = blockIdx.x / H, h = blockIdx.x % H;
+    // K rows are stored UNPADDED (128 B) with the 16-B chunk index XOR-swizzled by (row>>1)&7: a ds_read_b128 of 16
+    // distinct rows (mod 16) at one logical chunk then covers all 16 slots of the 256-B bank row -> conflict-free, and
+    // the workgroup's LDS drops to 54.4 KB (P=197), i.e. three workgroups per CU instead of two.
+    unsigned short* Ks = smem;                     // [P][64] swizzled
+    unsigned short* Vt = smem + (size_t)P * 64;    // [64][VLD]
+    const int bid = attn_xcd_remap(blockIdx.x, gridDim.x);
+    const int f = bid / H, h = bid % H;
     const int C = H * D;
     const int64_t ld = 3 * (int64_t)C;
     const bf16* base = qkv + (int64_t)f * P * ld + h * D;
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict_
             const int idx = tid + i * nthr;
             if (idx < P * 8) {
                 const int p = idx >> 3, c8 = (idx & 7) * 8;
-                *reinterpret_cast<uint4*>(Ks + p * KLD + c8) = kreg[i];
+                *reinterpret_cast<uint4*>(Ks + p * 64 + (((c8 >> 3) ^ ((p >> 1) & 7)) << 3)) = kreg[i];
                 const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -247,9 +260,10 @@ __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict_
             }
         }
     }
-    for (int idx = tid; idx < D * (VLD - P); idx += nthr) {  // zero the key padding of V^T
-        const int e = idx / (VLD - P), k = P + idx % (VLD - P);
-        Vt[e * VLD + k] = 0;
+    // zero the key padding of V^T (columns P .. VLD-1, at most 35): shifts only, no runtime integer division
+    for (int i = tid; i < D * 64; i += nthr) {
+        const int e = i >> 6, j = i & 63;
+        if (P + j < VLD) Vt[e * VLD + P + j] = 0;
     }
     __syncthreads();
 
@@ -268,26 +282,30 @@ __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict_
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         int krow = kt * 32 + l31;
         if (krow > P - 1) krow = P - 1;
-        const unsigned short* kp = Ks + krow * KLD + hi * 8;
+        const unsigned short* kp = Ks + krow * 64;
+        const int swz = (krow >> 1) & 7;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + t * 16);
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + (((2 * t + hi) ^ swz) << 3));
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s, 0, 0, 0);
         }
-        // lane holds keys k(r) = kt*32 + (r&3) + 8*(r>>2) + 4*hi of query q
-        float mt = -INFINITY;
+        // lane holds keys k(r) = kt*32 + (r&3) + 8*(r>>2) + 4*hi of query q; only the last tile has padding keys
+        if (kt == nkt - 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            s[r] = (k < P) ? s[r] * scale_log2e : -INFINITY;
-            mt = fmaxf(mt, s[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                s[r] = (k < P) ? s[r] : -INFINITY;
+            }
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;       // scale > 0: max commutes with the scaling
         const float mn = fmaxf(m, mt);
-        const float alpha = exp2f(m - mn);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mn); ps += s[r]; }
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -mn)); ps += s[r]; }
         l = l * alpha + ps;
         m = mn;
 #pragma unroll
@@ -361,7 +379,10 @@ __device__ __forceinline__ void stage_rowmajor_and_transposed(unsigned short* ro
         }
     }
     if (tr)
-        for (int idx = tid; idx < D * (VLD - P); idx += nthr) tr[(idx / (VLD - P)) * VLD + P + idx % (VLD - P)] = 0;
+        for (int i = tid; i < D * 64; i += nthr) {   // zero columns P .. VLD-1 (<= 35): no runtime integer division
+            const int e = i >> 6, j = i & 63;
+            if (P + j < VLD) tr[e * VLD + P + j] = 0;
+        }
 }
 
 __device__ __forceinline__ bf16x8_t lds_frag_tr(const unsigned short* base) {  // 4 + 4 elements, 8 apart
@@ -397,7 +418,8 @@ __global__ __launch_bounds__(640) void attn_sp_bwd_dq_mfma(const bf16* __restric
     unsigned short* Ks = smem;
     unsigned short* Vs = Ks + (size_t)P * KLD;
     unsigned short* Kt = Vs + (size_t)P * KLD;
-    const int f = blockIdx.x / H, h = blockIdx.x % H, C = H * D;
+    const int bid = attn_xcd_remap(blockIdx.x, gridDim.x);
+    const int f = bid / H, h = bid % H, C = H * D;
     const int64_t ld = 3 * (int64_t)C;
     const bf16* base = qkv + (int64_t)f * P * ld + h * D;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -444,7 +466,7 @@ __global__ __launch_bounds__(640) void attn_sp_bwd_dq_mfma(const bf16* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float p = (k < P) ? exp2f(s[r] * sl2e - L2) : 0.f;
+            const float p = (k < P) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, -L2)) : 0.f;
             s[r] = p * (dp[r] - Dq) * scale;  // dS
         }
 #pragma unroll
@@ -471,7 +493,8 @@ __global__ __launch_bounds__(640) void attn_sp_bwd_dkv_mfma(const bf16* __restri
     unsigned short* dOt = Qt + (size_t)D * VLD;
     float* Ls = reinterpret_cast<float*>(dOt + (size_t)D * VLD);
     float* Ds = Ls + Pk;
-    const int f = blockIdx.x / H, h = blockIdx.x % H, C = H * D;
+    const int bid = attn_xcd_remap(blockIdx.x, gridDim.x);
+    const int f = bid / H, h = bid % H, C = H * D;
     const int64_t ld = 3 * (int64_t)C;
     const bf16* base = qkv + (int64_t)f * P * ld + h * D;
     const bf16* obase = o + (int64_t)f * P * C + h * D;
@@ -526,7 +549,7 @@ __global__ __launch_bounds__(640) void attn_sp_bwd_dkv_mfma(const bf16* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float p = (qq < P) ? exp2f(s[r] * sl2e - Ls[qq]) : 0.f;
+            const float p = (qq < P) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, -Ls[qq])) : 0.f;
             dp[r] = p * (dp[r] - Ds[qq]) * scale;  // dS
             s[r] = p;                              // P
         }
@@ -563,7 +586,7 @@ extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F
     if (use_mfma) {
         const int Pk = (P + 31) & ~31;
         MAED_CHECK_ARG(Pk / 32 <= 16, MAED_ERR_SHAPE, "attn_spatial_fwd(mfma): P=%d > 512 tokens per frame", P);
-        const size_t lds = ((size_t)P * KLD + (size_t)D * (Pk + 4)) * 2;
+        const size_t lds = ((size_t)P * 64 + (size_t)D * (Pk + 4)) * 2;
         MAED_CHECK_ARG(lds <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_fwd(mfma): LDS %zu B", lds);
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute((const void*)attn_sp_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }

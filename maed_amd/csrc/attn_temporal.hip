@@ -157,13 +157,19 @@ __device__ __forceinline__ T* lds_row(char* base, int r, int gp) { return reinte
 // cooperative stage: rows r = gp*Tn + t  <-  src(frame n*Tn+t, token p0+gp) ; 16-B chunks, 8|16 per row
 template <typename T>
 __device__ __forceinline__ void stage_group_rows(char* dst, const T* src_base, int64_t ld, int64_t n, int Tn, int P, int p0, int GP, int nthr) {
-    constexpr int CH = RowGeom<T>::RS / 16;         // chunks per row
+    constexpr int CH = RowGeom<T>::RS / 16;         // chunks per row (power of two)
     constexpr int EPC = 16 / (int)sizeof(T);        // elements per chunk
-    for (int idx = threadIdx.x; idx < GP * Tn * CH; idx += nthr) {
-        const int r = idx / CH, c = idx % CH, gp = r / Tn, t = r % Tn;
+    // thread -> (row, chunk); rows advance by nthr/CH per trip.  (gp, t) is tracked incrementally: no runtime
+    // integer division inside the loop (Tn is a run-time value).
+    const int c = threadIdx.x % CH, rstep = nthr / CH;
+    int r = threadIdx.x / CH;
+    int gp = r / Tn, t = r - gp * Tn;
+    for (; r < GP * Tn; r += rstep) {
         int p = p0 + gp; if (p > P - 1) p = P - 1;
         const uint4 v = *reinterpret_cast<const uint4*>(src_base + ((n * Tn + t) * P + p) * ld + c * EPC);
         *reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds_row<T>(dst, r, gp)) + c * 16) = v;
+        t += rstep;
+        while (t >= Tn) { t -= Tn; ++gp; }
     }
 }
 

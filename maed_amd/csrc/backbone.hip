@@ -193,12 +193,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-// ---- backward pass 1: ab[n][c] = (sum_hw dy_eff, sum_hw dy_eff * xhat), dy_eff = dy * (y > 0) if RELU ----------
-template <typename T, bool RELU>
+// ---- backward pass 1: ab[n][c] = (sum_hw dy_eff, sum_hw dy_eff * xhat); dgamma/dbeta accumulated here too ----
+// dy_eff = dy * (out > 0) when RELU; `out` is recomputed from x when there is no residual (YMASK=false), read from y otherwise
+template <typename T, bool RELU, bool YMASK>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
-                                                            const double* __restrict__ sums, float* __restrict__ ab /* [N][C][2] */,
+                                                            const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ ab /* [N][C][2] */,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int HW, int C, float eps, int rows_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) float lab[];   // [C][2]
+    extern __shared__ __attribute__((aligned(16))) float lpart[];   // [256/cbn][C][2] = 16 KB
     __shared__ float lmu[GN_G], lrs[GN_G];
     const int n = blockIdx.y;
     if (threadIdx.x < GN_G) {
@@ -208,10 +211,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         if (var < 0.0) var = 0.0;
         lmu[threadIdx.x] = (float)m; lrs[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    for (int i = threadIdx.x; i < 2 * C; i += 256) lab[i] = 0.f;
     __syncthreads();
     const int cbn = C / 8, cb = threadIdx.x % cbn, rsub = threadIdx.x / cbn, rstep = 256 / cbn, cpg = C / GN_G;
-    float mu[8], rs[8], sa[8], sb[8];
+    float mu[8], rs[8], sa[8], sb[8], ga[8], be[8];
+    if (RELU && !YMASK) { ld8(gamma + cb * 8, ga); ld8(beta + cb * 8, be); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const int g = (cb * 8 + j) / cpg; mu[j] = lmu[g]; rs[j] = lrs[g]; sa[j] = 0.f; sb[j] = 0.f; }
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
@@ -219,23 +222,38 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     for (int r = r0 + rsub; r < r1; r += rstep) {
         float v[8], d[8];
         gn_load8(x + base + (int64_t)r * C, v); gn_load8(dy + base + (int64_t)r * C, d);
-        if (RELU) { float o[8]; gn_load8(y + base + (int64_t)r * C, o);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f; }
+        for (int j = 0; j < 8; ++j) v[j] = (v[j] - mu[j]) * rs[j];   // xhat
+        if (RELU) {
+            if (YMASK) { float o[8]; gn_load8(y + base + (int64_t)r * C, o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sa[j] += d[j]; sb[j] = fmaf(d[j], (v[j] - mu[j]) * rs[j], sb[j]); }
+                for (int j = 0; j < 8; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = fmaf(v[j], ga[j], be[j]) > 0.f ? d[j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sa[j] += d[j]; sb[j] = fmaf(d[j], v[j], sb[j]); }
     }
+    float* mine = lpart + ((size_t)rsub * C + cb * 8) * 2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { atomicAdd(&lab[(cb * 8 + j) * 2], sa[j]); atomicAdd(&lab[(cb * 8 + j) * 2 + 1], sb[j]); }
+    for (int j = 0; j < 8; ++j) { mine[2 * j] = sa[j]; mine[2 * j + 1] = sb[j]; }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(ab + (int64_t)n * C * 2 + i, lab[i]);
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float t = 0.f;
+        for (int k = 0; k < rstep; ++k) t += lpart[(size_t)k * 2 * C + i];
+        atomicAdd(ab + (int64_t)n * C * 2 + i, t);
+        atomicAdd(((i & 1) ? dgamma : dbeta) + (i >> 1), t);
+    }
 }
 
 // ---- backward pass 2: dx = rstd * (gamma*dy_eff - m1 - xhat*m2); optional d_res = dy_eff ------------------------
 template <typename T, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
                                                            const double* __restrict__ sums, const float* __restrict__ ab,
-                                                           const float* __restrict__ gamma, T* __restrict__ dx, T* __restrict__ dres,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           T* __restrict__ dx, T* __restrict__ dres,
                                                            int HW, int C, float eps, int rows_per_wg) {
     __shared__ float lmu[GN_G], lrs[GN_G], lm1[GN_G], lm2[GN_G];
     const int n = blockIdx.y, cpg = C / GN_G;
@@ -254,8 +272,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
     __syncthreads();
     const int cbn = C / 8, cb = threadIdx.x % cbn, rsub = threadIdx.x / cbn, rstep = 256 / cbn;
-    float mu[8], rs[8], gg[8], m1[8], m2[8];
-    ld8(gamma + cb * 8, gg);
+    float mu[8], rs[8], gg[8], be[8], m1[8], m2[8];
+    ld8(gamma + cb * 8, gg); ld8(beta + cb * 8, be);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const int g = (cb * 8 + j) / cpg; mu[j] = lmu[g]; rs[j] = lrs[g]; m1[j] = lm1[g]; m2[j] = lm2[g]; }
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
@@ -263,9 +281,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     for (int r = r0 + rsub; r < r1; r += rstep) {
         float v[8], d[8], o[8];
         gn_load8(x + base + (int64_t)r * C, v); gn_load8(dy + base + (int64_t)r * C, d);
-        if (RELU) { float yy[8]; gn_load8(y + base + (int64_t)r * C, yy);
+        if (RELU) {
+            if (RES) { float yy[8]; gn_load8(y + base + (int64_t)r * C, yy);   // out = GN(x) + residual: mask from the saved output
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] = yy[j] > 0.f ? d[j] : 0.f; }
+                for (int j = 0; j < 8; ++j) d[j] = yy[j] > 0.f ? d[j] : 0.f;
+            } else {                                                             // out = GN(x): recompute the mask, one tensor less to read
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = fmaf((v[j] - mu[j]) * rs[j], gg[j], be[j]) > 0.f ? d[j] : 0.f;
+            }
+        }
         if (RES) st8(dres + base + (int64_t)r * C, d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rs[j] * (gg[j] * d[j] - m1[j] - (v[j] - mu[j]) * rs[j] * m2[j]);
@@ -273,24 +297,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-// dgamma[c] += sum_n ab[n][c][1], dbeta[c] += sum_n ab[n][c][0]
-__global__ void gn_bwd_param_kernel(const float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int n = 0; n < N; ++n) { a += ab[((int64_t)n * C + c) * 2]; b += ab[((int64_t)n * C + c) * 2 + 1]; }
-    dbeta[c] += a; dgamma[c] += b;
-}
-
 static int gn_check(int C, int HW, const char* who) {
     MAED_CHECK_ARG(C % GN_G == 0 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, MAED_ERR_SHAPE, "%s: C=%d unsupported (need C%%32==0, C/8 a power of two <= 256)", who, C);
     MAED_CHECK_ARG(HW > 0, MAED_ERR_SHAPE, "%s: HW=%d", who, HW);
     return MAED_OK;
 }
-static int gn_rows_per_wg(int N, int HW, int C) {
-    // aim for ~2048 workgroups overall; at least one pass of the row tile (256 / (C/8) rows)
+static int gn_rows_per_wg(int N, int HW, int C, int target_wgs = 2048) {
+    // aim for ~target_wgs workgroups overall; at least one pass of the row tile (256 / (C/8) rows)
     const int tile = 256 / (C / 8);
-    int chunks = (2048 + N - 1) / N;
+    int chunks = (target_wgs + N - 1) / N;
     int rows = (HW + chunks - 1) / chunks;
     rows = (rows + tile - 1) / tile * tile;
     return rows < tile ? tile : rows;
@@ -316,26 +331,32 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
     return MAED_OK;
 }
 
-extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, void* dx, void* dres,
-                                  float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps, int relu, int dtype,
-                                  void* stream) {
-    MAED_CHECK_ARG(x && dy && sums && gamma && dx && dgamma && dbeta && ab_scratch && (!relu || y), MAED_ERR_ARG, "groupnorm_bwd: null pointer");
+extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, const float* beta,
+                                  void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
+                                  int relu, int dtype, void* stream) {
+    MAED_CHECK_ARG(x && dy && sums && gamma && beta && dx && dgamma && dbeta && ab_scratch, MAED_ERR_ARG, "groupnorm_bwd: null pointer");
+    MAED_CHECK_ARG(!(relu && dres) || y, MAED_ERR_ARG, "groupnorm_bwd: the saved output y is needed for the ReLU mask when a residual was added");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_bwd"));
     if (N <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     const int rows = gn_rows_per_wg(N, HW, C);
     dim3 grid((HW + rows - 1) / rows, N);
+    // the reduction pass ends with 4C atomics per workgroup: fewer, fatter workgroups (~768: 3 per CU) keep it HBM-bound
+    const int rrows = gn_rows_per_wg(N, HW, C, 768);
+    dim3 rgrid((HW + rrows - 1) / rrows, N);
     hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
-    const size_t lds = (size_t)2 * C * sizeof(float);
+    const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
+    const bool ymask = relu && dres;
+#define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, (const T*)y, (const T*)dy, \
+        sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows)
+#define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, \
+        sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
     MAED_DISPATCH_DTYPE(dtype, T, {
-        if (relu) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, true>), grid, dim3(256), lds, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, HW, C, eps, rows);
-        else hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, false>), grid, dim3(256), lds, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, HW, C, eps, rows);
-        if (dres && relu) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, gamma, (T*)dx, (T*)dres, HW, C, eps, rows);
-        else if (dres) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, gamma, (T*)dx, (T*)dres, HW, C, eps, rows);
-        else if (relu) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, gamma, (T*)dx, (T*)nullptr, HW, C, eps, rows);
-        else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, sums, ab_scratch, gamma, (T*)dx, (T*)nullptr, HW, C, eps, rows);
+        if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);
+        if (dres && relu) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);
     });
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ab_scratch, dgamma, dbeta, N, C);
+#undef GN_RED
+#undef GN_APP
     MAED_CHECK_LAUNCH("groupnorm_bwd");
     return MAED_OK;
 }

@@ -25,13 +25,13 @@ static inline bool is_aligned(const void* p, size_t a) { return (reinterpret_cas
 
 // ---- scalar conversions ----------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
+// fp32 -> bf16 round-to-nearest-even on the gfx950 converter (v_cvt_pk_bf16_f32): one instruction per PAIR
+__device__ __forceinline__ unsigned short f2bf(float f) { const __bf16 h = (__bf16)f; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const bf16x2_hw_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return bf2f(p->v); }
@@ -93,6 +93,28 @@ __device__ __forceinline__ float dgelu_erf(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+
+// bf16 throughput mode: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution) -- one v_exp,
+// one v_rcp and a 5-term Horner chain instead of libm erff (~3x fewer VALU issues in the GELU GEMM epilogues).
+// exp(-x^2/2) is shared between the erf tail and the Gaussian pdf of the derivative.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);   // exp(-x^2/2)
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erf_abs = 1.0f - poly * t * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    pdf = 0.39894228040143267794f * e;
+}
+template <typename T> __device__ __forceinline__ float gelu_fwd(float x);
+template <> __device__ __forceinline__ float gelu_fwd<float>(float x) { return gelu_erf(x); }      // parity mode: libm erff
+template <> __device__ __forceinline__ float gelu_fwd<struct bf16>(float x) { float c, p; gelu_parts_fast(x, c, p); return x * c; }
+template <typename T> __device__ __forceinline__ float gelu_bwd(float x);
+template <> __device__ __forceinline__ float gelu_bwd<float>(float x) { return dgelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_bwd<struct bf16>(float x) { float c, p; gelu_parts_fast(x, c, p); return fmaf(x, p, c); }
 
 template <typename T> struct dtype_of;
 template <> struct dtype_of<float> { static constexpr int value = MAED_F32; };

@@ -26,17 +26,58 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int6
         const float pre = acc + (e.bias ? e.bias[c] : 0.f);
         T* p2 = (T*)e.out2 + r * e.ldo + c;
         stf(p2, pre);
-        stf((T*)e.out + r * e.ldo + c, gelu_erf(ldf(p2)));  // activation of the STORED (rounded) pre-activation
+        stf((T*)e.out + r * e.ldo + c, gelu_fwd<T>(ldf(p2)));  // activation of the STORED (rounded) pre-activation
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         ((float*)e.out)[r * e.ldo + c] = ((const float*)e.aux)[r * e.ldaux + c] + (acc + (e.bias ? e.bias[c] : 0.f));
     } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
-        stf((T*)e.out + r * e.ldo + c, acc * dgelu_erf(ldf((const T*)e.aux + r * e.ldaux + c)));
+        stf((T*)e.out + r * e.ldo + c, acc * gelu_bwd<T>(ldf((const T*)e.aux + r * e.ldaux + c)));
     } else if constexpr (EPI == MAED_EPI_ATOMIC_F32) {
         atomicAdd((float*)e.out + r * e.ldo + c, acc);
     } else if constexpr (EPI == MAED_EPI_STORE_F32) {
         ((float*)e.out)[r * e.ldo + c] = acc + (e.bias ? e.bias[c] : 0.f);
     } else if constexpr (EPI == MAED_EPI_TANH) {
         stf((T*)e.out + r * e.ldo + c, tanhf(acc + (e.bias ? e.bias[c] : 0.f)));
+    }
+}
+
+// four consecutive columns c0..c0+3 of one row (c0 % 4 == 0): 8/16-byte accesses when the row base is aligned
+template <int EPI, typename T>
+__device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int64_t c0, int64_t N, const float (&acc)[4], bool vec_ok) {
+    if (!(vec_ok && c0 + 4 <= N)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c0 + j < N) epilogue_store<EPI, T>(e, r, c0 + j, acc[j]);
+        return;
+    }
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if constexpr (EPI == MAED_EPI_ATOMIC_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd((float*)e.out + r * e.ldo + c0 + j, v[j]);
+        return;
+    }
+    if constexpr (EPI != MAED_EPI_MUL_DGELU) {
+        if (e.bias) { float b[4]; ld4(e.bias + c0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    }
+    if constexpr (EPI == MAED_EPI_STORE) {
+        st4((T*)e.out + r * e.ldo + c0, v);
+    } else if constexpr (EPI == MAED_EPI_GELU) {
+        T* p2 = (T*)e.out2 + r * e.ldo + c0;
+        st4(p2, v);
+        float pre[4]; ld4(p2, pre);   // activation of the STORED (rounded) pre-activation, as the backward sees it
+        float a[4] = {gelu_fwd<T>(pre[0]), gelu_fwd<T>(pre[1]), gelu_fwd<T>(pre[2]), gelu_fwd<T>(pre[3])};
+        st4((T*)e.out + r * e.ldo + c0, a);
+    } else if constexpr (EPI == MAED_EPI_RESID_F32) {
+        float x[4]; ld4((const float*)e.aux + r * e.ldaux + c0, x);
+        float o[4] = {x[0] + v[0], x[1] + v[1], x[2] + v[2], x[3] + v[3]};
+        st4((float*)e.out + r * e.ldo + c0, o);
+    } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
+        float x[4]; ld4((const T*)e.aux + r * e.ldaux + c0, x);
+        float o[4] = {v[0] * gelu_bwd<T>(x[0]), v[1] * gelu_bwd<T>(x[1]), v[2] * gelu_bwd<T>(x[2]), v[3] * gelu_bwd<T>(x[3])};
+        st4((T*)e.out + r * e.ldo + c0, o);
+    } else if constexpr (EPI == MAED_EPI_STORE_F32) {
+        st4((float*)e.out + r * e.ldo + c0, v);
+    } else if constexpr (EPI == MAED_EPI_TANH) {
+        float o[4] = {tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
+        st4((T*)e.out + r * e.ldo + c0, o);
     }
 }
 
@@ -127,33 +168,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* _
 
     // staging map: 128 rows x 64 cols = 1024 16-byte chunks per operand, 4 per thread
     // chunk c = tid + 256*i : row = c >> 3, col chunk = c & 7  (8 lanes cover one 128-B row segment)
-    const bf16* ap[4]; const bf16* bp[4]; int soff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i, row = c >> 3, cc = (c & 7) * 8;
-        const int64_t ar = (m0 + row < M) ? m0 + row : M - 1;
-        const int64_t br = (n0 + row < N) ? n0 + row : N - 1;
-        ap[i] = A + ar * lda + cc;
-        bp[i] = B + br * ldb + cc;
-        soff[i] = row * GM_LD + cc;
+#define GM_PTRS(i)                                                                            \
+    const bf16* ap##i; const bf16* bp##i; int soff##i;                                        \
+    {                                                                                         \
+        const int c = tid + 256 * i, row = c >> 3, cc = (c & 7) * 8;                          \
+        const int64_t ar = (m0 + row < M) ? m0 + row : M - 1;                                 \
+        const int64_t br = (n0 + row < N) ? n0 + row : N - 1;                                 \
+        ap##i = A + ar * lda + cc; bp##i = B + br * ldb + cc; soff##i = row * GM_LD + cc;     \
     }
-    uint4 ra[4], rb[4];
-#define GM_LOAD_TILE(kt_)                                                         \
+    GM_PTRS(0) GM_PTRS(1) GM_PTRS(2) GM_PTRS(3)
+    // two register sets = global prefetch distance of TWO K tiles (K is short here: 8..32 tiles per output tile, so
+    // HBM/L2 latency, not MFMA issue, decides; with 2 workgroups per CU this keeps 4 tiles in flight per CU)
+    // (named scalars, not arrays: the register sets must never be demoted to scratch)
+    uint4 ra0_0, ra0_1, ra0_2, ra0_3, rb0_0, rb0_1, rb0_2, rb0_3, ra1_0, ra1_1, ra1_2, ra1_3, rb1_0, rb1_1, rb1_2, rb1_3;
+#define GM_LD1(S, i, k0__) ra##S##_##i = *reinterpret_cast<const uint4*>(ap##i + k0__); rb##S##_##i = *reinterpret_cast<const uint4*>(bp##i + k0__);
+#define GM_LOAD_TILE(S, kt_)                                                      \
     {                                                                             \
-        const int64_t k0__ = (int64_t)(kt_) * GM_BK;                              \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                           \
-            ra[i] = *reinterpret_cast<const uint4*>(ap[i] + k0__);                \
-            rb[i] = *reinterpret_cast<const uint4*>(bp[i] + k0__);                \
-        }                                                                         \
+        int ktc__ = (kt_); if (ktc__ > kt_end - 1) ktc__ = kt_end - 1;            \
+        const int64_t k0__ = (int64_t)ktc__ * GM_BK;                              \
+        GM_LD1(S, 0, k0__) GM_LD1(S, 1, k0__) GM_LD1(S, 2, k0__) GM_LD1(S, 3, k0__) \
     }
-#define GM_STORE_TILE(buf_)                                                       \
-    {                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                           \
-            *reinterpret_cast<uint4*>(&lds[buf_][0][soff[i]]) = ra[i];            \
-            *reinterpret_cast<uint4*>(&lds[buf_][1][soff[i]]) = rb[i];            \
-        }                                                                         \
-    }
+#define GM_ST1(S, i, buf_) *reinterpret_cast<uint4*>(&lds[buf_][0][soff##i]) = ra##S##_##i; *reinterpret_cast<uint4*>(&lds[buf_][1][soff##i]) = rb##S##_##i;
+#define GM_STORE_TILE(S, buf_) { GM_ST1(S, 0, buf_) GM_ST1(S, 1, buf_) GM_ST1(S, 2, buf_) GM_ST1(S, 3, buf_) }
 
+    // TR: accumulators hold the TRANSPOSED 32x32 tiles (A operand = weight rows n, B operand = activation rows m): a lane
+    // then owns one output row m and 4 consecutive columns per register group -> 8/16-byte epilogue accesses.
+    // The atomic (weight-gradient) epilogue keeps the natural orientation: for one register the 32 lanes of a half-wave
+    // hit 32 CONSECUTIVE columns of one row, which the L2 atomic unit coalesces (row-strided atomics ran 4.5x slower).
+    constexpr bool TR = (EPI != MAED_EPI_ATOMIC_F32);
     f32x16_t acc00, acc01, acc10, acc11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
@@ -167,27 +209,48 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* _
             bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(As + 32 * GM_LD + kk * 16);                   \
             bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(Bs + kk * 16);                                \
             bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(Bs + 32 * GM_LD + kk * 16);                   \
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);                       \
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);                       \
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);                       \
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);                       \
+            if constexpr (TR) {                                                                            \
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc00, 0, 0, 0);                   \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc01, 0, 0, 0);                   \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc10, 0, 0, 0);                   \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc11, 0, 0, 0);                   \
+            } else {                                                                                       \
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);                   \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);                   \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);                   \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);                   \
+            }                                                                                              \
         }                                                                                                  \
     }
-    GM_LOAD_TILE(kt_beg);
-    GM_STORE_TILE(0);
+    GM_LOAD_TILE(0, kt_beg);
+    GM_LOAD_TILE(1, kt_beg + 1);
+    GM_STORE_TILE(0, 0);
     __syncthreads();
-    int buf = 0;
-    for (int kt = kt_beg; kt < kt_end - 1; ++kt) {
-        GM_LOAD_TILE(kt + 1);       // global loads of the next tile fly under this tile's MFMAs
-        GM_COMPUTE_TILE(buf);
-        GM_STORE_TILE(buf ^ 1);
+    int kt = kt_beg;
+    for (; kt + 1 < kt_end; kt += 2) {      // two tiles per trip so both register sets are addressed statically
+        GM_LOAD_TILE(0, kt + 2);     // set 0 was written to LDS already; refill it two tiles ahead
+        GM_COMPUTE_TILE(0);
+        GM_STORE_TILE(1, 1);         // tile kt+1 (loaded one trip ago) -> the other LDS buffer
         __syncthreads();
-        buf ^= 1;
+        GM_LOAD_TILE(1, kt + 3);
+        GM_COMPUTE_TILE(1);
+        GM_STORE_TILE(0, 0);         // tile kt+2 (clamped duplicate past the end: harmless)
+        __syncthreads();
     }
-    GM_COMPUTE_TILE(buf);
-    // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (kt < kt_end) GM_COMPUTE_TILE(0);    // odd tile count: the last tile sits in buffer 0
+    // D^T tile layout: col (lane & 31) = output row m, row (reg&3) + 8*(reg>>2) + 4*(lane>>5) = output column n
+    const bool vec_ok = (e.ldo % 4 == 0) && (e.ldaux % 4 == 0);
 #define GM_EPILOGUE(acc_, i_, j_)                                                                     \
-    {                                                                                                 \
+    if constexpr (TR) {                                                                               \
+        const int64_t row = m0 + wr * 64 + (i_) * 32 + l31;                                           \
+        if (row < M) {                                                                                \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                           \
+                const int64_t c0 = n0 + wc * 64 + (j_) * 32 + 8 * g + 4 * hi;                         \
+                const float v4[4] = {acc_[4 * g], acc_[4 * g + 1], acc_[4 * g + 2], acc_[4 * g + 3]}; \
+                if (c0 < N) epilogue_store4<EPI, bf16>(e, row, c0, N, v4, vec_ok);                    \
+            }                                                                                         \
+        }                                                                                             \
+    } else {                                                                                          \
         const int64_t c = n0 + wc * 64 + (j_) * 32 + l31;                                             \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
             const int64_t row = m0 + wr * 64 + (i_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;           \

@@ -353,7 +353,7 @@ class WeightStdFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         weights, owner = ctx.weights, ctx.owner
-        params = owner.fused_parameters()
+        params = owner.conv_weights()
         keep, gptr, optr = [], [], []
         for w, p, g in zip(weights, params, gouts):
             if g is None:
@@ -375,10 +375,12 @@ class WeightStdFn(torch.autograd.Function):
 
 
 class GroupNormFn(torch.autograd.Function):
-    """y = act(GroupNorm32(x) * gamma + beta [+ residual]) on channels_last tensors (maed_groupnorm_fwd/bwd)."""
+    """y = act(GroupNorm32(x) * gamma + beta [+ residual]) on channels_last tensors (maed_groupnorm_fwd/bwd).
+    direct=True: gamma/beta gradients are accumulated by the kernel straight into gamma.grad / beta.grad (the
+    owner module reports them through its grads_ready callback) instead of travelling through autograd."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, relu):
+    def forward(ctx, x, residual, gamma, beta, eps, relu, direct):
         N, C_, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)
         if residual is not None:
@@ -387,22 +389,32 @@ class GroupNormFn(torch.autograd.Function):
         sums = torch.empty(N, 32, 2, dtype=torch.float64, device=x.device)
         check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), N, H * W, C_, eps, int(relu),
                                          dt_code(x.dtype), _stream()), "groupnorm_fwd")
-        ctx.save_for_backward(x, y if relu else None, gamma, sums)
-        ctx.eps, ctx.relu, ctx.has_res = eps, relu, residual is not None
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if (relu and ctx.has_res) else None, sums)
+        ctx.eps, ctx.relu, ctx.direct = eps, relu, direct
+        ctx.gamma, ctx.beta = gamma, beta   # parameters (leaf tensors): kept by reference for .grad access
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, sums = ctx.saved_tensors
+        x, y, sums = ctx.saved_tensors
+        gamma, beta = ctx.gamma, ctx.beta
         N, C_, H, W = x.shape
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
         dres = torch.empty_like(x, memory_format=torch.channels_last) if ctx.has_res else None
-        dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device)
-        dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device)
+        if ctx.direct:
+            if gamma.grad is None:
+                gamma.grad = torch.zeros_like(gamma)
+            if beta.grad is None:
+                beta.grad = torch.zeros_like(beta)
+            dgamma, dbeta = gamma.grad, beta.grad
+        else:
+            dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device)
+            dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device)
         ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
-        check(L.lib().maed_groupnorm_bwd(_p(x), _p(y), _p(dy), _p(sums), _p(gamma), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
+        check(L.lib().maed_groupnorm_bwd(_p(x), _p(y), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
                                          N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), _stream()), "groupnorm_bwd")
-        if ctx.has_res and not ctx.relu:
-            dres = dy
-        return dx, dres, dgamma, dbeta, None, None
+        if ctx.direct:
+            return dx, dres, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None

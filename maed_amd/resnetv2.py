@@ -65,6 +65,8 @@ class StdConv2dSame(nn.Conv2d):
 class GroupNormAct(nn.GroupNorm):
     """resnetv2.py:35-49"""
 
+    _direct_grad = False  # set by ResNetV2: the kernels accumulate dgamma/dbeta straight into .grad
+
     def __init__(self, num_channels, num_groups=32, eps=1e-5, affine=True, apply_act=True):
         super().__init__(num_groups, num_channels, eps=eps, affine=affine)
         self.apply_act = apply_act
@@ -73,7 +75,7 @@ class GroupNormAct(nn.GroupNorm):
         """y = act(GN(x) [+ residual]); relu defaults to the layer's own activation flag"""
         relu = self.apply_act if relu is None else relu
         if x.is_cuda and self.num_groups == 32:
-            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu)
+            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad)
         x = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
         if residual is not None:
             x = x + residual
@@ -163,18 +165,25 @@ class ResNetV2(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         self._convs = [m for m in self.modules() if isinstance(m, StdConv2dSame)]
+        self._norms = [m for m in self.modules() if isinstance(m, GroupNormAct)]
+        for m in self._norms:
+            m._direct_grad = True
         self._pending_backwards = 0
         self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
 
-    def fused_parameters(self):
-        """conv weights whose gradients are written by the batched weight-standardisation backward"""
+    def conv_weights(self):
         return [c.weight for c in self._convs]
+
+    def fused_parameters(self):
+        """parameters whose gradients the HIP kernels write directly into .grad: conv weights (batched
+        weight-standardisation backward, the LAST kernel of the backbone backward) and GroupNorm affine parameters"""
+        return self.conv_weights() + [t for m in self._norms for t in (m.weight, m.bias)]
 
     def forward_features(self, x):
         if not x.is_cuda:
             return self.stages(self.stem(x))
         x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
-        ws = ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.fused_parameters())
+        ws = ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
         try:
             for c, w in zip(self._convs, ws):
                 c._w_std = w

@@ -119,10 +119,12 @@ class SMPL(nn.Module):
         Rw[0], tw[0] = rotmat[:, 0], J[:, 0]
         for level in self._LEVELS[1:]:
             par = [SMPL_PARENTS[j] for j in level]
-            Rp = torch.stack([Rw[p] for p in par], 1)                                                    # (F,k,3,3)
+            lo, hi = level[0], level[-1] + 1                 # every level is a contiguous joint range: plain slices,
+            Rp = torch.stack([Rw[p] for p in par], 1)        # no host-built index tensors (hipGraph-capturable)   (F,k,3,3)
             tp = torch.stack([tw[p] for p in par], 1)
-            Rn = (Rp.unsqueeze(-1) * rotmat[:, level].unsqueeze(-3)).sum(-2)                             # Rp @ R_j
-            tn = (Rp * (J[:, level] - J[:, par]).unsqueeze(-2)).sum(-1) + tp                             # Rp @ rel + tp
+            Jp = torch.stack([J[:, p] for p in par], 1)
+            Rn = (Rp.unsqueeze(-1) * rotmat[:, lo:hi].unsqueeze(-3)).sum(-2)                             # Rp @ R_j
+            tn = (Rp * (J[:, lo:hi] - Jp).unsqueeze(-2)).sum(-1) + tp                                    # Rp @ rel + tp
             for i, j in enumerate(level):
                 Rw[j], tw[j] = Rn[:, i], tn[:, i]
         Rw, tw = torch.stack(Rw, 1), torch.stack(tw, 1)

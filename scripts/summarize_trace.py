@@ -22,6 +22,10 @@ with open(dst, "w", newline="") as fh:
     w.writerow(["kernel", "calls_per_step", "avg_us", "ms_per_step", "pct"])
     w.writerow([f"# steady state: {nsteps} train steps, wall {(t1 - t0) / 1e6 / nsteps:.3f} ms/step, sum of kernel time {tot / 1e6 / nsteps:.3f} ms/step"])
     for k, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        short = re.sub(r"\(.*", "", k)[:160]
+        short = k
+        for pat, rep in ((r"void ", ""), (r"at::native::", ""), (r"\(anonymous namespace\)::", ""), (r"<unnamed>::", "")):
+            short = re.sub(pat, rep, short)
+        short = re.sub(r"\((?:[^()]|\([^()]*\))*\)\s*$", "", short)   # drop the trailing argument list only
+        short = short[:200]
         w.writerow([short, round(c / nsteps, 2), round(d / c / 1e3, 2), round(d / 1e6 / nsteps, 4), round(100.0 * d / tot, 2)])
 print(f"steady state: {nsteps} steps, wall {(t1 - t0) / 1e6 / nsteps:.3f} ms/step, kernel time {tot / 1e6 / nsteps:.3f} ms/step -> {dst}")

@@ -346,7 +346,7 @@ def test_groupnorm_fused(dtype, N, C, H, W, res, relu):
     xg = cl(x).requires_grad_(True)
     rg = cl(r).requires_grad_(True) if res else None
     gg, bg = g.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
-    y = ops.GroupNormFn.apply(xg, rg, gg, bg, 1e-5, relu)
+    y = ops.GroupNormFn.apply(xg, rg, gg, bg, 1e-5, relu, False)
     y.backward(cl(dy))
     tag = f"[{dtype},{N}x{C}x{H}x{W},res={res},relu={relu}]"
     t = tol(dtype, 4)
@@ -372,6 +372,8 @@ def test_weight_std_batched(dtype):
 
         def fused_parameters(self):
             return self.ws
+
+        conv_weights = fused_parameters
 
     shapes = [(64, 3, 7, 7), (16, 32, 1, 1), (40, 24, 3, 3), (8, 256, 1, 1)]
     ws = [torch.nn.Parameter((rnd(*s, seed=i) * 0.3 + 0.05).to(DEV)) for i, s in enumerate(shapes)]
