@@ -65,10 +65,11 @@ int maed_version(void);
 int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
                        void* y, int dtype, float* mean, float* rstd,
                        int64_t rows, int C, float eps, void* stream);
-/* dx_out[f32] = (dres_in ? dres_in : 0) + LN'(dy) ; dgamma/dbeta += (fp32, atomics). */
+/* dx_out[f32] = (dres_in ? dres_in : 0) + LN'(dy) ; dgamma/dbeta += (fp32, atomics).
+ * dx_twin (optional): the same rows in the compute dtype (the operand of the next backward GEMMs). */
 int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int64_t x_row_stride,
                        const float* gamma, const float* mean, const float* rstd,
-                       const float* dres_in, float* dx_out, float* dgamma, float* dbeta,
+                       const float* dres_in, float* dx_out, void* dx_twin, float* dgamma, float* dbeta,
                        int64_t rows, int C, void* stream);
 
 /* ---- K2/K6/K7/K9/K10: nn.Linear as out = epi(A[M,K] * B[N,K]^T)  (vision_transformer.py:98-111,
@@ -78,7 +79,12 @@ int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb,
                  const float* bias, void* out, int64_t ldo, void* out2,
                  const void* aux, int64_t ldaux, int splitk, int impl, void* stream);
 
-/* transpose helper feeding the weight-gradient GEMMs (dW = dY^T X as an NT GEMM on transposed
+/* weight gradient dW[N,K] += Y[M,N]^T X[M,K] and (optional) bias gradient dbias[N] += colsum(Y), bf16 operands,
+ * fp32 atomics (split over M).  No transposed copies: 8x8 blocks are transposed in registers while staging. */
+int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K,
+                       float* dW, int64_t ldw, float* dbias, int dtype, void* stream);
+
+/* transpose helper feeding the weight-gradient GEMMs of the f32 parity mode (dW = dY^T X as an NT GEMM on transposed
  * copies): out_t[T](N, ldt) = in(M,N)^T with columns [M, ldt) zero-filled; optional plain cast copy
  * out_c[T](M,N); optional colsum[N] += sum over rows (bias gradient).  in_dtype may be MAED_F32
  * while dtype (of the outputs) is MAED_BF16.  */
@@ -156,10 +162,12 @@ size_t maed_ste_block_scratch_bytes(const maed_block_dims* d);
  * handed unchanged to maed_ste_block_bwd.  x_out may alias x_in only if no backward is wanted. */
 int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in,
                        float* x_out, void* saved, void* stream);
-/* dx_in[f32] = dBlock/dx_in(dx_out); parameter gradients are accumulated into g. dx_in may alias dx_out. */
+/* dx_in[f32] = dBlock/dx_in(dx_out); parameter gradients are accumulated into g. dx_in may alias dx_out.
+ * dx_out_twin (optional, in): dx_out already in the compute dtype; dx_in_twin (optional, out): dx_in in the compute
+ * dtype -- consecutive blocks hand the bf16 copy along so no cast pass is needed. */
 int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, const maed_block_grads* g,
                        const float* x_in, const float* dx_out, float* dx_in, void* saved, void* scratch,
-                       void* stream);
+                       const void* dx_out_twin, void* dx_in_twin, void* stream);
 
 /* measurement only: bracket selected launches inside the composite block calls with hipEvents on the
  * launch stream.  Tags: 0 attn_spatial_fwd, 1 attn_temporal_fwd, 2 qkv GEMM, 3 fc1 GEMM, 4 fc2 GEMM,

@@ -45,7 +45,8 @@ SIGNATURES = {
     "maed_last_error": (C.c_char_p, []),
     "maed_version": (i32, []),
     "maed_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i32, vp, vp, i64, i32, f32, vp]),
-    "maed_layernorm_bwd": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "maed_layernorm_bwd": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "maed_gemm_tn_wgrad": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp, i32, vp]),
     "maed_gemm_nt": (i32, [vp, i64, vp, i64, i64, i64, i64, i32, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp]),
     "maed_transpose_cast": (i32, [vp, i32, i64, i64, i64, vp, i64, vp, i64, vp, i32, vp]),
     "maed_attn_spatial_fwd": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),
@@ -61,7 +62,7 @@ SIGNATURES = {
     "maed_ste_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_scratch_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
-    "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp]),
+    "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp, vp, vp]),
     "maed_prof_enable": (i32, [i32]),
     "maed_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i32)]),
     "maed_ktd_chain_fwd": (i32, [vp, vp, vp, i32, vp]),

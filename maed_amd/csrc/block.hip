@@ -156,7 +156,8 @@ extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_par
 }
 
 extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, const maed_block_grads* g,
-                                  const float* x_in, const float* dx_out, float* dx_in, void* saved, void* scratch, void* stream) {
+                                  const float* x_in, const float* dx_out, float* dx_in, void* saved, void* scratch,
+                                  const void* dx_out_twin, void* dx_in_twin, void* stream) {
     MAED_PROPAGATE(check_dims(d, "ste_block_bwd"));
     MAED_CHECK_ARG(p && g && x_in && dx_out && dx_in && saved && scratch, MAED_ERR_ARG, "ste_block_bwd: null pointer");
     MAED_CHECK_ARG(p->wt_qkv && p->wt_ts && p->wt_proj && p->wt_fc1 && p->wt_fc2, MAED_ERR_ARG, "ste_block_bwd: transposed weights missing");
@@ -171,6 +172,38 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
     const float* logits = (const float*)(sv + L.logits);
     float* dxmid = (float*)(sc + S.dxmid);
 
+    if (dt == MAED_BF16 && d->impl != MAED_IMPL_VALU) {
+        // ---- bf16: weight gradients straight from the row-major operands (maed_gemm_tn_wgrad), no transposed copies ----
+        const void* dyc = dx_out_twin;                                   // dx_out in bf16
+        if (!dyc) {                                                      // first block of the backward: cast once
+            MAED_PROPAGATE(maed_transpose_cast(dx_out, MAED_F32, C, M, C, nullptr, 0, sc + S.dyc, C, nullptr, dt, stream));
+            dyc = sc + S.dyc;
+        }
+        void* dxmid_tw = sc + S.dyt;                                     // bf16 twin of dx_mid (reuses the old transpose slot)
+        // MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
+        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(dyc, C, sv + L.hact, Hd, M, C, Hd, g->w_fc2, Hd, g->b_fc2, dt, stream));
+        MAED_PROPAGATE(maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
+        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, stream));
+        MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
+        MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
+                                          dx_out, dxmid, dxmid_tw, g->ln2_g, g->ln2_b, M, C, stream));
+        // attention: x_mid = x_in + proj(mix(x_s, x_t))
+        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dt, stream));
+        MAED_PROPAGATE(maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
+        MAED_PROPAGATE(maed_st_mix_bwd_reduce(sc + S.act, sv + L.xs, sv + L.xt, logits, sc + S.dlog, (float*)(sc + S.ws), d->F, d->P, C, dt, stream));
+        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dt, stream));
+        MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
+        MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
+        PROF(PROF_ATTN_TM_BWD, maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
+        PROF(PROF_ATTN_SP_BWD, maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
+                                                     MAED_IMPL_AUTO, stream));
+        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, 3 * C, sv + L.ln1, C, M, 3 * C, C, g->w_qkv, C, g->b_qkv, dt, stream));
+        MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
+        MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in, dx_in_twin,
+                                          g->ln1_g, g->ln1_b, M, C, stream));
+        return MAED_OK;
+    }
+    // ---- f32 parity mode (and impl = VALU): NT GEMMs on transposed copies ---------------------------------------
     // ---- MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid)))) ------------------------------------------------
     MAED_PROPAGATE(maed_transpose_cast(dx_out, MAED_F32, C, M, C, sc + S.dyt, Mp, sc + S.dyc, C, g->b_fc2, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sv + L.hact, dt, Hd, M, Hd, sc + S.bigT, Mp, nullptr, 0, nullptr, dt, stream));
@@ -181,7 +214,7 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
     PROF(PROF_GEMM_WGRAD, wgrad(sc + S.bigT, sc + S.xT, Hd, C, Mp, g->w_fc1, *d, stream));
     MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
     MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
-                                      dx_out, dxmid, g->ln2_g, g->ln2_b, M, C, stream));
+                                      dx_out, dxmid, nullptr, g->ln2_g, g->ln2_b, M, C, stream));
     // ---- attention: x_mid = x_in + proj(mix(x_s, x_t)) ---------------------------------------------------
     MAED_PROPAGATE(maed_transpose_cast(dxmid, MAED_F32, C, M, C, sc + S.dyt, Mp, sc + S.dyc, C, g->b_proj, dt, stream));
     MAED_PROPAGATE(maed_transpose_cast(sv + L.mix, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
@@ -200,7 +233,7 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
     MAED_PROPAGATE(maed_transpose_cast(sv + L.ln1, dt, C, M, C, sc + S.xT, Mp, nullptr, 0, nullptr, dt, stream));
     PROF(PROF_GEMM_WGRAD, wgrad(sc + S.bigT, sc + S.xT, 3 * C, C, Mp, g->w_qkv, *d, stream));
     MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
-    MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in,
+    MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in, dx_in_twin,
                                       g->ln1_g, g->ln1_b, M, C, stream));
     return MAED_OK;
 }

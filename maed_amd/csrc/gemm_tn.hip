@@ -1,0 +1,142 @@
+// Weight-gradient GEMM  dW[N,K] += Y[M,N]^T * X[M,K]  (both operands row-major, the reduction runs over ROWS).
+// nn.Linear backward (vision_transformer.py:98-111,124-128 through autograd): dW = dY^T X, db = colsum(dY).
+//
+// The MFMA fragments want 8 consecutive reduction elements per lane, i.e. M-contiguous data, while memory is
+// N/K-contiguous.  Instead of materialising transposed copies in HBM (round-1 first version: ~2.7 ms/step of
+// transposes), each thread loads an 8(m) x 8(n) block (8 coalesced 16-B loads, 16 lanes cover a 256-B row
+// segment), transposes it in registers with v_perm_b32 and writes eight 16-B rows of the M-contiguous LDS image
+// (144-B padded rows + XOR slot swizzle: conflict-free ds_write_b128 AND ds_read_b128).  The main loop is the same
+// 128x128x64 / 4-wave / 2x2 v_mfma_f32_32x32x16_bf16 structure as gemm_nt with a register prefetch distance of two
+// M-tiles; split-M workgroups accumulate with coalesced fp32 atomics straight into the gradient arena.  The
+// workgroups of K-tile 0 also produce the bias gradient (column sums of Y).
+#include "common.cuh"
+
+#define TN_BM 64      // reduction rows per LDS tile
+#define TN_LD 72      // LDS row stride (elements): 144 B
+
+__device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }  // {b.lo16, a.lo16}
+__device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }  // {b.hi16, a.hi16}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* __restrict__ Y, int64_t ldy, const bf16* __restrict__ X,
+                                                                   int64_t ldx, int64_t M, int N, int K, float* __restrict__ dW,
+                                                                   int64_t ldw, float* __restrict__ dbias, int tiles_k, int mtiles_per_split) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][128 * TN_LD];  // [buf][Y^T | X^T][row n|k][m]
+    __shared__ float lcs[8][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x % tiles_k;
+    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const int nmt = (int)((M + TN_BM - 1) / TN_BM);
+    const int mt_beg = blockIdx.z * mtiles_per_split;
+    int mt_end = mt_beg + mtiles_per_split;
+    if (mt_end > nmt) mt_end = nmt;
+    if (mt_beg >= mt_end) return;
+
+    // staging role: threads 0..127 transpose the Y tile, 128..255 the X tile; each owns an 8(m) x 8(col) block
+    const int side = tid >> 7, st = tid & 127;
+    const int nc = st & 15, mg = st >> 4;                      // column chunk (8 cols), row group (8 rows)
+    const bf16* src = side ? X : Y;
+    const int64_t lds_src = side ? ldx : ldy;
+    const int c0 = (side ? k0 : n0) + nc * 8;
+    const int cmax = side ? K : N;
+    const bool col_ok = c0 < cmax;                            // N, K are multiples of 8 (checked by the launcher)
+    const bf16* sp = src + c0;
+    unsigned short* my_lds_base = &lds[0][side][0];
+    const int wr_off = (nc * 8) * TN_LD + ((mg ^ (nc & 7)) << 3);   // row (nc*8 + j), swizzled 16-B slot mg ^ ((row>>3)&7)
+    const bool do_bias = (dbias != nullptr) && (tile_k == 0) && (side == 0);
+    float cs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+
+    uint4 r0_0, r0_1, r0_2, r0_3, r0_4, r0_5, r0_6, r0_7, r1_0, r1_1, r1_2, r1_3, r1_4, r1_5, r1_6, r1_7;
+#define TN_LD1(S, i, mrow0) { const int64_t m__ = (mrow0) + mg * 8 + i; \
+        r##S##_##i = (col_ok && m__ < M) ? *reinterpret_cast<const uint4*>(sp + m__ * lds_src) : make_uint4(0u, 0u, 0u, 0u); }
+#define TN_LOAD(S, mt_) { int mtc__ = (mt_); if (mtc__ > mt_end - 1) mtc__ = mt_end - 1; const int64_t mrow0__ = (int64_t)mtc__ * TN_BM; \
+        TN_LD1(S, 0, mrow0__) TN_LD1(S, 1, mrow0__) TN_LD1(S, 2, mrow0__) TN_LD1(S, 3, mrow0__) \
+        TN_LD1(S, 4, mrow0__) TN_LD1(S, 5, mrow0__) TN_LD1(S, 6, mrow0__) TN_LD1(S, 7, mrow0__) }
+    // transposed 16-B row for column pair d (dword index) half b: rows 0..7 of that column
+#define TN_ROW(S, COMP, PERM) make_uint4(PERM(r##S##_0.COMP, r##S##_1.COMP), PERM(r##S##_2.COMP, r##S##_3.COMP), \
+                                         PERM(r##S##_4.COMP, r##S##_5.COMP), PERM(r##S##_6.COMP, r##S##_7.COMP))
+#define TN_CS(S, COMP, j0) { const uint32_t w__[8] = {r##S##_0.COMP, r##S##_1.COMP, r##S##_2.COMP, r##S##_3.COMP, r##S##_4.COMP, r##S##_5.COMP, r##S##_6.COMP, r##S##_7.COMP}; \
+        _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) { cs[j0] += __uint_as_float(w__[i__] << 16); cs[j0 + 1] += __uint_as_float(w__[i__] & 0xffff0000u); } }
+#define TN_STORE(S, buf_) { unsigned short* d__ = my_lds_base + (size_t)(buf_) * (2 * 128 * TN_LD) + wr_off; \
+        *reinterpret_cast<uint4*>(d__ + 0 * TN_LD) = TN_ROW(S, x, perm_lo); *reinterpret_cast<uint4*>(d__ + 1 * TN_LD) = TN_ROW(S, x, perm_hi); \
+        *reinterpret_cast<uint4*>(d__ + 2 * TN_LD) = TN_ROW(S, y, perm_lo); *reinterpret_cast<uint4*>(d__ + 3 * TN_LD) = TN_ROW(S, y, perm_hi); \
+        *reinterpret_cast<uint4*>(d__ + 4 * TN_LD) = TN_ROW(S, z, perm_lo); *reinterpret_cast<uint4*>(d__ + 5 * TN_LD) = TN_ROW(S, z, perm_hi); \
+        *reinterpret_cast<uint4*>(d__ + 6 * TN_LD) = TN_ROW(S, w, perm_lo); *reinterpret_cast<uint4*>(d__ + 7 * TN_LD) = TN_ROW(S, w, perm_hi); \
+        if (do_bias) { TN_CS(S, x, 0) TN_CS(S, y, 2) TN_CS(S, z, 4) TN_CS(S, w, 6) } }
+
+    f32x16_t acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    // fragment reads: row = sub-tile base + l31, logical 16-B slot 2*kk + hi, physical slot ^ ((row >> 3) & 7)
+    const int arow0 = wr * 64 + l31, arow1 = arow0 + 32, brow0 = wc * 64 + l31, brow1 = brow0 + 32;
+    const int asw0 = (arow0 >> 3) & 7, asw1 = (arow1 >> 3) & 7, bsw0 = (brow0 >> 3) & 7, bsw1 = (brow1 >> 3) & 7;
+#define TN_COMPUTE(buf_) { const unsigned short* A__ = &lds[buf_][0][0]; const unsigned short* B__ = &lds[buf_][1][0]; \
+        _Pragma("unroll") for (int kk = 0; kk < TN_BM / 16; ++kk) { const int sl = 2 * kk + hi; \
+            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(A__ + arow0 * TN_LD + ((sl ^ asw0) << 3)); \
+            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(A__ + arow1 * TN_LD + ((sl ^ asw1) << 3)); \
+            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(B__ + brow0 * TN_LD + ((sl ^ bsw0) << 3)); \
+            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(B__ + brow1 * TN_LD + ((sl ^ bsw1) << 3)); \
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0); \
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0); \
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0); \
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0); } }
+
+    TN_LOAD(0, mt_beg);
+    TN_LOAD(1, mt_beg + 1);
+    TN_STORE(0, 0);
+    __syncthreads();
+    int mt = mt_beg;
+    for (; mt + 1 < mt_end; mt += 2) {
+        TN_LOAD(0, mt + 2);
+        TN_COMPUTE(0);
+        TN_STORE(1, 1);
+        __syncthreads();
+        TN_LOAD(1, mt + 3);
+        TN_COMPUTE(1);
+        if (mt + 2 < mt_end) TN_STORE(0, 0);   // guarded: the column sums must not see a clamped duplicate tile
+        __syncthreads();
+    }
+    if (mt < mt_end) TN_COMPUTE(0);
+
+    // D[row n][col k]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*hi -> atomics of a half-wave hit 32 consecutive k
+#define TN_EPI(acc_, i_, j_) { const int kcol = k0 + wc * 64 + (j_) * 32 + l31; \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int nrow = n0 + wr * 64 + (i_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; \
+            if (nrow < N && kcol < K) atomicAdd(dW + (int64_t)nrow * ldw + kcol, acc_[r]); } }
+    TN_EPI(acc00, 0, 0) TN_EPI(acc01, 0, 1) TN_EPI(acc10, 1, 0) TN_EPI(acc11, 1, 1)
+
+    if (dbias != nullptr && tile_k == 0) {   // block-uniform branch
+        if (side == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lcs[mg][nc * 8 + j] = cs[j];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += lcs[g][tid];
+            if (n0 + tid < N) atomicAdd(dbias + n0 + tid, s);
+        }
+    }
+}
+
+extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw,
+                                  float* dbias, int dtype, void* stream) {
+    MAED_CHECK_ARG(Y && X && dW, MAED_ERR_ARG, "gemm_tn_wgrad: null pointer");
+    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "gemm_tn_wgrad: bf16 only (the f32 parity mode uses transposed copies + gemm_nt)");
+    MAED_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldw >= K, MAED_ERR_SHAPE,
+                   "gemm_tn_wgrad: need N, K, ldy, ldx multiples of 8 (N=%d K=%d)", N, K);
+    MAED_CHECK_ARG(is_aligned(Y, 16) && is_aligned(X, 16), MAED_ERR_ALIGN, "gemm_tn_wgrad: Y/X must be 16-B aligned");
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    const int nmt = (int)((M + TN_BM - 1) / TN_BM);
+    int splits = (1024 + tn * tk - 1) / (tn * tk);           // fill the chip: ~1024 workgroups
+    if (splits > (nmt + 3) / 4) splits = (nmt + 3) / 4;      // at least 4 M-tiles per workgroup
+    if (splits < 1) splits = 1;
+    const int per = (nmt + splits - 1) / splits;
+    const int z = (nmt + per - 1) / per;
+    hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
+                       N, K, dW, ldw, dbias, tk, per);
+    MAED_CHECK_LAUNCH("gemm_tn_wgrad");
+    return MAED_OK;
+}

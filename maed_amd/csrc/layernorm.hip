@@ -55,8 +55,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ g, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ dres,
-                                                     float* __restrict__ dx, float* __restrict__ dg, float* __restrict__ db,
-                                                     int64_t rows, int C) {
+                                                     float* __restrict__ dx, T* __restrict__ dx_twin, float* __restrict__ dg,
+                                                     float* __restrict__ db, int64_t rows, int C) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][4 waves][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C / 4;
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rr[j] + rstd * (gy[i][j] - s1 - xh[i][j] * s2);
                 st4(dxr + c4 * 4, o);
+                if (dx_twin) st4(dx_twin + row * (int64_t)C + c4 * 4, o);   // compute-dtype copy: next GEMM's operand
             }
         }
     }
@@ -138,7 +139,7 @@ extern "C" int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const fl
 }
 
 extern "C" int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma,
-                                  const float* mean, const float* rstd, const float* dres_in, float* dx_out,
+                                  const float* mean, const float* rstd, const float* dres_in, float* dx_out, void* dx_twin,
                                   float* dgamma, float* dbeta, int64_t rows, int C, void* stream) {
     MAED_CHECK_ARG(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta, MAED_ERR_ARG, "layernorm_bwd: null pointer");
     MAED_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXV, MAED_ERR_SHAPE, "layernorm_bwd: C=%d unsupported", C);
@@ -148,7 +149,7 @@ extern "C" int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int
     const size_t lds = (size_t)8 * C * sizeof(float);
     MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ln_bwd_kernel<T>), grid, dim3(256), lds, (hipStream_t)stream,
                                                       (const T*)dy, x, x_row_stride, gamma, mean, rstd, dres_in, dx_out,
-                                                      dgamma, dbeta, rows, C));
+                                                      (T*)dx_twin, dgamma, dbeta, rows, C));
     MAED_CHECK_LAUNCH("layernorm_bwd");
     return MAED_OK;
 }

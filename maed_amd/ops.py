@@ -63,16 +63,27 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-6, row_stride=None, rows=Non
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, want_twin=False):
     C_ = x.shape[-1]
     x, dy = _c(x), _c(dy)
     rows = x.numel() // C_
     dx = torch.empty(rows, C_, dtype=torch.float32, device=x.device)
+    twin = torch.empty(rows, C_, dtype=dy.dtype, device=x.device) if want_twin else None
     dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
     dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
-    check(L.lib().maed_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), C_, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+    check(L.lib().maed_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), C_, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(twin),
                                      _p(dgamma), _p(dbeta), rows, C_, _stream()), "layernorm_bwd")
-    return dx, dgamma, dbeta
+    return (dx, dgamma, dbeta, twin) if want_twin else (dx, dgamma, dbeta)
+
+
+def gemm_tn_wgrad(Y, X, dW=None, dbias=None):
+    """dW[N,K] += Y[M,N]^T X[M,K]; dbias[N] += colsum(Y)   (bf16 operands, fp32 accumulators)"""
+    M, N = Y.shape
+    K = X.shape[1]
+    dW = torch.zeros(N, K, dtype=torch.float32, device=Y.device) if dW is None else dW
+    check(L.lib().maed_gemm_tn_wgrad(_p(Y), Y.stride(0), _p(X), X.stride(0), M, N, K, _p(dW), dW.stride(0), _p(dbias), dt_code(Y.dtype), _stream()),
+          "gemm_tn_wgrad")
+    return dW
 
 
 def gemm_nt(A, B, epilogue=L.EPI_STORE, bias=None, out=None, out2=None, aux=None, splitk=1, impl=L.IMPL_AUTO, M=None, K=None):
@@ -269,6 +280,14 @@ class EmbedAddFn(torch.autograd.Function):
         return dpatch, dcls, dpos, dtemp, None
 
 
+import weakref
+
+# (weakref to the residual-gradient tensor a Block backward returned, its compute-dtype copy).  The next Block backward
+# uses the copy only if it receives THAT VERY tensor object as grad_output (identity, not data_ptr: allocator reuse).
+_TWIN = [None, None]
+TWIN_HITS = [0, 0]   # [hits, misses] -- diagnostics
+
+
 class STEBlockFn(torch.autograd.Function):
     """One STE Block through maed_ste_block_{fwd,bwd}.  Parameter gradients are accumulated by the
     kernels directly into p.grad (fp32, allocated on demand); autograd sees None for them, and the
@@ -299,8 +318,20 @@ class STEBlockFn(torch.autograd.Function):
         dy = _c(dy)
         dx = torch.empty_like(dy)
         scratch = _scratch(lib.maed_ste_block_scratch_bytes(C.byref(d)), dy.device)
-        check(lib.maed_ste_block_bwd(C.byref(d), C.byref(pr), C.byref(gr), _p(x), _p(dy), _p(dx), _p(saved), _p(scratch), _stream()),
-              "ste_block_bwd")
+        # consecutive blocks hand the compute-dtype copy of the residual gradient along (no cast pass in between)
+        cdt = block.compute_dtype
+        tw_in = None
+        if cdt != torch.float32:
+            ref, cand = _TWIN
+            if ref is not None and ref() is dy and cand.shape == dy.shape and cand.dtype == cdt:
+                tw_in = cand
+            TWIN_HITS[0 if tw_in is not None else 1] += 1
+        _TWIN[0], _TWIN[1] = None, None
+        tw_out = torch.empty(dy.shape, dtype=cdt, device=dy.device) if cdt != torch.float32 else None
+        check(lib.maed_ste_block_bwd(C.byref(d), C.byref(pr), C.byref(gr), _p(x), _p(dy), _p(dx), _p(saved), _p(scratch),
+                                     _p(tw_in), _p(tw_out), _stream()), "ste_block_bwd")
+        if tw_out is not None:
+            _TWIN[0], _TWIN[1] = weakref.ref(dx), tw_out
         block._pending_backwards -= 1
         if block._pending_backwards == 0 and block.grads_ready is not None:
             block.grads_ready(block)

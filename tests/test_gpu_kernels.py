@@ -390,3 +390,17 @@ def test_weight_std_batched(dtype):
         report(f"weight_std_fwd[{dtype},{shapes[i]}]", o.float(), ref, **tol(dtype, 2))
         report(f"weight_std_bwd[{dtype},{shapes[i]}]", w.grad, wd.grad, rtol=1e-4 if dtype == torch.float32 else 2e-2,
                atol=(1e-4 if dtype == torch.float32 else 2e-2) * wd.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (197 * 8, 512, 256), (64, 128, 128), (1000, 1536, 512), (37, 8, 8)])
+def test_gemm_tn_wgrad(M, N, K):
+    """dW += Y^T X and db += colsum(Y) straight from row-major bf16 operands (register 8x8 transposes, split-M atomics)"""
+    ops, _ = _ops()
+    Y = q(rnd(M, N, seed=1), torch.bfloat16)
+    X = q(rnd(M, K, seed=2), torch.bfloat16)
+    dW0, db0 = rnd(N, K, seed=3), rnd(N, seed=4)
+    dW, db = dW0.clone().to(DEV), db0.clone().to(DEV)
+    ops.gemm_tn_wgrad(Y.to(DEV).bfloat16(), X.to(DEV).bfloat16(), dW=dW, dbias=db)
+    ref = dW0.double() + Y.double().t() @ X.double()
+    report(f"gemm_tn_wgrad.dW[{M}x{N}x{K}]", dW, ref, rtol=2e-5, atol=2e-5 * max(1.0, M ** 0.5))
+    report(f"gemm_tn_wgrad.db[{M}x{N}]", db, db0.double() + Y.double().sum(0), rtol=2e-5, atol=2e-5 * max(1.0, M ** 0.5))

@@ -234,6 +234,8 @@ def test_train_step_arena_adam_bf16_runs_and_learns():
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
     assert all(p.grad.data_ptr() >= arena.grad.data_ptr() for p in arena.params)
+    from maed_amd import ops
+    assert ops.TWIN_HITS[0] > 0, f"bf16 residual-gradient hand-off between blocks never triggered: {ops.TWIN_HITS}"
 
 
 def test_graphed_training_tail_matches_eager():
