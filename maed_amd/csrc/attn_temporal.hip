@@ -210,8 +210,50 @@ __global__ __launch_bounds__(256) void attn_tm_fwd_lds(const T* __restrict__ qkv
     lse[(f * H + h) * P + p] = m + __logf(l);
 }
 
+// half-row helpers: two lanes (h2 = 0,1) share one (group, frame) row, each owning 32 of the 64 head dims, so the
+// backward needs ~100 VGPRs instead of 256 (4 waves per SIMD instead of 1); dot products are completed with one
+// lane-pair shuffle.
+#define DH 32
 template <typename T>
-__global__ __launch_bounds__(128) void attn_tm_bwd_lds(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
+__device__ __forceinline__ void load_half(const T* p, float (&v)[DH]) {
+#pragma unroll
+    for (int c = 0; c < DH; c += 8) { float t[8]; ld8(p + c, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c + j] = t[j]; }
+}
+template <typename T>
+__device__ __forceinline__ float dot_half(const T* p, const float (&v)[DH]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; c += 8) { float t[8]; ld8(p + c, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(v[c + j], t[j], s); }
+    return s + __shfl_xor(s, 1, 64);
+}
+template <typename T>
+__device__ __forceinline__ void axpy_half(const T* p, float a, float (&acc)[DH]) {
+#pragma unroll
+    for (int c = 0; c < DH; c += 8) { float t[8]; ld8(p + c, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[c + j] = fmaf(a, t[j], acc[c + j]); }
+}
+template <typename T>
+__device__ __forceinline__ void store_half(T* p, const float (&v)[DH], int accumulate) {
+#pragma unroll
+    for (int c = 0; c < DH; c += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v[c + j];
+        if (accumulate) { float o[8]; ld8(p + c, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] += o[j]; }
+        st8(p + c, t);
+    }
+}
+
+// blockDim = 256 = GP groups x Tn frames x 2 half-rows; tid = (gp*Tn + t)*2 + h2
+template <typename T>
+__global__ __launch_bounds__(256) void attn_tm_bwd_lds(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
                                                        const float* __restrict__ lse, T* __restrict__ dqkv, int accumulate,
                                                        int P, int H, int Tn, int GP, float scale) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -219,58 +261,59 @@ __global__ __launch_bounds__(128) void attn_tm_bwd_lds(const T* __restrict__ qkv
     const int chunks = (P + GP - 1) / GP;
     const int pc = blockIdx.x % chunks; int r0 = blockIdx.x / chunks;
     const int h = r0 % H; const int64_t n = r0 / H;
-    const int p0 = pc * GP, nthr = GP * Tn;
-    const size_t arr = (size_t)GP * Tn * RowGeom<T>::RS + GP * 16;
+    const int p0 = pc * GP, nrows = GP * Tn;
+    const size_t arr = (size_t)nrows * RowGeom<T>::RS + GP * 16;
     char* Qs = sm; char* Ks = sm + arr; char* Vs = sm + 2 * arr; char* dOs = sm + 3 * arr;
-    float* Ls = reinterpret_cast<float*>(sm + 4 * arr); float* Ds = Ls + nthr;
-    stage_group_rows<T>(Qs, qkv + h * D, ld, n, Tn, P, p0, GP, nthr);
-    stage_group_rows<T>(Ks, qkv + C + h * D, ld, n, Tn, P, p0, GP, nthr);
-    stage_group_rows<T>(Vs, qkv + 2 * C + h * D, ld, n, Tn, P, p0, GP, nthr);
-    stage_group_rows<T>(dOs, d_o + h * D, (int64_t)C, n, Tn, P, p0, GP, nthr);
-    const int gp = threadIdx.x / Tn, t = threadIdx.x % Tn;
+    float* Ls = reinterpret_cast<float*>(sm + 4 * arr); float* Ds = Ls + nrows;
+    stage_group_rows<T>(Qs, qkv + h * D, ld, n, Tn, P, p0, GP, 256);
+    stage_group_rows<T>(Ks, qkv + C + h * D, ld, n, Tn, P, p0, GP, 256);
+    stage_group_rows<T>(Vs, qkv + 2 * C + h * D, ld, n, Tn, P, p0, GP, 256);
+    stage_group_rows<T>(dOs, d_o + h * D, (int64_t)C, n, Tn, P, p0, GP, 256);
+    const int h2 = threadIdx.x & 1, rt = threadIdx.x >> 1;     // half-row, row within the workgroup
+    const int gp = rt / Tn, t = rt - gp * Tn;
     const int p = p0 + gp;
     const int pcl = p < P ? p : P - 1;
     const int64_t f = n * Tn + t;
     const int64_t row = f * P + pcl;
-    const int g0 = gp * Tn;
-    float a[D], b[D], acc[D];
-    load_row(d_o + row * C + h * D, b);                       // dO (own row)
-    const float Dq = dot_row(o + row * C + h * D, b);
+    const int g0 = gp * Tn, ho = h2 * DH;
+    float a[DH], b[DH], acc[DH];
+    load_half(d_o + row * C + h * D + ho, b);                           // dO (own half row)
+    const float Dq = dot_half(o + row * C + h * D + ho, b);
     const float L = lse[(f * H + h) * P + pcl];
-    Ds[threadIdx.x] = Dq; Ls[threadIdx.x] = L;
+    if (h2 == 0) { Ds[rt] = Dq; Ls[rt] = L; }
     __syncthreads();
-    if (p >= P) return;
+    if (p >= P) return;                                                 // both lanes of a pair leave together
     // ---- as query t: dQ = sum_t2 ds[t][t2] K[t2] ----
-    load_row(lds_row<T>(Qs, g0 + t, gp), a);
+    load_half(lds_row<T>(Qs, g0 + t, gp) + ho, a);
 #pragma unroll
-    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int c = 0; c < DH; ++c) acc[c] = 0.f;
     for (int t2 = 0; t2 < Tn; ++t2) {
-        const T* kr = lds_row<T>(Ks, g0 + t2, gp);
-        const float pr = __expf(dot_row(kr, a) * scale - L);
-        const float ds = pr * (dot_row(lds_row<T>(Vs, g0 + t2, gp), b) - Dq) * scale;
-        axpy_row(kr, ds, acc);
+        const T* kr = lds_row<T>(Ks, g0 + t2, gp) + ho;
+        const float pr = __expf(dot_half(kr, a) * scale - L);
+        const float ds = pr * (dot_half(lds_row<T>(Vs, g0 + t2, gp) + ho, b) - Dq) * scale;
+        axpy_half(kr, ds, acc);
     }
-    store_row(dqkv + row * ld + h * D, acc, 1.f, accumulate);
+    store_half(dqkv + row * ld + h * D + ho, acc, accumulate);
     // ---- as key t: dV = sum_t1 p[t1][t] dO[t1] ----
-    load_row(lds_row<T>(Ks, g0 + t, gp), a);                   // k (own row)
+    load_half(lds_row<T>(Ks, g0 + t, gp) + ho, a);                     // k (own half row)
 #pragma unroll
-    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int c = 0; c < DH; ++c) acc[c] = 0.f;
     for (int t1 = 0; t1 < Tn; ++t1) {
-        const float pr = __expf(dot_row(lds_row<T>(Qs, g0 + t1, gp), a) * scale - Ls[g0 + t1]);
-        axpy_row(lds_row<T>(dOs, g0 + t1, gp), pr, acc);
+        const float pr = __expf(dot_half(lds_row<T>(Qs, g0 + t1, gp) + ho, a) * scale - Ls[g0 + t1]);
+        axpy_half(lds_row<T>(dOs, g0 + t1, gp) + ho, pr, acc);
     }
-    store_row(dqkv + row * ld + 2 * C + h * D, acc, 1.f, accumulate);
+    store_half(dqkv + row * ld + 2 * C + h * D + ho, acc, accumulate);
     // ---- as key t: dK = sum_t1 ds[t1][t] Q[t1] ----
-    load_row(lds_row<T>(Vs, g0 + t, gp), b);                   // v (own row)
+    load_half(lds_row<T>(Vs, g0 + t, gp) + ho, b);                     // v (own half row)
 #pragma unroll
-    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    for (int c = 0; c < DH; ++c) acc[c] = 0.f;
     for (int t1 = 0; t1 < Tn; ++t1) {
-        const T* q1 = lds_row<T>(Qs, g0 + t1, gp);
-        const float pr = __expf(dot_row(q1, a) * scale - Ls[g0 + t1]);
-        const float ds = pr * (dot_row(lds_row<T>(dOs, g0 + t1, gp), b) - Ds[g0 + t1]) * scale;
-        axpy_row(q1, ds, acc);
+        const T* q1 = lds_row<T>(Qs, g0 + t1, gp) + ho;
+        const float pr = __expf(dot_half(q1, a) * scale - Ls[g0 + t1]);
+        const float ds = pr * (dot_half(lds_row<T>(dOs, g0 + t1, gp) + ho, b) - Ds[g0 + t1]) * scale;
+        axpy_half(q1, ds, acc);
     }
-    store_row(dqkv + row * ld + C + h * D, acc, 1.f, accumulate);
+    store_half(dqkv + row * ld + C + h * D + ho, acc, accumulate);
 }
 
 template <typename T>
@@ -295,7 +338,7 @@ static bool launch_tm_bwd_lds(const void* qkv, const void* o, const void* d_o, c
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)attn_tm_bwd_lds<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const int chunks = (P + GP - 1) / GP;
-    hipLaunchKernelGGL((attn_tm_bwd_lds<T>), dim3((unsigned)((F / Tn) * H * chunks)), dim3(128), lds, s, (const T*)qkv, (const T*)o, (const T*)d_o,
+    hipLaunchKernelGGL((attn_tm_bwd_lds<T>), dim3((unsigned)((F / Tn) * H * chunks)), dim3(256), lds, s, (const T*)qkv, (const T*)o, (const T*)d_o,
                        lse, (T*)dqkv, accumulate, P, H, Tn, GP, scale);
     return true;
 }

@@ -73,10 +73,13 @@ class ParamArena:
 class GradBucketer:
     """Bucketed, overlapped gradient all-reduce over the gradient arena."""
 
-    def __init__(self, arena, model, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, arena, model, bucket_bytes=32 << 20, process_group=None, force_collectives=False):
         self.arena = arena
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # world == 1 normally skips the collectives; force_collectives issues them anyway (exercises the RCCL
+        # stream/event plumbing on a single GPU: tests/test_gpu_model.py)
+        self.collectives = (self.world > 1) or (force_collectives and dist.is_available() and dist.is_initialized())
         cap = max(1, bucket_bytes // 4)
         # buckets are built from the END of the arena (first to complete in backward)
         self.buckets = []  # [start, end, n_params]
@@ -126,7 +129,7 @@ class GradBucketer:
         if self._launched[b]:
             return
         self._launched[b] = True
-        if self.world > 1:
+        if self.collectives:
             s, e, _ = self.buckets[b]
             self._works.append(dist.all_reduce(self.arena.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -143,7 +146,7 @@ class GradBucketer:
 
     def broadcast_parameters(self, src=0):
         """train.py:113 DDP construction broadcasts rank 0's parameters once."""
-        if self.world > 1:
+        if self.collectives:
             dist.broadcast(self.arena.flat, src=src, group=self.pg)
             ops.bump_weight_epoch()
 

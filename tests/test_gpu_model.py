@@ -264,3 +264,44 @@ def test_graphed_training_tail_matches_eager():
     report("graphed tail: worst rel-to-max gradient difference vs eager (STE+decoder)", torch.tensor([worst]), torch.zeros(1), rtol=0, atol=1e-4)
     worst2 = max((g_g2[n] - g_g[n]).abs().max().item() / (g_g[n].abs().max().item() + 1e-12) for n in g_g if "backbone" not in n)
     report("graphed tail: replay reproducibility", torch.tensor([worst2]), torch.zeros(1), rtol=0, atol=1e-4)
+
+
+def test_rccl_bucketed_allreduce_single_rank():
+    """exercise the RCCL path on one GPU (world_size 1, collectives forced): process-group init, async bucket
+    all-reduces on RCCL's stream during backward, wait + fused Adam.  The result must equal the no-DDP step."""
+    import torch.distributed as dist
+    from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        clip = rnd(2, 2, 3, 64, 64, seed=21).to(DEV)
+        results = []
+        for force in (False, True):
+            m, _ = _small_maed(torch.float32, depth=1, img=64, seed=9)   # f32: run-to-run noise is atomics order only
+            m.train()
+            m.decoder.drop1.p = 0.0
+            m.decoder.drop2.p = 0.0
+            arena = ParamArena(m)
+            buck = GradBucketer(arena, m, bucket_bytes=1 << 18, force_collectives=force)
+            buck.broadcast_parameters(0)
+            opt = FusedAdam(arena, lr=1e-3, bucketer=buck)
+            opt.zero_grad()
+            out = m(clip)
+            ((out["kp_3d"] ** 2).mean() + (out["theta"] ** 2).mean()).backward()
+            buck.finish()                      # waits for every (forced) bucket all-reduce on the current stream
+            torch.cuda.synchronize()
+            assert len(buck.buckets) > 2
+            results.append(arena.grad.clone())
+            opt.step()                         # Adam after the collectives: must run without error
+            torch.cuda.synchronize()
+            assert torch.isfinite(arena.flat).all()
+        # Adam normalises updates to +-lr, so parameters are compared through the reduced GRADIENTS (atomics: order noise)
+        scale = results[0].abs().max().item()
+        report("RCCL(world=1) bucketed gradients == plain gradients", results[1], results[0], rtol=1e-3, atol=2e-4 * scale)
+    finally:
+        if created:
+            dist.destroy_process_group()
