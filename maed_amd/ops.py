@@ -417,7 +417,7 @@ class GroupNormFn(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous(memory_format=torch.channels_last).to(x.dtype)
         y = torch.empty_like(x, memory_format=torch.channels_last)
-        sums = torch.empty(N, 32, 2, dtype=torch.float64, device=x.device)
+        sums = torch.empty(32, N, 32, 2, dtype=torch.float64, device=x.device)   # per-chunk partials (<= 32 chunks)
         check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), N, H * W, C_, eps, int(relu),
                                          dt_code(x.dtype), _stream()), "groupnorm_fwd")
         ctx.has_res = residual is not None
@@ -443,9 +443,51 @@ class GroupNormFn(torch.autograd.Function):
         else:
             dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device)
             dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device)
-        ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
+        ab = torch.empty(8, N, C_, 2, dtype=torch.float32, device=x.device)     # per-chunk partials (<= 8 chunks)
         check(L.lib().maed_groupnorm_bwd(_p(x), _p(y), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
                                          N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), _stream()), "groupnorm_bwd")
         if ctx.direct:
             return dx, dres, None, None, None, None, None
         return dx, dres, dgamma, dbeta, None, None, None
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    """EXPERIMENT, not on the product path (measured slower than MIOpen at the backbone's short-K shapes: backbone
+    fwd+bwd 24.8 ms vs 22.6 ms at cfg3; kept with its parity test as the starting point for a fused conv+GroupNorm-stats
+    epilogue).  1x1 convolution on a channels_last bf16 tensor as a GEMM on libmaed_hip (37 of the 53 convolutions):
+    y[(n,h,w), o] = sum_i x[(n,h,w), i] w[o, i].  Forward = maed_gemm_nt, input gradient = maed_gemm_nt on the
+    transposed weight, weight gradient = maed_gemm_tn_wgrad (no transposed activation copies, no MIOpen workspace
+    zero/cast passes).  stride 2 (the two downsample convolutions) = spatial subsampling before the GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        N, I, H0, W0 = x.shape
+        if stride > 1:
+            x = x[:, :, ::stride, ::stride]
+        x = x.contiguous(memory_format=torch.channels_last)
+        _, _, H, W = x.shape
+        O = w.shape[0]
+        A = x.permute(0, 2, 3, 1).reshape(N * H * W, I)
+        w2 = w.reshape(O, I)
+        w2 = w2 if w2.is_contiguous() else w2.contiguous()
+        y = gemm_nt(A, w2, L.EPI_STORE)
+        ctx.save_for_backward(A, w2)
+        ctx.geom = (N, I, H0, W0, H, W, O, stride)
+        return y.view(N, H, W, O).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        A, w2 = ctx.saved_tensors
+        N, I, H0, W0, H, W, O, stride = ctx.geom
+        Y = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(N * H * W, O)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt, _ = transpose_cast(w2, w2.dtype, pad_to=1)            # (I, O)
+            dA = gemm_nt(Y, wt, L.EPI_STORE).view(N, H, W, I).permute(0, 3, 1, 2)
+            if stride > 1:
+                dx = torch.zeros(N, I, H0, W0, dtype=dA.dtype, device=dA.device).contiguous(memory_format=torch.channels_last)
+                dx[:, :, ::stride, ::stride] = dA
+            else:
+                dx = dA
+        dW = gemm_tn_wgrad(Y, A).view(O, I, 1, 1)
+        return dx, dW, None

@@ -53,6 +53,8 @@ class StdConv2dSame(nn.Conv2d):
             if x.is_cuda:
                 w = w.contiguous(memory_format=torch.channels_last)
         k, s = self.kernel_size[0], self.stride[0]
+        # (1x1 convolutions as GEMMs on libmaed_hip -- ops.Conv1x1Fn -- were measured 2.2 ms/step SLOWER than MIOpen's
+        #  igemm kernels at these short-K shapes, so every convolution stays on MIOpen: DESIGN.md section 5)
         ih, iw = x.shape[-2:]
         ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
         pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
