@@ -223,11 +223,10 @@ typedef struct {
 int maed_weight_std_fwd(const void* conv_table, int n_convs, int n_filters, void* out, int dtype, float* stats, float eps, void* stream);
 int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int dtype, const float* stats, float eps, void* stream);
 /* GroupNorm(32 groups)(+ residual)(+ ReLU) on channels_last activations x (N, HW, C) (resnetv2.py:35-49,189-204):
- * y = act(GN(x) * gamma + beta [+ residual]).  sums: (32,N,32,2) doubles (per-chunk partial sums, <= 32 row chunks)
- * written by forward, read by backward.  No memset, no atomics on the statistics. */
+ * y = act(GN(x) * gamma + beta [+ residual]).  sums: (N,32,2) doubles written by forward, read by backward. */
 int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
                        int N, int HW, int C, float eps, int relu, int dtype, void* stream);
-/* dx (and dres = masked dy when dres != NULL); dgamma/dbeta += (atomics); ab_scratch: 8*N*C*2 floats;
+/* dx (and dres = masked dy when dres != NULL); dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats;
  * y (the saved forward output) is needed only for relu with a residual, otherwise the mask is recomputed from x */
 int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, const float* beta,
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,

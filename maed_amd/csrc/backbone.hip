@@ -146,8 +146,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         }
     }
     __syncthreads();
-    // per-chunk partial sums: sums[chunk][n][32][2]; consumers add the chunks up in their prologue
-    if (threadIdx.x < GN_G * 2) sums[((int64_t)blockIdx.x * gridDim.y + n) * GN_G * 2 + threadIdx.x] = (&ls[0][0])[threadIdx.x];
+    if (threadIdx.x < GN_G * 2) atomicAdd(sums + (int64_t)n * GN_G * 2 + threadIdx.x, (&ls[0][0])[threadIdx.x]);
 }
 
 
@@ -155,18 +154,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 template <typename T, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const double* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
-                                                       int HW, int C, float eps, int rows_per_wg, int schunks) {
+                                                       int HW, int C, float eps, int rows_per_wg) {
     __shared__ float lmu[GN_G], lrs[GN_G];
     const int n = blockIdx.y;
     if (threadIdx.x < GN_G) {
         const double cnt = (double)HW * (C / GN_G);
-        double s1 = 0.0, s2 = 0.0;
-        for (int ch = 0; ch < schunks; ++ch) {
-            const double* sp = sums + (((int64_t)ch * gridDim.y + n) * GN_G + threadIdx.x) * 2;
-            s1 += sp[0]; s2 += sp[1];
-        }
-        const double m = s1 / cnt;
-        double var = s2 / cnt - m * m;
+        const double m = sums[((int64_t)n * GN_G + threadIdx.x) * 2] / cnt;
+        double var = sums[((int64_t)n * GN_G + threadIdx.x) * 2 + 1] / cnt - m * m;
         if (var < 0.0) var = 0.0;
         lmu[threadIdx.x] = (float)m; lrs[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
     }
@@ -206,19 +200,14 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
                                                             const double* __restrict__ sums, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ ab /* [N][C][2] */,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int HW, int C, float eps, int rows_per_wg, int schunks) {
+                                                            int HW, int C, float eps, int rows_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float lpart[];   // [256/cbn][C][2] = 16 KB
     __shared__ float lmu[GN_G], lrs[GN_G];
     const int n = blockIdx.y;
     if (threadIdx.x < GN_G) {
         const double cnt = (double)HW * (C / GN_G);
-        double s1 = 0.0, s2 = 0.0;
-        for (int ch = 0; ch < schunks; ++ch) {
-            const double* sp = sums + (((int64_t)ch * gridDim.y + n) * GN_G + threadIdx.x) * 2;
-            s1 += sp[0]; s2 += sp[1];
-        }
-        const double m = s1 / cnt;
-        double var = s2 / cnt - m * m;
+        const double m = sums[((int64_t)n * GN_G + threadIdx.x) * 2] / cnt;
+        double var = sums[((int64_t)n * GN_G + threadIdx.x) * 2 + 1] / cnt - m * m;
         if (var < 0.0) var = 0.0;
         lmu[threadIdx.x] = (float)m; lrs[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
     }
@@ -254,7 +243,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < 2 * C; i += 256) {
         float t = 0.f;
         for (int k = 0; k < rstep; ++k) t += lpart[(size_t)k * 2 * C + i];
-        ab[((int64_t)blockIdx.x * gridDim.y + n) * C * 2 + i] = t;              // per-chunk partial (no memset, no atomics)
+        atomicAdd(ab + (int64_t)n * C * 2 + i, t);
         atomicAdd(((i & 1) ? dgamma : dbeta) + (i >> 1), t);
     }
 }
@@ -265,29 +254,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const double* __restrict__ sums, const float* __restrict__ ab,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            T* __restrict__ dx, T* __restrict__ dres,
-                                                           int HW, int C, float eps, int rows_per_wg, int schunks, int rchunks) {
+                                                           int HW, int C, float eps, int rows_per_wg) {
     __shared__ float lmu[GN_G], lrs[GN_G], lm1[GN_G], lm2[GN_G];
     const int n = blockIdx.y, cpg = C / GN_G;
     if (threadIdx.x < GN_G) {
         const double cnt = (double)HW * cpg;
-        double s1 = 0.0, s2 = 0.0;
-        for (int ch = 0; ch < schunks; ++ch) {
-            const double* sp = sums + (((int64_t)ch * gridDim.y + n) * GN_G + threadIdx.x) * 2;
-            s1 += sp[0]; s2 += sp[1];
-        }
-        const double m = s1 / cnt;
-        double var = s2 / cnt - m * m;
+        const double m = sums[((int64_t)n * GN_G + threadIdx.x) * 2] / cnt;
+        double var = sums[((int64_t)n * GN_G + threadIdx.x) * 2 + 1] / cnt - m * m;
         if (var < 0.0) var = 0.0;
         lmu[threadIdx.x] = (float)m; lrs[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
         float m1 = 0.f, m2 = 0.f;
         for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
-            float a0 = 0.f, a1 = 0.f;
-            for (int ch = 0; ch < rchunks; ++ch) {   // per-chunk partials written by the reduction pass
-                const float* ap = ab + (((int64_t)ch * gridDim.y + n) * C + c) * 2;
-                a0 += ap[0]; a1 += ap[1];
-            }
-            m1 = fmaf(gamma[c], a0, m1);
-            m2 = fmaf(gamma[c], a1, m2);
+            m1 = fmaf(gamma[c], ab[((int64_t)n * C + c) * 2], m1);
+            m2 = fmaf(gamma[c], ab[((int64_t)n * C + c) * 2 + 1], m2);
         }
         lm1[threadIdx.x] = m1 / (float)cnt; lm2[threadIdx.x] = m2 / (float)cnt;
     }
@@ -323,12 +302,10 @@ static int gn_check(int C, int HW, const char* who) {
     MAED_CHECK_ARG(HW > 0, MAED_ERR_SHAPE, "%s: HW=%d", who, HW);
     return MAED_OK;
 }
-static int gn_rows_per_wg(int N, int HW, int C, int target_wgs = 2048, int max_chunks = 32) {
-    // aim for ~target_wgs workgroups overall, at most max_chunks row chunks per sample (the partial-sum buffers are
-    // sized for that); at least one pass of the row tile (256 / (C/8) rows)
+static int gn_rows_per_wg(int N, int HW, int C, int target_wgs = 2048) {
+    // aim for ~target_wgs workgroups overall; at least one pass of the row tile (256 / (C/8) rows)
     const int tile = 256 / (C / 8);
     int chunks = (target_wgs + N - 1) / N;
-    if (chunks > max_chunks) chunks = max_chunks;
     int rows = (HW + chunks - 1) / chunks;
     rows = (rows + tile - 1) / tile * tile;
     return rows < tile ? tile : rows;
@@ -342,13 +319,13 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
     hipStream_t s = (hipStream_t)stream;
     const int rows = gn_rows_per_wg(N, HW, C);
     dim3 grid((HW + rows - 1) / rows, N);
-    const int schunks = (int)grid.x;   // <= 32: sums is (32, N, 32, 2) doubles
+    hipMemsetAsync(sums, 0, (size_t)N * GN_G * 2 * sizeof(double), s);
     MAED_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)x, sums, HW, C, rows);
-        if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows, schunks);
-        else if (residual) hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows, schunks);
-        else if (relu) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, HW, C, eps, rows, schunks);
-        else hipLaunchKernelGGL((gn_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, HW, C, eps, rows, schunks);
+        if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows);
+        else if (residual) hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows);
+        else if (relu) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, HW, C, eps, rows);
+        else hipLaunchKernelGGL((gn_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, HW, C, eps, rows);
     });
     MAED_CHECK_LAUNCH("groupnorm_fwd");
     return MAED_OK;
@@ -365,15 +342,15 @@ extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, 
     const int rows = gn_rows_per_wg(N, HW, C);
     dim3 grid((HW + rows - 1) / rows, N);
     // the reduction pass ends with 4C atomics per workgroup: fewer, fatter workgroups (~768: 3 per CU) keep it HBM-bound
-    const int rrows = gn_rows_per_wg(N, HW, C, 768, 8);
+    const int rrows = gn_rows_per_wg(N, HW, C, 768);
     dim3 rgrid((HW + rrows - 1) / rrows, N);
-    const int schunks = (int)grid.x, rchunks = (int)rgrid.x;   // ab_scratch is (8, N, C, 2) floats
+    hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
     const bool ymask = relu && dres;
 #define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, (const T*)y, (const T*)dy, \
-        sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows, schunks)
+        sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows)
 #define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, \
-        sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows, schunks, rchunks)
+        sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
     MAED_DISPATCH_DTYPE(dtype, T, {
         if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);
         if (dres && relu) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);

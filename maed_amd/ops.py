@@ -417,7 +417,7 @@ class GroupNormFn(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous(memory_format=torch.channels_last).to(x.dtype)
         y = torch.empty_like(x, memory_format=torch.channels_last)
-        sums = torch.empty(32, N, 32, 2, dtype=torch.float64, device=x.device)   # per-chunk partials (<= 32 chunks)
+        sums = torch.empty(N, 32, 2, dtype=torch.float64, device=x.device)
         check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), N, H * W, C_, eps, int(relu),
                                          dt_code(x.dtype), _stream()), "groupnorm_fwd")
         ctx.has_res = residual is not None
@@ -443,7 +443,7 @@ class GroupNormFn(torch.autograd.Function):
         else:
             dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device)
             dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device)
-        ab = torch.empty(8, N, C_, 2, dtype=torch.float32, device=x.device)     # per-chunk partials (<= 8 chunks)
+        ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
         check(L.lib().maed_groupnorm_bwd(_p(x), _p(y), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
                                          N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), _stream()), "groupnorm_bwd")
         if ctx.direct:
