@@ -44,20 +44,22 @@ def build_model(dtype, device):
     import maed_amd
     torch.manual_seed(0)
     m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["heads"], embed_dim=CFG["dim"], hidden_dim=CFG["hidden"],
-                      img_size=CFG["img"], compute_dtype=dtype)
+                      img_size=CFG["img"], max_seqlen=max(16, CFG["T"]), compute_dtype=dtype)
     return m.to(device)
 
 
-def proxy_loss(out, tgt):
-    """stand-in for lib/core/loss.py (not built yet): squared error on the outputs the
-    real loss consumes (2D/3D keypoints, pose, shape) against fixed random targets."""
-    return (((out["kp_2d"] - tgt["kp_2d"]) ** 2).mean() + ((out["kp_3d"] - tgt["kp_3d"]) ** 2).mean()
-            + ((out["theta"][..., 3:75] - tgt["pose"]) ** 2).mean() + 1e-3 * ((out["theta"][..., 75:] - tgt["shape"]) ** 2).mean())
+# configs/config_stage2.yaml:34-39 (LOSS: KP_2D_W 300, KP_3D_W 600, SHAPE_W 0.06, POSE_W 60; SMPL_NORM/ACCL_W = config.py defaults)
+LOSS_W = dict(e_loss_weight=300.0, e_3d_loss_weight=600.0, e_pose_loss_weight=60.0, e_shape_loss_weight=0.06, e_smpl_norm_loss=1.0, e_smpl_accl_loss=0.0)
 
 
 def make_targets(n, T, device, gen):
-    r = lambda *s: torch.randn(*s, generator=gen).to(device)
-    return dict(kp_2d=r(n, T, 49, 2) * 0.3, kp_3d=r(n, T, 49, 3) * 0.3, pose=r(n, T, 72) * 0.2, shape=r(n, T, 10))
+    """synthetic labels in lib/core/loss.py's LossVideo layout (data_3d only: every clip carries 3D + SMPL labels)"""
+    r = lambda *s: torch.randn(*s, generator=gen)
+    return {k: v.to(device) for k, v in dict(
+        kp_2d=torch.cat([r(n, T, 49, 2) * 0.3, torch.rand(n, T, 49, 1, generator=gen)], -1),
+        kp_3d=torch.cat([r(n, T, 49, 3) * 0.3, torch.ones(n, T, 49, 1)], -1),
+        theta=torch.cat([r(n, T, 3) * 0.1, r(n, T, 72) * 0.2, r(n, T, 10)], -1),
+        w_smpl=(torch.rand(n, T, generator=gen) > 0.2).float()).items()}
 
 
 def usable_cores(cap=32):
@@ -75,6 +77,7 @@ def usable_cores(cap=32):
 
 def cpu_baseline(budget_s=25.0):
     """oracle train step (fwd + autograd bwd + torch Adam) on host cores; bounded sample: 1 clip x 16 frames."""
+    from oracle import loss_ref
     from oracle import maed_ref as R
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -90,7 +93,8 @@ def cpu_baseline(budget_s=25.0):
 
     def step():
         opt.zero_grad()
-        loss = proxy_loss(R.maed_forward(clip, params, sp, CFG["depth"], CFG["heads"]), tgt)
+        loss, _ = loss_ref.loss_video(R.maed_forward(clip, params, sp, CFG["depth"], CFG["heads"]), tgt, None, LOSS_W["e_loss_weight"],
+                                      LOSS_W["e_3d_loss_weight"], LOSS_W["e_pose_loss_weight"], LOSS_W["e_shape_loss_weight"], LOSS_W["e_smpl_norm_loss"])
         loss.backward()
         opt.step()
 
@@ -119,9 +123,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="cfg2: inference forward instead of the train step")
-    ap.add_argument("--graph-tail", type=int, default=int(os.environ.get("MAED_GRAPH_TAIL", "0")), help="capture the decoder tail fwd+bwd into hipGraphs")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"], help="cfg3 = BASELINE's metric workload (default); cfg5 = long-clip stress")
     args = ap.parse_args()
 
+    if args.workload == "cfg5":   # BASELINE.json configs[4]: long-clip stress (per-GPU clips stated in config.workload)
+        CFG.update(clips=2, T=64, img=256, depth=12, heads=12, dim=768)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,6 +141,7 @@ def main():
 
     from maed_amd import _lib as L
     from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+    from maed_amd.loss import LossVideo
     lib = L.lib()  # raises if libmaed_hip.so is missing: no fallback
 
     log(f"building model ({args.dtype}) on {dev}")
@@ -155,13 +162,11 @@ def main():
         bucketer = GradBucketer(arena, model)
         bucketer.broadcast_parameters(0)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=bucketer)  # configs/config_stage2.yaml:63-66
-        if args.graph_tail:
-            model.graph_training_tail(CFG["clips"] * CFG["T"])
-            log("decoder tail captured into hipGraphs")
+        criterion = LossVideo(**LOSS_W)                                        # lib/core/loss.py via maed_loss_fwd_bwd
 
         def step():
             opt.zero_grad()
-            loss = proxy_loss(model(clip), tgt)
+            loss, _ = criterion(model(clip), tgt, None)
             loss.backward()
             opt.step()
 
@@ -258,11 +263,11 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "frames_per_sec": round(clips * CFG["T"] * args.steps / dt, 1),
-            "config": {"workload": ("cfg3/cfg4" if not args.forward_only else "cfg2") + f": {CFG['clips']} clips x {CFG['T']} frames x 3x{CFG['img']}x{CFG['img']} per GPU, "
+            "config": {"workload": (args.workload if args.workload != "cfg3" else "cfg3/cfg4" if not args.forward_only else "cfg2") + f": {CFG['clips']} clips x {CFG['T']} frames x 3x{CFG['img']}x{CFG['img']} per GPU, "
                        f"hybrid R50(3,4,9)+STE depth{CFG['depth']} heads{CFG['heads']} dim{CFG['dim']}+KTD hidden{CFG['hidden']}, "
                        + ("train step fwd+bwd+allreduce+Adam" if not args.forward_only else "inference forward"),
                        "global_batch_clips": clips, "frames_per_clip": CFG["T"], "parallelism": f"dp{world}",
-                       "loss": "proxy squared error on kp_2d/kp_3d/pose/shape (lib/core/loss.py is SURVEY 8(f) 'next')",
+                       "loss": "lib/core/loss.py LossVideo (config_stage2 weights) on synthetic labels, fused fwd+bwd kernel",
                        "smpl": "synthetic SMPL-shaped parameters (licensed model file unavailable)"},
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }

@@ -196,9 +196,10 @@ typedef struct {
     const float* lbs_weights; /* (6890,24)     */
     const int32_t* parents;   /* (24) root -1  */
 } maed_smpl_params;
-/* verts (F,6890,3), posed joints (F,24,3); scratch: F*24*12 floats (skinning transforms A) */
+/* verts (F,6890,3), posed joints (F,24,3); scratch_A: F*24*12 floats (skinning transforms A, also the backward's
+ * saved state); v_posed (F,6890,3) optional out: the un-skinned posed vertices, kept for maed_smpl_skin_bwd */
 int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas, const float* rotmat,
-                      float* verts, float* joints24, float* scratch_A, int F, void* stream);
+                      float* verts, float* joints24, float* scratch_A, float* v_posed, int F, void* stream);
 /* out[f][j][:] = sum_v Jreg[j][v] verts[f][v][:]  (J <= 32 rows; MFMA f32 32x32x2) */
 int maed_joint_regress_fwd(const float* Jreg, int J, const float* verts, float* out, int F, void* stream);
 /* joints49 = gather(cat(joints24, verts[extra_vertex_ids(21)], extra9), joint_map(49 int64)) -- the
@@ -207,6 +208,55 @@ int maed_joint_regress_fwd(const float* Jreg, int J, const float* verts, float* 
 int maed_smpl_joints_project_fwd(const float* joints24, const float* verts, const int64_t* extra_vertex_ids,
                                  const float* extra9, const int64_t* joint_map, const float* cam,
                                  const float* joints_override, int Jo, float* kp3d, float* kp2d, int F, void* stream);
+
+/* ---- decoder tail, BACKWARD (the training graph of ktd.py:69-124; fp32 throughout) ------------------------------
+ * Order of calls for one step, given the gradients of the five outputs of KTD.get_output:
+ *   joints_project_bwd -> smpl_skin_bwd -> [dvp (F,20670) x PS^T (217,20670) GEMM by the caller] -> smpl_chain_bwd
+ *   -> rot6d_pose_bwd -> ktd_chain_bwd -> [two GEMMs by the caller] -> ktd_unpack_add.                            */
+
+/* K14/K15 backward: gradient of (kp3d, kp2d) w.r.t. the 54 source joints (scatter-ADD through the integer joint_map,
+ * duplicates summed in index order) and the camera.  kp3d = the forward's output.  d_kp3d / d_kp2d may be NULL (= 0).
+ * d_cam (F,3) = projection gradient + d_cam_in (optional, row stride cam_in_stride floats).                          */
+int maed_smpl_joints_project_bwd(const float* kp3d, const float* cam, const int64_t* joint_map, const float* d_kp3d,
+                                 const float* d_kp2d, const float* d_cam_in, int64_t cam_in_stride, float* d_joints24,
+                                 float* d_extra21, float* d_extra9, float* d_cam, int F, void* stream);
+/* K12 backward, vertex part.  d_v = d_verts (optional) + scatter(d_extra21 at extra_vertex_ids) + Jextra^T d_extra9;
+ * writes d_vposed (F,20670) = T_v^T d_v and ACCUMULATES (+=, atomics; caller zeroes) dA (F,24,12) = sum_v w_vj d_v [v_posed,1]^T */
+int maed_smpl_skin_bwd(const maed_smpl_params* sp, const float* A, const float* v_posed, const float* d_verts,
+                       const float* d_extra21, const int64_t* extra_vertex_ids, const float* d_extra9, const float* Jextra,
+                       float* d_vposed, float* dA, int F, void* stream);
+/* K12 backward, kinematic chain.  dpf_dbeta (F,217): columns 0..206 = d pose_feature (posedirs . d_vposed), 207..216 =
+ * shapedirs^T d_vposed (both from the caller's GEMM).  d_rotmat_in (F,24,9) / d_betas_in (row stride given) optional
+ * upstream gradients.  Outputs d_rotmat (F,24,9), d_betas (F,10).                                                    */
+int maed_smpl_chain_bwd(const maed_smpl_params* sp, const float* betas, const float* rotmat, const float* dA,
+                        const float* d_joints24, const float* dpf_dbeta, const float* d_rotmat_in, const float* d_betas_in,
+                        int64_t betas_in_stride, float* d_rotmat, float* d_betas, int F, void* stream);
+/* K11 backward: d_pose6d (n,6) from d_rotmat (n,9) and d_angle_axis (row n at d_aa + (n/24)*aa_stride + (n%24)*3; optional) */
+int maed_rot6d_pose_bwd(const float* pose6d, const float* d_rotmat, const float* d_aa, int64_t aa_stride,
+                        float* d_pose6d, int64_t n_joints, void* stream);
+/* K10 backward: d_out (F, ld_out>=157): [:, :144] = d_base (chain transposed), [:, 144:154] = d_shape, [:, 154:157] = d_cam;
+ * d_w_anc (3420, overwritten) and d_b_feat (157, overwritten = column sums of d_out).                                 */
+int maed_ktd_chain_bwd(const float* pose, const float* w_anc, const float* d_pose, const float* d_shape, const float* d_cam,
+                       float* d_out, int64_t ld_out, float* d_w_anc, float* d_b_feat, int F, void* stream);
+/* KTD regressor weights <-> the packed operands of the head GEMM (ktd.py:58-67: joint_regs.{0..23}, decshape, deccam).
+ * w[j] is the (6, hidden + 6*n_anc(j)) weight of regressor j (j = 24: decshape (10,hidden), 25: deccam (3,hidden)).
+ * pack: w_feat (157,hidden), b_feat (157), w_anc (3420).  unpack_add: the reverse, ACCUMULATING (+=) into gw/gb.      */
+#define MAED_KTD_W_ANC 3420
+typedef struct { const float* w[26]; const float* b[26]; float* gw[26]; float* gb[26]; } maed_ktd_ptrs;
+int maed_ktd_pack(const maed_ktd_ptrs* t, int hidden, float* w_feat, float* b_feat, float* w_anc, void* stream);
+int maed_ktd_unpack_add(const maed_ktd_ptrs* t, int hidden, const float* d_w_feat, const float* d_b_feat, const float* d_w_anc, void* stream);
+
+/* ---- lib/core/loss.py LossVideo / LossImage as ONE fused forward+backward ------------------------
+ * Frames are flattened: M2 frames carry 2D keypoints, the LAST M3 <= M2 of them also 3D keypoints and SMPL parameters
+ * (loss.py:165-181: preds[sample_2d_count:]).  pred_kp3d / pred_theta / gradients point at frame M2-M3.
+ * losses[8] (device): 0 kp_2d, 1 kp_3d, 2 shape, 3 pose, 4 norm (each already weighted), 5 total, 6 n_valid, 7 unused.
+ * Gradients of the TOTAL w.r.t. the predictions are written to d_kp2d (M2,49,2), d_kp3d (M3,49,3), d_theta (M3,85).
+ * partials: scratch of max(M2,M3)*8 doubles.  gt_kp3d may be NULL (LossImage without 3D labels: loss.py:266,279).     */
+typedef struct { float w_kp2d, w_kp3d, w_pose, w_shape, w_norm; } maed_loss_weights;
+int maed_loss_fwd_bwd(const float* pred_kp2d, const float* gt_kp2d, int M2, const float* pred_kp3d, const float* gt_kp3d,
+                      const float* pred_theta, const float* gt_theta, const uint8_t* w_smpl, int M3,
+                      const maed_loss_weights* w, float* losses, float* d_kp2d, float* d_kp3d, float* d_theta,
+                      double* partials, void* stream);
 
 /* ---- backbone helpers (the convolutions themselves ride on MIOpen) ---------------------------------- */
 /* StdConv2dSame weight standardisation (resnetv2.py:74-93) for ALL convolutions in one launch.

@@ -40,6 +40,16 @@ class SmplParams(C.Structure):
     _fields_ = [(n, vp) for n in ["v_template", "shapedirs", "posedirs", "J_template", "J_shapedirs", "lbs_weights", "parents"]]
 
 
+class KtdPtrs(C.Structure):
+    _fields_ = [("w", vp * 26), ("b", vp * 26), ("gw", vp * 26), ("gb", vp * 26)]
+
+
+class LossWeights(C.Structure):
+    _fields_ = [(n, f32) for n in ["w_kp2d", "w_kp3d", "w_pose", "w_shape", "w_norm"]]
+
+
+KTD_W_ANC = 3420
+
 # name -> (restype, argtypes): mirrors include/maed_hip.h one to one (tests/test_cabi.py checks it)
 SIGNATURES = {
     "maed_last_error": (C.c_char_p, []),
@@ -67,9 +77,17 @@ SIGNATURES = {
     "maed_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i32)]),
     "maed_ktd_chain_fwd": (i32, [vp, vp, vp, i32, vp]),
     "maed_rot6d_pose_fwd": (i32, [vp, vp, vp, i64, vp]),
-    "maed_smpl_lbs_fwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, i32, vp]),
+    "maed_smpl_lbs_fwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, vp, i32, vp]),
     "maed_joint_regress_fwd": (i32, [vp, i32, vp, vp, i32, vp]),
     "maed_smpl_joints_project_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
+    "maed_smpl_joints_project_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, vp]),
+    "maed_smpl_skin_bwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "maed_smpl_chain_bwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp]),
+    "maed_rot6d_pose_bwd": (i32, [vp, vp, vp, i64, vp, i64, vp]),
+    "maed_ktd_chain_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp]),
+    "maed_ktd_pack": (i32, [C.POINTER(KtdPtrs), i32, vp, vp, vp, vp]),
+    "maed_ktd_unpack_add": (i32, [C.POINTER(KtdPtrs), i32, vp, vp, vp, vp]),
+    "maed_loss_fwd_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, i32, C.POINTER(LossWeights), vp, vp, vp, vp, vp, vp]),
     "maed_weight_std_fwd": (i32, [vp, i32, i32, vp, i32, vp, f32, vp]),
     "maed_weight_std_bwd": (i32, [vp, i32, i32, i32, vp, f32, vp]),
     "maed_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),

@@ -2,17 +2,7 @@
 // skinning (K12), joint regressor GEMM on f32 MFMA (K13), integer joint gather (K14, bit-exact) and
 // weak-perspective projection (K15).  Everything here is fp32: these are SMPL parameters (1e-3 bar).
 #include "common.cuh"
-
-#define NJ 24
-#define NV 6890
-
-// lib/models/ktd.py:10-35 ANCESTOR_INDEX, flattened
-__constant__ int c_anc_cnt[NJ] = {0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7, 7, 8, 8};
-__constant__ int c_anc_start[NJ] = {0, 0, 1, 2, 3, 5, 7, 9, 12, 15, 18, 22, 26, 30, 34, 38, 43, 48, 53, 59, 65, 72, 79, 87};
-__constant__ int c_anc[95] = {
-    0, 0, 0, 0, 1, 0, 2, 0, 3, 0, 1, 4, 0, 2, 5, 0, 3, 6, 0, 1, 4, 7, 0, 2, 5, 8, 0, 3, 6, 9, 0, 3, 6, 9, 0, 3, 6, 9,
-    0, 3, 6, 9, 12, 0, 3, 6, 9, 13, 0, 3, 6, 9, 14, 0, 3, 6, 9, 13, 16, 0, 3, 6, 9, 14, 17,
-    0, 3, 6, 9, 13, 16, 18, 0, 3, 6, 9, 14, 17, 19, 0, 3, 6, 9, 13, 16, 18, 20, 0, 3, 6, 9, 14, 17, 19, 21};
+#include "ktd_tables.cuh"
 
 // ---- K10: pose[f][6j+o] = base[f][6j+o] + sum_{slot,i} W_j[o][6*slot+i] * pose[f][6*anc(j,slot)+i] ------------
 __global__ void ktd_chain_kernel(const float* __restrict__ base, const float* __restrict__ w_anc, float* __restrict__ pose, int F) {
@@ -148,7 +138,8 @@ __global__ void lbs_chain_kernel(maed_smpl_params sp, const float* __restrict__ 
 // kernel B: thread per vertex, LBS_FB frames per workgroup so posedirs (17 MB) is streamed once per LBS_FB frames
 #define LBS_FB 4
 __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
-                                                       const float* __restrict__ A, float* __restrict__ verts, int F) {
+                                                       const float* __restrict__ A, float* __restrict__ verts,
+                                                       float* __restrict__ v_posed, int F) {
     __shared__ float s_pf[LBS_FB][208];
     __shared__ float s_A[LBS_FB][NJ * 12];
     __shared__ float s_b[LBS_FB][10];
@@ -197,6 +188,10 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, cons
     for (int fb = 0; fb < LBS_FB; ++fb) {
         if (f0 + fb >= F) break;
         const float x = vp[fb][0] + po[fb][0], y = vp[fb][1] + po[fb][1], z = vp[fb][2] + po[fb][2];
+        if (v_posed) {   // kept for the backward pass (maed_smpl_skin_bwd) instead of a second sweep over posedirs
+            float* q = v_posed + ((int64_t)(f0 + fb) * NV + v) * 3;
+            q[0] = x; q[1] = y; q[2] = z;
+        }
         float T[12];
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
         for (int j = 0; j < NJ; ++j)
@@ -209,14 +204,14 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, cons
 }
 
 extern "C" int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas, const float* rotmat, float* verts,
-                                 float* joints24, float* scratch_A, int F, void* stream) {
+                                 float* joints24, float* scratch_A, float* v_posed, int F, void* stream) {
     MAED_CHECK_ARG(sp && betas && rotmat && verts && joints24 && scratch_A, MAED_ERR_ARG, "smpl_lbs_fwd: null pointer");
     MAED_CHECK_ARG(sp->v_template && sp->shapedirs && sp->posedirs && sp->J_template && sp->J_shapedirs && sp->lbs_weights && sp->parents,
                    MAED_ERR_ARG, "smpl_lbs_fwd: null SMPL parameter");
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lbs_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
-    hipLaunchKernelGGL(lbs_skin_kernel, dim3((NV + 255) / 256, (F + LBS_FB - 1) / LBS_FB), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, F);
+    hipLaunchKernelGGL(lbs_skin_kernel, dim3((NV + 255) / 256, (F + LBS_FB - 1) / LBS_FB), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
     MAED_CHECK_LAUNCH("smpl_lbs_fwd");
     return MAED_OK;
 }

@@ -1,0 +1,425 @@
+// Decoder tail BACKWARD (training graph of lib/models/ktd.py:69-124): projection + integer joint gather (K14/K15),
+// SMPL linear blend skinning (K12: vertex part and kinematic chain), 6D -> rotmat -> axis-angle (K11) and the KTD
+// ancestor chain (K10), plus the pack/unpack of the 26 regressor weights into the operands of one head GEMM.
+// ~10 launches replace the ~1000 tiny ATen kernels autograd needs for the same graph.  fp32 throughout; these are
+// (F, .)-row problems, HBM/latency bound: thread-per-frame / thread-per-vertex kernels, no MFMA.
+#include "common.cuh"
+#include "ktd_tables.cuh"
+#include "dual.cuh"
+
+// ---- K14/K15 backward ---------------------------------------------------------------------------------------------------
+// one wave per frame: lane jj < 49 differentiates the projection of joint jj (spin.py:113-157), the wave reduces the
+// camera gradient, then lane idx < 54 gathers the scatter-add through joint_map (smpl.py:98-99) in index order.
+__global__ __launch_bounds__(64) void joints_project_bwd_kernel(const float* __restrict__ kp3d, const float* __restrict__ cam,
+                                                                const int64_t* __restrict__ joint_map, const float* __restrict__ d_kp3d,
+                                                                const float* __restrict__ d_kp2d, const float* __restrict__ d_cam_in,
+                                                                int64_t cam_in_stride, float* __restrict__ d_j24, float* __restrict__ d_e21,
+                                                                float* __restrict__ d_e9, float* __restrict__ d_cam, int F) {
+    __shared__ float s_dp[49][3];
+    __shared__ int s_map[49];
+    const int64_t f = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* cm = cam + f * 3;
+    const float den = 224.0f * cm[0] + 1e-9f;
+    float c1 = 0.f, c2 = 0.f, ctz = 0.f;
+    if (lane < 49) {
+        const int64_t i = f * 49 + lane;
+        const float tz = 2.0f * 5000.0f / den;
+        const float X = kp3d[i * 3 + 0] + cm[1], Y = kp3d[i * 3 + 1] + cm[2], Z = kp3d[i * 3 + 2] + tz;
+        const float s = 5000.0f / 112.0f;
+        const float du = d_kp2d ? d_kp2d[i * 2 + 0] : 0.f, dv = d_kp2d ? d_kp2d[i * 2 + 1] : 0.f;
+        c1 = s * du / Z; c2 = s * dv / Z; ctz = -s * (du * X + dv * Y) / (Z * Z);
+        s_dp[lane][0] = c1 + (d_kp3d ? d_kp3d[i * 3 + 0] : 0.f);
+        s_dp[lane][1] = c2 + (d_kp3d ? d_kp3d[i * 3 + 1] : 0.f);
+        s_dp[lane][2] = ctz + (d_kp3d ? d_kp3d[i * 3 + 2] : 0.f);
+        s_map[lane] = (int)joint_map[lane];
+    }
+    c1 = wave_sum(c1); c2 = wave_sum(c2); ctz = wave_sum(ctz);
+    __syncthreads();
+    if (lane == 0) {
+        const float* ci = d_cam_in ? d_cam_in + f * cam_in_stride : nullptr;
+        d_cam[f * 3 + 0] = ctz * (-2.0f * 5000.0f * 224.0f / (den * den)) + (ci ? ci[0] : 0.f);
+        d_cam[f * 3 + 1] = c1 + (ci ? ci[1] : 0.f);
+        d_cam[f * 3 + 2] = c2 + (ci ? ci[2] : 0.f);
+    }
+    if (lane < 54) {
+        float g[3] = {0.f, 0.f, 0.f};
+        for (int jj = 0; jj < 49; ++jj)
+            if (s_map[jj] == lane) { g[0] += s_dp[jj][0]; g[1] += s_dp[jj][1]; g[2] += s_dp[jj][2]; }
+        float* dst = lane < 24 ? d_j24 + (f * 24 + lane) * 3 : lane < 45 ? d_e21 + (f * 21 + (lane - 24)) * 3 : d_e9 + (f * 9 + (lane - 45)) * 3;
+        dst[0] = g[0]; dst[1] = g[1]; dst[2] = g[2];
+    }
+}
+
+extern "C" int maed_smpl_joints_project_bwd(const float* kp3d, const float* cam, const int64_t* joint_map, const float* d_kp3d,
+                                            const float* d_kp2d, const float* d_cam_in, int64_t cam_in_stride, float* d_joints24,
+                                            float* d_extra21, float* d_extra9, float* d_cam, int F, void* stream) {
+    MAED_CHECK_ARG(kp3d && cam && joint_map && d_joints24 && d_extra21 && d_extra9 && d_cam, MAED_ERR_ARG, "smpl_joints_project_bwd: null pointer");
+    if (F <= 0) return MAED_OK;
+    hipLaunchKernelGGL(joints_project_bwd_kernel, dim3(F), dim3(64), 0, (hipStream_t)stream, kp3d, cam, joint_map, d_kp3d, d_kp2d, d_cam_in,
+                       cam_in_stride, d_joints24, d_extra21, d_extra9, d_cam, F);
+    MAED_CHECK_LAUNCH("smpl_joints_project_bwd");
+    return MAED_OK;
+}
+
+// ---- K12 backward, vertex part ------------------------------------------------------------------------------------------
+// thread per vertex, SK_FB frames per workgroup (lbs_weights / Jextra columns are read once per SK_FB frames).
+// verts_v = T_v [vp_v, 1],  T_v = sum_j w_vj A_j  =>  d vp_v = T_v[:, :3]^T d_v,   dA_j += w_vj d_v [vp_v, 1]^T.
+// dA is reduced in LDS (ds_add_f32; only vertices with a non-zero d_v and joints with a non-zero weight take part --
+// with the 9+21 extra joints as the only consumers that is ~300 of 6890 vertices) and flushed with one global atomic
+// per (frame, joint, entry) per workgroup.
+#define SK_FB 4
+__global__ __launch_bounds__(256) void smpl_skin_bwd_kernel(maed_smpl_params sp, const float* __restrict__ A, const float* __restrict__ v_posed,
+                                                            const float* __restrict__ d_verts, const float* __restrict__ d_e21,
+                                                            const int64_t* __restrict__ extra_ids, const float* __restrict__ d_e9,
+                                                            const float* __restrict__ Jextra, float* __restrict__ d_vposed,
+                                                            float* __restrict__ dA, int F) {
+    __shared__ float s_A[SK_FB][NJ * 12];
+    __shared__ float s_dA[SK_FB][NJ * 12];
+    __shared__ float s_de9[SK_FB][27];
+    __shared__ float s_de21[SK_FB][63];
+    __shared__ int s_ids[21];
+    const int f0 = blockIdx.y * SK_FB;
+    for (int i = threadIdx.x; i < SK_FB * NJ * 12; i += 256) {
+        const int fb = i / (NJ * 12), k = i % (NJ * 12);
+        s_A[fb][k] = A[(int64_t)min(f0 + fb, F - 1) * NJ * 12 + k];
+        s_dA[fb][k] = 0.f;
+    }
+    for (int i = threadIdx.x; i < SK_FB * 27; i += 256) s_de9[i / 27][i % 27] = d_e9[(int64_t)min(f0 + i / 27, F - 1) * 27 + i % 27];
+    for (int i = threadIdx.x; i < SK_FB * 63; i += 256) s_de21[i / 63][i % 63] = d_e21[(int64_t)min(f0 + i / 63, F - 1) * 63 + i % 63];
+    if (threadIdx.x < 21) s_ids[threadIdx.x] = (int)extra_ids[threadIdx.x];
+    __syncthreads();
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v < NV) {
+        float w[NJ], jx[9];
+        for (int j = 0; j < NJ; ++j) w[j] = sp.lbs_weights[v * NJ + j];
+        for (int r = 0; r < 9; ++r) jx[r] = Jextra[(int64_t)r * NV + v];
+#pragma unroll
+        for (int fb = 0; fb < SK_FB; ++fb) {
+            const int f = f0 + fb;
+            if (f >= F) break;
+            const int64_t o = ((int64_t)f * NV + v) * 3;
+            float dv[3] = {0.f, 0.f, 0.f};
+            if (d_verts) { dv[0] = d_verts[o]; dv[1] = d_verts[o + 1]; dv[2] = d_verts[o + 2]; }
+            for (int r = 0; r < 9; ++r)
+                for (int c = 0; c < 3; ++c) dv[c] = fmaf(jx[r], s_de9[fb][r * 3 + c], dv[c]);
+            for (int k = 0; k < 21; ++k)
+                if (s_ids[k] == v) { dv[0] += s_de21[fb][k * 3]; dv[1] += s_de21[fb][k * 3 + 1]; dv[2] += s_de21[fb][k * 3 + 2]; }
+            float T[12];
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+            for (int j = 0; j < NJ; ++j)
+                for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], s_A[fb][j * 12 + e], T[e]);
+            d_vposed[o + 0] = T[0] * dv[0] + T[4] * dv[1] + T[8] * dv[2];
+            d_vposed[o + 1] = T[1] * dv[0] + T[5] * dv[1] + T[9] * dv[2];
+            d_vposed[o + 2] = T[2] * dv[0] + T[6] * dv[1] + T[10] * dv[2];
+            if (dv[0] != 0.f || dv[1] != 0.f || dv[2] != 0.f) {
+                const float vh[4] = {v_posed[o], v_posed[o + 1], v_posed[o + 2], 1.0f};
+                for (int j = 0; j < NJ; ++j) {
+                    if (w[j] == 0.f) continue;
+                    for (int r = 0; r < 3; ++r)
+                        for (int e = 0; e < 4; ++e) atomicAdd(&s_dA[fb][j * 12 + r * 4 + e], w[j] * dv[r] * vh[e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SK_FB * NJ * 12; i += 256) {
+        const int fb = i / (NJ * 12), k = i % (NJ * 12);
+        const float x = s_dA[fb][k];
+        if (f0 + fb < F && x != 0.f) atomicAdd(dA + (int64_t)(f0 + fb) * NJ * 12 + k, x);
+    }
+}
+
+extern "C" int maed_smpl_skin_bwd(const maed_smpl_params* sp, const float* A, const float* v_posed, const float* d_verts,
+                                  const float* d_extra21, const int64_t* extra_vertex_ids, const float* d_extra9, const float* Jextra,
+                                  float* d_vposed, float* dA, int F, void* stream) {
+    MAED_CHECK_ARG(sp && A && v_posed && d_extra21 && extra_vertex_ids && d_extra9 && Jextra && d_vposed && dA, MAED_ERR_ARG, "smpl_skin_bwd: null pointer");
+    MAED_CHECK_ARG(sp->lbs_weights, MAED_ERR_ARG, "smpl_skin_bwd: null SMPL parameter");
+    if (F <= 0) return MAED_OK;
+    hipLaunchKernelGGL(smpl_skin_bwd_kernel, dim3((NV + 255) / 256, (F + SK_FB - 1) / SK_FB), dim3(256), 0, (hipStream_t)stream, *sp, A, v_posed,
+                       d_verts, d_extra21, extra_vertex_ids, d_extra9, Jextra, d_vposed, dA, F);
+    MAED_CHECK_LAUNCH("smpl_skin_bwd");
+    return MAED_OK;
+}
+
+// ---- K12 backward, kinematic chain -----------------------------------------------------------------------------------------
+// thread per frame (mirror of lbs_chain_kernel): recompute J, Rw, tw, then walk the tree from the leaves.
+//   forward:  Rw_j = Rw_p R_j,  tw_j = Rw_p (J_j - J_p) + tw_p,  A_j = [Rw_j | tw_j - Rw_j J_j],  joints24_j = tw_j
+__global__ void smpl_chain_bwd_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
+                                      const float* __restrict__ dA, const float* __restrict__ d_j24, const float* __restrict__ dpf_dbeta,
+                                      const float* __restrict__ d_rot_in, const float* __restrict__ d_betas_in, int64_t betas_in_stride,
+                                      float* __restrict__ d_rotmat, float* __restrict__ d_betas, int F) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float J[NJ][3], Rw[NJ][9], tw[NJ][3], gRw[NJ][9], gtw[NJ][3], gJ[NJ][3];
+    const float* b = betas + (int64_t)f * 10;
+    for (int j = 0; j < NJ; ++j)
+        for (int c = 0; c < 3; ++c) {
+            float s = sp.J_template[j * 3 + c];
+            for (int l = 0; l < 10; ++l) s = fmaf(sp.J_shapedirs[(j * 3 + c) * 10 + l], b[l], s);
+            J[j][c] = s;
+        }
+    const float* R = rotmat + (int64_t)f * NJ * 9;
+    for (int j = 0; j < NJ; ++j) {
+        const int p = sp.parents[j];
+        const float* Rj = R + j * 9;
+        if (p < 0) {
+            for (int k = 0; k < 9; ++k) Rw[j][k] = Rj[k];
+            for (int c = 0; c < 3; ++c) tw[j][c] = J[j][c];
+        } else {
+            const float rel[3] = {J[j][0] - J[p][0], J[j][1] - J[p][1], J[j][2] - J[p][2]};
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c)
+                    Rw[j][r * 3 + c] = Rw[p][r * 3 + 0] * Rj[0 * 3 + c] + Rw[p][r * 3 + 1] * Rj[1 * 3 + c] + Rw[p][r * 3 + 2] * Rj[2 * 3 + c];
+                tw[j][r] = Rw[p][r * 3 + 0] * rel[0] + Rw[p][r * 3 + 1] * rel[1] + Rw[p][r * 3 + 2] * rel[2] + tw[p][r];
+            }
+        }
+    }
+    // outputs -> chain variables
+    for (int j = 0; j < NJ; ++j) {
+        const float* g = dA + ((int64_t)f * NJ + j) * 12;
+        const float* gj = d_j24 + ((int64_t)f * NJ + j) * 3;
+        for (int c = 0; c < 3; ++c) gJ[j][c] = 0.f;
+        for (int r = 0; r < 3; ++r) {
+            const float gt = g[r * 4 + 3];                       // d trel_j[r]
+            for (int c = 0; c < 3; ++c) {
+                gRw[j][r * 3 + c] = g[r * 4 + c] - gt * J[j][c];
+                gJ[j][c] -= Rw[j][r * 3 + c] * gt;
+            }
+            gtw[j][r] = gt + gj[r];
+        }
+    }
+    float* gR = d_rotmat + (int64_t)f * NJ * 9;
+    const float* gin = d_rot_in ? d_rot_in + (int64_t)f * NJ * 9 : nullptr;
+    const float* gpf = dpf_dbeta + (int64_t)f * 217;
+    for (int j = NJ - 1; j >= 1; --j) {
+        const int p = sp.parents[j];
+        const float* Rj = R + j * 9;
+        const float rel[3] = {J[j][0] - J[p][0], J[j][1] - J[p][1], J[j][2] - J[p][2]};
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                const float s = Rw[p][0 * 3 + a] * gRw[j][0 * 3 + c] + Rw[p][1 * 3 + a] * gRw[j][1 * 3 + c] + Rw[p][2 * 3 + a] * gRw[j][2 * 3 + c];
+                gR[j * 9 + a * 3 + c] = s + gpf[(j - 1) * 9 + a * 3 + c] + (gin ? gin[j * 9 + a * 3 + c] : 0.f);
+            }
+        for (int r = 0; r < 3; ++r)
+            for (int a = 0; a < 3; ++a)
+                gRw[p][r * 3 + a] += gRw[j][r * 3 + 0] * Rj[a * 3 + 0] + gRw[j][r * 3 + 1] * Rj[a * 3 + 1] + gRw[j][r * 3 + 2] * Rj[a * 3 + 2]
+                                     + gtw[j][r] * rel[a];
+        for (int a = 0; a < 3; ++a) {
+            const float grel = Rw[p][0 * 3 + a] * gtw[j][0] + Rw[p][1 * 3 + a] * gtw[j][1] + Rw[p][2 * 3 + a] * gtw[j][2];
+            gJ[j][a] += grel; gJ[p][a] -= grel;
+        }
+        for (int r = 0; r < 3; ++r) gtw[p][r] += gtw[j][r];
+    }
+    for (int k = 0; k < 9; ++k) gR[k] = gRw[0][k] + (gin ? gin[k] : 0.f);
+    for (int c = 0; c < 3; ++c) gJ[0][c] += gtw[0][c];
+    const float* bi = d_betas_in ? d_betas_in + (int64_t)f * betas_in_stride : nullptr;
+    for (int l = 0; l < 10; ++l) {
+        float s = gpf[207 + l] + (bi ? bi[l] : 0.f);
+        for (int j = 0; j < NJ; ++j)
+            for (int c = 0; c < 3; ++c) s = fmaf(sp.J_shapedirs[(j * 3 + c) * 10 + l], gJ[j][c], s);
+        d_betas[(int64_t)f * 10 + l] = s;
+    }
+}
+
+extern "C" int maed_smpl_chain_bwd(const maed_smpl_params* sp, const float* betas, const float* rotmat, const float* dA,
+                                   const float* d_joints24, const float* dpf_dbeta, const float* d_rotmat_in, const float* d_betas_in,
+                                   int64_t betas_in_stride, float* d_rotmat, float* d_betas, int F, void* stream) {
+    MAED_CHECK_ARG(sp && betas && rotmat && dA && d_joints24 && dpf_dbeta && d_rotmat && d_betas, MAED_ERR_ARG, "smpl_chain_bwd: null pointer");
+    MAED_CHECK_ARG(sp->J_template && sp->J_shapedirs && sp->parents, MAED_ERR_ARG, "smpl_chain_bwd: null SMPL parameter");
+    if (F <= 0) return MAED_OK;
+    hipLaunchKernelGGL(smpl_chain_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, *sp, betas, rotmat, dA, d_joints24, dpf_dbeta,
+                       d_rotmat_in, d_betas_in, betas_in_stride, d_rotmat, d_betas, F);
+    MAED_CHECK_LAUNCH("smpl_chain_bwd");
+    return MAED_OK;
+}
+
+// ---- K11 backward -------------------------------------------------------------------------------------------------------------
+// The forward (smpl.hip rot6d_pose_kernel; geometry.py:320-334,143-223,90-140) is re-evaluated on dual numbers carrying the six
+// partial derivatives (forward-mode AD: the 6 -> 12 Jacobian costs 7x the forward, ~2 kFLOP per joint), then contracted
+// with the incoming gradient.  Branches are taken on the VALUES, exactly as the forward takes them.
+template <typename S>
+__device__ __forceinline__ void rot6d_pose_eval(const S (&x)[6], S (&R)[9], S (&aa)[3]) {
+    const S a1[3] = {x[0], x[2], x[4]}, a2[3] = {x[1], x[3], x[5]};
+    const S n1 = clamp_min(dsqrt(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-6f);
+    const S b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const S dot = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    const S u[3] = {a2[0] - dot * b1[0], a2[1] - dot * b1[1], a2[2] - dot * b1[2]};
+    const S n2 = clamp_min(dsqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-6f);
+    const S b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    const S b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+    for (int r = 0; r < 3; ++r) { R[r * 3 + 0] = b1[r]; R[r * 3 + 1] = b2[r]; R[r * 3 + 2] = b3[r]; }
+#define RT(a, b) R[(b) * 3 + (a)]
+    const bool d2 = val(RT(2, 2)) < 1e-6f, d0d1 = val(RT(0, 0)) > val(RT(1, 1)), d0nd1 = val(RT(0, 0)) < -val(RT(1, 1));
+    S q[4], t;
+    if (d2 && d0d1) {
+        t = 1.0f + RT(0, 0) - RT(1, 1) - RT(2, 2);
+        q[0] = RT(1, 2) - RT(2, 1); q[1] = t; q[2] = RT(0, 1) + RT(1, 0); q[3] = RT(2, 0) + RT(0, 2);
+    } else if (d2 && !d0d1) {
+        t = 1.0f - RT(0, 0) + RT(1, 1) - RT(2, 2);
+        q[0] = RT(2, 0) - RT(0, 2); q[1] = RT(0, 1) + RT(1, 0); q[2] = t; q[3] = RT(1, 2) + RT(2, 1);
+    } else if (!d2 && d0nd1) {
+        t = 1.0f - RT(0, 0) - RT(1, 1) + RT(2, 2);
+        q[0] = RT(0, 1) - RT(1, 0); q[1] = RT(2, 0) + RT(0, 2); q[2] = RT(1, 2) + RT(2, 1); q[3] = t;
+    } else {
+        t = 1.0f + RT(0, 0) + RT(1, 1) + RT(2, 2);
+        q[0] = t; q[1] = RT(1, 2) - RT(2, 1); q[2] = RT(2, 0) - RT(0, 2); q[3] = RT(0, 1) - RT(1, 0);
+    }
+#undef RT
+    const S st = dsqrt(t);
+    for (int k = 0; k < 4; ++k) q[k] = (q[k] / st) * 0.5f;
+    const S ss = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const S sn = dsqrt(ss), cs = q[0];
+    const S two_theta = (val(cs) < 0.0f ? datan2(-sn, -cs) : datan2(sn, cs)) * 2.0f;
+    const S k = val(ss) > 0.0f ? two_theta / sn : constant<S>(2.0f);
+    for (int c = 0; c < 3; ++c) aa[c] = zero_if_nan(q[1 + c] * k);    // geometry.py:86
+}
+
+__global__ void rot6d_pose_bwd_kernel(const float* __restrict__ x6, const float* __restrict__ d_rot, const float* __restrict__ d_aa,
+                                      int64_t aa_stride, float* __restrict__ d_x6, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef Dual<6> D;
+    D x[6], R[9], aa[3];
+    for (int k = 0; k < 6; ++k) x[k] = seed<6>(x6[i * 6 + k], k);
+    rot6d_pose_eval<D>(x, R, aa);
+    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 9; ++k) {
+        const float gr = d_rot[i * 9 + k];
+        for (int m = 0; m < 6; ++m) g[m] = fmaf(gr, R[k].d[m], g[m]);
+    }
+    if (d_aa) {
+        const float* ga = d_aa + (i / NJ) * aa_stride + (i % NJ) * 3;
+        for (int c = 0; c < 3; ++c)
+            for (int m = 0; m < 6; ++m) g[m] = fmaf(ga[c], aa[c].d[m], g[m]);
+    }
+    for (int m = 0; m < 6; ++m) d_x6[i * 6 + m] = g[m];
+}
+
+extern "C" int maed_rot6d_pose_bwd(const float* pose6d, const float* d_rotmat, const float* d_aa, int64_t aa_stride, float* d_pose6d,
+                                   int64_t n_joints, void* stream) {
+    MAED_CHECK_ARG(pose6d && d_rotmat && d_pose6d, MAED_ERR_ARG, "rot6d_pose_bwd: null pointer");
+    if (n_joints <= 0) return MAED_OK;
+    hipLaunchKernelGGL(rot6d_pose_bwd_kernel, dim3((unsigned)((n_joints + 127) / 128)), dim3(128), 0, (hipStream_t)stream, pose6d, d_rotmat, d_aa,
+                       aa_stride, d_pose6d, n_joints);
+    MAED_CHECK_LAUNCH("rot6d_pose_bwd");
+    return MAED_OK;
+}
+
+// ---- K10 backward ---------------------------------------------------------------------------------------------------------------
+// pose_j = base_j + sum_slot W_j[:, slot] pose_anc(j,slot):  walking j = 23..1, g_anc += W_j[:, slot]^T g_j (ancestors have
+// smaller indices, so g_j is final when j is visited).  d_base = g.
+__global__ void ktd_chain_bwd_kernel(const float* __restrict__ w_anc, const float* __restrict__ d_pose, const float* __restrict__ d_shape,
+                                     const float* __restrict__ d_cam, float* __restrict__ d_out, int64_t ld, int F) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float g[NJ * 6];
+    for (int i = 0; i < NJ * 6; ++i) g[i] = d_pose[(int64_t)f * NJ * 6 + i];
+    for (int j = NJ - 1; j >= 1; --j) {
+        const int na = c_anc_cnt[j];
+        const float* W = w_anc + 36 * c_anc_start[j];
+        for (int sl = 0; sl < na; ++sl) {
+            const int a = c_anc[c_anc_start[j] + sl];
+            for (int i = 0; i < 6; ++i) {
+                float s = g[a * 6 + i];
+                for (int o = 0; o < 6; ++o) s = fmaf(W[o * 6 * na + sl * 6 + i], g[j * 6 + o], s);
+                g[a * 6 + i] = s;
+            }
+        }
+    }
+    float* o = d_out + (int64_t)f * ld;
+    for (int i = 0; i < NJ * 6; ++i) o[i] = g[i];
+    for (int i = 0; i < 10; ++i) o[144 + i] = d_shape ? d_shape[(int64_t)f * 10 + i] : 0.f;
+    for (int i = 0; i < 3; ++i) o[154 + i] = d_cam ? d_cam[(int64_t)f * 3 + i] : 0.f;
+}
+
+// thread per ancestor-weight element: dW_j[o][6*slot+i] = sum_f d_base[f][6j+o] pose[f][6*anc+i]; the last 157 threads
+// produce the bias gradient (column sums of d_out)
+__global__ void ktd_wanc_bwd_kernel(const float* __restrict__ pose, const float* __restrict__ d_out, int64_t ld, float* __restrict__ d_w_anc,
+                                    float* __restrict__ d_b_feat, int F) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= MAED_KTD_W_ANC + KTD_OUT) return;
+    if (e >= MAED_KTD_W_ANC) {
+        const int c = e - MAED_KTD_W_ANC;
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) s += d_out[(int64_t)f * ld + c];
+        d_b_feat[c] = s;
+        return;
+    }
+    int j = 1;
+    while (36 * c_anc_start[j + 1] <= e) ++j;
+    const int na = c_anc_cnt[j], t = e - 36 * c_anc_start[j];
+    const int o = t / (6 * na), col = t % (6 * na);
+    const int a = c_anc[c_anc_start[j] + col / 6], i = col % 6;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s = fmaf(d_out[(int64_t)f * ld + j * 6 + o], pose[(int64_t)f * NJ * 6 + a * 6 + i], s);
+    d_w_anc[e] = s;
+}
+
+extern "C" int maed_ktd_chain_bwd(const float* pose, const float* w_anc, const float* d_pose, const float* d_shape, const float* d_cam,
+                                  float* d_out, int64_t ld_out, float* d_w_anc, float* d_b_feat, int F, void* stream) {
+    MAED_CHECK_ARG(pose && w_anc && d_pose && d_out && d_w_anc && d_b_feat, MAED_ERR_ARG, "ktd_chain_bwd: null pointer");
+    MAED_CHECK_ARG(ld_out >= KTD_OUT, MAED_ERR_SHAPE, "ktd_chain_bwd: ld_out=%lld < 157", (long long)ld_out);
+    hipStream_t s = (hipStream_t)stream;
+    if (F > 0)
+        hipLaunchKernelGGL(ktd_chain_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, s, w_anc, d_pose, d_shape, d_cam, d_out, ld_out, F);
+    hipLaunchKernelGGL(ktd_wanc_bwd_kernel, dim3((MAED_KTD_W_ANC + KTD_OUT + 127) / 128), dim3(128), 0, s, pose, d_out, ld_out, d_w_anc, d_b_feat, F);
+    MAED_CHECK_LAUNCH("ktd_chain_bwd");
+    return MAED_OK;
+}
+
+// ---- pack / unpack of the 26 regressor weights ------------------------------------------------------------------------------------
+// packed row r < 144: regressor j = r/6, output o = r%6 (row length hidden + 6*n_anc(j)); 144..153 decshape; 154..156 deccam
+__device__ __forceinline__ void ktd_row(int r, int hidden, int& j, int& o, int& ld) {
+    if (r < 144) { j = r / 6; o = r % 6; ld = hidden + 6 * c_anc_cnt[j]; }
+    else if (r < 154) { j = 24; o = r - 144; ld = hidden; }
+    else { j = 25; o = r - 154; ld = hidden; }
+}
+
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void ktd_pack_kernel(maed_ktd_ptrs t, int hidden, float* __restrict__ w_feat, float* __restrict__ b_feat,
+                                                       float* __restrict__ w_anc) {
+    const int r = blockIdx.x;
+    if (r < KTD_OUT) {
+        int j, o, ld;
+        ktd_row(r, hidden, j, o, ld);
+        for (int c = threadIdx.x; c < hidden; c += 256) {
+            if (UNPACK) t.gw[j][(int64_t)o * ld + c] += w_feat[(int64_t)r * hidden + c];
+            else w_feat[(int64_t)r * hidden + c] = t.w[j][(int64_t)o * ld + c];
+        }
+        if (threadIdx.x == 0) {
+            if (UNPACK) t.gb[j][o] += b_feat[r];
+            else b_feat[r] = t.b[j][o];
+        }
+        if (r < 144 && threadIdx.x < 6 * c_anc_cnt[j]) {   // the ancestor columns of this row
+            const int na = c_anc_cnt[j];
+            const int e = 36 * c_anc_start[j] + o * 6 * na + threadIdx.x;
+            if (UNPACK) t.gw[j][(int64_t)o * ld + hidden + threadIdx.x] += w_anc[e];
+            else w_anc[e] = t.w[j][(int64_t)o * ld + hidden + threadIdx.x];
+        }
+    }
+}
+
+static int ktd_ptrs_ok(const maed_ktd_ptrs* t, bool grads) {
+    for (int j = 0; j < 26; ++j)
+        if (grads ? !(t->gw[j] && t->gb[j]) : !(t->w[j] && t->b[j])) return 0;
+    return 1;
+}
+
+extern "C" int maed_ktd_pack(const maed_ktd_ptrs* t, int hidden, float* w_feat, float* b_feat, float* w_anc, void* stream) {
+    MAED_CHECK_ARG(t && w_feat && b_feat && w_anc && ktd_ptrs_ok(t, false), MAED_ERR_ARG, "ktd_pack: null pointer");
+    MAED_CHECK_ARG(hidden > 0, MAED_ERR_SHAPE, "ktd_pack: hidden=%d", hidden);
+    hipLaunchKernelGGL((ktd_pack_kernel<false>), dim3(KTD_OUT), dim3(256), 0, (hipStream_t)stream, *t, hidden, w_feat, b_feat, w_anc);
+    MAED_CHECK_LAUNCH("ktd_pack");
+    return MAED_OK;
+}
+
+extern "C" int maed_ktd_unpack_add(const maed_ktd_ptrs* t, int hidden, const float* d_w_feat, const float* d_b_feat, const float* d_w_anc,
+                                   void* stream) {
+    MAED_CHECK_ARG(t && d_w_feat && d_b_feat && d_w_anc && ktd_ptrs_ok(t, true), MAED_ERR_ARG, "ktd_unpack_add: null pointer");
+    MAED_CHECK_ARG(hidden > 0, MAED_ERR_SHAPE, "ktd_unpack_add: hidden=%d", hidden);
+    hipLaunchKernelGGL((ktd_pack_kernel<true>), dim3(KTD_OUT), dim3(256), 0, (hipStream_t)stream, *t, hidden, (float*)d_w_feat, (float*)d_b_feat,
+                       (float*)d_w_anc);
+    MAED_CHECK_LAUNCH("ktd_unpack_add");
+    return MAED_OK;
+}

@@ -5,8 +5,12 @@ Inference (eval mode, no grad) runs on libmaed_hip.so: two f32 GEMMs, ONE GEMM f
 feature part of all 24 joint regressors + shape + cam, the serial ancestor chain in one kernel
 (maed_ktd_chain_fwd, replaces 24 cat+Linear launches, ktd.py:81-84), fused 6D->rotmat->axis-angle,
 SMPL LBS, the joint-regressor GEMM on f32 MFMA, the int64 joint_map gather and the projection.
-Training keeps the decoder tail ((F, .) rows; <1% of the step) on ATen ops so autograd carries it.
+Training on the GPU runs the same forward kernels inside two autograd Functions (maed_amd/tail.py) whose backward
+is ~10 hand-written launches; fc1/fc2 + Dropout stay ATen (two plain GEMMs and the framework's RNG).  The
+ATen composition of the whole tail is kept for CPU tensors and for a differentiable J_regressor override.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -16,6 +20,7 @@ from . import ops
 from .geometry import rot6d_to_rotmat, rotation_matrix_to_angle_axis
 from .smpl import SMPL
 from .spin import projection
+from . import tail
 
 # lib/models/ktd.py:10-35
 ANCESTOR_INDEX = [
@@ -47,6 +52,32 @@ class KTD(nn.Module):
         nn.init.xavier_uniform_(self.decshape.weight, gain=0.01)
         nn.init.xavier_uniform_(self.deccam.weight, gain=0.01)
         self._packed_key, self._packed = None, None
+        self._pending_backwards = 0
+        self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
+
+    def _regressors(self):
+        return list(self.joint_regs) + [self.decshape, self.deccam]
+
+    def fused_parameters(self):
+        """parameters whose gradients tail.KtdChainFn writes straight into .grad (maed_ktd_unpack_add)"""
+        return [t for m in self._regressors() for t in (m.weight, m.bias)]
+
+    def _ptr_table(self, grads):
+        t = L.KtdPtrs()
+        for j, m in enumerate(self._regressors()):
+            t.w[j], t.b[j] = ops._p(m.weight), ops._p(m.bias)
+            if grads:
+                for p in (m.weight, m.bias):
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                t.gw[j], t.gb[j] = ops._p(m.weight.grad), ops._p(m.bias.grad)
+        return t
+
+    def _head_train(self, x):
+        """ktd.py:71-86 with the 26 small regressors as ONE packed GEMM + the chain kernel (differentiable)"""
+        x = self.drop1(self.fc1(x))
+        x = self.drop2(self.fc2(x))
+        return tail.KtdChainFn.apply(x, self, *self.fused_parameters())
 
     # ---- ATen path (training) -------------------------------------------------------------------
     def _head_torch(self, x):
@@ -84,11 +115,23 @@ class KTD(nn.Module):
     def _use_hip(self, x):
         return x.is_cuda and not self.training and not (torch.is_grad_enabled() and (x.requires_grad or self.fc1.weight.requires_grad))
 
+    def _use_hip_train(self, x, J_regressor):
+        return x.is_cuda and J_regressor is None and not self._use_hip(x)
+
     def forward(self, x, seqlen, J_regressor=None, return_shape_cam=False, **kwargs):
         hip = self._use_hip(x)
-        pred_pose, pred_shape, pred_cam = self._head_hip(x) if hip else self._head_torch(x.float())
+        hip_train = self._use_hip_train(x, J_regressor)
+        if hip:
+            pred_pose, pred_shape, pred_cam = self._head_hip(x)
+        elif hip_train:
+            pred_pose, pred_shape, pred_cam = self._head_train(x.float())
+        else:
+            pred_pose, pred_shape, pred_cam = self._head_torch(x.float())
         if return_shape_cam:
             return pred_shape, pred_cam
+        if hip_train:
+            theta, verts, kp2d, kp3d, rotmat = tail.SmplTailFn.apply(pred_pose, pred_shape, pred_cam, self.smpl)
+            return dict(theta=theta, verts=verts, kp_2d=kp2d, kp_3d=kp3d, rotmat=rotmat)
         return self.get_output(pred_pose, pred_shape, pred_cam, J_regressor, hip)
 
     def get_output(self, pred_pose, pred_shape, pred_cam, J_regressor, hip=None):

@@ -18,22 +18,6 @@ from .ktd import KTD
 from .vision_transformer import vit_custom_resnet50_224_in21k
 
 
-class _TrainingTail(nn.Module):
-    """final LayerNorm on the cls rows + pre_logits + KTD + SMPL + projection: the (F, .)-row ATen part of the
-    training graph (~1500 tiny launches per step), isolated so it can be captured into ONE hipGraph."""
-
-    def __init__(self, encoder, decoder):
-        super().__init__()
-        self.norm, self.pre_logits, self.decoder = encoder.norm, encoder.pre_logits, decoder
-
-    def forward(self, cls_tok):
-        y = F.layer_norm(cls_tok, (cls_tok.shape[-1],), self.norm.weight, self.norm.bias, self.norm.eps)
-        if isinstance(self.pre_logits, nn.Sequential):
-            y = torch.tanh(F.linear(y, self.pre_logits.fc.weight, self.pre_logits.fc.bias))
-        o = self.decoder(y, seqlen=1)
-        return o['theta'], o['verts'], o['kp_2d'], o['kp_3d'], o['rotmat']
-
-
 class MAED(nn.Module):
     def __init__(self, encoder='ste', num_blocks=6, num_heads=12, st_mode='parallel', decoder='ktd', hidden_dim=1024,
                  embed_dim=768, max_seqlen=16, img_size=224, compute_dtype=torch.bfloat16, impl=L.IMPL_AUTO,
@@ -48,18 +32,6 @@ class MAED(nn.Module):
         if decoder.lower() != 'ktd':
             raise NotImplementedError(decoder)       # maed.py:29 ('iterative' SPIN regressor: SURVEY 8(f) rank 3)
         self.decoder = KTD(feat_dim=self.encoder.num_features, hidden_dim=hidden_dim, smpl_arrays=smpl_arrays)
-        self._graphed_tail, self._graphed_frames = None, 0
-
-    def graph_training_tail(self, n_frames):
-        """Capture forward AND backward of the decoder tail for a fixed number of frames into hipGraphs
-        (torch.cuda.make_graphed_callables): launch-bound work replayed as two graph launches per step.
-        Call AFTER parameters have reached their final storage (e.g. after ddp.ParamArena) and in train mode."""
-        tail = _TrainingTail(self.encoder, self.decoder)
-        dev = self.encoder.norm.weight.device
-        sample = torch.randn(n_frames, self.encoder.embed_dim, device=dev, requires_grad=True)
-        self._graphed_tail = torch.cuda.make_graphed_callables(tail, (sample,))
-        self._graphed_frames = n_frames
-        return self
 
     def extract_feature(self, x):
         batch_size, seqlen = x.shape[:2]
@@ -69,15 +41,8 @@ class MAED(nn.Module):
     def forward(self, x, J_regressor=None, **kwargs):
         batch_size, seqlen = x.shape[:2]
         x = x.reshape(-1, x.shape[-3], x.shape[-2], x.shape[-1])
-        use_graph = (self._graphed_tail is not None and self.training and torch.is_grad_enabled() and J_regressor is None
-                     and not kwargs and x.shape[0] == self._graphed_frames)
-        if use_graph:
-            tok = self.encoder.forward_tokens(x, seqlen)
-            theta, verts, kp_2d, kp_3d, rotmat = self._graphed_tail(tok[:, 0].contiguous())
-            output = dict(theta=theta, verts=verts, kp_2d=kp_2d, kp_3d=kp_3d, rotmat=rotmat)
-        else:
-            xf = self.encoder(x, seqlen=seqlen)
-            output = self.decoder(xf, seqlen=seqlen, J_regressor=J_regressor, **kwargs)
+        xf = self.encoder(x, seqlen=seqlen)
+        output = self.decoder(xf, seqlen=seqlen, J_regressor=J_regressor, **kwargs)
         output['theta'] = output['theta'].reshape(batch_size, seqlen, -1)
         output['verts'] = output['verts'].reshape(batch_size, seqlen, -1, 3)
         output['kp_2d'] = output['kp_2d'].reshape(batch_size, seqlen, -1, 2)

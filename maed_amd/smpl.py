@@ -101,6 +101,13 @@ class SMPL(nn.Module):
         self.register_buffer('J_template', self.J_regressor @ self.v_template, persistent=False)
         self.register_buffer('J_shapedirs', torch.einsum('jv,vcl->jcl', self.J_regressor, self.shapedirs).contiguous(), persistent=False)
         self.faces = None
+        self._ps_t = None
+
+    def pose_shape_dirs_t(self):
+        """(20670, 207+10) = [posedirs ; shapedirs^T]^T: the one GEMM operand of the LBS backward (tail.SmplTailFn)"""
+        if self._ps_t is None or self._ps_t.device != self.posedirs.device:
+            self._ps_t = torch.cat([self.posedirs, self.shapedirs.reshape(-1, 10).t()], dim=0).t().contiguous()
+        return self._ps_t
 
     # ---- ATen path (training graph; differentiable) ------------------------------------------------
     # Written for the GPU: every contraction is ONE large GEMM (frames folded into the N dimension) or a
@@ -160,7 +167,7 @@ class SMPL(nn.Module):
         A = torch.empty(Fr, 24, 12, dtype=torch.float32, device=dev)
         sp = self._c_params()
         ops.check(L.lib().maed_smpl_lbs_fwd(C.byref(sp), ops._p(betas.contiguous()), ops._p(rotmat.contiguous()), ops._p(verts),
-                                            ops._p(j24), ops._p(A), Fr, ops._stream()), 'smpl_lbs_fwd')
+                                            ops._p(j24), ops._p(A), None, Fr, ops._stream()), 'smpl_lbs_fwd')
         return verts, j24
 
     def joint_regress_hip(self, Jreg, verts):

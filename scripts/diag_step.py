@@ -8,7 +8,7 @@ from maed_amd import _lib as L
 from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
 
 ap = argparse.ArgumentParser(); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--clips", type=int, default=8)
-ap.add_argument("--miopen-benchmark", action="store_true"); ap.add_argument("--graph-tail", action="store_true")
+ap.add_argument("--miopen-benchmark", action="store_true")
 args = ap.parse_args()
 if args.miopen_benchmark:
     torch.backends.cudnn.benchmark = True
@@ -43,15 +43,17 @@ def ste_train():
     for blk in model.encoder.blocks: x = blk(x, 16)
     x.square().mean().backward()
 timed("6 blocks fwd+bwd", ste_train)
+from maed_amd.loss import LossVideo
+criterion = LossVideo(**bench.LOSS_W)
+feat = model.encoder(img, seqlen=16).detach().requires_grad_(True)
+def tail_train():
+    arena.zero_grad(); out = model.decoder(feat, seqlen=16)
+    out = {k: v.reshape(bench.CFG["clips"], 16, *v.shape[1:]) for k, v in out.items()}
+    loss, _ = criterion(out, tgt, None); loss.backward(); return loss
+timed("decoder tail + loss fwd+bwd", tail_train)
 def step():
-    opt.zero_grad(); loss = bench.proxy_loss(model(clip), tgt); loss.backward(); opt.step(); return loss
+    opt.zero_grad(); loss, _ = criterion(model(clip), tgt, None); loss.backward(); opt.step(); return loss
 timed("full train step", step, n=4)
-if args.graph_tail:
-    try:
-        model.graph_training_tail(bench.CFG["clips"] * 16)
-        timed("full train step (graphed tail)", step, n=4)
-    except Exception as e:
-        P(f"graph capture FAILED: {e!r}")
 lib = L.lib(); lib.maed_prof_enable(1); step(); torch.cuda.synchronize()
 ms = (ctypes.c_double * 8)(); cnt = (ctypes.c_int * 8)(); lib.maed_prof_collect(ms, cnt); lib.maed_prof_enable(0)
 names = ["attn_sp_fwd", "attn_tm_fwd", "gemm_qkv", "gemm_fc1", "gemm_fc2", "attn_sp_bwd", "attn_tm_bwd", "gemm_wgrad"]

@@ -1,0 +1,36 @@
+"""TEST INFRASTRUCTURE: run the decoder-tail / loss kernels of libmaed_hip on the host simulator
+(tests/hostsim) so their arithmetic and the ctypes/autograd wiring are checked without a GPU.
+`patched()` swaps the library handle and the pointer/stream helpers for the duration of a test only."""
+import contextlib
+import ctypes as C
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "hostsim"))
+
+
+def load():
+    import build_sim
+    from maed_amd import _lib as L
+    h = C.CDLL(build_sim.build())
+    for name, (res, args) in L.SIGNATURES.items():
+        if hasattr(h, name):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+    assert h.maed_version() < 0, "this must be the simulator, not the product library"
+    return h
+
+
+@contextlib.contextmanager
+def patched():
+    from maed_amd import _lib as L
+    from maed_amd import ops
+    saved = (L._lib, ops._p, ops._stream)
+    L._lib = load()
+    ops._p = lambda t: None if t is None else t.data_ptr()
+    ops._stream = lambda: None
+    try:
+        yield L._lib
+    finally:
+        L._lib, ops._p, ops._stream = saved

@@ -1,0 +1,34 @@
+"""TEST INFRASTRUCTURE: compile the decoder-tail / loss kernel SOURCES of libmaed_hip for x86 against the
+host-simulation shim (tests/hostsim/hip/hip_runtime.h) -> tests/hostsim/_build/libmaed_hostsim.so.
+
+The simulator checks kernel arithmetic and the ctypes/autograd wiring on a box without a GPU.  It is
+loaded only by tests (tests/test_hostsim_*.py monkeypatch maed_amd._lib); the product never sees it.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "maed_amd", "csrc")
+OUT_DIR = os.path.join(HERE, "_build")
+OUT = os.path.join(OUT_DIR, "libmaed_hostsim.so")
+SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip"]
+CLANG = os.environ.get("MAED_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + [os.path.join(HERE, "sim_support.cpp")]
+    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "common.cuh"), os.path.join(ROOT, "include", "maed_hip.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = [CLANG, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-I", HERE, "-Wno-unused-value"]
+    for s in srcs:
+        cmd += ["-x", "c++", s]
+    cmd += ["-o", OUT]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

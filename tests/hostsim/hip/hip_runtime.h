@@ -1,0 +1,140 @@
+// TEST INFRASTRUCTURE -- host simulation of the small subset of the HIP programming model that the
+// decoder-tail / loss kernels of libmaed_hip use, so their ARITHMETIC can be checked on a machine without a
+// GPU (tests/test_hostsim_*.py).  It is found as <hip/hip_runtime.h> when the kernel sources are compiled
+// for x86 by tests/hostsim/build_sim.py; nothing in maed_amd/ ever loads the resulting library.
+//
+// Model: every GPU thread of a workgroup is a real host thread; workgroups run one after another.
+//   __syncthreads()      -> block barrier;  __shfl_xor / MFMA -> exchange through a per-wave (64 threads) barrier
+//   __shared__           -> function-local static (one workgroup is alive at a time)
+//   atomicAdd            -> std::atomic_ref
+// Threads that return early drop out of the barriers, as exited lanes do on hardware.
+#pragma once
+#define MAED_HOSTSIM 1
+#include <algorithm>
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __constant__ const
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hostsim"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+namespace hostsim {
+struct WaveCtx {
+    std::barrier<> bar;
+    float fx[64];
+    float fa[64], fb[64];
+    explicit WaveCtx(int n) : bar(n) {}
+};
+struct BlockCtx {
+    std::barrier<> bar;
+    std::vector<std::unique_ptr<WaveCtx>> waves;
+    explicit BlockCtx(int n) : bar(n) {
+        for (int w = 0; w * 64 < n; ++w) waves.emplace_back(new WaveCtx(std::min(64, n - w * 64)));
+    }
+};
+struct Idx { unsigned x, y, z; };
+extern thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local BlockCtx* t_block;
+extern thread_local int t_tid;
+
+template <typename K, typename... Args>
+void launch(K kernel, dim3 grid, dim3 block, size_t /*dyn_lds*/, hipStream_t, Args... args) {
+    const int nthr = (int)(block.x * block.y * block.z);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                BlockCtx ctx(nthr);
+                std::vector<std::thread> th;
+                th.reserve(nthr);
+                for (int t = 0; t < nthr; ++t)
+                    th.emplace_back([&, t]() {
+                        t_threadIdx = Idx{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+                        t_blockIdx = Idx{bx, by, bz};
+                        t_blockDim = Idx{block.x, block.y, block.z};
+                        t_gridDim = Idx{grid.x, grid.y, grid.z};
+                        t_block = &ctx;
+                        t_tid = t;
+                        kernel(args...);
+                        ctx.waves[t / 64]->bar.arrive_and_drop();
+                        ctx.bar.arrive_and_drop();
+                    });
+                for (auto& t : th) t.join();
+            }
+}
+}  // namespace hostsim
+
+#define threadIdx hostsim::t_threadIdx
+#define blockIdx hostsim::t_blockIdx
+#define blockDim hostsim::t_blockDim
+#define gridDim hostsim::t_gridDim
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) hostsim::launch(kernel, grid, block, lds, stream, __VA_ARGS__)
+
+static inline void __syncthreads() { hostsim::t_block->bar.arrive_and_wait(); }
+
+static inline float __shfl_xor(float v, int mask, int /*width*/ = 64) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    w.fx[lane] = v;
+    w.bar.arrive_and_wait();
+    const float r = w.fx[lane ^ mask];
+    w.bar.arrive_and_wait();
+    return r;
+}
+
+typedef float hostsim_f32x16 __attribute__((ext_vector_type(16)));
+// v_mfma_f32_32x32x2_f32: A[i][k] from lane k*32+i, B[k][j] from lane k*32+j, D[(r&3)+8*(r>>2)+4*(lane>>5)][lane&31] in reg r
+static inline hostsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hostsim_f32x16 acc, int, int, int) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    w.fa[lane] = a; w.fb[lane] = b;
+    w.bar.arrive_and_wait();
+    const int j = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        acc[r] = fmaf(w.fa[32 + i], w.fb[32 + j], fmaf(w.fa[i], w.fb[j], acc[r]));
+    }
+    w.bar.arrive_and_wait();
+    return acc;
+}
+
+template <typename T> static inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }
+
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline int64_t min(int64_t a, int64_t b) { return a < b ? a : b; }
+static inline int64_t max(int64_t a, int64_t b) { return a > b ? a : b; }
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+#define __expf(x) expf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }

@@ -179,7 +179,7 @@ def test_maed_cfg1_golden_f32(golden):
 
 
 def test_maed_train_gradients_small_vs_oracle_f32():
-    """whole-model gradients (backbone via ATen/MIOpen, STE via HIP kernels, decoder tail via ATen) against
+    """whole-model gradients (backbone via ATen/MIOpen, STE and decoder tail via HIP kernels) against
     fp64 CPU autograd through the oracle (dropout disabled for comparability).  The backbone's GroupNorm
     makes its gradients ill-conditioned in fp32 (the oracle itself moves by several % between fp32 and
     fp64), so backbone gradients are checked as a whole by direction; everything else elementwise."""
@@ -236,34 +236,6 @@ def test_train_step_arena_adam_bf16_runs_and_learns():
     assert all(p.grad.data_ptr() >= arena.grad.data_ptr() for p in arena.params)
     from maed_amd import ops
     assert ops.TWIN_HITS[0] > 0, f"bf16 residual-gradient hand-off between blocks never triggered: {ops.TWIN_HITS}"
-
-
-def test_graphed_training_tail_matches_eager():
-    """decoder tail replayed from hipGraphs (fwd + bwd) == eager tail: outputs and parameter gradients"""
-    m, _ = _small_maed(torch.float32, depth=1, img=64, seed=8)
-    m.train()
-    m.decoder.drop1.p = 0.0
-    m.decoder.drop2.p = 0.0
-    clip = rnd(2, 2, 3, 64, 64, seed=13).to(DEV)
-
-    def run():
-        for p in m.parameters():
-            p.grad = None
-        out = m(clip)
-        loss = (out["kp_3d"] ** 2).mean() + (out["theta"] ** 2).mean() + 0.01 * (out["kp_2d"] ** 2).mean()
-        loss.backward()
-        return {k: v.detach().clone() for k, v in out.items()}, {n: p.grad.detach().clone() for n, p in m.named_parameters()}
-
-    out_e, g_e = run()
-    m.graph_training_tail(4)
-    out_g, g_g = run()
-    out_g2, g_g2 = run()   # replay twice: static buffers must not leak state between steps
-    for k in out_e:
-        report(f"graphed tail output {k}", out_g[k], out_e[k], rtol=1e-5, atol=1e-6)
-    worst = max((g_g[n] - g_e[n]).abs().max().item() / (g_e[n].abs().max().item() + 1e-12) for n in g_e if "backbone" not in n)
-    report("graphed tail: worst rel-to-max gradient difference vs eager (STE+decoder)", torch.tensor([worst]), torch.zeros(1), rtol=0, atol=1e-4)
-    worst2 = max((g_g2[n] - g_g[n]).abs().max().item() / (g_g[n].abs().max().item() + 1e-12) for n in g_g if "backbone" not in n)
-    report("graphed tail: replay reproducibility", torch.tensor([worst2]), torch.zeros(1), rtol=0, atol=1e-4)
 
 
 def test_rccl_bucketed_allreduce_single_rank():

@@ -1,0 +1,121 @@
+"""Decoder-tail kernels (maed_amd/csrc/smpl.hip forward, tail_bwd.hip backward) on the host simulator: the same
+sources that hipcc compiles for gfx950 are compiled for x86 (tests/hostsim) and driven through the product's own
+ctypes signatures and autograd Functions (maed_amd/tail.py), then compared with the ATen composition of the same
+graph (which tests/test_gpu_model.py ties to the float64 oracle).  Checks arithmetic + wiring without a GPU; the
+`-m gpu` suite repeats the comparison on the real library."""
+import numpy as np
+import pytest
+import torch
+
+from maed_amd import tail
+from maed_amd.geometry import rot6d_to_rotmat
+from maed_amd.ktd import KTD
+
+from _hostsim import patched
+
+
+def make_ktd(seed=0, feat=48, hidden=32):
+    torch.manual_seed(seed)
+    ktd = KTD(feat_dim=feat, hidden_dim=hidden).eval()        # eval: Dropout off so both paths see the same graph
+    for r in ktd._regressors():
+        torch.nn.init.normal_(r.weight, std=0.05)
+        torch.nn.init.normal_(r.bias, std=0.3)
+    with torch.no_grad():
+        ktd.deccam.bias.copy_(torch.tensor([0.9, 0.05, -0.05]))
+    return ktd
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def run_both(ktd, x, out_keys, seed=1):
+    """-> (reference outputs, reference grads, simulated outputs, simulated grads) for a random cotangent on out_keys"""
+    params = list(ktd.parameters())
+    out_ref = ktd.get_output(*ktd._head_torch(x), None, hip=False)
+    g = torch.Generator().manual_seed(seed)
+    cot = {k: torch.randn(out_ref[k].shape, generator=g) for k in out_keys}
+    gref = torch.autograd.grad(sum((out_ref[k] * cot[k]).sum() for k in cot), [x] + params, allow_unused=True)
+    for p in params:
+        p.grad = None
+    x.grad = None
+    with patched():
+        pose, shape, cam = ktd._head_train(x)
+        theta, verts, kp2d, kp3d, rotmat = tail.SmplTailFn.apply(pose, shape, cam, ktd.smpl)
+        out = dict(theta=theta, verts=verts, kp_2d=kp2d, kp_3d=kp3d, rotmat=rotmat)
+        sum((out[k] * cot[k]).sum() for k in cot).backward()
+    return out_ref, gref, out, [x.grad] + [p.grad for p in params]
+
+
+@pytest.mark.parametrize("out_keys", [("theta", "verts", "kp_2d", "kp_3d", "rotmat"), ("kp_2d", "kp_3d", "theta"), ("kp_2d",), ("rotmat",)])
+def test_tail_forward_backward_vs_aten(out_keys):
+    ktd = make_ktd()
+    x = torch.randn(3, 48, requires_grad=True)
+    out_ref, gref, out, gsim = run_both(ktd, x, out_keys)
+    for k in out_ref:
+        assert rel(out[k].detach(), out_ref[k].detach()) < 5e-6, k
+    names = ["x"] + [n for n, _ in ktd.named_parameters()]
+    for n, a, b in zip(names, gsim, gref):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, n
+            continue
+        assert a is not None, n
+        assert rel(a, b) < 2e-4, (n, rel(a, b))
+
+
+def test_all_quaternion_branches_differentiated():
+    """rotation_matrix_to_angle_axis takes one of four branches per joint (geometry.py:143-223); the dual-number backward
+    must follow the same branch.  Random 6D poses hit all four; compare d(theta)/d(pose6d) joint by joint."""
+    g = torch.Generator().manual_seed(3)
+    x6 = torch.randn(40, 144, generator=g)
+    R = rot6d_to_rotmat(x6).reshape(-1, 3, 3).transpose(1, 2)
+    d2, d0d1, d0nd1 = R[:, 2, 2] < 1e-6, R[:, 0, 0] > R[:, 1, 1], R[:, 0, 0] < -R[:, 1, 1]
+    branches = {int(b) for b in (d2 & d0d1) * 0 + (d2 & ~d0d1) * 1 + (~d2 & d0nd1) * 2 + (~d2 & ~d0nd1) * 3}
+    assert branches == {0, 1, 2, 3}
+    from maed_amd.geometry import rotation_matrix_to_angle_axis
+    x_ref = x6.clone().requires_grad_(True)
+    Rr = rot6d_to_rotmat(x_ref)
+    aa_ref = rotation_matrix_to_angle_axis(Rr).reshape(40, 72)
+    cot_aa, cot_R = torch.randn(40, 72, generator=g), torch.randn(40, 24, 9, generator=g)
+    ((aa_ref * cot_aa).sum() + (Rr.reshape(40, 24, 9) * cot_R).sum()).backward()
+    from maed_amd import _lib as L, ops
+    with patched() as lib:
+        d_x6 = torch.empty(40, 144)
+        d_aa = torch.zeros(40, 85)
+        d_aa[:, 3:75] = cot_aa
+        L.check(lib.maed_rot6d_pose_bwd(x6.data_ptr(), cot_R.data_ptr(), d_aa.data_ptr() + 12, 85, d_x6.data_ptr(), 40 * 24, None))
+    assert rel(d_x6, x_ref.grad) < 1e-4
+
+
+def test_ktd_pack_unpack_round_trip():
+    from maed_amd import _lib as L
+    import ctypes as C
+    ktd = make_ktd(hidden=32)
+    with patched() as lib:
+        w_feat, b_feat, w_anc = torch.empty(157, 32), torch.empty(157), torch.empty(L.KTD_W_ANC)
+        L.check(lib.maed_ktd_pack(C.byref(ktd._ptr_table(False)), 32, w_feat.data_ptr(), b_feat.data_ptr(), w_anc.data_ptr(), None))
+        ref_w = torch.cat([r.weight[:, :32] for r in ktd._regressors()], 0)
+        ref_b = torch.cat([r.bias for r in ktd._regressors()], 0)
+        ref_a = torch.cat([r.weight[:, 32:].reshape(-1) for r in ktd.joint_regs[1:]], 0)
+        assert torch.equal(w_feat, ref_w.detach()) and torch.equal(b_feat, ref_b.detach()) and torch.equal(w_anc, ref_a.detach())
+        # unpack_add ACCUMULATES into .grad: run twice, expect 2x
+        tbl = ktd._ptr_table(True)
+        for _ in range(2):
+            L.check(lib.maed_ktd_unpack_add(C.byref(tbl), 32, w_feat.data_ptr(), b_feat.data_ptr(), w_anc.data_ptr(), None))
+    for r in ktd._regressors():
+        assert torch.allclose(r.weight.grad, 2 * r.weight.detach()) and torch.allclose(r.bias.grad, 2 * r.bias.detach())
+
+
+def test_grads_ready_protocol_and_fused_parameter_list():
+    ktd = make_ktd()
+    fired = []
+    ktd.grads_ready = lambda m: fired.append(m)
+    x = torch.randn(2, 48, requires_grad=True)
+    with patched():
+        pose, shape, cam = ktd._head_train(x)
+        assert ktd._pending_backwards == 1
+        (pose.sum() + shape.sum() + cam.sum()).backward()
+    assert fired == [ktd] and ktd._pending_backwards == 0
+    fused = {id(p) for p in ktd.fused_parameters()}
+    assert len(fused) == 52 and all(p.grad is not None for p in ktd.fused_parameters())
+    assert id(ktd.fc1.weight) not in fused and ktd.fc1.weight.grad is not None      # fc1/fc2 travel through autograd
