@@ -159,7 +159,11 @@ def main():
     else:
         model.train()
         arena = ParamArena(model)
-        bucketer = GradBucketer(arena, model)
+        comm = None
+        if os.environ.get("MAED_COMM", "torch") == "direct":   # the library's own RCCL communicator + side stream (maed_comm_*)
+            from maed_amd.ddp import RcclComm
+            comm = RcclComm()
+        bucketer = GradBucketer(arena, model, comm=comm)
         bucketer.broadcast_parameters(0)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=bucketer)  # configs/config_stage2.yaml:63-66
         criterion = LossVideo(**LOSS_W)                                        # lib/core/loss.py via maed_loss_fwd_bwd

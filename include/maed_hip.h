@@ -289,6 +289,21 @@ int maed_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_corr1, float bias_corr2, float gscale, void* stream);
 
+/* ---- gradient all-reduce: RCCL over xGMI on a side HIP stream (train.py:113,182 DDP/NCCL) ----------------------- */
+/* One communicator per process.  RCCL is bound at run time from the library the host names (NULL = "librccl.so.1");
+ * pass the copy PyTorch-ROCm already loaded so the process holds one RCCL.  unique_id: MAED_COMM_ID_BYTES made by
+ * maed_comm_unique_id on rank 0 and distributed by the caller (the host uses the torch.distributed store).
+ * allreduce_async: SUM in place over n elements; ordered after everything already enqueued on compute_stream, runs on the
+ * library's side stream (overlaps later kernels of compute_stream).  wait: compute_stream waits for all issued collectives. */
+#define MAED_COMM_ID_BYTES 128
+int maed_comm_load(const char* librccl_path);
+int maed_comm_unique_id(void* id128);
+int maed_comm_init(int rank, int world, const void* unique_id);
+int maed_comm_allreduce_async(void* buf, size_t n, int dtype, void* compute_stream);
+int maed_comm_wait(void* compute_stream);
+int maed_comm_world(void);
+int maed_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

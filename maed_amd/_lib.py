@@ -92,6 +92,13 @@ SIGNATURES = {
     "maed_weight_std_bwd": (i32, [vp, i32, i32, i32, vp, f32, vp]),
     "maed_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),
     "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp]),
+    "maed_comm_load": (i32, [C.c_char_p]),
+    "maed_comm_unique_id": (i32, [vp]),
+    "maed_comm_init": (i32, [i32, i32, vp]),
+    "maed_comm_allreduce_async": (i32, [vp, C.c_size_t, i32, vp]),
+    "maed_comm_wait": (i32, [vp]),
+    "maed_comm_world": (i32, []),
+    "maed_comm_destroy": (i32, []),
     "maed_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
 }
 

@@ -14,9 +14,13 @@ MI355X-first layout instead of torch DDP + per-tensor Adam:
   * the division by world size is folded into the Adam kernel (gscale).
 One process per GPU; rank/world come from torch.distributed (backend "nccl" == RCCL on ROCm).
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
+from . import _lib as L
 from . import ops
 from .vision_transformer import Block
 
@@ -70,16 +74,51 @@ class ParamArena:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
 
-class GradBucketer:
-    """Bucketed, overlapped gradient all-reduce over the gradient arena."""
+class RcclComm:
+    """The library's own communicator (maed_comm_*: RCCL bound from the copy PyTorch-ROCm ships, side HIP stream, event
+    fences) instead of torch.distributed's ProcessGroupNCCL.  The 128-byte unique id travels from rank 0 through the
+    already-initialised torch.distributed group (any backend) -- or no exchange at all for world == 1."""
 
-    def __init__(self, arena, model, bucket_bytes=32 << 20, process_group=None, force_collectives=False):
+    def __init__(self, rank=None, world=None):
+        lib = L.lib()
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank() if have_pg else 0)
+        self.world = world if world is not None else (dist.get_world_size() if have_pg else 1)
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        L.check(lib.maed_comm_load(bundled.encode() if os.path.exists(bundled) else None), "comm_load")
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            L.check(lib.maed_comm_unique_id(uid), "comm_unique_id")
+        if self.world > 1:
+            box = [uid.raw]
+            dist.broadcast_object_list(box, src=0)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        L.check(lib.maed_comm_init(self.rank, self.world, uid), "comm_init")
+
+    def allreduce_async(self, t):
+        L.check(L.lib().maed_comm_allreduce_async(ops._p(t), t.numel(), ops.dt_code(t.dtype), ops._stream()), "comm_allreduce_async")
+
+    def wait(self):
+        L.check(L.lib().maed_comm_wait(ops._stream()), "comm_wait")
+
+    def destroy(self):
+        L.check(L.lib().maed_comm_destroy(), "comm_destroy")
+
+
+class GradBucketer:
+    """Bucketed, overlapped gradient all-reduce over the gradient arena.  comm=None: torch.distributed (backend "nccl" is
+    RCCL); comm=RcclComm(): the library's own RCCL communicator and side stream (MAED_COMM=direct in bench.py)."""
+
+    def __init__(self, arena, model, bucket_bytes=32 << 20, process_group=None, force_collectives=False, comm=None):
         self.arena = arena
         self.pg = process_group
+        self.comm = comm
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if comm is not None:
+            self.world = comm.world
         # world == 1 normally skips the collectives; force_collectives issues them anyway (exercises the RCCL
         # stream/event plumbing on a single GPU: tests/test_gpu_model.py)
-        self.collectives = (self.world > 1) or (force_collectives and dist.is_available() and dist.is_initialized())
+        self.collectives = (self.world > 1) or (force_collectives and (comm is not None or (dist.is_available() and dist.is_initialized())))
         cap = max(1, bucket_bytes // 4)
         # buckets are built from the END of the arena (first to complete in backward)
         self.buckets = []  # [start, end, n_params]
@@ -131,7 +170,10 @@ class GradBucketer:
         self._launched[b] = True
         if self.collectives:
             s, e, _ = self.buckets[b]
-            self._works.append(dist.all_reduce(self.arena.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            if self.comm is not None:
+                self.comm.allreduce_async(self.arena.grad[s:e])
+            else:
+                self._works.append(dist.all_reduce(self.arena.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
         """Launch whatever has not fired (parameters without a gradient this step), then make the
@@ -141,12 +183,14 @@ class GradBucketer:
         for w in self._works:
             w.wait()
         self._works = []
+        if self.comm is not None and self.collectives:
+            self.comm.wait()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
 
     def broadcast_parameters(self, src=0):
         """train.py:113 DDP construction broadcasts rank 0's parameters once."""
-        if self.collectives:
+        if self.collectives and dist.is_available() and dist.is_initialized():
             dist.broadcast(self.arena.flat, src=src, group=self.pg)
             ops.bump_weight_epoch()
 

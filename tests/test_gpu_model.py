@@ -277,3 +277,72 @@ def test_rccl_bucketed_allreduce_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_direct_rccl_comm_single_rank():
+    """the library's own communicator (maed_comm_*: dlsym-bound RCCL, side stream, event fences) on one GPU, world 1:
+    all-reduce(SUM) over one rank is the identity, so the bucketed step must reproduce the plain gradients bit for bit,
+    and a second all-reduce of a known buffer must leave it unchanged."""
+    from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena, RcclComm
+    comm = RcclComm(rank=0, world=1)
+    try:
+        clip = rnd(2, 2, 3, 64, 64, seed=22).to(DEV)
+        grads = []
+        for use in (None, comm):
+            m, _ = _small_maed(torch.float32, depth=1, img=64, seed=9)
+            m.train()
+            m.decoder.drop1.p = 0.0
+            m.decoder.drop2.p = 0.0
+            arena = ParamArena(m)
+            buck = GradBucketer(arena, m, bucket_bytes=1 << 18, force_collectives=use is not None, comm=use)
+            opt = FusedAdam(arena, lr=1e-3, bucketer=buck)
+            opt.zero_grad()
+            out = m(clip)
+            ((out["kp_3d"] ** 2).mean() + (out["theta"] ** 2).mean()).backward()
+            buck.finish()
+            torch.cuda.synchronize()
+            grads.append(arena.grad.clone())
+            opt.step()
+            torch.cuda.synchronize()
+        report("direct RCCL (world 1) bucketed gradients vs plain", grads[1], grads[0], rtol=0, atol=1e-6 * grads[0].abs().max().item())
+        buf = torch.arange(1 << 20, dtype=torch.float32, device=DEV)
+        comm.allreduce_async(buf)
+        comm.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(buf, torch.arange(1 << 20, dtype=torch.float32, device=DEV))
+    finally:
+        comm.destroy()
+
+
+def test_cfg5_long_clip_train_step():
+    """BASELINE.json configs[4] shapes on one GPU: T = 64 frames of 256x256 (P = 257 tokens), STE depth 12 / dim 768 / 12 heads,
+    `max_seqlen=64`.  One clip per GPU; a full bf16 train step (LossVideo, arena Adam) must run through the MFMA
+    attention kernels (P = 257 <= 320), the T = 64 LDS temporal kernels, and produce finite, non-trivial gradients."""
+    import maed_amd
+    from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+    from maed_amd.loss import LossVideo
+    torch.manual_seed(0)
+    m = maed_amd.MAED(num_blocks=12, num_heads=12, embed_dim=768, hidden_dim=1024, img_size=256, max_seqlen=64, compute_dtype=torch.bfloat16).to(DEV).train()
+    assert m.encoder.temp_embed.shape[1] == 64 and m.encoder.pos_embed.shape[1] == 257
+    arena = ParamArena(m)
+    opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=GradBucketer(arena, m))
+    g = torch.Generator().manual_seed(3)
+    N, T = 1, 64
+    clip = torch.randn(N, T, 3, 256, 256, generator=g).to(DEV)
+    tgt = {k: v.to(DEV) for k, v in dict(
+        kp_2d=torch.cat([torch.randn(N, T, 49, 2, generator=g) * 0.3, torch.rand(N, T, 49, 1, generator=g)], -1),
+        kp_3d=torch.cat([torch.randn(N, T, 49, 3, generator=g) * 0.3, torch.ones(N, T, 49, 1)], -1),
+        theta=torch.randn(N, T, 85, generator=g) * 0.2, w_smpl=torch.ones(N, T)).items()}
+    crit = LossVideo()
+    losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        out = m(clip)
+        assert out["theta"].shape == (N, T, 85) and out["verts"].shape == (N, T, 6890, 3) and out["kp_2d"].shape == (N, T, 49, 2)
+        loss, terms = crit(out, tgt, None)
+        loss.backward()
+        gnorm = arena.grad.norm().item()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and np.isfinite(gnorm) and gnorm > 0, (losses, gnorm)
+    report("cfg5 (T=64, 256x256, depth 12, dim 768) train-step loss finite, grad norm > 0", torch.tensor([float(np.isfinite(losses).all())]), torch.ones(1), rtol=0, atol=0)
