@@ -55,7 +55,8 @@ typedef enum {
 } maed_epilogue;
 
 /* kernel implementation selector for ops that have both */
-typedef enum { MAED_IMPL_AUTO = 0, MAED_IMPL_VALU = 1, MAED_IMPL_MFMA = 2 } maed_impl;
+typedef enum { MAED_IMPL_AUTO = 0, MAED_IMPL_VALU = 1, MAED_IMPL_MFMA = 2,
+               MAED_IMPL_MFMA_GLDS1 = 3, MAED_IMPL_MFMA_GLDS2 = 4 /* gemm_nt only: direct global->LDS staging, 1 or 2 LDS buffers */ } maed_impl;
 
 const char* maed_last_error(void);
 int maed_version(void);

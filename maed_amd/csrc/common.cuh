@@ -116,6 +116,11 @@ template <typename T> __device__ __forceinline__ float gelu_bwd(float x);
 template <> __device__ __forceinline__ float gelu_bwd<float>(float x) { return dgelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_bwd<struct bf16>(float x) { float c, p; gelu_parts_fast(x, c, p); return fmaf(x, p, c); }
 
+// value a float takes after a round trip through storage type T (what a later kernel reading the stored tensor sees)
+template <typename T> __device__ __forceinline__ float round_to(float x);
+template <> __device__ __forceinline__ float round_to<float>(float x) { return x; }
+template <> __device__ __forceinline__ float round_to<struct bf16>(float x) { return bf2f(f2bf(x)); }
+
 template <typename T> struct dtype_of;
 template <> struct dtype_of<float> { static constexpr int value = MAED_F32; };
 template <> struct dtype_of<bf16> { static constexpr int value = MAED_BF16; };

@@ -24,9 +24,8 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int6
         stf((T*)e.out + r * e.ldo + c, acc + (e.bias ? e.bias[c] : 0.f));
     } else if constexpr (EPI == MAED_EPI_GELU) {
         const float pre = acc + (e.bias ? e.bias[c] : 0.f);
-        T* p2 = (T*)e.out2 + r * e.ldo + c;
-        stf(p2, pre);
-        stf((T*)e.out + r * e.ldo + c, gelu_fwd<T>(ldf(p2)));  // activation of the STORED (rounded) pre-activation
+        stf((T*)e.out2 + r * e.ldo + c, pre);
+        stf((T*)e.out + r * e.ldo + c, gelu_fwd<T>(round_to<T>(pre)));  // activation of the STORED (rounded) pre-activation
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         ((float*)e.out)[r * e.ldo + c] = ((const float*)e.aux)[r * e.ldaux + c] + (acc + (e.bias ? e.bias[c] : 0.f));
     } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
@@ -60,10 +59,9 @@ __device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int
     if constexpr (EPI == MAED_EPI_STORE) {
         st4((T*)e.out + r * e.ldo + c0, v);
     } else if constexpr (EPI == MAED_EPI_GELU) {
-        T* p2 = (T*)e.out2 + r * e.ldo + c0;
-        st4(p2, v);
-        float pre[4]; ld4(p2, pre);   // activation of the STORED (rounded) pre-activation, as the backward sees it
-        float a[4] = {gelu_fwd<T>(pre[0]), gelu_fwd<T>(pre[1]), gelu_fwd<T>(pre[2]), gelu_fwd<T>(pre[3])};
+        st4((T*)e.out2 + r * e.ldo + c0, v);
+        // activation of the STORED (rounded) pre-activation, as the backward sees it -- rounded in registers, not read back
+        float a[4] = {gelu_fwd<T>(round_to<T>(v[0])), gelu_fwd<T>(round_to<T>(v[1])), gelu_fwd<T>(round_to<T>(v[2])), gelu_fwd<T>(round_to<T>(v[3]))};
         st4((T*)e.out + r * e.ldo + c0, a);
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         float x[4]; ld4((const float*)e.aux + r * e.ldaux + c0, x);
@@ -264,6 +262,111 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// MFMA bf16 kernel, direct global->LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
+// The LDS image of a 128x64 operand tile is unpadded (128-B rows) with the 16-B chunk index XOR-ed by (row>>1)&7
+// (conflict-free ds_read_b128 fragment reads); because an LDS-DMA writes wave-uniform base + lane*16, the swizzle is
+// applied on the per-lane SOURCE address: lane l of the wave that fills rows 8q..8q+7 loads chunk (l&7)^swz(row) of
+// row 8q + (l>>3) -- still one full 128-B line per 8 lanes.
+//   NBUF == 1: 32 KB LDS, <=128 VGPRs -> 4 workgroups per CU, latency hidden by the other workgroups
+//   NBUF == 2: 64 KB LDS, tile t+1 lands while tile t is multiplied, one barrier per K tile
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int EPI, int NBUF>
+__global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                                                     const bf16* __restrict__ B, int64_t ldb, int64_t M,
+                                                                                     int64_t N, int64_t K, int tiles_n,
+                                                                                     int ktiles_per_split, EpiArgs e) {
+    __shared__ __attribute__((aligned(1024))) unsigned short lds[NBUF][2][GM_BM * GM_BK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nwg = gridDim.x;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int64_t m0 = (int64_t)(id / tiles_n) * GM_BM, n0 = (int64_t)(id % tiles_n) * GM_BN;
+    const int nkt_total = (int)(K / GM_BK);
+    const int kt_beg = blockIdx.z * ktiles_per_split;
+    int kt_end = kt_beg + ktiles_per_split;
+    if (kt_end > nkt_total) kt_end = nkt_total;
+    if (kt_beg >= kt_end) return;
+
+    // staging: round i = 0..3, this wave fills rows (4i + wave)*8 .. +7; (row>>1)&7 = (4*wave + (lane>>4)) & 7 for every round
+    const int srow = wave * 8 + (lane >> 3);                                        // + 32*i
+    const int schunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+#define GL_PTRS(i)                                                                              \
+    const bf16* gap##i; const bf16* gbp##i;                                                     \
+    {                                                                                           \
+        const int row = srow + 32 * i;                                                          \
+        const int64_t ar = (m0 + row < M) ? m0 + row : M - 1;                                   \
+        const int64_t br = (n0 + row < N) ? n0 + row : N - 1;                                   \
+        gap##i = A + ar * lda + schunk * 8; gbp##i = B + br * ldb + schunk * 8;                 \
+    }
+    GL_PTRS(0) GL_PTRS(1) GL_PTRS(2) GL_PTRS(3)
+#define GL_ISSUE1(i, buf_, k0__)                                                                                                         \
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(gap##i + k0__), (lds_void_t*)&lds[buf_][0][(4 * i + wave) * 8 * GM_BK], 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(gbp##i + k0__), (lds_void_t*)&lds[buf_][1][(4 * i + wave) * 8 * GM_BK], 16, 0, 0);
+#define GL_ISSUE_TILE(buf_, kt_) { const int64_t k0__ = (int64_t)(kt_) * GM_BK; GL_ISSUE1(0, buf_, k0__) GL_ISSUE1(1, buf_, k0__) GL_ISSUE1(2, buf_, k0__) GL_ISSUE1(3, buf_, k0__) }
+
+    constexpr bool TR = (EPI != MAED_EPI_ATOMIC_F32);
+    f32x16_t acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    const int fsw = (l31 >> 1) & 7;                                                 // swizzle term of this lane's fragment rows
+#define GL_COMPUTE_TILE(buf_)                                                                              \
+    {                                                                                                      \
+        const unsigned short* As = &lds[buf_][0][(wr * 64 + l31) * GM_BK];                                 \
+        const unsigned short* Bs = &lds[buf_][1][(wc * 64 + l31) * GM_BK];                                 \
+        _Pragma("unroll") for (int kk = 0; kk < GM_BK / 16; ++kk) {                                        \
+            const int co = ((kk * 2 + hi) ^ fsw) * 8;                                                      \
+            bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(As + co);                                     \
+            bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(As + 32 * GM_BK + co);                        \
+            bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(Bs + co);                                     \
+            bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(Bs + 32 * GM_BK + co);                        \
+            if constexpr (TR) {                                                                            \
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc00, 0, 0, 0);                   \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc01, 0, 0, 0);                   \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc10, 0, 0, 0);                   \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc11, 0, 0, 0);                   \
+            } else {                                                                                       \
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);                   \
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);                   \
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);                   \
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);                   \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+    if constexpr (NBUF == 1) {
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            GL_ISSUE_TILE(0, kt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            GL_COMPUTE_TILE(0);
+            __syncthreads();
+        }
+    } else {
+        GL_ISSUE_TILE(0, kt_beg);
+        for (int kt = kt_beg; kt < kt_end; kt += 2) {      // two tiles per trip: the buffer index is static
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                // tile kt landed for every wave; buffer 1 is free again
+            if (kt + 1 < kt_end) GL_ISSUE_TILE(NBUF - 1, kt + 1);
+            GL_COMPUTE_TILE(0);
+            if (kt + 1 < kt_end) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 2 < kt_end) GL_ISSUE_TILE(0, kt + 2);
+                GL_COMPUTE_TILE(NBUF - 1);
+            }
+        }
+    }
+    const bool vec_ok = (e.ldo % 4 == 0) && (e.ldaux % 4 == 0);
+    GM_EPILOGUE(acc00, 0, 0);
+    GM_EPILOGUE(acc01, 0, 1);
+    GM_EPILOGUE(acc10, 1, 0);
+    GM_EPILOGUE(acc11, 1, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int EPI, typename T>
 static int launch_valu(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                        const EpiArgs& e, int splitk, hipStream_t s) {
@@ -289,6 +392,19 @@ static int launch_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, i
     return MAED_OK;
 }
 
+template <int EPI, int NBUF>
+static int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                       const EpiArgs& e, int splitk, hipStream_t s) {
+    const int tm = (int)((M + GM_BM - 1) / GM_BM), tn = (int)((N + GM_BN - 1) / GM_BN);
+    const int nkt = (int)(K / GM_BK);
+    int kps = (nkt + splitk - 1) / splitk;
+    if (kps < 1) kps = 1;
+    const int z = (nkt + kps - 1) / kps;
+    hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
+                       (const bf16*)B, ldb, M, N, K, tn, kps, e);
+    return MAED_OK;
+}
+
 template <int EPI>
 static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype,
                     const EpiArgs& e, int splitk, int impl, hipStream_t s) {
@@ -298,12 +414,22 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
     }
     const bool mfma_ok = (K % GM_BK == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && is_aligned(A, 16) && is_aligned(B, 16);
     if (impl == MAED_IMPL_VALU) return launch_valu<EPI, bf16>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    if (impl == MAED_IMPL_MFMA_GLDS1 || impl == MAED_IMPL_MFMA_GLDS2) {
+        MAED_CHECK_ARG(mfma_ok, MAED_ERR_ALIGN, "gemm_nt(glds): need K%%64==0 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B", (long long)K);
+        return impl == MAED_IMPL_MFMA_GLDS1 ? launch_glds<EPI, 1>(A, lda, B, ldb, M, N, K, e, splitk, s)
+                                            : launch_glds<EPI, 2>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    }
     if (impl == MAED_IMPL_MFMA) {
         MAED_CHECK_ARG(mfma_ok, MAED_ERR_ALIGN, "gemm_nt(mfma): need K%%64==0 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B", (long long)K);
         return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
     }
-    return mfma_ok ? launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s)
-                   : launch_valu<EPI, bf16>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    if (!mfma_ok) return launch_valu<EPI, bf16>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    // measured at the cfg3 shapes (scripts/gemm_micro.py, profiles/r01_gemm_staging_variants.txt): light epilogues run best
+    // with one LDS buffer and 4 workgroups per CU, epilogues that move extra tensors with two buffers at 2 per CU;
+    // the split-K atomic epilogue keeps the register-staged kernel
+    if constexpr (EPI == MAED_EPI_STORE || EPI == MAED_EPI_STORE_F32 || EPI == MAED_EPI_TANH) return launch_glds<EPI, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    else if constexpr (EPI == MAED_EPI_ATOMIC_F32) return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    else return launch_glds<EPI, 2>(A, lda, B, ldb, M, N, K, e, splitk, s);
 }
 
 extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
