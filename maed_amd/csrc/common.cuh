@@ -8,6 +8,11 @@
 
 #define HEAD_DIM 64
 
+// dynamic LDS of a kernel (the host simulator of tests/hostsim substitutes its own definition)
+#ifndef MAED_DYN_SHARED
+#define MAED_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
 struct bf16 { unsigned short v; };
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

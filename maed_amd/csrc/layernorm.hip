@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd_i, const float* __restrict__ dres,
                                                      float* __restrict__ dx, T* __restrict__ dx_twin, float* __restrict__ dg,
                                                      float* __restrict__ db, int64_t rows, int C) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][4 waves][C]
+    MAED_DYN_SHARED(float, lds);  // [2][4 waves][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C / 4;
     float gg[LN_MAXV][4], pg[LN_MAXV][4], pb[LN_MAXV][4];

@@ -195,30 +195,88 @@ class GradBucketer:
             ops.bump_weight_epoch()
 
 
-class FusedAdam:
-    """torch.optim.Adam semantics (L2 weight decay) as one kernel over the arena; refreshes nothing
-    else: compute-dtype weight copies are rebuilt lazily by the modules (ops.WEIGHT_EPOCH)."""
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (L2 weight decay) as ONE kernel over the arena (maed_adam_step).
 
-    def __init__(self, arena, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucketer=None):
+    Drop-in for the optimizer `lib/utils/utils.py:127-132` builds: a torch.optim.Optimizer with one parameter group per
+    tensor in `model.named_parameters()` order (pass `model`), so `LambdaLR` (train.py:123-127) drives `param_groups[*]['lr']`
+    and `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format -- the 'optimizer' entry of the reference's
+    `epoch_N.pth.tar` checkpoints (trainer.py:330-368) resumes here and vice versa.  Compute-dtype weight copies are
+    rebuilt lazily by the modules after a step (ops.WEIGHT_EPOCH)."""
+
+    def __init__(self, arena, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucketer=None, model=None):
         self.arena, self.bucketer = arena, bucketer
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        order = list(range(len(arena.params)))
+        if model is not None:   # the reference's group order = named_parameters() order (the arena is in forward order)
+            order = [arena.index[id(p)] for _, p in model.named_parameters() if id(p) in arena.index]
+            assert len(order) == len(arena.params)
+        self._order = order
+        groups = [{"params": [arena.params[i]], "name": arena.names[i]} for i in order]
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self.exp_avg = torch.zeros_like(arena.flat)
         self.exp_avg_sq = torch.zeros_like(arena.flat)
         self.step_count = 0
 
+    # kept as attributes for callers that read them
+    lr = property(lambda self: self.param_groups[0]["lr"])
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
+
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
-    def step(self):
+    def _uniform(self):
+        g0 = self.param_groups[0]
+        key = (g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"])
+        return all((g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]) == key for g in self.param_groups)
+
+    @torch.no_grad()
+    def step(self, closure=None):
         world = 1
         if self.bucketer is not None:
             self.bucketer.finish()
             world = self.bucketer.world
         self.step_count += 1
-        ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, None, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.weight_decay, self.step_count, gscale=1.0 / world)
+        a = self.arena
+        if self._uniform():     # the reference's case: every group shares the schedule -> one launch over the whole arena
+            g = self.param_groups[0]
+            ops.adam_step(a.flat, a.grad, self.exp_avg, self.exp_avg_sq, None, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                          g["weight_decay"], self.step_count, gscale=1.0 / world)
+        else:                   # per-group hyper-parameters: one launch per tensor
+            for g, i in zip(self.param_groups, self._order):
+                o, n = a.offsets[i], a.params[i].numel()
+                ops.adam_step(a.flat[o:o + n], a.grad[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], None, g["lr"],
+                              g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count, gscale=1.0 / world)
         ops.bump_weight_epoch()
 
+    # ---- torch.optim.Adam-compatible (de)serialisation ------------------------------------------------------------
+    def _views(self, i):
+        o, p = self.arena.offsets[i], self.arena.params[i]
+        return self.exp_avg[o:o + p.numel()].view(p.shape), self.exp_avg_sq[o:o + p.numel()].view(p.shape)
+
     def state_dict(self):
-        return dict(step=self.step_count, lr=self.lr, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, names=self.arena.names,
-                    offsets=self.arena.offsets)
+        if self.step_count > 0:
+            for i in self._order:
+                m, v = self._views(i)
+                self.state[self.arena.params[i]] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        try:
+            return super().state_dict()
+        finally:
+            self.state.clear()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)     # validates group structure, casts state to the parameters' device/dtype
+        steps = []
+        for i in self._order:
+            st = self.state.get(self.arena.params[i])
+            if not st:
+                continue
+            m, v = self._views(i)
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            steps.append(int(float(st["step"])))
+        if steps:
+            assert len(set(steps)) == 1, "per-tensor step counts differ: not an Adam state this optimizer can represent"
+            self.step_count = steps[0]
+        self.state.clear()

@@ -65,10 +65,12 @@ struct Idx { unsigned x, y, z; };
 extern thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local BlockCtx* t_block;
 extern thread_local int t_tid;
+extern thread_local void* t_dyn_lds;
 
 template <typename K, typename... Args>
-void launch(K kernel, dim3 grid, dim3 block, size_t /*dyn_lds*/, hipStream_t, Args... args) {
+void launch(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, Args... args) {
     const int nthr = (int)(block.x * block.y * block.z);
+    std::vector<double> dyn((dyn_lds + 7) / 8 + 2);   // dynamic LDS of the workgroup (16-B aligned)
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
@@ -83,6 +85,7 @@ void launch(K kernel, dim3 grid, dim3 block, size_t /*dyn_lds*/, hipStream_t, Ar
                         t_gridDim = Idx{grid.x, grid.y, grid.z};
                         t_block = &ctx;
                         t_tid = t;
+                        t_dyn_lds = (void*)(((uintptr_t)dyn.data() + 15) & ~(uintptr_t)15);
                         kernel(args...);
                         ctx.waves[t / 64]->bar.arrive_and_drop();
                         ctx.bar.arrive_and_drop();
@@ -92,6 +95,7 @@ void launch(K kernel, dim3 grid, dim3 block, size_t /*dyn_lds*/, hipStream_t, Ar
 }
 }  // namespace hostsim
 
+#define MAED_DYN_SHARED(T, name) T* name = (T*)hostsim::t_dyn_lds
 #define threadIdx hostsim::t_threadIdx
 #define blockIdx hostsim::t_blockIdx
 #define blockDim hostsim::t_blockDim

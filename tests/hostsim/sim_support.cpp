@@ -5,6 +5,7 @@ namespace hostsim {
 thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local BlockCtx* t_block = nullptr;
 thread_local int t_tid = 0;
+thread_local void* t_dyn_lds = nullptr;
 }
 static thread_local char g_err[512] = "";
 void maed_set_error(const char* fmt, ...) {

@@ -1,0 +1,99 @@
+"""FusedAdam (maed_adam_step through the host simulator) as a drop-in for the optimizer the reference builds
+(lib/utils/utils.py:127-132: torch.optim.Adam, one group per tensor; train.py:123-127: LambdaLR; trainer.py:330-368:
+checkpoints carry optimizer.state_dict()).  Also LayerNorm forward/backward kernels against ATen on the simulator."""
+import copy
+
+import torch
+import torch.nn as nn
+
+from maed_amd.ddp import FusedAdam, ParamArena
+
+from _hostsim import patched
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.decoder = nn.Linear(7, 5)                       # arena order (forward-order key) differs from definition order
+        self.encoder = nn.ModuleDict({"blocks": nn.ModuleList([nn.Linear(6, 7), nn.Linear(7, 7)])})
+
+    def forward(self, x):
+        for b in self.encoder["blocks"]:
+            x = torch.tanh(b(x))
+        return self.decoder(x)
+
+
+def reference_optimizer(model, lr, wd):
+    return torch.optim.Adam(lr=lr, params=[{"params": p, "name": n} for n, p in model.named_parameters()], weight_decay=wd)
+
+
+def test_fused_adam_matches_torch_adam_with_lambda_lr_and_checkpoints():
+    torch.manual_seed(0)
+    ref_model = Tiny()
+    model = copy.deepcopy(ref_model)
+    x, y = torch.randn(16, 6), torch.randn(16, 5)
+    warm = lambda epoch: (epoch + 1) * 0.2 if epoch < 3 else 0.1 ** len([m for m in (4,) if m <= epoch])   # train.py:123
+    ref_opt = reference_optimizer(ref_model, 1e-2, 1e-3)
+    ref_sched = torch.optim.lr_scheduler.LambdaLR(ref_opt, lr_lambda=warm)
+    with patched():
+        arena = ParamArena(model)
+        opt = FusedAdam(arena, lr=1e-2, weight_decay=1e-3, model=model)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=warm)
+        assert [g["name"] for g in opt.param_groups] == [n for n, _ in model.named_parameters()]
+        for epoch in range(6):
+            for m, o in ((ref_model, ref_opt), (model, opt)):
+                o.zero_grad()
+                ((m(x) - y) ** 2).mean().backward()
+                o.step()
+            ref_sched.step()
+            sched.step()
+            assert abs(opt.param_groups[0]["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-12
+            if epoch == 2:   # checkpoint hand-over in both directions, mid-run
+                sd_ref, sd = ref_opt.state_dict(), opt.state_dict()
+                assert sd["param_groups"][0].keys() >= {"lr", "betas", "eps", "weight_decay", "params", "name"}
+                assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in sd_ref["param_groups"]]
+                for i in sd_ref["state"]:
+                    assert torch.allclose(sd["state"][i]["exp_avg"], sd_ref["state"][i]["exp_avg"], rtol=1e-5, atol=1e-8)
+                    assert float(sd["state"][i]["step"]) == float(sd_ref["state"][i]["step"])
+                ref_opt.load_state_dict(copy.deepcopy(sd))          # torch Adam resumes from OUR state
+                opt.load_state_dict(copy.deepcopy(sd_ref))          # we resume from torch Adam's state
+                assert opt.step_count == 3
+        for (n, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
+            assert torch.allclose(p, q, rtol=2e-5, atol=2e-7), n
+
+
+def test_fused_adam_per_group_hyperparameters_slow_path():
+    torch.manual_seed(1)
+    ref_model = Tiny()
+    model = copy.deepcopy(ref_model)
+    x, y = torch.randn(8, 6), torch.randn(8, 5)
+    ref_opt = reference_optimizer(ref_model, 1e-2, 0.0)
+    ref_opt.param_groups[1]["lr"] = 3e-3
+    with patched():
+        opt = FusedAdam(ParamArena(model), lr=1e-2, model=model)
+        opt.param_groups[1]["lr"] = 3e-3
+        for _ in range(3):
+            for m, o in ((ref_model, ref_opt), (model, opt)):
+                o.zero_grad()
+                ((m(x) - y) ** 2).mean().backward()
+                o.step()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-7), n
+
+
+def test_layernorm_kernels_on_simulator():
+    from maed_amd import ops
+    torch.manual_seed(2)
+    rows, C = 37, 128
+    x = torch.randn(rows, C, requires_grad=True)
+    g, b = torch.randn(C, requires_grad=True), torch.randn(C, requires_grad=True)
+    dres = torch.randn(rows, C)
+    y_ref = torch.nn.functional.layer_norm(x, (C,), g, b, 1e-6)
+    dy = torch.randn(rows, C)
+    y_ref.backward(dy)
+    with patched():
+        y, mean, rstd = ops.layernorm_fwd(x.detach(), g.detach(), b.detach(), torch.float32)
+        dx, dg, db = ops.layernorm_bwd(dy, x.detach(), g.detach(), mean, rstd, dres=dres)
+    assert torch.allclose(y, y_ref.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(dx, x.grad + dres, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(dg, g.grad, rtol=1e-4, atol=1e-4) and torch.allclose(db, b.grad, rtol=1e-4, atol=1e-4)
