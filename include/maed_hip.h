@@ -269,7 +269,11 @@ typedef struct {
     float* gw;          /* fp32 gradient of w, same layout (backward; NULL in forward)       */
     const void* gout;   /* grad w.r.t. the standardised weight, (O, kh, kw, I); NULL = skip  */
     int64_t dst_off;    /* element offset of this convolution inside `out`                   */
+    int64_t dst_t_off;  /* >= 0: forward also writes the transposed (kh*kw*I, O) image at this offset of `out`
+                         * (B operand of the input-gradient GEMM when a 1x1 convolution runs on maed_gemm_nt); -1 = none */
     int32_t O, I, KHW, fstart;
+    int32_t gout_f32;   /* backward: gout is fp32 (a maed_gemm_tn_wgrad result) instead of the compute dtype */
+    int32_t pad_;
 } maed_ws_conv;
 int maed_weight_std_fwd(const void* conv_table, int n_convs, int n_filters, void* out, int dtype, float* stats, float eps, void* stream);
 int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int dtype, const float* stats, float eps, void* stream);

@@ -17,7 +17,9 @@ struct WsConv {           // one per convolution (host builds the table; <= 64 e
     float* gw;            // fp32 gradient of w (same layout), += target            (backward only)
     const void* gout;     // gradient w.r.t. the standardised weight, (O, kh, kw, I) (backward only)
     int64_t dst_off;      // element offset of this conv in the standardised-weight arena, (O, kh, kw, I)
+    int64_t dst_t_off;    // >= 0: also write the TRANSPOSED (kh*kw*I, O) image there (operand of the input-gradient GEMM of a 1x1 conv)
     int32_t O, I, KHW, fstart;  // fstart = index of this conv's first filter in the global filter numbering
+    int32_t gout_f32, pad_;     // gout is fp32 (written by maed_gemm_tn_wgrad) instead of the compute dtype
 };
 #define WS_MAX_CONVS 64
 
@@ -44,9 +46,12 @@ __global__ __launch_bounds__(256) void ws_fwd_kernel(const WsConv* __restrict__ 
     const float inv = 1.f / (sqrtf(wave_sum(q) / (float)K) + eps);   // biased std, eps added to the std (resnetv2.py:87-88)
     if (lane == 0) { stats[2 * fi] = mean; stats[2 * fi + 1] = inv; }
     T* dst = out + d.dst_off + (int64_t)o * K;
+    T* dst_t = d.dst_t_off >= 0 ? out + d.dst_t_off + o : nullptr;
     for (int i = lane; i < K; i += 64) {           // i = ci*KHW + r in the source; destination is (r, ci)
         const int ci = i / d.KHW, r = i % d.KHW;
-        stf(dst + (int64_t)r * d.I + ci, (src[i] - mean) * inv);
+        const float v = (src[i] - mean) * inv;
+        stf(dst + (int64_t)r * d.I + ci, v);
+        if (dst_t) stf(dst_t + ((int64_t)r * d.I + ci) * d.O, v);
     }
 }
 
@@ -61,11 +66,13 @@ __global__ __launch_bounds__(256) void ws_bwd_kernel(const WsConv* __restrict__ 
     const int K = d.I * d.KHW, o = fi - d.fstart;
     const float* src = d.w + (int64_t)o * K;
     const T* g = (const T*)d.gout + (int64_t)o * K;
+    const float* g32 = (const float*)d.gout + (int64_t)o * K;
+    const bool f32 = d.gout_f32 != 0;               // wave-uniform
     const float mean = stats[2 * fi], inv = stats[2 * fi + 1];
     float sg = 0.f, sgw = 0.f;
     for (int i = lane; i < K; i += 64) {
         const int ci = i / d.KHW, r = i % d.KHW;
-        const float gi = ldf(g + (int64_t)r * d.I + ci);
+        const float gi = f32 ? g32[(int64_t)r * d.I + ci] : ldf(g + (int64_t)r * d.I + ci);
         sg += gi; sgw += gi * (src[i] - mean);
     }
     sg = wave_sum(sg); sgw = wave_sum(sgw);
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256) void ws_bwd_kernel(const WsConv* __restrict__ 
     float* dst = d.gw + (int64_t)o * K;
     for (int i = lane; i < K; i += 64) {
         const int ci = i / d.KHW, r = i % d.KHW;
-        const float gi = ldf(g + (int64_t)r * d.I + ci);
+        const float gi = f32 ? g32[(int64_t)r * d.I + ci] : ldf(g + (int64_t)r * d.I + ci);
         dst[i] += inv * (gi - gm) - (src[i] - mean) * c2;
     }
 }
@@ -219,23 +226,33 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     for (int j = 0; j < 8; ++j) { const int g = (cb * 8 + j) / cpg; mu[j] = lmu[g]; rs[j] = lrs[g]; sa[j] = 0.f; sb[j] = 0.f; }
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
     const int64_t base = ((int64_t)n * HW) * C + cb * 8;
-    for (int r = r0 + rsub; r < r1; r += rstep) {
-        float v[8], d[8];
-        gn_load8(x + base + (int64_t)r * C, v); gn_load8(dy + base + (int64_t)r * C, d);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (v[j] - mu[j]) * rs[j];   // xhat
-        if (RELU) {
-            if (YMASK) { float o[8]; gn_load8(y + base + (int64_t)r * C, o);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = fmaf(v[j], ga[j], be[j]) > 0.f ? d[j] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sa[j] += d[j]; sb[j] = fmaf(d[j], v[j], sb[j]); }
+    // four rows per trip: 8-12 independent 16-B loads in flight per thread (this pass runs on ~3 workgroups per CU to keep
+    // the closing atomics few, so the memory-level parallelism has to come from inside the thread)
+#define GN_RED_ROW(v_, d_, o_)                                                                                  \
+    {                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) v_[j] = (v_[j] - mu[j]) * rs[j];   /* xhat */            \
+        if (RELU) {                                                                                             \
+            if (YMASK) { _Pragma("unroll") for (int j = 0; j < 8; ++j) d_[j] = o_[j] > 0.f ? d_[j] : 0.f; }     \
+            else { _Pragma("unroll") for (int j = 0; j < 8; ++j) d_[j] = fmaf(v_[j], ga[j], be[j]) > 0.f ? d_[j] : 0.f; } \
+        }                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) { sa[j] += d_[j]; sb[j] = fmaf(d_[j], v_[j], sb[j]); }    \
     }
+    int r = r0 + rsub;
+    for (; r + 3 * rstep < r1; r += 4 * rstep) {
+        float v0[8], v1[8], v2[8], v3[8], d0[8], d1[8], d2[8], d3[8], o0[8], o1[8], o2[8], o3[8];
+        const int64_t a0 = base + (int64_t)r * C, a1 = a0 + (int64_t)rstep * C, a2 = a1 + (int64_t)rstep * C, a3 = a2 + (int64_t)rstep * C;
+        gn_load8(x + a0, v0); gn_load8(x + a1, v1); gn_load8(x + a2, v2); gn_load8(x + a3, v3);
+        gn_load8(dy + a0, d0); gn_load8(dy + a1, d1); gn_load8(dy + a2, d2); gn_load8(dy + a3, d3);
+        if (RELU && YMASK) { gn_load8(y + a0, o0); gn_load8(y + a1, o1); gn_load8(y + a2, o2); gn_load8(y + a3, o3); }
+        GN_RED_ROW(v0, d0, o0) GN_RED_ROW(v1, d1, o1) GN_RED_ROW(v2, d2, o2) GN_RED_ROW(v3, d3, o3)
+    }
+    for (; r < r1; r += rstep) {
+        float v[8], d[8], o[8];
+        gn_load8(x + base + (int64_t)r * C, v); gn_load8(dy + base + (int64_t)r * C, d);
+        if (RELU && YMASK) gn_load8(y + base + (int64_t)r * C, o);
+        GN_RED_ROW(v, d, o)
+    }
+#undef GN_RED_ROW
     float* mine = lpart + ((size_t)rsub * C + cb * 8) * 2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { mine[2 * j] = sa[j]; mine[2 * j + 1] = sb[j]; }

@@ -10,6 +10,7 @@
 // M-tiles; split-M workgroups accumulate with coalesced fp32 atomics straight into the gradient arena.  The
 // workgroups of K-tile 0 also produce the bias gradient (column sums of Y).
 #include "common.cuh"
+#include <stdlib.h>
 
 #define TN_BM 64      // reduction rows per LDS tile
 #define TN_LD 72      // LDS row stride (elements): 144 B
@@ -130,7 +131,11 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     MAED_CHECK_ARG(is_aligned(Y, 16) && is_aligned(X, 16), MAED_ERR_ALIGN, "gemm_tn_wgrad: Y/X must be 16-B aligned");
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     const int nmt = (int)((M + TN_BM - 1) / TN_BM);
-    int splits = (1024 + tn * tk - 1) / (tn * tk);           // fill the chip: ~1024 workgroups
+    static int target = 0;                                   // MAED_TN_TARGET_WGS: measurement knob for the split heuristic
+    if (!target) { const char* ev = getenv("MAED_TN_TARGET_WGS"); target = ev ? atoi(ev) : 384; if (target < 64) target = 384; }
+    // ~384 workgroups (1.5 per CU): measured optimum at the STE and backbone shapes (profiles/r01_tn_split_sweep.txt) -- every
+    // extra split adds a 128x128 tile of fp32 atomics, and the kernel runs at two workgroups per CU anyway
+    int splits = (target + tn * tk - 1) / (tn * tk);
     if (splits > (nmt + 3) / 4) splits = (nmt + 3) / 4;      // at least 4 M-tiles per workgroup
     if (splits < 1) splits = 1;
     const int per = (nmt + splits - 1) / splits;

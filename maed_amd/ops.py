@@ -343,29 +343,43 @@ class STEBlockFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 import numpy as _np
 
-_WS_DTYPE = _np.dtype([("w", "u8"), ("gw", "u8"), ("gout", "u8"), ("dst_off", "i8"), ("O", "i4"), ("I", "i4"), ("KHW", "i4"), ("fstart", "i4")])
+_WS_DTYPE = _np.dtype([("w", "u8"), ("gw", "u8"), ("gout", "u8"), ("dst_off", "i8"), ("dst_t_off", "i8"), ("O", "i4"), ("I", "i4"), ("KHW", "i4"),
+                       ("fstart", "i4"), ("gout_f32", "i4"), ("pad_", "i4")])
 
 
-def _ws_table(weights, grads=None, gouts=None):
+def _ws_table(weights, grads=None, gouts=None, transposed=None, gout_f32=None):
+    """transposed: set of conv indices that also get a transposed image (offsets appended after the regular arena)"""
     tab = _np.zeros(len(weights), dtype=_WS_DTYPE)
     off = fstart = 0
     for i, w in enumerate(weights):
         O, I, kh, kw = w.shape
-        tab[i] = (w.data_ptr(), 0 if grads is None else grads[i], 0 if gouts is None else gouts[i], off, O, I, kh * kw, fstart)
+        tab[i] = (w.data_ptr(), 0 if grads is None else grads[i], 0 if gouts is None else gouts[i], off, -1, O, I, kh * kw, fstart,
+                  0 if gout_f32 is None else int(gout_f32[i]), 0)
         off += w.numel()
         fstart += O
-    return tab, off, fstart
+    total = off
+    t_offs = {}
+    for i in sorted(transposed or ()):
+        tab[i]["dst_t_off"] = total
+        t_offs[i] = total
+        total += weights[i].numel()
+    return tab, off, fstart, total, t_offs
 
 
 class WeightStdFn(torch.autograd.Function):
     """All StdConv2dSame weights of a backbone standardised in ONE launch (forward) / ONE launch (backward).
     Outputs are channels_last-strided (O,I,kh,kw) views of one arena in the compute dtype.  Like STEBlockFn
-    the backward accumulates straight into p.grad and reports through owner.grads_ready."""
+    the backward accumulates straight into p.grad and reports through owner.grads_ready.
+
+    Convolutions listed in owner._gemm_convs (1x1, stride 1: they run on maed_gemm_nt / maed_gemm_tn_wgrad through
+    Conv1x1Fn) additionally get the transposed (I, O) image (owner._w_std_t[i]) and hand their weight gradient over as
+    an fp32 slice of owner._dw_arena instead of through autograd."""
 
     @staticmethod
     def forward(ctx, owner, dtype, eps, *weights):
         weights = [_c(w) for w in weights]
-        tab, total, nf = _ws_table(weights)
+        gemm = set(getattr(owner, "_gemm_convs", ()) or ()) if dtype != torch.float32 else set()
+        tab, _, nf, total, t_offs = _ws_table(weights, transposed=gemm)
         dev = weights[0].device
         out = torch.empty(total, dtype=dtype, device=dev)
         stats = torch.empty(nf * 2, dtype=torch.float32, device=dev)
@@ -379,24 +393,39 @@ class WeightStdFn(torch.autograd.Function):
             O, I, kh, kw = w.shape
             views.append(out[off:off + w.numel()].view(O, kh, kw, I).permute(0, 3, 1, 2))
             off += w.numel()
+        owner._w_std_t = {i: out[o:o + weights[i].numel()].view(weights[i].shape[1], weights[i].shape[0]) for i, o in t_offs.items()}
+        # fp32 weight-gradient arena of the GEMM convolutions (maed_gemm_tn_wgrad accumulates with atomics: zero it once per step)
+        owner._dw_arena, owner._dw_slices = None, {}
+        if gemm and any(ctx.needs_input_grad[3:]):   # (grad mode is off inside Function.forward: ask autograd, not torch.is_grad_enabled)
+            n = sum(weights[i].numel() for i in gemm)
+            owner._dw_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+            o = 0
+            for i in sorted(gemm):
+                owner._dw_slices[i] = owner._dw_arena[o:o + weights[i].numel()].view(weights[i].shape[0], weights[i].shape[1])
+                o += weights[i].numel()
+        ctx.dw_slices = owner._dw_slices
         return tuple(views)
 
     @staticmethod
     def backward(ctx, *gouts):
         weights, owner = ctx.weights, ctx.owner
         params = owner.conv_weights()
-        keep, gptr, optr = [], [], []
-        for w, p, g in zip(weights, params, gouts):
-            if g is None:
-                gptr.append(0); optr.append(0)
+        keep, gptr, optr, f32 = [], [], [], []
+        for i, (w, p, g) in enumerate(zip(weights, params, gouts)):
+            direct = ctx.dw_slices.get(i)
+            if g is None and direct is None:
+                gptr.append(0); optr.append(0); f32.append(0)
+                continue
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            if direct is not None:      # fp32 dW written by Conv1x1Fn.backward (autograd carried nothing for this conv)
+                gptr.append(p.grad.data_ptr()); optr.append(direct.data_ptr()); f32.append(1)
                 continue
             g = g.to(ctx.dtype)
             g = g.contiguous(memory_format=torch.channels_last) if w.shape[2] * w.shape[3] > 1 else g.contiguous()
             keep.append(g)
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            gptr.append(p.grad.data_ptr()); optr.append(g.data_ptr())
-        tab, _, nf = _ws_table(weights, gptr, optr)
+            gptr.append(p.grad.data_ptr()); optr.append(g.data_ptr()); f32.append(0)
+        tab, _, nf, _, _ = _ws_table(weights, gptr, optr, gout_f32=f32)
         tab_dev = torch.from_numpy(tab.view(_np.uint8)).to(weights[0].device)
         check(L.lib().maed_weight_std_bwd(_p(tab_dev), len(weights), nf, dt_code(ctx.dtype), _p(ctx.stats), ctx.eps, _stream()), "weight_std_bwd")
         owner._pending_backwards -= 1
@@ -452,42 +481,37 @@ class GroupNormFn(torch.autograd.Function):
 
 
 class Conv1x1Fn(torch.autograd.Function):
-    """EXPERIMENT, not on the product path (measured slower than MIOpen at the backbone's short-K shapes: backbone
-    fwd+bwd 24.8 ms vs 22.6 ms at cfg3; kept with its parity test as the starting point for a fused conv+GroupNorm-stats
-    epilogue).  1x1 convolution on a channels_last bf16 tensor as a GEMM on libmaed_hip (37 of the 53 convolutions):
-    y[(n,h,w), o] = sum_i x[(n,h,w), i] w[o, i].  Forward = maed_gemm_nt, input gradient = maed_gemm_nt on the
-    transposed weight, weight gradient = maed_gemm_tn_wgrad (no transposed activation copies, no MIOpen workspace
-    zero/cast passes).  stride 2 (the two downsample convolutions) = spatial subsampling before the GEMM."""
+    """1x1 stride-1 convolution on a channels_last bf16 tensor as GEMMs on libmaed_hip (33 of the backbone's 53
+    convolutions): y[(n,h,w), o] = sum_i x[(n,h,w), i] w[o, i].  Forward = maed_gemm_nt on the standardised weight (O, I),
+    input gradient = maed_gemm_nt on its transposed image (I, O) (both written by the batched weight-standardisation
+    kernel), weight gradient = maed_gemm_tn_wgrad accumulating in fp32 straight into the slice the weight-standardisation
+    backward reads -- no output zero-fill, no fp32-workspace cast passes, no transposed activation copies.
+    Measured against MIOpen's asm implicit-GEMM solvers at cfg3 (profiles/r01_conv1x1_micro.txt): forward 1.35 vs
+    2.31 ms, input gradient 1.26 vs 1.80 ms, weight gradient 2.21 vs 2.67 ms per step."""
 
     @staticmethod
-    def forward(ctx, x, w, stride):
-        N, I, H0, W0 = x.shape
-        if stride > 1:
-            x = x[:, :, ::stride, ::stride]
+    def forward(ctx, x, w, wt, dw):
+        """x (N,I,H,W) channels_last; w (O,I,1,1) standardised weight (an output of WeightStdFn: the autograd edge orders
+        its backward after ours); wt (I,O) transposed image; dw (O,I) fp32 accumulator (None when no gradient is wanted)"""
+        N, I, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)
-        _, _, H, W = x.shape
         O = w.shape[0]
-        A = x.permute(0, 2, 3, 1).reshape(N * H * W, I)
         w2 = w.reshape(O, I)
         w2 = w2 if w2.is_contiguous() else w2.contiguous()
+        A = x.permute(0, 2, 3, 1).reshape(N * H * W, I)
         y = gemm_nt(A, w2, L.EPI_STORE)
-        ctx.save_for_backward(A, w2)
-        ctx.geom = (N, I, H0, W0, H, W, O, stride)
+        ctx.save_for_backward(A, wt)
+        ctx.dw, ctx.geom = dw, (N, I, H, W, O)
         return y.view(N, H, W, O).permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dy):
-        A, w2 = ctx.saved_tensors
-        N, I, H0, W0, H, W, O, stride = ctx.geom
+        A, wt = ctx.saved_tensors
+        N, I, H, W, O = ctx.geom
         Y = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(N * H * W, O)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wt, _ = transpose_cast(w2, w2.dtype, pad_to=1)            # (I, O)
-            dA = gemm_nt(Y, wt, L.EPI_STORE).view(N, H, W, I).permute(0, 3, 1, 2)
-            if stride > 1:
-                dx = torch.zeros(N, I, H0, W0, dtype=dA.dtype, device=dA.device).contiguous(memory_format=torch.channels_last)
-                dx[:, :, ::stride, ::stride] = dA
-            else:
-                dx = dA
-        dW = gemm_tn_wgrad(Y, A).view(O, I, 1, 1)
-        return dx, dW, None
+        dx = gemm_nt(Y, wt, L.EPI_STORE).view(N, H, W, I).permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
+        if ctx.dw is not None:
+            gemm_tn_wgrad(Y, A, dW=ctx.dw)
+        return dx, None, None, None
+
+

@@ -13,6 +13,7 @@ projection GEMM as a (F*H*W, C) row-major matrix without a transpose copy.
 Module / parameter names match the reference so its checkpoints load unchanged.
 """
 import math
+import os
 from collections import OrderedDict
 from functools import partial
 
@@ -45,16 +46,20 @@ class StdConv2dSame(nn.Conv2d):
         return (self.weight - mean) / (std + self.eps)
 
     _w_std = None  # set by ResNetV2 for the duration of a forward: weight standardised by the batched HIP kernel
+    _w_t = None    # 1x1 stride-1 convolutions in bf16 mode: transposed standardised weight (I, O) -> the GEMM path
+    _dw = None     # ... and the fp32 slice their weight gradient accumulates into
 
     def forward(self, x):
         w = self._w_std
+        if w is not None and self._w_t is not None:
+            # 1x1, stride 1, bf16: three GEMMs on libmaed_hip instead of MIOpen's implicit-GEMM solvers (which zero-fill the
+            # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
+            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw)
         if w is None:  # stand-alone use / CPU: per-conv ATen composition
             w = self.get_weight().to(x.dtype)
             if x.is_cuda:
                 w = w.contiguous(memory_format=torch.channels_last)
         k, s = self.kernel_size[0], self.stride[0]
-        # (1x1 convolutions as GEMMs on libmaed_hip -- ops.Conv1x1Fn -- were measured 2.2 ms/step SLOWER than MIOpen's
-        #  igemm kernels at these short-K shapes, so every convolution stays on MIOpen: DESIGN.md section 5)
         ih, iw = x.shape[-2:]
         ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
         pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
@@ -170,6 +175,12 @@ class ResNetV2(nn.Module):
         self._norms = [m for m in self.modules() if isinstance(m, GroupNormAct)]
         for m in self._norms:
             m._direct_grad = True
+        # 1x1 stride-1 convolutions with GEMM-friendly channel counts run on libmaed_hip in bf16 mode (ops.Conv1x1Fn)
+        self._gemm_convs = [i for i, c in enumerate(self._convs) if c.kernel_size == (1, 1) and c.stride == (1, 1)
+                            and c.in_channels % 64 == 0 and c.out_channels % 64 == 0]
+        if os.environ.get("MAED_GEMM_CONVS", "1") == "0":      # measurement knob: every convolution on MIOpen
+            self._gemm_convs = []
+        self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
         self._pending_backwards = 0
         self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
 
@@ -187,12 +198,12 @@ class ResNetV2(nn.Module):
         x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
         ws = ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
         try:
-            for c, w in zip(self._convs, ws):
-                c._w_std = w
+            for i, (c, w) in enumerate(zip(self._convs, ws)):
+                c._w_std, c._w_t, c._dw = w, self._w_std_t.get(i), self._dw_slices.get(i)
             return self.stages(self.stem(x))
         finally:
             for c in self._convs:
-                c._w_std = None
+                c._w_std = c._w_t = c._dw = None
 
     def forward(self, x, seqlen=8):
         return self.forward_features(x)

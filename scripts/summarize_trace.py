@@ -29,3 +29,12 @@ with open(dst, "w", newline="") as fh:
         short = short[:200]
         w.writerow([short, round(c / nsteps, 2), round(d / c / 1e3, 2), round(d / 1e6 / nsteps, 4), round(100.0 * d / tot, 2)])
 print(f"steady state: {nsteps} steps, wall {(t1 - t0) / 1e6 / nsteps:.3f} ms/step, kernel time {tot / 1e6 / nsteps:.3f} ms/step -> {dst}")
+# ordered kernel sequence of the LAST step (name truncated, duration us, gap to the previous kernel us): where the launches go
+seq = [r for r in rows if marks[-2] < int(r["Start_Timestamp"]) <= marks[-1]]
+with open(dst.replace(".csv", "_last_step_sequence.txt"), "w") as fh:
+    prev_end = None
+    for r in seq:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        name = re.sub(r"^void ", "", r["Kernel_Name"])[:70]
+        fh.write(f"{(e - s) / 1e3:9.2f} {((s - prev_end) / 1e3 if prev_end else 0.0):8.2f}  {name}\n")
+        prev_end = e

@@ -7,6 +7,25 @@ from maed_amd import ops
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 Fr = 128
 # (H, I, O, count in the backbone)
+M_STE = 128 * 197
+ste = [("qkv", 1536, 512), ("fc1", 2048, 512), ("fc2", 512, 2048), ("proj", 512, 512)]
+if os.environ.get("WGRAD_STE", "0") == "1":
+    tot = 0.0
+    for name, N, K in ste:
+        Y = torch.randn(M_STE, N, device="cuda").bfloat16(); X = torch.randn(M_STE, K, device="cuda").bfloat16()
+        dW = torch.zeros(N, K, device="cuda")
+        for _ in range(3):
+            ops.gemm_tn_wgrad(Y, X, dW=dW)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.gemm_tn_wgrad(Y, X, dW=dW)
+        e1.record(); torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / iters
+        tot += us
+        print(f"STE wgrad {name:5s} N={N} K={K}: {us:7.1f} us  {2.0 * M_STE * N * K / us / 1e6:6.1f} TF", flush=True)
+    print(f"STE wgrad per block: {tot:.1f} us")
 shapes = [(56, 64, 64, 1), (56, 64, 256, 4), (56, 256, 64, 2), (56, 256, 128, 1), (28, 128, 512, 4), (28, 512, 128, 3), (28, 512, 256, 1),
           (14, 256, 1024, 9), (14, 1024, 256, 8)]
 tot_m = tot_g = 0.0

@@ -347,3 +347,49 @@ def test_cfg5_long_clip_train_step():
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and np.isfinite(gnorm) and gnorm > 0, (losses, gnorm)
     report("cfg5 (T=64, 256x256, depth 12, dim 768) train-step loss finite, grad norm > 0", torch.tensor([float(np.isfinite(losses).all())]), torch.ones(1), rtol=0, atol=0)
+
+
+def test_backbone_gemm_convolutions_match_miopen_path():
+    """the 1x1 stride-1 convolutions on libmaed_hip GEMMs (ops.Conv1x1Fn; weight gradients handed to the batched
+    weight-standardisation backward as fp32) against the same bf16 backbone with every convolution on MIOpen, and both
+    against the fp64 CPU oracle: features and ALL parameter gradients, two forwards accumulated into one backward
+    (trainer.py:188-202).  GroupNorm makes backbone gradients ill-conditioned in bf16 (two correct bf16 implementations
+    differ by tens of percent in L2), so the criterion is per-parameter DIRECTION against the oracle: the GEMM path must
+    be as close to fp64 as the MIOpen path is (a mis-routed weight gradient shows up as cosine ~ 0 on that tensor)."""
+    from maed_amd.resnetv2 import ResNetV2
+    torch.manual_seed(3)
+    net = ResNetV2(layers=(1, 2, 1), channels=(256, 512, 1024), compute_dtype=torch.bfloat16).to(DEV)
+    assert len(net._gemm_convs) == 9
+    xa, xb = rnd(3, 3, 64, 64, seed=31), rnd(2, 3, 64, 64, seed=32)
+    pd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    ra, rb = R.resnetv2_features(xa.double(), pd, "", layers=(1, 2, 1)), R.resnetv2_features(xb.double(), pd, "", layers=(1, 2, 1))
+    g = torch.Generator().manual_seed(33)
+    cot = (torch.randn(ra.shape, generator=g), torch.randn(rb.shape, generator=g))
+    ((ra * cot[0].double()).sum() + (rb * cot[1].double()).sum()).backward()
+    results = []
+    for use_gemm in (True, False):
+        saved = net._gemm_convs
+        if not use_gemm:
+            net._gemm_convs = []
+        for p in net.parameters():
+            p.grad = None
+        ya, yb = net(xa.to(DEV)), net(xb.to(DEV))
+        ((ya.float() * cot[0].to(DEV)).sum() + (yb.float() * cot[1].to(DEV)).sum()).backward()
+        results.append((ya.detach().float().cpu(), {n: p.grad.detach().double().cpu() for n, p in net.named_parameters()}))
+        net._gemm_convs = saved
+    (y1, g1), (y0, g0) = results
+    report("backbone features, GEMM 1x1 convs vs fp64 oracle (bf16)", y1, ra.detach().float(), rtol=5e-2, atol=5e-2 * ra.abs().max().item())
+    report("backbone features, all-MIOpen vs fp64 oracle (bf16)", y0, ra.detach().float(), rtol=5e-2, atol=5e-2 * ra.abs().max().item())
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+    worst_gemm, worst_mio, worst_name = 1.0, 1.0, ""
+    for n in g0:
+        ref = pd[n].grad
+        c1, c0 = cos(g1[n], ref), cos(g0[n], ref)
+        if c1 < worst_gemm:
+            worst_gemm, worst_name = c1, n
+        worst_mio = min(worst_mio, c0)
+        assert torch.isfinite(g1[n]).all(), n
+        assert c1 > c0 - 0.1, f"{n}: cosine to the fp64 gradient {c1:.3f} (GEMM path) vs {c0:.3f} (MIOpen path)"
+    allc = lambda gg: cos(torch.cat([gg[n].flatten() for n in g0]), torch.cat([pd[n].grad.flatten() for n in g0]))
+    report(f"1 - cosine(backbone gradient, fp64 oracle): GEMM path (worst tensor {worst_name}: {worst_gemm:.3f})", torch.tensor([1 - allc(g1)]), torch.zeros(1), rtol=0, atol=0.1)
+    report(f"1 - cosine(backbone gradient, fp64 oracle): all-MIOpen path (worst tensor: {worst_mio:.3f})", torch.tensor([1 - allc(g0)]), torch.zeros(1), rtol=0, atol=0.1)
