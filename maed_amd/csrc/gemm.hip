@@ -79,6 +79,50 @@ __device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int
     }
 }
 
+// eight consecutive columns c0..c0+7 of one row (c0 % 8 == 0): 16/32-byte accesses (the LDS-shuffled epilogue of the
+// direct-to-LDS kernels: 8 lanes cover a 64-column row segment = one or two full cache lines per row)
+template <int EPI, typename T>
+__device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int64_t c0, int64_t N, const float (&acc)[8], bool vec_ok) {
+    if (!(vec_ok && c0 + 8 <= N)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (c0 + j < N) epilogue_store<EPI, T>(e, r, c0 + j, acc[j]);
+        return;
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = acc[j];
+    if constexpr (EPI != MAED_EPI_MUL_DGELU) {
+        if (e.bias) { float b[8]; ld8(e.bias + c0, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b[j]; }
+    }
+    if constexpr (EPI == MAED_EPI_STORE) {
+        st8((T*)e.out + r * e.ldo + c0, v);
+    } else if constexpr (EPI == MAED_EPI_GELU) {
+        st8((T*)e.out2 + r * e.ldo + c0, v);
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = gelu_fwd<T>(round_to<T>(v[j]));   // activation of the STORED (rounded) pre-activation
+        st8((T*)e.out + r * e.ldo + c0, a);
+    } else if constexpr (EPI == MAED_EPI_RESID_F32) {
+        float x[8]; ld8((const float*)e.aux + r * e.ldaux + c0, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += v[j];
+        st8((float*)e.out + r * e.ldo + c0, x);
+    } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
+        float x[8]; ld8((const T*)e.aux + r * e.ldaux + c0, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = v[j] * gelu_bwd<T>(x[j]);
+        st8((T*)e.out + r * e.ldo + c0, x);
+    } else if constexpr (EPI == MAED_EPI_STORE_F32) {
+        st8((float*)e.out + r * e.ldo + c0, v);
+    } else if constexpr (EPI == MAED_EPI_TANH) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
+        st8((T*)e.out + r * e.ldo + c0, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // VALU kernel (any T; used for f32 and as the cross-check for the MFMA kernel)
 // ------------------------------------------------------------------------------------------------
@@ -270,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* _
 //   NBUF == 1: 32 KB LDS, <=128 VGPRs -> 4 workgroups per CU, latency hidden by the other workgroups
 //   NBUF == 2: 64 KB LDS, tile t+1 lands while tile t is multiplied, one barrier per K tile
 // ------------------------------------------------------------------------------------------------
+#define GL_ST 68   // fp32 row stride of the epilogue staging area: 272 B -> conflict-free ds_write_b128 per 16-lane group
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
@@ -278,7 +323,10 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
                                                                                      const bf16* __restrict__ B, int64_t ldb, int64_t M,
                                                                                      int64_t N, int64_t K, int tiles_n,
                                                                                      int ktiles_per_split, EpiArgs e) {
-    __shared__ __attribute__((aligned(1024))) unsigned short lds[NBUF][2][GM_BM * GM_BK];
+    // operand tiles [NBUF][A|B][128*64] bf16; re-used by the epilogue as 4 per-wave fp32 staging areas of 32 rows x 68 floats
+    constexpr int kTileElems = NBUF * 2 * GM_BM * GM_BK, kStageElems = 4 * 32 * GL_ST * 2;     // in 2-byte units
+    __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kTileElems > kStageElems ? kTileElems : kStageElems];
+    unsigned short (*lds)[2][GM_BM * GM_BK] = reinterpret_cast<unsigned short (*)[2][GM_BM * GM_BK]>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -359,11 +407,38 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
             }
         }
     }
-    const bool vec_ok = (e.ldo % 4 == 0) && (e.ldaux % 4 == 0);
-    GM_EPILOGUE(acc00, 0, 0);
-    GM_EPILOGUE(acc01, 0, 1);
-    GM_EPILOGUE(acc10, 1, 0);
-    GM_EPILOGUE(acc11, 1, 1);
+    if constexpr (!TR) {
+        const bool vec_ok = (e.ldo % 4 == 0) && (e.ldaux % 4 == 0);
+        GM_EPILOGUE(acc00, 0, 0);
+        GM_EPILOGUE(acc01, 0, 1);
+        GM_EPILOGUE(acc10, 1, 0);
+        GM_EPILOGUE(acc11, 1, 1);
+    } else {
+        // LDS-shuffled epilogue: a lane owns one output row in the accumulators (4 columns per register group), which would
+        // mean 8-byte global accesses scattered over 32 rows per instruction.  Each wave parks its 32 x 64 half-tile in LDS
+        // (fp32) and re-reads it so that 8 lanes cover one row's 64 columns: 16/32-byte accesses, full lines per row, for the
+        // stores AND for the auxiliary reads of the residual / GELU' epilogues.
+        const bool vec_ok = (e.ldo % 8 == 0) && (e.ldaux % 8 == 0);
+        float* stg = reinterpret_cast<float*>(lds_raw) + wave * 32 * GL_ST;
+        const int rr = lane >> 3, cc = (lane & 7) * 8;
+#define GL_SHUFFLE_HALF(accA_, accB_, i_)                                                                              \
+        __syncthreads();                                                                                               \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+            *reinterpret_cast<float4*>(stg + l31 * GL_ST + 8 * g + 4 * hi) = make_float4(accA_[4 * g], accA_[4 * g + 1], accA_[4 * g + 2], accA_[4 * g + 3]);      \
+            *reinterpret_cast<float4*>(stg + l31 * GL_ST + 32 + 8 * g + 4 * hi) = make_float4(accB_[4 * g], accB_[4 * g + 1], accB_[4 * g + 2], accB_[4 * g + 3]); \
+        }                                                                                                              \
+        __syncthreads();                                                                                               \
+        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                             \
+            const int lr = ps * 8 + rr;                                                                                \
+            const int64_t row = m0 + wr * 64 + (i_) * 32 + lr, c0 = n0 + wc * 64 + cc;                                 \
+            float v8[8];                                                                                               \
+            ld8(stg + lr * GL_ST + cc, v8);                                                                            \
+            if (row < M && c0 < N) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);                              \
+        }
+        GL_SHUFFLE_HALF(acc00, acc01, 0)
+        GL_SHUFFLE_HALF(acc10, acc11, 1)
+#undef GL_SHUFFLE_HALF
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
