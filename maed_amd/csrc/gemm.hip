@@ -499,12 +499,12 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
     }
     if (!mfma_ok) return launch_valu<EPI, bf16>(A, lda, B, ldb, M, N, K, e, splitk, s);
-    // measured at the cfg3 shapes (scripts/gemm_micro.py, profiles/r01_gemm_staging_variants.txt): light epilogues run best
-    // with one LDS buffer and 4 workgroups per CU, epilogues that move extra tensors with two buffers at 2 per CU;
-    // the split-K atomic epilogue keeps the register-staged kernel
-    if constexpr (EPI == MAED_EPI_STORE || EPI == MAED_EPI_STORE_F32 || EPI == MAED_EPI_TANH) return launch_glds<EPI, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
-    else if constexpr (EPI == MAED_EPI_ATOMIC_F32) return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
-    else return launch_glds<EPI, 2>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    // measured at the cfg3 shapes (scripts/gemm_micro.py, profiles/r01_gemm_staging_variants_v3.txt): with the LDS-shuffled
+    // epilogue the one-buffer kernel at 4 workgroups per CU wins or ties for every epilogue (fc1+GELU 110 vs 128 us, GELU'
+    // 92 vs 112 us); the two-buffer kernel stays selectable (MAED_IMPL_MFMA_GLDS2); the split-K atomic epilogue keeps the
+    // register-staged kernel
+    if constexpr (EPI == MAED_EPI_ATOMIC_F32) return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    else return launch_glds<EPI, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
 }
 
 extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
