@@ -32,35 +32,57 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     int mt_end = mt_beg + mtiles_per_split;
     if (mt_end > nmt) mt_end = nmt;
     if (mt_beg >= mt_end) return;
+    // the main loop runs over FULL M-tiles with unconditional loads; the (at most one, globally last) ragged tile is a
+    // separate bound-checked step of the workgroup that owns it
+    const int n_full = (int)(M / TN_BM);
+    const bool own_tail = (mt_end > n_full);                  // block-uniform
+    const int mt_endf = own_tail ? n_full : mt_end;           // end of this workgroup's full tiles
 
-    // staging role: threads 0..127 transpose the Y tile, 128..255 the X tile; each owns an 8(m) x 8(col) block
-    const int side = tid >> 7, st = tid & 127;
+    // staging role: waves 0,1 transpose the Y tile, waves 2,3 the X tile; each thread owns an 8(m) x 8(col) block.
+    // `side` is wave-uniform (readfirstlane): the source pointer and row stride live in SGPRs and a load is
+    // global_load_dwordx4 v, v_off, s[base] with a loop-invariant 32-bit lane offset.  The first version recomputed 64-bit
+    // row*ld products and branched on a row bound for every load: ~10 VALU/SALU instructions per MFMA.
+    const int side = __builtin_amdgcn_readfirstlane(tid >> 7), st = tid & 127;
     const int nc = st & 15, mg = st >> 4;                      // column chunk (8 cols), row group (8 rows)
     const bf16* src = side ? X : Y;
     const int64_t lds_src = side ? ldx : ldy;
     const int c0 = (side ? k0 : n0) + nc * 8;
     const int cmax = side ? K : N;
-    const bool col_ok = c0 < cmax;                            // N, K are multiples of 8 (checked by the launcher)
-    const bf16* sp = src + c0;
+    const bool col_ok = c0 < cmax;                            // N, K are multiples of 8 (checked by the launcher); loop-invariant
     unsigned short* my_lds_base = &lds[0][side][0];
     const int wr_off = (nc * 8) * TN_LD + ((mg ^ (nc & 7)) << 3);   // row (nc*8 + j), swizzled 16-B slot mg ^ ((row>>3)&7)
-    const bool do_bias = (dbias != nullptr) && (tile_k == 0) && (side == 0);
+    const bool do_bias = (dbias != nullptr) && (tile_k == 0) && (side == 0);   // wave-uniform
     float cs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+    // lanes whose columns lie beyond N / K load column 0 instead (always valid), never store, and their LDS rows are zeroed once
+    const int ldi = (int)lds_src;
+    const int vo0 = (mg * 8) * ldi + (col_ok ? c0 : 0), vo1 = vo0 + ldi, vo2 = vo1 + ldi, vo3 = vo2 + ldi, vo4 = vo3 + ldi, vo5 = vo4 + ldi,
+              vo6 = vo5 + ldi, vo7 = vo6 + ldi;               // fits 32 bits: the launcher checks ld < 2^24
+    if (!col_ok) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<uint4*>(my_lds_base + (size_t)b * (2 * 128 * TN_LD) + wr_off + j * TN_LD) = make_uint4(0u, 0u, 0u, 0u);
+    }
 
     uint4 r0_0, r0_1, r0_2, r0_3, r0_4, r0_5, r0_6, r0_7, r1_0, r1_1, r1_2, r1_3, r1_4, r1_5, r1_6, r1_7;
-#define TN_LD1(S, i, mrow0) { const int64_t m__ = (mrow0) + mg * 8 + i; \
-        r##S##_##i = (col_ok && m__ < M) ? *reinterpret_cast<const uint4*>(sp + m__ * lds_src) : make_uint4(0u, 0u, 0u, 0u); }
-#define TN_LOAD(S, mt_) { int mtc__ = (mt_); if (mtc__ > mt_end - 1) mtc__ = mt_end - 1; const int64_t mrow0__ = (int64_t)mtc__ * TN_BM; \
-        TN_LD1(S, 0, mrow0__) TN_LD1(S, 1, mrow0__) TN_LD1(S, 2, mrow0__) TN_LD1(S, 3, mrow0__) \
-        TN_LD1(S, 4, mrow0__) TN_LD1(S, 5, mrow0__) TN_LD1(S, 6, mrow0__) TN_LD1(S, 7, mrow0__) }
+#define TN_LD1(S, i, tb_) r##S##_##i = *reinterpret_cast<const uint4*>((tb_) + vo##i);
+#define TN_LOAD(S, mt_) { int mtc__ = (mt_); if (mtc__ > mt_endf - 1) mtc__ = mt_endf - 1; \
+        const bf16* tb__ = src + (int64_t)mtc__ * TN_BM * lds_src; \
+        TN_LD1(S, 0, tb__) TN_LD1(S, 1, tb__) TN_LD1(S, 2, tb__) TN_LD1(S, 3, tb__) TN_LD1(S, 4, tb__) TN_LD1(S, 5, tb__) TN_LD1(S, 6, tb__) TN_LD1(S, 7, tb__) }
+    // ragged tile: rows >= M contribute zeros
+#define TN_LD1C(S, i, tb_, mrow0) r##S##_##i = ((mrow0) + mg * 8 + i < M) ? *reinterpret_cast<const uint4*>((tb_) + vo##i) : make_uint4(0u, 0u, 0u, 0u);
+#define TN_LOAD_TAIL(S) { const int64_t mrow0__ = (int64_t)n_full * TN_BM; const bf16* tb__ = src + mrow0__ * lds_src; \
+        TN_LD1C(S, 0, tb__, mrow0__) TN_LD1C(S, 1, tb__, mrow0__) TN_LD1C(S, 2, tb__, mrow0__) TN_LD1C(S, 3, tb__, mrow0__) \
+        TN_LD1C(S, 4, tb__, mrow0__) TN_LD1C(S, 5, tb__, mrow0__) TN_LD1C(S, 6, tb__, mrow0__) TN_LD1C(S, 7, tb__, mrow0__) }
     // transposed 16-B row for column pair d (dword index) half b: rows 0..7 of that column
 #define TN_ROW(S, COMP, PERM) make_uint4(PERM(r##S##_0.COMP, r##S##_1.COMP), PERM(r##S##_2.COMP, r##S##_3.COMP), \
                                          PERM(r##S##_4.COMP, r##S##_5.COMP), PERM(r##S##_6.COMP, r##S##_7.COMP))
 #define TN_CS(S, COMP, j0) { const uint32_t w__[8] = {r##S##_0.COMP, r##S##_1.COMP, r##S##_2.COMP, r##S##_3.COMP, r##S##_4.COMP, r##S##_5.COMP, r##S##_6.COMP, r##S##_7.COMP}; \
         _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) { cs[j0] += __uint_as_float(w__[i__] << 16); cs[j0 + 1] += __uint_as_float(w__[i__] & 0xffff0000u); } }
-#define TN_STORE(S, buf_) { unsigned short* d__ = my_lds_base + (size_t)(buf_) * (2 * 128 * TN_LD) + wr_off; \
+#define TN_STORE(S, buf_) if (col_ok) { unsigned short* d__ = my_lds_base + (size_t)(buf_) * (2 * 128 * TN_LD) + wr_off; \
         *reinterpret_cast<uint4*>(d__ + 0 * TN_LD) = TN_ROW(S, x, perm_lo); *reinterpret_cast<uint4*>(d__ + 1 * TN_LD) = TN_ROW(S, x, perm_hi); \
         *reinterpret_cast<uint4*>(d__ + 2 * TN_LD) = TN_ROW(S, y, perm_lo); *reinterpret_cast<uint4*>(d__ + 3 * TN_LD) = TN_ROW(S, y, perm_hi); \
         *reinterpret_cast<uint4*>(d__ + 4 * TN_LD) = TN_ROW(S, z, perm_lo); *reinterpret_cast<uint4*>(d__ + 5 * TN_LD) = TN_ROW(S, z, perm_hi); \
@@ -84,22 +106,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
             acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0); \
             acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0); } }
 
-    TN_LOAD(0, mt_beg);
-    TN_LOAD(1, mt_beg + 1);
-    TN_STORE(0, 0);
-    __syncthreads();
-    int mt = mt_beg;
-    for (; mt + 1 < mt_end; mt += 2) {
-        TN_LOAD(0, mt + 2);
-        TN_COMPUTE(0);
-        TN_STORE(1, 1);
+    __syncthreads();                            // (zeroed LDS rows of out-of-range columns are in place)
+    if (mt_beg < mt_endf) {
+        TN_LOAD(0, mt_beg);
+        TN_LOAD(1, mt_beg + 1);
+        TN_STORE(0, 0);
         __syncthreads();
-        TN_LOAD(1, mt + 3);
-        TN_COMPUTE(1);
-        if (mt + 2 < mt_end) TN_STORE(0, 0);   // guarded: the column sums must not see a clamped duplicate tile
-        __syncthreads();
+        int mt = mt_beg;
+        for (; mt + 1 < mt_endf; mt += 2) {
+            TN_LOAD(0, mt + 2);
+            TN_COMPUTE(0);
+            TN_STORE(1, 1);
+            __syncthreads();
+            TN_LOAD(1, mt + 3);
+            TN_COMPUTE(1);
+            if (mt + 2 < mt_endf) TN_STORE(0, 0);   // guarded: the column sums must not see a clamped duplicate tile
+            __syncthreads();
+        }
+        if (mt < mt_endf) TN_COMPUTE(0);
     }
-    if (mt < mt_end) TN_COMPUTE(0);
+    if (own_tail) {                             // block-uniform
+        __syncthreads();
+        TN_LOAD_TAIL(0);
+        TN_STORE(0, 0);
+        __syncthreads();
+        TN_COMPUTE(0);
+    }
 
     // D[row n][col k]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*hi -> atomics of a half-wave hit 32 consecutive k
 #define TN_EPI(acc_, i_, j_) { const int kcol = k0 + wc * 64 + (j_) * 32 + l31; \
@@ -129,6 +161,7 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     MAED_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldw >= K, MAED_ERR_SHAPE,
                    "gemm_tn_wgrad: need N, K, ldy, ldx multiples of 8 (N=%d K=%d)", N, K);
     MAED_CHECK_ARG(is_aligned(Y, 16) && is_aligned(X, 16), MAED_ERR_ALIGN, "gemm_tn_wgrad: Y/X must be 16-B aligned");
+    MAED_CHECK_ARG(ldy < (1 << 24) && ldx < (1 << 24), MAED_ERR_SHAPE, "gemm_tn_wgrad: row strides must be < 2^24 elements");
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     const int nmt = (int)((M + TN_BM - 1) / TN_BM);
     static int target = 0;                                   // MAED_TN_TARGET_WGS: measurement knob for the split heuristic
