@@ -278,14 +278,16 @@ typedef struct {
 int maed_weight_std_fwd(const void* conv_table, int n_convs, int n_filters, void* out, int dtype, float* stats, float eps, void* stream);
 int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int dtype, const float* stats, float eps, void* stream);
 /* GroupNorm(32 groups)(+ residual)(+ ReLU) on channels_last activations x (N, HW, C) (resnetv2.py:35-49,189-204):
- * y = act(GN(x) * gamma + beta [+ residual]).  sums: (N,32,2) doubles written by forward, read by backward. */
+ * y = act(GN(x) * gamma + beta [+ residual]).  sums: (N,32,2) doubles written by forward, read by backward.
+ * sums_zeroed / ab_zeroed != 0: the caller hands in scratch that is already zero (one memset for all 52 layers of a
+ * backbone pass instead of one per layer). */
 int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
-                       int N, int HW, int C, float eps, int relu, int dtype, void* stream);
+                       int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream);
 /* dx (and dres = masked dy when dres != NULL); dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats;
  * y (the saved forward output) is needed only for relu with a residual, otherwise the mask is recomputed from x */
 int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, const float* beta,
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
-                       int relu, int dtype, void* stream);
+                       int relu, int dtype, int ab_zeroed, void* stream);
 
 /* ---- optimizer: Adam (lib/utils/utils.py:127-132; torch.optim.Adam semantics, L2 weight decay) - */
 /* flat fp32 arenas p,g,m,v of n elements; grad is scaled by gscale first (1/world for DDP mean).

@@ -329,14 +329,14 @@ static int gn_rows_per_wg(int N, int HW, int C, int target_wgs = 2048) {
 }
 
 extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
-                                  int N, int HW, int C, float eps, int relu, int dtype, void* stream) {
+                                  int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream) {
     MAED_CHECK_ARG(x && gamma && beta && y && sums, MAED_ERR_ARG, "groupnorm_fwd: null pointer");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_fwd"));
     if (N <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     const int rows = gn_rows_per_wg(N, HW, C);
     dim3 grid((HW + rows - 1) / rows, N);
-    hipMemsetAsync(sums, 0, (size_t)N * GN_G * 2 * sizeof(double), s);
+    if (!sums_zeroed) hipMemsetAsync(sums, 0, (size_t)N * GN_G * 2 * sizeof(double), s);
     MAED_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)x, sums, HW, C, rows);
         if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows);
@@ -350,7 +350,7 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
 
 extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, const float* beta,
                                   void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
-                                  int relu, int dtype, void* stream) {
+                                  int relu, int dtype, int ab_zeroed, void* stream) {
     MAED_CHECK_ARG(x && dy && sums && gamma && beta && dx && dgamma && dbeta && ab_scratch, MAED_ERR_ARG, "groupnorm_bwd: null pointer");
     MAED_CHECK_ARG(!(relu && dres) || y, MAED_ERR_ARG, "groupnorm_bwd: the saved output y is needed for the ReLU mask when a residual was added");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_bwd"));
@@ -361,7 +361,7 @@ extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, 
     // the reduction pass ends with 4C atomics per workgroup: fewer, fatter workgroups (~768: 3 per CU) keep it HBM-bound
     const int rrows = gn_rows_per_wg(N, HW, C, 768);
     dim3 rgrid((HW + rrows - 1) / rrows, N);
-    hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
+    if (!ab_zeroed) hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
     const bool ymask = relu && dres;
 #define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, (const T*)y, (const T*)dy, \

@@ -440,16 +440,21 @@ class GroupNormFn(torch.autograd.Function):
     owner module reports them through its grads_ready callback) instead of travelling through autograd."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, relu, direct):
+    def forward(ctx, x, residual, gamma, beta, eps, relu, direct, sums=None, ab=None):
+        """sums (N,32,2) f64 / ab (N,C,2) f32: optional PRE-ZEROED scratch slices (ResNetV2 zeroes one arena per pass for all
+        its 52 layers instead of one memset per layer and direction)"""
         N, C_, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)
         if residual is not None:
             residual = residual.contiguous(memory_format=torch.channels_last).to(x.dtype)
         y = torch.empty_like(x, memory_format=torch.channels_last)
-        sums = torch.empty(N, 32, 2, dtype=torch.float64, device=x.device)
+        zeroed = sums is not None
+        if sums is None:
+            sums = torch.empty(N, 32, 2, dtype=torch.float64, device=x.device)
         check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), N, H * W, C_, eps, int(relu),
-                                         dt_code(x.dtype), _stream()), "groupnorm_fwd")
+                                         dt_code(x.dtype), int(zeroed), _stream()), "groupnorm_fwd")
         ctx.has_res = residual is not None
+        ctx.ab = ab
         ctx.save_for_backward(x, y if (relu and ctx.has_res) else None, sums)
         ctx.eps, ctx.relu, ctx.direct = eps, relu, direct
         ctx.gamma, ctx.beta = gamma, beta   # parameters (leaf tensors): kept by reference for .grad access
@@ -472,12 +477,15 @@ class GroupNormFn(torch.autograd.Function):
         else:
             dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device)
             dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device)
-        ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
+        ab, ab_zeroed = ctx.ab, ctx.ab is not None
+        ctx.ab = None                                   # single use: a second backward through this node gets fresh scratch
+        if ab is None:
+            ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
         check(L.lib().maed_groupnorm_bwd(_p(x), _p(y), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
-                                         N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), _stream()), "groupnorm_bwd")
+                                         N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), _stream()), "groupnorm_bwd")
         if ctx.direct:
-            return dx, dres, None, None, None, None, None
-        return dx, dres, dgamma, dbeta, None, None, None
+            return dx, dres, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None
 
 
 class Conv1x1Fn(torch.autograd.Function):

@@ -73,6 +73,8 @@ class GroupNormAct(nn.GroupNorm):
     """resnetv2.py:35-49"""
 
     _direct_grad = False  # set by ResNetV2: the kernels accumulate dgamma/dbeta straight into .grad
+    _sums_buf = None      # set by ResNetV2 per pass: pre-zeroed (N,32,2) f64 / (N,C,2) f32 scratch slices
+    _ab_buf = None
 
     def __init__(self, num_channels, num_groups=32, eps=1e-5, affine=True, apply_act=True):
         super().__init__(num_groups, num_channels, eps=eps, affine=affine)
@@ -82,7 +84,7 @@ class GroupNormAct(nn.GroupNorm):
         """y = act(GN(x) [+ residual]); relu defaults to the layer's own activation flag"""
         relu = self.apply_act if relu is None else relu
         if x.is_cuda and self.num_groups == 32:
-            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad)
+            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad, self._sums_buf, self._ab_buf)
         x = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
         if residual is not None:
             x = x + residual
@@ -197,13 +199,28 @@ class ResNetV2(nn.Module):
             return self.stages(self.stem(x))
         x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
         ws = ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
+        # GroupNorm scratch for all layers of this pass: ONE zero-fill each instead of a memset per layer and direction
+        N = x.shape[0]
+        sums = torch.zeros(len(self._norms), N, 32, 2, dtype=torch.float64, device=x.device)
+        ab = None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in (self._norms[0].weight, self._convs[0].weight)):
+            ab = torch.zeros(N * 2 * sum(m.num_channels for m in self._norms), dtype=torch.float32, device=x.device)
         try:
             for i, (c, w) in enumerate(zip(self._convs, ws)):
                 c._w_std, c._w_t, c._dw = w, self._w_std_t.get(i), self._dw_slices.get(i)
+            off = 0
+            for i, m in enumerate(self._norms):
+                m._sums_buf = sums[i]
+                if ab is not None:
+                    n = N * 2 * m.num_channels
+                    m._ab_buf = ab[off:off + n].view(N, m.num_channels, 2)
+                    off += n
             return self.stages(self.stem(x))
         finally:
             for c in self._convs:
                 c._w_std = c._w_t = c._dw = None
+            for m in self._norms:
+                m._sums_buf = m._ab_buf = None
 
     def forward(self, x, seqlen=8):
         return self.forward_features(x)
