@@ -289,6 +289,13 @@ int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const doubl
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
                        int relu, int dtype, int ab_zeroed, void* stream);
 
+/* compute-dtype images of the nn.Linear master weights after an optimizer step (ops.WeightCache), all in one launch:
+ * for every entry dst_c (rows, cols) = cast(src) (NULL = skip) and dst_t (cols, rows) = cast(src)^T.
+ * table: device array of n_entries maed_wt_entry; tile0 = index of the entry's first 64x64 tile, tiles_n = ceil(cols/64);
+ * n_tiles = total tile count = launch grid. */
+typedef struct { const float* src; void* dst_c; void* dst_t; int32_t rows, cols, tile0, tiles_n; } maed_wt_entry;
+int maed_weight_refresh(const void* table, int n_entries, int n_tiles, int dtype, void* stream);
+
 /* ---- optimizer: Adam (lib/utils/utils.py:127-132; torch.optim.Adam semantics, L2 weight decay) - */
 /* flat fp32 arenas p,g,m,v of n elements; grad is scaled by gscale first (1/world for DDP mean).
  * Optionally refreshes the bf16 shadow copy of the parameters (shadow_bf16 may be NULL). */

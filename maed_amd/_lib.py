@@ -99,6 +99,7 @@ SIGNATURES = {
     "maed_comm_wait": (i32, [vp]),
     "maed_comm_world": (i32, []),
     "maed_comm_destroy": (i32, []),
+    "maed_weight_refresh": (i32, [vp, i32, i32, i32, vp]),
     "maed_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
 }
 

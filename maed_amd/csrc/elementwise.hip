@@ -298,6 +298,52 @@ extern "C" int maed_transpose_cast(const void* in, int in_dtype, int64_t ldi, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// batched weight refresh: for every fp32 master weight W_i (rows_i x cols_i) of the table write the compute-dtype copy and the
+// transposed compute-dtype copy in ONE launch (after an optimizer step the STE needs both images of 32 matrices: that was 32
+// launches of the kernel above)
+// ---------------------------------------------------------------------------------------------------
+struct WtEntry { const float* src; void* dst_c; void* dst_t; int32_t rows, cols, tile0, tiles_n; };   // tile0 = first 64x64 tile of this matrix
+#define WT_MAX_ENTRIES 256
+
+template <typename TO>
+__global__ __launch_bounds__(256) void weight_refresh_kernel(const WtEntry* __restrict__ tab, int n_entries) {
+    __shared__ float tile[64][65];
+    int e = 0;
+    for (int i = 1; i < n_entries; ++i) e = ((int)blockIdx.x >= tab[i].tile0) ? i : e;     // block-uniform, table is tiny
+    const WtEntry d = tab[e];
+    const int t = blockIdx.x - d.tile0;
+    const int m0 = (t / d.tiles_n) * 64, n0 = (t % d.tiles_n) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    TO* out_c = (TO*)d.dst_c;
+    TO* out_t = (TO*)d.dst_t;
+    for (int r = ty; r < 64; r += 4) {
+        const int m = m0 + r, n = n0 + tx;
+        float v = 0.f;
+        if (m < d.rows && n < d.cols) {
+            v = d.src[(int64_t)m * d.cols + n];
+            if (out_c) stf(out_c + (int64_t)m * d.cols + n, v);
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (out_t)
+        for (int r = ty; r < 64; r += 4) {
+            const int n = n0 + r, m = m0 + tx;
+            if (n < d.cols && m < d.rows) stf(out_t + (int64_t)n * d.rows + m, tile[tx][r]);
+        }
+}
+
+extern "C" int maed_weight_refresh(const void* table, int n_entries, int n_tiles, int dtype, void* stream) {
+    MAED_CHECK_ARG(table, MAED_ERR_ARG, "weight_refresh: null table");
+    MAED_CHECK_ARG(n_entries > 0 && n_entries <= WT_MAX_ENTRIES, MAED_ERR_SHAPE, "weight_refresh: n_entries=%d out of range", n_entries);
+    if (n_tiles <= 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((weight_refresh_kernel<T>), dim3(n_tiles), dim3(256), 0, (hipStream_t)stream,
+                                                      (const WtEntry*)table, n_entries));
+    MAED_CHECK_LAUNCH("weight_refresh");
+    return MAED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam semantics: L2 weight decay folded into the gradient)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,

@@ -3,8 +3,10 @@
 #include "common.cuh"
 
 #define LN_MAXV 8  // float4 chunks per lane: C <= 64*4*8 = 2048
+// The kernels are instantiated per chunk count (C <= 256*NV): the per-lane arrays are sized by NV, so C = 512 runs with a
+// quarter of the registers of the generic NV = 8 version (backward: ~180 -> ~60 VGPRs, 2 -> 8 waves per SIMD in flight).
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ g, const float* __restrict__ b,
                                                      T* __restrict__ y, float* __restrict__ mean_o,
@@ -13,18 +15,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * xs;
-    float v[LN_MAXV][4];
+    float v[NV][4];
     float s = 0.f;
     const int nv = C / 4;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c4 = lane + i * 64;
         if (c4 < nv) { ld4(xr + c4 * 4, v[i]); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
     }
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c4 = lane + i * 64;
         if (c4 < nv) {
 #pragma unroll
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
     T* yr = y + row * (int64_t)C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c4 = lane + i * 64;
         if (c4 < nv) {
             float gg[4], bb[4], o[4];
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // are combined across the 4 waves through LDS and leave the workgroup as one atomicAdd per column.
 #define LN_ROWS_PER_WG 32
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ g, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ dres,
@@ -60,9 +62,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     MAED_DYN_SHARED(float, lds);  // [2][4 waves][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C / 4;
-    float gg[LN_MAXV][4], pg[LN_MAXV][4], pb[LN_MAXV][4];
+    float gg[NV][4], pg[NV][4], pb[NV][4];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c4 = lane + i * 64;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; gg[i][j] = 0.f; }
@@ -75,10 +77,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         const float mean = mean_i[row], rstd = rstd_i[row];
         const float* xr = x + row * xs;
         const T* dyr = dy + row * (int64_t)C;
-        float xh[LN_MAXV][4], gy[LN_MAXV][4];
+        float xh[NV][4], gy[NV][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c4 = lane + i * 64;
             if (c4 < nv) {
                 float xv[4], dv[4];
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         float* dxr = dx + row * (int64_t)C;
         const float* drr = dres ? dres + row * (int64_t)C : nullptr;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c4 = lane + i * 64;
             if (c4 < nv) {
                 float o[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     float* lg = lds + (size_t)wave * C;
     float* lb = lds + (size_t)(4 + wave) * C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c4 = lane + i * 64;
         if (c4 < nv) { st4(lg + c4 * 4, pg[i]); st4(lb + c4 * 4, pb[i]); }
     }
@@ -132,8 +134,9 @@ extern "C" int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const fl
     MAED_CHECK_ARG(x_row_stride % 4 == 0 && is_aligned(x, 16) && is_aligned(y, 8), MAED_ERR_ALIGN, "layernorm_fwd: x/y/stride alignment");
     if (rows == 0) return MAED_OK;
     dim3 grid((unsigned)((rows + 3) / 4));
-    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ln_fwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                      x, x_row_stride, gamma, beta, (T*)y, mean, rstd, rows, C, eps));
+#define LN_FWD(NV_) hipLaunchKernelGGL((ln_fwd_kernel<T, NV_>), grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, gamma, beta, (T*)y, mean, rstd, rows, C, eps)
+    MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_FWD(2); else if (C <= 768) LN_FWD(3); else if (C <= 1024) LN_FWD(4); else LN_FWD(8); });
+#undef LN_FWD
     MAED_CHECK_LAUNCH("layernorm_fwd");
     return MAED_OK;
 }
@@ -147,9 +150,10 @@ extern "C" int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int
     if (rows == 0) return MAED_OK;
     dim3 grid((unsigned)((rows + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG));
     const size_t lds = (size_t)8 * C * sizeof(float);
-    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ln_bwd_kernel<T>), grid, dim3(256), lds, (hipStream_t)stream,
-                                                      (const T*)dy, x, x_row_stride, gamma, mean, rstd, dres_in, dx_out,
-                                                      (T*)dx_twin, dgamma, dbeta, rows, C));
+#define LN_BWD(NV_) hipLaunchKernelGGL((ln_bwd_kernel<T, NV_>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)dy, x, x_row_stride, gamma, mean, \
+                                      rstd, dres_in, dx_out, (T*)dx_twin, dgamma, dbeta, rows, C)
+    MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_BWD(2); else if (C <= 768) LN_BWD(3); else if (C <= 1024) LN_BWD(4); else LN_BWD(8); });
+#undef LN_BWD
     MAED_CHECK_LAUNCH("layernorm_bwd");
     return MAED_OK;
 }

@@ -6,6 +6,9 @@ is no PyTorch/CPU fallback (a CPU tensor or a missing library is an error).
 """
 import ctypes as C
 import math
+import weakref
+
+import numpy as _np
 
 import torch
 
@@ -193,25 +196,67 @@ def adam_step(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, gscale=1.0):
 # ----------------------------------------------------------------------------------------------
 # compute-dtype weight cache
 # ----------------------------------------------------------------------------------------------
+_WT_DTYPE = _np.dtype([("src", "u8"), ("dst_c", "u8"), ("dst_t", "u8"), ("rows", "i4"), ("cols", "i4"), ("tile0", "i4"), ("tiles_n", "i4")])
+
+
 class WeightCache:
-    """(cast copy [out,in], transposed cast copy [in,out]) of nn.Linear weights in the compute dtype,
-    rebuilt when the fp32 master changes (tensor version counter or FusedAdam's epoch)."""
+    """(cast copy [out,in], transposed cast copy [in,out]) of nn.Linear weights in the compute dtype, rebuilt when the fp32
+    master changes (tensor version counter, storage pointer or FusedAdam's epoch).  Every cache registers itself; the first
+    stale lookup after an optimizer step refreshes ALL registered caches of that (device, dtype) in one launch
+    (maed_weight_refresh) into persistent buffers -- 32 matrices per step at cfg3 used to be 32 launches."""
+
+    _registry = weakref.WeakSet()
 
     def __init__(self):
-        self._key = None
-        self._val = None
+        self._key = None        # state the images were built from
+        self._val = None        # what get() returns: [(compute-dtype [out,in] image or the fp32 master itself, transposed image)]
+        self._images = None     # persistent buffers [(cast copy or None in f32 mode, transposed copy)]
+        self._weights = None
+        self._dtype = None
+        WeightCache._registry.add(self)
+
+    @staticmethod
+    def _make_key(weights, dtype):
+        return (WEIGHT_EPOCH, dtype, tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in weights))
 
     def get(self, weights, dtype):
-        key = (WEIGHT_EPOCH, dtype, tuple((w.data_ptr(), w._version) for w in weights))
-        if key != self._key:
-            val = []
-            with torch.no_grad():
-                for w in weights:
-                    w2 = _c(w.detach())
-                    wt, wc = transpose_cast(w2, dtype, want_t=True, want_c=(dtype != torch.float32), pad_to=1)
-                    val.append((w2 if dtype == torch.float32 else wc, wt))
-            self._key, self._val = key, val
+        if self._make_key(weights, dtype) != self._key:
+            self._weights, self._dtype = list(weights), dtype
+            WeightCache._refresh_group(self)
         return self._val
+
+    @classmethod
+    def _refresh_group(cls, me):
+        dev, dtype = me._weights[0].device, me._dtype
+        group = [c for c in cls._registry if c._weights is not None and c._dtype == dtype and c._weights[0].device == dev]
+        rows, keep = [], []
+        tile0 = 0
+        with torch.no_grad():
+            for c in group:
+                ok = c._images is not None and len(c._images) == len(c._weights) and all(
+                    im[1].shape == (w.shape[1], w.shape[0]) and im[1].dtype == dtype and im[1].device == dev for im, w in zip(c._images, c._weights))
+                if not ok:      # (re)allocate the persistent images
+                    c._images = [(None if dtype == torch.float32 else torch.empty(w.shape, dtype=dtype, device=dev),
+                                  torch.empty(w.shape[1], w.shape[0], dtype=dtype, device=dev)) for w in c._weights]
+                val = []
+                for w, (wc, wt) in zip(c._weights, c._images):
+                    src = _c(w.detach())
+                    keep.append(src)
+                    R, Cn = src.shape
+                    tn = (Cn + 63) // 64
+                    rows.append((_p(src), 0 if wc is None else _p(wc), _p(wt), R, Cn, tile0, tn))
+                    tile0 += ((R + 63) // 64) * tn
+                    val.append((src if dtype == torch.float32 else wc, wt))
+                c._val = val
+        for lo in range(0, len(rows), 256):     # WT_MAX_ENTRIES per launch
+            chunk = rows[lo:lo + 256]
+            base = chunk[0][5]
+            tab = _np.array([r[:5] + (r[5] - base, r[6]) for r in chunk], dtype=_WT_DTYPE)
+            ntiles = (chunk[-1][5] - base) + ((chunk[-1][3] + 63) // 64) * chunk[-1][6]
+            tab_dev = torch.from_numpy(tab.view(_np.uint8)).to(dev)
+            check(L.lib().maed_weight_refresh(_p(tab_dev), len(chunk), ntiles, dt_code(dtype), _stream()), "weight_refresh")
+        for c in group:
+            c._key = cls._make_key(c._weights, dtype)
 
 
 _SCRATCH = {}
@@ -280,7 +325,6 @@ class EmbedAddFn(torch.autograd.Function):
         return dpatch, dcls, dpos, dtemp, None
 
 
-import weakref
 
 # (weakref to the residual-gradient tensor a Block backward returned, its compute-dtype copy).  The next Block backward
 # uses the copy only if it receives THAT VERY tensor object as grad_output (identity, not data_ptr: allocator reuse).
@@ -341,7 +385,6 @@ class STEBlockFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # backbone helpers: batched weight standardisation, fused GroupNorm(+residual)(+ReLU)
 # ----------------------------------------------------------------------------------------------
-import numpy as _np
 
 _WS_DTYPE = _np.dtype([("w", "u8"), ("gw", "u8"), ("gout", "u8"), ("dst_off", "i8"), ("dst_t_off", "i8"), ("O", "i4"), ("I", "i4"), ("KHW", "i4"),
                        ("fstart", "i4"), ("gout_f32", "i4"), ("pad_", "i4")])

@@ -97,3 +97,44 @@ def test_layernorm_kernels_on_simulator():
     assert torch.allclose(y, y_ref.detach(), rtol=1e-5, atol=1e-5)
     assert torch.allclose(dx, x.grad + dres, rtol=1e-4, atol=1e-5)
     assert torch.allclose(dg, g.grad, rtol=1e-4, atol=1e-4) and torch.allclose(db, b.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_weight_cache_batched_refresh_on_simulator():
+    """ops.WeightCache: all registered caches of a (device, dtype) are refreshed by ONE maed_weight_refresh launch into
+    persistent buffers; stale detection through FusedAdam's epoch, in-place edits and re-homed storage."""
+    from maed_amd import ops
+    torch.manual_seed(4)
+    w1, w2, w3 = torch.randn(70, 130), torch.randn(64, 64), torch.randn(5, 200)   # ragged 64x64 tiles
+    with patched() as lib:
+        calls = []
+        real = lib.maed_weight_refresh
+
+        def counting(*a):
+            calls.append(a[1])          # entries refreshed by this launch
+            return real(*a)
+        lib.maed_weight_refresh = counting
+        try:
+            ca, cb = ops.WeightCache(), ops.WeightCache()
+            (a1c, a1t), (a2c, a2t) = ca.get([w1, w2], torch.bfloat16)
+            assert calls and calls[-1] >= 2
+            (b3c, b3t), = cb.get([w3], torch.bfloat16)
+            for w, c, t in ((w1, a1c, a1t), (w2, a2c, a2t), (w3, b3c, b3t)):
+                assert torch.equal(c, w.bfloat16()) and torch.equal(t, w.bfloat16().t().contiguous())
+            n = len(calls)
+            ca.get([w1, w2], torch.bfloat16); cb.get([w3], torch.bfloat16)
+            assert len(calls) == n, "fresh caches must not relaunch"
+            ptr = a1t.data_ptr()
+            w1.mul_(2.0); w3.add_(1.0)                          # optimizer-like in-place update + epoch bump
+            ops.bump_weight_epoch()
+            (a1c, a1t), _ = ca.get([w1, w2], torch.bfloat16)
+            assert len(calls) == n + 1 and calls[-1] == 3, "one launch refreshes every registered cache"
+            assert a1t.data_ptr() == ptr, "persistent buffers are reused"
+            (b3c, b3t), = cb.get([w3], torch.bfloat16)
+            assert len(calls) == n + 1, "the second cache was refreshed by the same launch"
+            assert torch.equal(a1c, w1.bfloat16()) and torch.equal(b3t, w3.bfloat16().t().contiguous())
+            # parity mode: the [out,in] image is the fp32 master itself, only the transposed copy is built
+            cf = ops.WeightCache()
+            (f1, f1t), = cf.get([w2], torch.float32)
+            assert f1.data_ptr() == w2.data_ptr() and torch.equal(f1t, w2.t().contiguous())
+        finally:
+            lib.maed_weight_refresh = real
