@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmaed_hip.so")
+LIB_PATH = os.environ.get("MAED_HIP_LIB") or os.path.join(HERE, "libmaed_hip.so")   # override: A/B builds of the same C-ABI
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID_F32, EPI_MUL_DGELU, EPI_ATOMIC_F32, EPI_STORE_F32, EPI_TANH = range(7)
