@@ -49,6 +49,16 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _upload_table(tab, dev):
+    """small host-built pointer table -> device WITHOUT a host/device synchronisation point: staged in pinned memory and copied
+    asynchronously on the current stream (a pageable .to(device) blocks the host until the stream has drained, so the GPU
+    idled ~1 ms per step at three such uploads); the caching host allocator keeps the pinned block alive until the copy ran"""
+    host = torch.from_numpy(tab.view(_np.uint8))
+    if dev.type != "cuda":
+        return host.clone()
+    return host.pin_memory().to(dev, non_blocking=True)
+
+
 # ----------------------------------------------------------------------------------------------
 # primitive wrappers (no autograd)
 # ----------------------------------------------------------------------------------------------
@@ -253,7 +263,7 @@ class WeightCache:
             base = chunk[0][5]
             tab = _np.array([r[:5] + (r[5] - base, r[6]) for r in chunk], dtype=_WT_DTYPE)
             ntiles = (chunk[-1][5] - base) + ((chunk[-1][3] + 63) // 64) * chunk[-1][6]
-            tab_dev = torch.from_numpy(tab.view(_np.uint8)).to(dev)
+            tab_dev = _upload_table(tab, dev)
             check(L.lib().maed_weight_refresh(_p(tab_dev), len(chunk), ntiles, dt_code(dtype), _stream()), "weight_refresh")
         for c in group:
             c._key = cls._make_key(c._weights, dtype)
@@ -426,7 +436,7 @@ class WeightStdFn(torch.autograd.Function):
         dev = weights[0].device
         out = torch.empty(total, dtype=dtype, device=dev)
         stats = torch.empty(nf * 2, dtype=torch.float32, device=dev)
-        tab_dev = torch.from_numpy(tab.view(_np.uint8)).to(dev)
+        tab_dev = _upload_table(tab, dev)
         check(L.lib().maed_weight_std_fwd(_p(tab_dev), len(weights), nf, _p(out), dt_code(dtype), _p(stats), eps, _stream()), "weight_std_fwd")
         ctx.owner, ctx.dtype, ctx.eps, ctx.stats, ctx.nf = owner, dtype, eps, stats, nf
         ctx.weights = weights
@@ -469,7 +479,7 @@ class WeightStdFn(torch.autograd.Function):
             keep.append(g)
             gptr.append(p.grad.data_ptr()); optr.append(g.data_ptr()); f32.append(0)
         tab, _, nf, _, _ = _ws_table(weights, gptr, optr, gout_f32=f32)
-        tab_dev = torch.from_numpy(tab.view(_np.uint8)).to(weights[0].device)
+        tab_dev = _upload_table(tab, weights[0].device)
         check(L.lib().maed_weight_std_bwd(_p(tab_dev), len(weights), nf, dt_code(ctx.dtype), _p(ctx.stats), ctx.eps, _stream()), "weight_std_bwd")
         owner._pending_backwards -= 1
         if owner._pending_backwards == 0 and owner.grads_ready is not None:

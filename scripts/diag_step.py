@@ -54,6 +54,12 @@ timed("decoder tail + loss fwd+bwd", tail_train)
 def step():
     opt.zero_grad(); loss, _ = criterion(model(clip), tgt, None); loss.backward(); opt.step(); return loss
 timed("full train step", step, n=4)
+# host enqueue time vs GPU time: if enqueueing a step takes as long as the GPU needs to run it, the step is host-bound
+torch.cuda.synchronize(); t0 = time.perf_counter(); enq = []
+for _ in range(10):
+    t1 = time.perf_counter(); step(); enq.append(1e3 * (time.perf_counter() - t1))
+t_enq = time.perf_counter() - t0; torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+P(f"10 back-to-back steps: host enqueue {1e3 * t_enq / 10:.2f} ms/step (per step: {' '.join(f'{e:.1f}' for e in enq)}), wall incl. drain {1e3 * t_all / 10:.2f} ms/step")
 lib = L.lib(); lib.maed_prof_enable(1); step(); torch.cuda.synchronize()
 ms = (ctypes.c_double * 8)(); cnt = (ctypes.c_int * 8)(); lib.maed_prof_collect(ms, cnt); lib.maed_prof_enable(0)
 names = ["attn_sp_fwd", "attn_tm_fwd", "gemm_qkv", "gemm_fc1", "gemm_fc2", "attn_sp_bwd", "attn_tm_bwd", "gemm_wgrad"]
