@@ -289,6 +289,11 @@ int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const doubl
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
                        int relu, int dtype, int ab_zeroed, void* stream);
 
+/* MaxPool2dSame(kernel 3, stride 2) of the stem (resnetv2.py:61-72) on channels_last x (N,H,W,C), C % 8 == 0: y (N,ceil(H/2),
+ * ceil(W/2),C) and the winning tap per output element (idx, uint8, same shape as y; ATen tie/NaN rule); backward gathers dx. */
+int maed_maxpool3s2_same_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype, void* stream);
+int maed_maxpool3s2_same_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int dtype, void* stream);
+
 /* compute-dtype images of the nn.Linear master weights after an optimizer step (ops.WeightCache), all in one launch:
  * for every entry dst_c (rows, cols) = cast(src) (NULL = skip) and dst_t (cols, rows) = cast(src)^T.
  * table: device array of n_entries maed_wt_entry; tile0 = index of the entry's first 64x64 tile, tiles_n = ceil(cols/64);

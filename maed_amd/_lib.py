@@ -99,6 +99,8 @@ SIGNATURES = {
     "maed_comm_wait": (i32, [vp]),
     "maed_comm_world": (i32, []),
     "maed_comm_destroy": (i32, []),
+    "maed_maxpool3s2_same_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "maed_maxpool3s2_same_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "maed_weight_refresh": (i32, [vp, i32, i32, i32, vp]),
     "maed_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
 }

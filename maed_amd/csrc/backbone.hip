@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ beta, float* __restrict__ ab /* [N][C][2] */,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int HW, int C, float eps, int rows_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) float lpart[];   // [256/cbn][C][2] = 16 KB
+    MAED_DYN_SHARED(float, lpart);   // [256/cbn][C][2] = 16 KB
     __shared__ float lmu[GN_G], lrs[GN_G];
     const int n = blockIdx.y;
     if (threadIdx.x < GN_G) {
@@ -375,5 +375,112 @@ extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, 
 #undef GN_RED
 #undef GN_APP
     MAED_CHECK_LAUNCH("groupnorm_bwd");
+    return MAED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MaxPool2dSame(3, stride 2) of the stem (resnetv2.py:61-72: TF 'SAME' padding with -inf, then max_pool2d) on channels_last.
+// One pass forward (no padded copy) that also records the winning tap; backward GATHERS (each input pixel looks at the <= 4
+// windows that cover it) instead of ATen's scatter -- 341 -> ~100 us at cfg3.  Ties / NaN follow ATen: the first strictly
+// greater value in (kh, kw) scan order wins, a NaN always wins.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int N, int H, int W,
+                                                             int C, int Ho, int Wo, int top, int left) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread: 8 channels of one output pixel
+    const int cb = C / 8;
+    if (i >= (int64_t)N * Ho * Wo * cb) return;
+    const int c8 = (int)(i % cb) * 8;
+    const int64_t pix = i / cb;
+    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((int64_t)Wo * Ho));
+    float m[8]; int am[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; am[j] = 0; }
+    bool first = true;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = 2 * ho - top + kh;
+        if (h < 0 || h >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int w = 2 * wo - left + kw;
+            if (w < 0 || w >= W) continue;
+            float v[8];
+            ld8(x + (((int64_t)n * H + h) * W + w) * C + c8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (first || v[j] > m[j] || v[j] != v[j]) { m[j] = v[j]; am[j] = kh * 3 + kw; }
+            first = false;
+        }
+    }
+    st8(y + i * 8, m);
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lo |= (uint32_t)am[j] << (8 * j); hi |= (uint32_t)am[4 + j] << (8 * j); }
+    *reinterpret_cast<uint2*>(idx + i * 8) = make_uint2(lo, hi);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int N, int H,
+                                                             int W, int C, int Ho, int Wo, int top, int left) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread: 8 channels of one INPUT pixel
+    const int cb = C / 8;
+    if (i >= (int64_t)N * H * W * cb) return;
+    const int c8 = (int)(i % cb) * 8;
+    const int64_t pix = i / cb;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((int64_t)W * H));
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    // windows ho with 2*ho - top <= h <= 2*ho - top + 2
+    const int ho_hi = (h + top) >> 1, wo_hi = (w + left) >> 1;
+    for (int ho = ho_hi - 1; ho <= ho_hi; ++ho) {
+        const int kh = h - (2 * ho - top);
+        if (ho < 0 || ho >= Ho || kh < 0 || kh > 2) continue;
+        for (int wo = wo_hi - 1; wo <= wo_hi; ++wo) {
+            const int kw = w - (2 * wo - left);
+            if (wo < 0 || wo >= Wo || kw < 0 || kw > 2) continue;
+            const int64_t o = ((((int64_t)n * Ho + ho) * Wo + wo) * C + c8);
+            const uint2 a = *reinterpret_cast<const uint2*>(idx + o);
+            float d[8];
+            ld8(dy + o, d);
+            const uint32_t tap = (uint32_t)(kh * 3 + kw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (((a.x >> (8 * j)) & 0xffu) == tap) g[j] += d[j];
+                if (((a.y >> (8 * j)) & 0xffu) == tap) g[4 + j] += d[4 + j];
+            }
+        }
+    }
+    st8(dx + i * 8, g);
+}
+
+static void maxpool_geom(int H, int W, int& Ho, int& Wo, int& top, int& left) {
+    Ho = (H + 1) / 2; Wo = (W + 1) / 2;
+    const int ph = (Ho - 1) * 2 + 3 - H, pw = (Wo - 1) * 2 + 3 - W;
+    top = (ph > 0 ? ph : 0) / 2; left = (pw > 0 ? pw : 0) / 2;
+}
+
+extern "C" int maed_maxpool3s2_same_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype, void* stream) {
+    MAED_CHECK_ARG(x && y && idx, MAED_ERR_ARG, "maxpool3s2_same_fwd: null pointer");
+    MAED_CHECK_ARG(N >= 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, MAED_ERR_SHAPE, "maxpool3s2_same_fwd: C=%d must be a multiple of 8", C);
+    int Ho, Wo, top, left;
+    maxpool_geom(H, W, Ho, Wo, top, left);
+    const int64_t n = (int64_t)N * Ho * Wo * (C / 8);
+    if (n == 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool3s2_fwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                                      (const T*)x, (T*)y, idx, N, H, W, C, Ho, Wo, top, left));
+    MAED_CHECK_LAUNCH("maxpool3s2_same_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_maxpool3s2_same_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int dtype, void* stream) {
+    MAED_CHECK_ARG(dy && idx && dx, MAED_ERR_ARG, "maxpool3s2_same_bwd: null pointer");
+    MAED_CHECK_ARG(N >= 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, MAED_ERR_SHAPE, "maxpool3s2_same_bwd: C=%d must be a multiple of 8", C);
+    int Ho, Wo, top, left;
+    maxpool_geom(H, W, Ho, Wo, top, left);
+    const int64_t n = (int64_t)N * H * W * (C / 8);
+    if (n == 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool3s2_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                                      (const T*)dy, idx, (T*)dx, N, H, W, C, Ho, Wo, top, left));
+    MAED_CHECK_LAUNCH("maxpool3s2_same_bwd");
     return MAED_OK;
 }

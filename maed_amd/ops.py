@@ -541,6 +541,31 @@ class GroupNormFn(torch.autograd.Function):
         return dx, dres, dgamma, dbeta, None, None, None, None, None
 
 
+class MaxPool3s2SameFn(torch.autograd.Function):
+    """MaxPool2dSame(3, 2) on a channels_last tensor (maed_maxpool3s2_same_fwd/bwd): no -inf padded copy, gather backward"""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C_, H, W = x.shape
+        x = x.contiguous(memory_format=torch.channels_last)
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty((N, C_, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty(N * Ho * Wo * C_, dtype=torch.uint8, device=x.device)
+        check(L.lib().maed_maxpool3s2_same_fwd(_p(x), _p(y), _p(idx), N, H, W, C_, dt_code(x.dtype), _stream()), "maxpool3s2_same_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, C_, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        N, C_, H, W = ctx.geom
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((N, C_, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        check(L.lib().maed_maxpool3s2_same_bwd(_p(dy), _p(idx), _p(dx), N, H, W, C_, dt_code(dy.dtype), _stream()), "maxpool3s2_same_bwd")
+        return dx
+
+
 class Conv1x1Fn(torch.autograd.Function):
     """1x1 stride-1 convolution on a channels_last bf16 tensor as GEMMs on libmaed_hip (33 of the backbone's 53
     convolutions): y[(n,h,w), o] = sum_i x[(n,h,w), i] w[o, i].  Forward = maed_gemm_nt on the standardised weight (O, I),

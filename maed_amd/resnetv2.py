@@ -99,6 +99,8 @@ class MaxPool2dSame(nn.Module):
         self.kernel_size, self.stride = kernel_size, stride
 
     def forward(self, x):
+        if x.is_cuda and self.kernel_size == 3 and self.stride == 2 and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16):
+            return ops.MaxPool3s2SameFn.apply(x)
         return F.max_pool2d(_same_pad(x, self.kernel_size, self.stride, value=-float("inf")), self.kernel_size, self.stride, 0)
 
 

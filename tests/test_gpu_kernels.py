@@ -427,3 +427,22 @@ def test_conv1x1_as_gemm(N, I, O, H, W):
     report(f"conv1x1 dx{tag}", xg.grad.float(), xd.grad, **tol(torch.bfloat16, 2))
     report(f"conv1x1 dw{tag} (fp32 accumulator)", dw - 1.0, wd.grad.reshape(O, I), rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())
     assert wg.grad is None, "the weight gradient travels through the fp32 accumulator, not autograd"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(3, 64, 112, 112), (2, 8, 7, 9), (1, 16, 16, 16)])
+def test_maxpool_same_3x3s2(dtype, N, C, H, W):
+    """ops.MaxPool3s2SameFn (no padded copy forward, gather backward) == F.max_pool2d on the -inf padded tensor (resnetv2.py:61-72),
+    bit-exact including ATen's tie rule on the ReLU zeros"""
+    ops, _ = _ops()
+    x = F.relu(rnd(N, C, H, W, seed=3)).to(DEV).to(dtype)
+    xr = x.clone().requires_grad_(True)
+    ph = max((-(-H // 2) - 1) * 2 + 3 - H, 0); pw = max((-(-W // 2) - 1) * 2 + 3 - W, 0)
+    ref = F.max_pool2d(F.pad(xr, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2], value=-float("inf")), 3, 2, 0)
+    g = rnd(*ref.shape, seed=4).to(DEV).to(dtype)
+    ref.backward(g)
+    xs = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.MaxPool3s2SameFn.apply(xs)
+    y.backward(g.contiguous(memory_format=torch.channels_last))
+    assert torch.equal(y.detach(), ref.detach())
+    report(f"maxpool3s2_same bwd[{dtype},{N}x{C}x{H}x{W}]", xs.grad.float(), xr.grad.float(), rtol=0, atol=(0 if dtype == torch.float32 else 2e-2))
