@@ -51,7 +51,8 @@ typedef enum {
     MAED_EPI_MUL_DGELU = 3,  /* out[T]   = acc * gelu_erf'(aux[T]) (backward through GELU)          */
     MAED_EPI_ATOMIC_F32 = 4, /* out[f32] += acc  (atomic; weight gradients, split-K allowed)        */
     MAED_EPI_STORE_F32 = 5,  /* out[f32] = acc + bias                                               */
-    MAED_EPI_TANH = 6        /* out[T]   = tanh(acc + bias)                                         */
+    MAED_EPI_TANH = 6,       /* out[T]   = tanh(acc + bias)                                         */
+    MAED_EPI_ADD = 7         /* out[T]   = aux[T] + acc + bias  (gradient accumulation at a residual fork) */
 } maed_epilogue;
 
 /* kernel implementation selector for ops that have both */

@@ -36,6 +36,8 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int6
         ((float*)e.out)[r * e.ldo + c] = acc + (e.bias ? e.bias[c] : 0.f);
     } else if constexpr (EPI == MAED_EPI_TANH) {
         stf((T*)e.out + r * e.ldo + c, tanhf(acc + (e.bias ? e.bias[c] : 0.f)));
+    } else if constexpr (EPI == MAED_EPI_ADD) {
+        stf((T*)e.out + r * e.ldo + c, ldf((const T*)e.aux + r * e.ldaux + c) + acc + (e.bias ? e.bias[c] : 0.f));
     }
 }
 
@@ -75,6 +77,10 @@ __device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int
         st4((float*)e.out + r * e.ldo + c0, v);
     } else if constexpr (EPI == MAED_EPI_TANH) {
         float o[4] = {tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
+        st4((T*)e.out + r * e.ldo + c0, o);
+    } else if constexpr (EPI == MAED_EPI_ADD) {
+        float x[4]; ld4((const T*)e.aux + r * e.ldaux + c0, x);
+        float o[4] = {x[0] + v[0], x[1] + v[1], x[2] + v[2], x[3] + v[3]};
         st4((T*)e.out + r * e.ldo + c0, o);
     }
 }
@@ -120,6 +126,11 @@ __device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
         st8((T*)e.out + r * e.ldo + c0, v);
+    } else if constexpr (EPI == MAED_EPI_ADD) {
+        float x[8]; ld8((const T*)e.aux + r * e.ldaux + c0, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += v[j];
+        st8((T*)e.out + r * e.ldo + c0, x);
     }
 }
 
@@ -533,6 +544,9 @@ extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
         case MAED_EPI_ATOMIC_F32: rc = dispatch<MAED_EPI_ATOMIC_F32>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
         case MAED_EPI_STORE_F32: rc = dispatch<MAED_EPI_STORE_F32>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
         case MAED_EPI_TANH: rc = dispatch<MAED_EPI_TANH>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
+        case MAED_EPI_ADD:
+            MAED_CHECK_ARG(aux, MAED_ERR_ARG, "gemm_nt: ADD epilogue needs aux");
+            rc = dispatch<MAED_EPI_ADD>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
         default: maed_set_error("gemm_nt: bad epilogue %d", epilogue); return MAED_ERR_ARG;
     }
     if (rc != MAED_OK) return rc;

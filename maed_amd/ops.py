@@ -576,9 +576,11 @@ class Conv1x1Fn(torch.autograd.Function):
     2.31 ms, input gradient 1.26 vs 1.80 ms, weight gradient 2.21 vs 2.67 ms per step."""
 
     @staticmethod
-    def forward(ctx, x, w, wt, dw):
+    def forward(ctx, x, w, wt, dw, fork=False):
         """x (N,I,H,W) channels_last; w (O,I,1,1) standardised weight (an output of WeightStdFn: the autograd edge orders
-        its backward after ours); wt (I,O) transposed image; dw (O,I) fp32 accumulator (None when no gradient is wanted)"""
+        its backward after ours); wt (I,O) transposed image; dw (O,I) fp32 accumulator (None when no gradient is wanted).
+        fork=True additionally returns an alias of x for the block's identity shortcut: its gradient then arrives HERE and is
+        added inside the input-gradient GEMM's epilogue (MAED_EPI_ADD) instead of by a separate autograd accumulation kernel."""
         N, I, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)
         O = w.shape[0]
@@ -588,16 +590,27 @@ class Conv1x1Fn(torch.autograd.Function):
         y = gemm_nt(A, w2, L.EPI_STORE)
         ctx.save_for_backward(A, wt)
         ctx.dw, ctx.geom = dw, (N, I, H, W, O)
-        return y.view(N, H, W, O).permute(0, 3, 1, 2)
+        ctx.set_materialize_grads(False)
+        y = y.view(N, H, W, O).permute(0, 3, 1, 2)
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_short=None):
         A, wt = ctx.saved_tensors
         N, I, H, W, O = ctx.geom
+        dx = None
+        if dy is None:              # only the shortcut carried a gradient
+            return g_short, None, None, None, None
         Y = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(N * H * W, O)
-        dx = gemm_nt(Y, wt, L.EPI_STORE).view(N, H, W, I).permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[0]:
+            if g_short is not None:
+                G = g_short.contiguous(memory_format=torch.channels_last).to(Y.dtype).permute(0, 2, 3, 1).reshape(N * H * W, I)
+                dx = gemm_nt(Y, wt, L.EPI_ADD, aux=G)
+            else:
+                dx = gemm_nt(Y, wt, L.EPI_STORE)
+            dx = dx.view(N, H, W, I).permute(0, 3, 1, 2)
         if ctx.dw is not None:
             gemm_tn_wgrad(Y, A, dW=ctx.dw)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 

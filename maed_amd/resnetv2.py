@@ -49,12 +49,14 @@ class StdConv2dSame(nn.Conv2d):
     _w_t = None    # 1x1 stride-1 convolutions in bf16 mode: transposed standardised weight (I, O) -> the GEMM path
     _dw = None     # ... and the fp32 slice their weight gradient accumulates into
 
-    def forward(self, x):
+    def forward(self, x, fork=False):
+        """fork=True (GEMM convolutions only): returns (conv(x), alias of x) -- see ops.Conv1x1Fn"""
         w = self._w_std
         if w is not None and self._w_t is not None:
             # 1x1, stride 1, bf16: three GEMMs on libmaed_hip instead of MIOpen's implicit-GEMM solvers (which zero-fill the
             # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
-            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw)
+            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork)
+        assert not fork
         if w is None:  # stand-alone use / CPU: per-conv ATen composition
             w = self.get_weight().to(x.dtype)
             if x.is_cuda:
@@ -132,8 +134,13 @@ class Bottleneck(nn.Module):
         self.drop_path = nn.Identity()
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        x = self.norm1(self.conv1(x))
+        if self.downsample is None and self.conv1._w_t is not None and torch.is_grad_enabled() and x.requires_grad:
+            # identity shortcut + GEMM convolution: the shortcut's gradient is added inside conv1's input-gradient GEMM
+            y, shortcut = self.conv1(x, fork=True)
+            x = self.norm1(y)
+        else:
+            shortcut = x if self.downsample is None else self.downsample(x)
+            x = self.norm1(self.conv1(x))
         x = self.norm2(self.conv2(x))
         return self.norm3(self.conv3(x), residual=shortcut, relu=True)   # GN + shortcut add + ReLU in one pass
 

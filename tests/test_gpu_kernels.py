@@ -446,3 +446,27 @@ def test_maxpool_same_3x3s2(dtype, N, C, H, W):
     y.backward(g.contiguous(memory_format=torch.channels_last))
     assert torch.equal(y.detach(), ref.detach())
     report(f"maxpool3s2_same bwd[{dtype},{N}x{C}x{H}x{W}]", xs.grad.float(), xr.grad.float(), rtol=0, atol=(0 if dtype == torch.float32 else 2e-2))
+
+
+def test_conv1x1_fork_adds_shortcut_gradient_in_epilogue():
+    """Conv1x1Fn(fork=True) hands out an alias of its input for the identity shortcut; the alias' gradient is added inside the
+    input-gradient GEMM (MAED_EPI_ADD) -- must equal dgrad + shortcut gradient."""
+    ops, _ = _ops()
+    N, I, O, H, W = 2, 128, 64, 9, 7
+    x = q(rnd(N, I, H, W, seed=5), torch.bfloat16)
+    w = q(rnd(O, I, 1, 1, seed=6, scale=I ** -0.5), torch.bfloat16)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    gy, gs = q(rnd(N, O, H, W, seed=7), torch.bfloat16), q(rnd(N, I, H, W, seed=8), torch.bfloat16)
+    (F.conv2d(xd, wd) * gy.double()).sum().backward()
+    ref = xd.grad + gs.double()
+    xg = x.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = w.to(DEV).bfloat16().requires_grad_(True)
+    y, xa = ops.Conv1x1Fn.apply(xg, wg, wg.detach().reshape(O, I).t().contiguous(), torch.zeros(O, I, device=DEV), True)
+    assert xa.data_ptr() == xg.data_ptr()
+    ((y * gy.to(DEV)).sum() + (xa * gs.to(DEV)).sum()).backward()
+    report("conv1x1 fork: dx = dgrad + shortcut gradient", xg.grad.float(), ref, **tol(torch.bfloat16, 2))
+    # shortcut only (main branch unused): the gradient passes through untouched
+    xg2 = x.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y2, xa2 = ops.Conv1x1Fn.apply(xg2, wg, wg.detach().reshape(O, I).t().contiguous(), None, True)
+    (xa2 * gs.to(DEV)).sum().backward()
+    assert torch.equal(xg2.grad, gs.to(DEV).to(xg2.grad.dtype))
