@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     const bool col_ok = c0 < cmax;                            // N, K are multiples of 8 (checked by the launcher); loop-invariant
     unsigned short* my_lds_base = &lds[0][side][0];
     const int wr_off = (nc * 8) * TN_LD + ((mg ^ (nc & 7)) << 3);   // row (nc*8 + j), swizzled 16-B slot mg ^ ((row>>3)&7)
-    const bool do_bias = (dbias != nullptr) && (tile_k == 0) && (side == 0);   // wave-uniform
+    // the column sums of a Y tile are needed once per (N-tile, M-split): the K-tile that takes them rotates with the split
+    // index so the extra VALU work is spread over all workgroups instead of making the K-tile-0 ones stragglers
+    const bool bias_blk = (dbias != nullptr) && (tile_k == (int)(blockIdx.z % tiles_k));   // block-uniform
+    const bool do_bias = bias_blk && (side == 0);   // wave-uniform
     float cs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[j] = 0.f;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
             if (nrow < N && kcol < K) atomicAdd(dW + (int64_t)nrow * ldw + kcol, acc_[r]); } }
     TN_EPI(acc00, 0, 0) TN_EPI(acc01, 0, 1) TN_EPI(acc10, 1, 0) TN_EPI(acc11, 1, 1)
 
-    if (dbias != nullptr && tile_k == 0) {   // block-uniform branch
+    if (bias_blk) {   // block-uniform branch
         if (side == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) lcs[mg][nc * 8 + j] = cs[j];

@@ -572,8 +572,8 @@ class Conv1x1Fn(torch.autograd.Function):
     input gradient = maed_gemm_nt on its transposed image (I, O) (both written by the batched weight-standardisation
     kernel), weight gradient = maed_gemm_tn_wgrad accumulating in fp32 straight into the slice the weight-standardisation
     backward reads -- no output zero-fill, no fp32-workspace cast passes, no transposed activation copies.
-    Measured against MIOpen's asm implicit-GEMM solvers at cfg3 (profiles/r01_conv1x1_micro.txt): forward 1.35 vs
-    2.31 ms, input gradient 1.26 vs 1.80 ms, weight gradient 2.21 vs 2.67 ms per step."""
+    Measured against MIOpen's asm implicit-GEMM solvers at cfg3 (profiles/r01_conv1x1_micro.txt, r01_wgrad_micro.txt):
+    forward 1.01 vs 2.33 ms, input gradient 1.02 vs 1.88 ms, weight gradient 1.47 vs 2.63 ms per step."""
 
     @staticmethod
     def forward(ctx, x, w, wt, dw, fork=False):
