@@ -134,9 +134,12 @@ class Bottleneck(nn.Module):
         self.drop_path = nn.Identity()
 
     def forward(self, x):
-        if self.downsample is None and self.conv1._w_t is not None and torch.is_grad_enabled() and x.requires_grad:
-            # identity shortcut + GEMM convolution: the shortcut's gradient is added inside conv1's input-gradient GEMM
-            y, shortcut = self.conv1(x, fork=True)
+        if self.conv1._w_t is not None and torch.is_grad_enabled() and x.requires_grad:
+            # x feeds conv1 AND the shortcut (identity or downsample): conv1 (a GEMM convolution) hands out an alias of x for
+            # the shortcut, so the shortcut branch's gradient is added inside conv1's input-gradient GEMM epilogue instead of
+            # by a separate autograd accumulation kernel
+            y, xa = self.conv1(x, fork=True)
+            shortcut = xa if self.downsample is None else self.downsample(xa)
             x = self.norm1(y)
         else:
             shortcut = x if self.downsample is None else self.downsample(x)
