@@ -232,6 +232,7 @@ class WeightCache:
     def get(self, weights, dtype):
         if self._make_key(weights, dtype) != self._key:
             self._weights, self._dtype = list(weights), dtype
+            WeightCache._registry.add(self)     # (copy.deepcopy / unpickling create caches without running __init__)
             WeightCache._refresh_group(self)
         return self._val
 

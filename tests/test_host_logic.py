@@ -198,3 +198,71 @@ def test_param_arena_views_and_order():
     assert covered[0][0] == 0 and covered[-1][1] == arena.numel
     assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
     assert sum(n for _, _, n in b.buckets) == len(arena.params)
+
+
+class _StubMAED(torch.nn.Module):
+    """CPU stand-in with MAED's output contract (clip (N,T,3,H,W) -> dict of (N,T,...) tensors): the train-step logic under test is
+    model-agnostic, and the real STE has no CPU path by design"""
+
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Linear(3, 16)
+        self.dec = torch.nn.Linear(16, 49 * 2 + 49 * 3 + 85)
+        self.register_buffer("smpl_like", torch.zeros(3))
+
+    def forward(self, x, J_regressor=None):
+        N, T = x.shape[:2]
+        o = self.dec(torch.tanh(self.enc(x.mean(dim=(-1, -2)))))
+        return dict(kp_2d=o[..., :98].reshape(N, T, 49, 2), kp_3d=o[..., 98:245].reshape(N, T, 49, 3), theta=o[..., 245:])
+
+
+def test_train_step_semantics_and_checkpoint_format(tmp_path):
+    """maed_amd.trainer.TrainStep == lib/core/trainer.py:159-204,240-262 (video forward over cat(2D clips, 3D clips), image
+    forward with T = 1, frame-count weights, one backward, merge_loss), and checkpoints in the reference's layout
+    (trainer.py:330-368): 'module.'-prefixed state_dict + torch.optim.Adam-style optimizer state."""
+    import copy
+    from maed_amd.loss import Loss
+    from maed_amd.trainer import TrainStep, load_checkpoint, save_checkpoint
+    torch.manual_seed(0)
+    model = _StubMAED()
+    crit = Loss(device="cpu")
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g)
+    T = 2
+    t2d = dict(images=r(1, T, 3, 8, 8), kp_2d=torch.cat([r(1, T, 49, 2), torch.rand(1, T, 49, 1, generator=g)], -1))
+    t3d = dict(images=r(2, T, 3, 8, 8), kp_2d=torch.cat([r(2, T, 49, 2), torch.ones(2, T, 49, 1)], -1),
+               kp_3d=torch.cat([r(2, T, 49, 3), torch.ones(2, T, 49, 1)], -1), theta=r(2, T, 85) * 0.2, w_smpl=torch.tensor([[1., 0.], [1., 1.]]))
+    timg = dict(image=r(3, 3, 8, 8), kp_2d=torch.cat([r(3, 49, 2), torch.ones(3, 49, 1)], -1), theta=r(3, 85) * 0.2, w_smpl=torch.ones(3),
+                kp_3d=torch.cat([r(3, 49, 3), torch.ones(3, 49, 1)], -1))
+    # expected, spelled out as the reference does it
+    ref = copy.deepcopy(model)
+    lv, dv = crit(preds=ref(torch.cat((t2d["images"], t3d["images"]), 0)), target_3d=t3d, target_2d=t2d)
+    li, di = crit(preds=ref(timg["image"].unsqueeze(1)), target_img=timg)
+    nt_vid, nt_img = 3 * T, 3
+    w_vid = nt_vid / (nt_img + nt_vid)
+    (li * (1 - w_vid) + lv * w_vid).backward()
+    exp_total, exp_terms = crit.merge_loss(lv, dv, li, di, vid_w=w_vid, img_w=1 - w_vid)
+    opt = torch.optim.Adam([{"params": p, "name": n} for n, p in model.named_parameters()], lr=1e-3)    # utils.py:127-132
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    total, terms = TrainStep(model, crit, opt)(target_2d=t2d, target_3d=t3d, target_img=timg)
+    assert torch.allclose(total, exp_total) and terms.keys() == exp_terms.keys()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-8), n
+    assert all(not torch.equal(before[n], p) for n, p in model.named_parameters()), "the optimizer stepped"
+    # video-only and image-only iterations (img_use_freq > 1: trainer.py:148)
+    tot_v, _ = TrainStep(model, crit, opt)(target_3d=t3d)
+    tot_i, _ = TrainStep(model, crit, opt)(target_img=timg)
+    assert torch.isfinite(tot_v) and torch.isfinite(tot_i)
+    # checkpoint layout
+    path = str(tmp_path / "epoch_1.pth.tar")
+    save_checkpoint(path, model, opt, epoch=1, performance=55.5)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"epoch", "state_dict", "performance", "optimizer"} and all(k.startswith("module.") for k in ck["state_dict"])
+    assert [gr["name"] for gr in ck["optimizer"]["param_groups"]] == [n for n, _ in model.named_parameters()]
+    fresh = _StubMAED()
+    fopt = torch.optim.Adam([{"params": p, "name": n} for n, p in fresh.named_parameters()], lr=1e-3)
+    epoch, perf = load_checkpoint(path, fresh, fopt)
+    assert (epoch, perf) == (1, 55.5)
+    for (n, p), (_, q) in zip(fresh.named_parameters(), model.named_parameters()):
+        assert torch.equal(p, q), n
+    assert len(fopt.state_dict()["state"]) == len(opt.state_dict()["state"])
