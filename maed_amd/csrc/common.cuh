@@ -8,6 +8,17 @@
 
 #define HEAD_DIM 64
 
+// the two places where kernels speak raw ISA; tests/hostsim (x86 build of the same sources) substitutes no-ops / plain pointers
+#ifdef MAED_HOSTSIM
+#define MAED_WAIT_VMCNT0() do { } while (0)
+typedef void maed_lds_void_t;
+typedef const void maed_glb_void_t;
+#else
+#define MAED_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+typedef __attribute__((address_space(3))) void maed_lds_void_t;
+typedef const __attribute__((address_space(1))) void maed_glb_void_t;
+#endif
+
 // dynamic LDS of a kernel (the host simulator of tests/hostsim substitutes its own definition)
 #ifndef MAED_DYN_SHARED
 #define MAED_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]

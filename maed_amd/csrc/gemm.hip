@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* _
 //   NBUF == 2: 64 KB LDS, tile t+1 lands while tile t is multiplied, one barrier per K tile
 // ------------------------------------------------------------------------------------------------
 #define GL_ST 68   // fp32 row stride of the epilogue staging area: 272 B -> conflict-free ds_write_b128 per 16-lane group
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
+typedef maed_lds_void_t lds_void_t;
+typedef maed_glb_void_t glb_void_t;
 
 template <int EPI, int NBUF>
 __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_kernel(const bf16* __restrict__ A, int64_t lda,
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
     if constexpr (NBUF == 1) {
         for (int kt = kt_beg; kt < kt_end; ++kt) {
             GL_ISSUE_TILE(0, kt);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MAED_WAIT_VMCNT0();
             __syncthreads();
             GL_COMPUTE_TILE(0);
             __syncthreads();
@@ -406,12 +406,12 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
     } else {
         GL_ISSUE_TILE(0, kt_beg);
         for (int kt = kt_beg; kt < kt_end; kt += 2) {      // two tiles per trip: the buffer index is static
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MAED_WAIT_VMCNT0();
             __syncthreads();                                // tile kt landed for every wave; buffer 1 is free again
             if (kt + 1 < kt_end) GL_ISSUE_TILE(NBUF - 1, kt + 1);
             GL_COMPUTE_TILE(0);
             if (kt + 1 < kt_end) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MAED_WAIT_VMCNT0();
                 __syncthreads();
                 if (kt + 2 < kt_end) GL_ISSUE_TILE(0, kt + 2);
                 GL_COMPUTE_TILE(NBUF - 1);

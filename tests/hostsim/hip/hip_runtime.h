@@ -52,7 +52,10 @@ struct WaveCtx {
     std::barrier<> bar;
     float fx[64];
     float fa[64], fb[64];
-    explicit WaveCtx(int n) : bar(n) {}
+    float ha[64][8], hb[64][8];     // bf16 MFMA operands, widened
+    uint64_t u64[64];               // ballot / readfirstlane / LDS-DMA base exchange
+    int live;                       // threads of this wave that exist (the last wave of a block may be partial)
+    explicit WaveCtx(int n) : bar(n), live(n) {}
 };
 struct BlockCtx {
     std::barrier<> bar;
@@ -129,6 +132,55 @@ static inline hostsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float
     w.bar.arrive_and_wait();
     return acc;
 }
+
+typedef __bf16 hostsim_bf16x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_bf16: A[i][k] = lane (k/8)*32 + i, element k%8;  B[k][j] = lane (k/8)*32 + j, element k%8;  D as above
+static inline hostsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hostsim_bf16x8 a, hostsim_bf16x8 b, hostsim_f32x16 acc, int, int, int) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    for (int e = 0; e < 8; ++e) { w.ha[lane][e] = (float)a[e]; w.hb[lane][e] = (float)b[e]; }
+    w.bar.arrive_and_wait();
+    const int j = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float s = acc[r];
+        for (int kg = 0; kg < 2; ++kg)
+            for (int e = 0; e < 8; ++e) s = fmaf(w.ha[kg * 32 + i][e], w.hb[kg * 32 + j][e], s);
+        acc[r] = s;
+    }
+    w.bar.arrive_and_wait();
+    return acc;
+}
+
+// wave-uniform value of the first live lane
+static inline int __builtin_amdgcn_readfirstlane(int v) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    if (lane == 0) w.u64[0] = (uint64_t)(uint32_t)v;
+    w.bar.arrive_and_wait();
+    const int r = (int)(uint32_t)w.u64[0];
+    w.bar.arrive_and_wait();
+    return r;
+}
+// global_load_lds_dwordx4: every lane's 16 bytes land at (lane 0's LDS pointer) + lane * size
+static inline void __builtin_amdgcn_global_load_lds(const void* gptr, void* lds_ptr, unsigned size, int offset, unsigned) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    if (lane == 0) w.u64[1] = (uint64_t)(uintptr_t)lds_ptr;
+    w.bar.arrive_and_wait();
+    memcpy((char*)(uintptr_t)w.u64[1] + (size_t)lane * size + offset, (const char*)gptr + offset, size);
+    w.bar.arrive_and_wait();
+}
+// v_perm_b32: byte select from the 8-byte pool {src0 (bytes 7..4), src1 (bytes 3..0)}; selector values 0..7 only (what the kernels use)
+static inline uint32_t __builtin_amdgcn_perm(uint32_t src0, uint32_t src1, uint32_t sel) {
+    const uint64_t pool = ((uint64_t)src0 << 32) | src1;
+    uint32_t r = 0;
+    for (int b = 0; b < 4; ++b) r |= (uint32_t)((pool >> (8 * ((sel >> (8 * b)) & 7))) & 0xff) << (8 * b);
+    return r;
+}
+static inline void __builtin_amdgcn_s_barrier() { hostsim::t_block->bar.arrive_and_wait(); }
+#define hipFuncAttributeMaxDynamicSharedMemorySize 0
+template <typename K> static inline hipError_t hipFuncSetAttribute(K, int, int) { return hipSuccess; }
 
 template <typename T> static inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }
 

@@ -1,0 +1,84 @@
+"""The bf16 MFMA GEMM kernels (maed_amd/csrc/gemm.hip, gemm_tn.hip) on the host simulator: the x86 build of the same sources
+with v_mfma_f32_32x32x16_bf16, global_load_lds_dwordx4, v_perm_b32 and the LDS swizzles emulated lane for lane
+(tests/hostsim/hip/hip_runtime.h).  Checks fragment layouts, swizzle algebra, the LDS-shuffled epilogue, ragged edges and
+every fused epilogue against torch on the bf16-rounded operands -- without a GPU."""
+import pytest
+import torch
+
+from maed_amd import _lib as L
+from maed_amd import ops
+
+from _hostsim import patched
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / 2 ** 0.5))
+
+
+def dgelu(x):
+    return 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+
+
+@pytest.mark.parametrize("impl", [L.IMPL_MFMA, 3, 4])      # register-staged, direct-to-LDS with one / two buffers
+@pytest.mark.parametrize("M,N,K", [(130, 136, 128), (64, 256, 64)])
+def test_gemm_nt_store_variants(impl, M, N, K):
+    A, B, bias = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=K ** -0.5).bfloat16(), rnd(N, seed=3)
+    ref = A.float() @ B.float().t() + bias
+    with patched():
+        out = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias, impl=impl)
+    assert torch.allclose(out.float(), ref, rtol=2e-2, atol=2e-2)
+    assert (out.float() - ref.bfloat16().float()).abs().max() <= 2 * 2 ** -8 * ref.abs().max()
+
+
+@pytest.mark.parametrize("epi", ["gelu", "resid", "dgelu", "store_f32", "tanh", "add"])
+def test_gemm_nt_fused_epilogues(epi):
+    M, N, K = 96, 200, 128                      # ragged M tile, N not a multiple of 8*... (exercises the scalar epilogue tail)
+    A, B, bias = rnd(M, K, seed=4).bfloat16(), rnd(N, K, seed=5, scale=K ** -0.5).bfloat16(), rnd(N, seed=6)
+    acc = A.float() @ B.float().t()
+    with patched():
+        if epi == "gelu":
+            out, pre = ops.gemm_nt(A, B, L.EPI_GELU, bias=bias)
+            want_pre = (acc + bias).bfloat16()
+            assert torch.allclose(pre.float(), want_pre.float(), atol=2e-2)
+            assert torch.allclose(out.float(), gelu(pre.float()), rtol=2e-2, atol=2e-2)     # activation of the STORED pre-activation
+        elif epi == "resid":
+            aux = rnd(M, N, seed=7)
+            out = ops.gemm_nt(A, B, L.EPI_RESID_F32, bias=bias, aux=aux)
+            assert out.dtype == torch.float32 and torch.allclose(out, aux + acc + bias, rtol=1e-4, atol=1e-4)
+        elif epi == "dgelu":
+            aux = rnd(M, N, seed=8).bfloat16()
+            out = ops.gemm_nt(A, B, L.EPI_MUL_DGELU, aux=aux)
+            assert torch.allclose(out.float(), acc * dgelu(aux.float()), rtol=3e-2, atol=3e-2)
+        elif epi == "store_f32":
+            out = ops.gemm_nt(A, B, L.EPI_STORE_F32, bias=bias)
+            assert torch.allclose(out, acc + bias, rtol=1e-4, atol=1e-4)
+        elif epi == "tanh":
+            out = ops.gemm_nt(A, B, L.EPI_TANH, bias=bias)
+            assert torch.allclose(out.float(), torch.tanh(acc + bias), atol=1e-2)
+        else:
+            aux = rnd(M, N, seed=9).bfloat16()
+            out = ops.gemm_nt(A, B, L.EPI_ADD, aux=aux)
+            assert torch.allclose(out.float(), acc + aux.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_gemm_nt_splitk_atomic():
+    M, N, K = 70, 128, 256
+    A, B = rnd(M, K, seed=10).bfloat16(), rnd(N, K, seed=11, scale=K ** -0.5).bfloat16()
+    with patched():
+        out = ops.gemm_nt(A, B, L.EPI_ATOMIC_F32, splitk=2)
+    assert torch.allclose(out, A.float() @ B.float().t(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 72), (64, 128, 128), (37, 8, 8), (130, 64, 256)])
+def test_gemm_tn_wgrad_and_bias(M, N, K):
+    Y, X = rnd(M, N, seed=12).bfloat16(), rnd(M, K, seed=13).bfloat16()
+    dW0, db0 = rnd(N, K, seed=14), rnd(N, seed=15)
+    dW, db = dW0.clone(), db0.clone()
+    with patched():
+        ops.gemm_tn_wgrad(Y, X, dW=dW, dbias=db)          # ACCUMULATES into dW / dbias
+    assert torch.allclose(dW, dW0 + Y.float().t() @ X.float(), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(db, db0 + Y.float().sum(0), rtol=1e-4, atol=1e-3)
