@@ -36,7 +36,7 @@ __device__ __forceinline__ void stage_rows_f32(float* dst, int ldd, const T* src
 template <typename T>
 __global__ __launch_bounds__(256) void attn_sp_fwd_valu(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
                                                         int P, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    MAED_DYN_SHARED(float, sm);
     float* Ks = sm; float* Vs = sm + (size_t)P * LDF;
     const int f = blockIdx.x / H, h = blockIdx.x % H;
     const int C = H * D;
@@ -77,7 +77,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_sp_bwd_dq_valu(const T* __restrict__ qkv, const T* __restrict__ o,
                                                            const T* __restrict__ d_o, const float* __restrict__ lse,
                                                            T* __restrict__ dqkv, int accumulate, int P, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    MAED_DYN_SHARED(float, sm);
     float* Ks = sm; float* Vs = sm + (size_t)P * LDF;
     const int f = blockIdx.x / H, h = blockIdx.x % H;
     const int C = H * D;
@@ -123,7 +123,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_sp_bwd_dkv_valu(const T* __restrict__ qkv, const T* __restrict__ o,
                                                             const T* __restrict__ d_o, const float* __restrict__ lse,
                                                             T* __restrict__ dqkv, int accumulate, int P, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    MAED_DYN_SHARED(float, sm);
     float* Qs = sm; float* dOs = sm + (size_t)P * LDF; float* Ls = dOs + (size_t)P * LDF; float* Ds = Ls + P;
     const int f = blockIdx.x / H, h = blockIdx.x % H;
     const int C = H * D;
@@ -207,7 +207,7 @@ __device__ __forceinline__ int attn_xcd_remap(int bid, int nwg) {
 
 __global__ __launch_bounds__(1024) void attn_sp_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                          float* __restrict__ lse, int P, int H, float scale_log2e) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    MAED_DYN_SHARED(unsigned short, smem);
     const int Pk = (P + 31) & ~31;
     const int VLD = Pk + 4;                        // V^T row stride (elements): (Pk+4)/2 dwords = 2*odd -> conflict-free b64
     // K rows are stored UNPADDED (128 B) with the 16-B chunk index XOR-swizzled by (row>>1)&7: a ds_read_b128 of 16
@@ -413,7 +413,7 @@ __device__ __forceinline__ void store_rowT(bf16* row, const f32x16_t (&acc)[2], 
 __global__ __launch_bounds__(640) void attn_sp_bwd_dq_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                             const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                             bf16* __restrict__ dqkv, int accumulate, int P, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    MAED_DYN_SHARED(unsigned short, smem);
     const int Pk = (P + 31) & ~31, VLD = Pk + 4;
     unsigned short* Ks = smem;
     unsigned short* Vs = Ks + (size_t)P * KLD;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(640) void attn_sp_bwd_dq_mfma(const bf16* __restric
 __global__ __launch_bounds__(640) void attn_sp_bwd_dkv_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                              const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                              bf16* __restrict__ dqkv, int accumulate, int P, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    MAED_DYN_SHARED(unsigned short, smem);
     const int Pk = (P + 31) & ~31, VLD = Pk + 4;
     unsigned short* Qs = smem;
     unsigned short* dOs = Qs + (size_t)P * KLD;

@@ -176,7 +176,7 @@ __device__ __forceinline__ void stage_group_rows(char* dst, const T* src_base, i
 template <typename T>
 __global__ __launch_bounds__(256) void attn_tm_fwd_lds(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
                                                        int P, int H, int Tn, int GP, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char sm[];
+    MAED_DYN_SHARED(char, sm);
     const int C = H * D; const int64_t ld = 3 * (int64_t)C;
     const int chunks = (P + GP - 1) / GP;
     const int pc = blockIdx.x % chunks; int r0 = blockIdx.x / chunks;
@@ -256,7 +256,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_tm_bwd_lds(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
                                                        const float* __restrict__ lse, T* __restrict__ dqkv, int accumulate,
                                                        int P, int H, int Tn, int GP, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char sm[];
+    MAED_DYN_SHARED(char, sm);
     const int C = H * D; const int64_t ld = 3 * (int64_t)C;
     const int chunks = (P + GP - 1) / GP;
     const int pc = blockIdx.x % chunks; int r0 = blockIdx.x / chunks;

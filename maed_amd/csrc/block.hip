@@ -247,4 +247,8 @@ void maed_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* maed_last_error(void) { return g_err; }
+#ifdef MAED_HOSTSIM
+extern "C" int maed_version(void) { return -100; }   // x86 build for tests/hostsim: never the product library
+#else
 extern "C" int maed_version(void) { return 100; }
+#endif

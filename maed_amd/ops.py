@@ -273,11 +273,19 @@ class WeightCache:
 _SCRATCH = {}
 
 
+def _aligned_bytes(nbytes, device, align=256):
+    """uint8 buffer whose data pointer is `align`-byte aligned (the block kernels carve 256-B aligned sub-buffers out of it;
+    the HIP caching allocator already aligns to 512 B, a host allocation -- tests/hostsim -- does not)"""
+    buf = torch.empty(nbytes + align, dtype=torch.uint8, device=device)
+    off = (-buf.data_ptr()) % align
+    return buf[off:off + nbytes]
+
+
 def _scratch(nbytes, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _stream())
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        buf = _aligned_bytes(nbytes, device)
         _SCRATCH[key] = buf
     return buf
 
@@ -354,7 +362,7 @@ class STEBlockFn(torch.autograd.Function):
         x = _c(x)
         d = L.BlockDims(*dims)
         pr = block._c_params(x.dtype if False else block.compute_dtype)
-        saved = torch.empty(lib.maed_ste_block_saved_bytes(C.byref(d)), dtype=torch.uint8, device=x.device)
+        saved = _aligned_bytes(lib.maed_ste_block_saved_bytes(C.byref(d)), x.device)
         y = torch.empty_like(x)
         check(lib.maed_ste_block_fwd(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _stream()), "ste_block_fwd")
         ctx.block, ctx.dims = block, dims

@@ -179,6 +179,12 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t src0, uint32_t src1, uint3
     return r;
 }
 static inline void __builtin_amdgcn_s_barrier() { hostsim::t_block->bar.arrive_and_wait(); }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 0
 template <typename K> static inline hipError_t hipFuncSetAttribute(K, int, int) { return hipSuccess; }
 
@@ -191,6 +197,8 @@ static inline int64_t max(int64_t a, int64_t b) { return a > b ? a : b; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 #define __expf(x) expf(x)
+#define __logf(x) logf(x)
+#define __log2f(x) log2f(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }

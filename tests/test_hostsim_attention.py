@@ -1,0 +1,91 @@
+"""Attention kernels (maed_amd/csrc/attn_spatial.hip incl. the MFMA forward and both MFMA backward passes, attn_temporal.hip)
+and the whole fused STE Block (block.hip: LayerNorm, GEMMs, both attentions, attentive addition, MLP -- 11 launches forward,
+~20 backward) on the host simulator against fp64 autograd through the CPU oracle.  Same comparisons as the `-m gpu` suite at
+sizes a CPU finishes in seconds; the simulator emulates the MFMA fragment layouts lane for lane, so a wrong layout, swizzle
+or k-slot permutation fails HERE."""
+import pytest
+import torch
+
+from oracle import maed_ref as R
+from maed_amd import _lib as L
+from maed_amd import ops
+
+from _hostsim import patched
+from _util import q, rnd, tol
+
+CASES = [("f32-valu", torch.float32, 1), ("bf16-valu", torch.bfloat16, 1), ("bf16-mfma", torch.bfloat16, 2)]
+
+
+def close(got, ref, rtol, atol):
+    assert torch.allclose(got.double(), ref.double(), rtol=rtol, atol=atol), (got.double() - ref.double()).abs().max().item()
+
+
+@pytest.mark.parametrize("name,dtype,impl", CASES)
+@pytest.mark.parametrize("Fr,P,H", [(2, 5, 2), (1, 70, 1), (1, 197, 1)])
+def test_attn_spatial_fwd_bwd(name, dtype, impl, Fr, P, H):
+    if P == 197 and impl != 2:
+        pytest.skip("the long case is for the MFMA path (7 key tiles, masked last tile)")
+    qkv = q(rnd(Fr, P, 3 * 64 * H, seed=P), dtype)
+    do = q(rnd(Fr, P, 64 * H, seed=4), dtype)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_spatial(qq, kk, vv, 64 ** -0.5)
+    lse_ref = torch.logsumexp((qq @ kk.transpose(-2, -1)) * 64 ** -0.5, dim=-1)
+    oref.backward(do.double())
+    with patched():
+        o, lse = ops.attn_spatial_fwd(qkv.to(dtype), H, impl)
+        dqkv = ops.attn_spatial_bwd(qkv.to(dtype), o, do.to(dtype), lse, H, impl=impl)
+    t = tol(dtype)
+    close(o.float(), oref.detach(), **t)
+    close(lse, lse_ref.detach(), rtol=1e-4, atol=1e-3 if dtype == torch.float32 else 2e-2)
+    close(dqkv.float(), x.grad, **tol(dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,T,P,H", [(2, 3, 5, 2), (1, 16, 9, 1), (1, 64, 3, 1)])
+def test_attn_temporal_fwd_bwd(dtype, N, T, P, H):
+    Fr = N * T
+    qkv = q(rnd(Fr, P, 3 * 64 * H, seed=5), dtype)
+    do = q(rnd(Fr, P, 64 * H, seed=6), dtype)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_temporal(qq, kk, vv, T, 64 ** -0.5)
+    oref.backward(do.double())
+    with patched():
+        o, lse = ops.attn_temporal_fwd(qkv.to(dtype), H, T)
+        dqkv = ops.attn_temporal_bwd(qkv.to(dtype), o, do.to(dtype), lse, H, T)
+    close(o.float(), oref.detach(), **tol(dtype))
+    close(dqkv.float(), x.grad, **tol(dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype,impl", [(torch.float32, 0), (torch.bfloat16, 0)])      # f32 parity mode, bf16 MFMA throughput mode
+def test_ste_block_forward_backward_vs_oracle(dtype, impl):
+    """one whole Block through maed_ste_block_fwd/bwd (vision_transformer.py:244-261) incl. every parameter gradient"""
+    from functools import partial
+    import torch.nn as nn
+    from maed_amd.vision_transformer import Block
+    N, T, P, H = 1, 2, 9, 2
+    C, Fr = 64 * H, N * T
+    p = {k[len("encoder.blocks.0."):]: v for k, v in R.make_params(embed_dim=C, depth=1, hidden_dim=64, layers=(1, 1, 1), n_tokens=P, seed=3).items()
+         if k.startswith("encoder.blocks.0.")}
+    p = {k: v * (3.0 if k.endswith("weight") and v.dim() == 2 else 1.0) for k, v in p.items()}
+    x, dy = rnd(Fr, P, C, seed=1), rnd(Fr, P, C, seed=2)
+    pd = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    xr = x.double().requires_grad_(True)
+    yref = R.block(xr, pd, "", H, T)
+    yref.backward(dy.double())
+    blk = Block(C, H, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", compute_dtype=dtype, impl=impl)
+    blk.load_state_dict(p)
+    xg = x.clone().requires_grad_(True)
+    with patched():
+        y = blk(xg, T)
+        y.backward(dy)
+    f32 = dtype == torch.float32
+    tl = dict(rtol=1e-4, atol=1e-4) if f32 else dict(rtol=3e-2, atol=3e-2)
+    close(y.detach(), yref.detach(), **tl)
+    close(xg.grad, xr.grad, **tl)
+    for name, prm in blk.named_parameters():
+        ref = pd[name].grad
+        scale = max(ref.abs().max().item(), 1e-3)
+        assert prm.grad is not None, name
+        close(prm.grad, ref, rtol=1e-3 if f32 else 5e-2, atol=(1e-4 if f32 else 3e-2) * scale)
