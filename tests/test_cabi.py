@@ -28,7 +28,11 @@ def test_header_declares_the_survey_minimum_set():
     for need in ["maed_layernorm_fwd", "maed_layernorm_bwd", "maed_gemm_nt", "maed_attn_spatial_fwd", "maed_attn_spatial_bwd",
                  "maed_attn_temporal_fwd", "maed_attn_temporal_bwd", "maed_st_mix_fwd", "maed_st_mix_bwd_apply", "maed_embed_add_fwd",
                  "maed_embed_add_bwd", "maed_ste_block_fwd", "maed_ste_block_bwd", "maed_ktd_chain_fwd", "maed_rot6d_pose_fwd",
-                 "maed_smpl_lbs_fwd", "maed_joint_regress_fwd", "maed_smpl_joints_project_fwd", "maed_adam_step", "maed_last_error"]:
+                 "maed_smpl_lbs_fwd", "maed_joint_regress_fwd", "maed_smpl_joints_project_fwd", "maed_adam_step", "maed_last_error",
+                 # SURVEY 8(b) backward / comm entries and the 8(f) rank-1 loss
+                 "maed_ktd_chain_bwd", "maed_rot6d_pose_bwd", "maed_smpl_skin_bwd", "maed_smpl_chain_bwd", "maed_smpl_joints_project_bwd",
+                 "maed_gemm_tn_wgrad", "maed_groupnorm_fwd", "maed_groupnorm_bwd", "maed_weight_std_fwd", "maed_weight_std_bwd",
+                 "maed_loss_fwd_bwd", "maed_comm_init", "maed_comm_allreduce_async", "maed_comm_wait", "maed_comm_destroy"]:
         assert need in names, need
 
 
