@@ -283,10 +283,12 @@ int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int 
  * sums_zeroed / ab_zeroed != 0: the caller hands in scratch that is already zero (one memset for all 52 layers of a
  * backbone pass instead of one per layer). */
 int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
-                       int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream);
-/* dx (and dres = masked dy when dres != NULL); dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats;
- * y (the saved forward output) is needed only for relu with a residual, otherwise the mask is recomputed from x */
-int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, const float* beta,
+                       uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream);
+/* relu_mask (N*HW*C/8 bytes, bit j of byte (n,hw,c/8) = output channel 8*(c/8)+j > 0): written by forward when a residual is
+ * added before the ReLU (optional: inference passes NULL), required by backward in that case -- without a residual the mask is
+ * recomputed from x.  16x less traffic than re-reading the saved output in both backward passes.
+ * dx (and dres = masked dy when dres != NULL); dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats */
+int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
                        int relu, int dtype, int ab_zeroed, void* stream);
 

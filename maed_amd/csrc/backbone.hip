@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 template <typename T, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const double* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
-                                                       int HW, int C, float eps, int rows_per_wg) {
+                                                       uint8_t* __restrict__ mask, int HW, int C, float eps, int rows_per_wg) {
     __shared__ float lmu[GN_G], lrs[GN_G];
     const int n = blockIdx.y;
     if (threadIdx.x < GN_G) {
@@ -194,6 +194,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += rr[j]; }
         if (RELU) {
+            if (RES && mask) {   // 1 bit per element for the backward (the ReLU mask cannot be recomputed from x once a residual was added)
+                uint32_t bits = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bits |= (o[j] > 0.f ? 1u : 0u) << j;
+                mask[((int64_t)n * HW + r) * cbn + cb] = (uint8_t)bits;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f); }
         st8(y + base + (int64_t)r * C, o);
@@ -201,9 +207,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ---- backward pass 1: ab[n][c] = (sum_hw dy_eff, sum_hw dy_eff * xhat); dgamma/dbeta accumulated here too ----
-// dy_eff = dy * (out > 0) when RELU; `out` is recomputed from x when there is no residual (YMASK=false), read from y otherwise
+// dy_eff = dy * (out > 0) when RELU; the mask is recomputed from x when there is no residual (YMASK=false), read from the forward's
+// 1-bit-per-element mask otherwise (16x less traffic than re-reading the saved output)
 template <typename T, bool RELU, bool YMASK>
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask, const T* __restrict__ dy,
                                                             const double* __restrict__ sums, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ ab /* [N][C][2] */,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -232,24 +239,29 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     {                                                                                                           \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) v_[j] = (v_[j] - mu[j]) * rs[j];   /* xhat */            \
         if (RELU) {                                                                                             \
-            if (YMASK) { _Pragma("unroll") for (int j = 0; j < 8; ++j) d_[j] = o_[j] > 0.f ? d_[j] : 0.f; }     \
+            if (YMASK) { _Pragma("unroll") for (int j = 0; j < 8; ++j) d_[j] = ((o_ >> j) & 1u) ? d_[j] : 0.f; }  \
             else { _Pragma("unroll") for (int j = 0; j < 8; ++j) d_[j] = fmaf(v_[j], ga[j], be[j]) > 0.f ? d_[j] : 0.f; } \
         }                                                                                                       \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) { sa[j] += d_[j]; sb[j] = fmaf(d_[j], v_[j], sb[j]); }    \
     }
     int r = r0 + rsub;
     for (; r + 3 * rstep < r1; r += 4 * rstep) {
-        float v0[8], v1[8], v2[8], v3[8], d0[8], d1[8], d2[8], d3[8], o0[8], o1[8], o2[8], o3[8];
+        float v0[8], v1[8], v2[8], v3[8], d0[8], d1[8], d2[8], d3[8];
+        uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
         const int64_t a0 = base + (int64_t)r * C, a1 = a0 + (int64_t)rstep * C, a2 = a1 + (int64_t)rstep * C, a3 = a2 + (int64_t)rstep * C;
         gn_load8(x + a0, v0); gn_load8(x + a1, v1); gn_load8(x + a2, v2); gn_load8(x + a3, v3);
         gn_load8(dy + a0, d0); gn_load8(dy + a1, d1); gn_load8(dy + a2, d2); gn_load8(dy + a3, d3);
-        if (RELU && YMASK) { gn_load8(y + a0, o0); gn_load8(y + a1, o1); gn_load8(y + a2, o2); gn_load8(y + a3, o3); }
+        if (RELU && YMASK) {
+            const int64_t m0 = ((int64_t)n * HW + r) * cbn + cb;
+            o0 = mask[m0]; o1 = mask[m0 + (int64_t)rstep * cbn]; o2 = mask[m0 + 2 * (int64_t)rstep * cbn]; o3 = mask[m0 + 3 * (int64_t)rstep * cbn];
+        }
         GN_RED_ROW(v0, d0, o0) GN_RED_ROW(v1, d1, o1) GN_RED_ROW(v2, d2, o2) GN_RED_ROW(v3, d3, o3)
     }
     for (; r < r1; r += rstep) {
-        float v[8], d[8], o[8];
+        float v[8], d[8];
+        uint32_t o = 0;
         gn_load8(x + base + (int64_t)r * C, v); gn_load8(dy + base + (int64_t)r * C, d);
-        if (RELU && YMASK) gn_load8(y + base + (int64_t)r * C, o);
+        if (RELU && YMASK) o = mask[((int64_t)n * HW + r) * cbn + cb];
         GN_RED_ROW(v, d, o)
     }
 #undef GN_RED_ROW
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
 
 // ---- backward pass 2: dx = rstd * (gamma*dy_eff - m1 - xhat*m2); optional d_res = dy_eff ------------------------
 template <typename T, bool RES, bool RELU>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask, const T* __restrict__ dy,
                                                            const double* __restrict__ sums, const float* __restrict__ ab,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            T* __restrict__ dx, T* __restrict__ dres,
@@ -299,9 +311,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         float v[8], d[8], o[8];
         gn_load8(x + base + (int64_t)r * C, v); gn_load8(dy + base + (int64_t)r * C, d);
         if (RELU) {
-            if (RES) { float yy[8]; gn_load8(y + base + (int64_t)r * C, yy);   // out = GN(x) + residual: mask from the saved output
+            if (RES) { const uint32_t bits = mask[((int64_t)n * HW + r) * cbn + cb];   // out = GN(x) + residual: the forward's bit mask
 #pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = yy[j] > 0.f ? d[j] : 0.f;
+                for (int j = 0; j < 8; ++j) d[j] = ((bits >> j) & 1u) ? d[j] : 0.f;
             } else {                                                             // out = GN(x): recompute the mask, one tensor less to read
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d[j] = fmaf((v[j] - mu[j]) * rs[j], gg[j], be[j]) > 0.f ? d[j] : 0.f;
@@ -329,7 +341,7 @@ static int gn_rows_per_wg(int N, int HW, int C, int target_wgs = 2048) {
 }
 
 extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
-                                  int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream) {
+                                  uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream) {
     MAED_CHECK_ARG(x && gamma && beta && y && sums, MAED_ERR_ARG, "groupnorm_fwd: null pointer");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_fwd"));
     if (N <= 0) return MAED_OK;
@@ -339,20 +351,20 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
     if (!sums_zeroed) hipMemsetAsync(sums, 0, (size_t)N * GN_G * 2 * sizeof(double), s);
     MAED_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)x, sums, HW, C, rows);
-        if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows);
-        else if (residual) hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, HW, C, eps, rows);
-        else if (relu) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, HW, C, eps, rows);
-        else hipLaunchKernelGGL((gn_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, HW, C, eps, rows);
+        if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
+        else if (residual) hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
+        else if (relu) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
+        else hipLaunchKernelGGL((gn_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
     });
     MAED_CHECK_LAUNCH("groupnorm_fwd");
     return MAED_OK;
 }
 
-extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, const double* sums, const float* gamma, const float* beta,
+extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                                   void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
                                   int relu, int dtype, int ab_zeroed, void* stream) {
     MAED_CHECK_ARG(x && dy && sums && gamma && beta && dx && dgamma && dbeta && ab_scratch, MAED_ERR_ARG, "groupnorm_bwd: null pointer");
-    MAED_CHECK_ARG(!(relu && dres) || y, MAED_ERR_ARG, "groupnorm_bwd: the saved output y is needed for the ReLU mask when a residual was added");
+    MAED_CHECK_ARG(!(relu && dres) || relu_mask, MAED_ERR_ARG, "groupnorm_bwd: the forward's relu_mask is needed when a residual was added before the ReLU");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_bwd"));
     if (N <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -364,9 +376,9 @@ extern "C" int maed_groupnorm_bwd(const void* x, const void* y, const void* dy, 
     if (!ab_zeroed) hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
     const bool ymask = relu && dres;
-#define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, (const T*)y, (const T*)dy, \
+#define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows)
-#define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy, \
+#define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
     MAED_DISPATCH_DTYPE(dtype, T, {
         if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);

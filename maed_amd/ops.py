@@ -513,18 +513,21 @@ class GroupNormFn(torch.autograd.Function):
         zeroed = sums is not None
         if sums is None:
             sums = torch.empty(N, 32, 2, dtype=torch.float64, device=x.device)
-        check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), N, H * W, C_, eps, int(relu),
-                                         dt_code(x.dtype), int(zeroed), _stream()), "groupnorm_fwd")
         ctx.has_res = residual is not None
+        # ReLU after a residual add: the backward cannot recompute the mask from x -> 1 bit per element instead of re-reading y
+        need_mask = relu and ctx.has_res and (x.requires_grad or residual.requires_grad or gamma.requires_grad)
+        mask = torch.empty(N * H * W * (C_ // 8), dtype=torch.uint8, device=x.device) if need_mask else None
+        check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), _p(mask), N, H * W, C_, eps, int(relu),
+                                         dt_code(x.dtype), int(zeroed), _stream()), "groupnorm_fwd")
         ctx.ab = ab
-        ctx.save_for_backward(x, y if (relu and ctx.has_res) else None, sums)
+        ctx.save_for_backward(x, mask, sums)
         ctx.eps, ctx.relu, ctx.direct = eps, relu, direct
         ctx.gamma, ctx.beta = gamma, beta   # parameters (leaf tensors): kept by reference for .grad access
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, sums = ctx.saved_tensors
+        x, mask, sums = ctx.saved_tensors
         gamma, beta = ctx.gamma, ctx.beta
         N, C_, H, W = x.shape
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -543,7 +546,7 @@ class GroupNormFn(torch.autograd.Function):
         ctx.ab = None                                   # single use: a second backward through this node gets fresh scratch
         if ab is None:
             ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
-        check(L.lib().maed_groupnorm_bwd(_p(x), _p(y), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
+        check(L.lib().maed_groupnorm_bwd(_p(x), _p(mask), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
                                          N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), _stream()), "groupnorm_bwd")
         if ctx.direct:
             return dx, dres, None, None, None, None, None, None, None
