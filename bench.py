@@ -202,12 +202,15 @@ def main():
     kernels = {}
     roofline = None
     roofline_dominant = None
+    # EVERY rank runs the extra steps (a train step contains the gradient all-reduce: a rank stepping alone would wait for
+    # collectives nobody else issues); only rank 0 brackets its launches with events and reports
+    nprof = 3
     if rank == 0:
-        nprof = 3
         lib.maed_prof_enable(1)
-        for _ in range(nprof):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(nprof):
+        step()
+    fence()
+    if rank == 0:
         ms = (ctypes.c_double * 8)()
         cnt = (ctypes.c_int * 8)()
         lib.maed_prof_collect(ms, cnt)
