@@ -18,15 +18,24 @@ CLANG = os.environ.get("MAED_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 def build(force=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + [os.path.join(HERE, "sim_support.cpp")]
-    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "common.cuh"), os.path.join(ROOT, "include", "maed_hip.h")]
+    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "dual.cuh"),
+                   os.path.join(CSRC, "ktd_tables.cuh"), os.path.join(ROOT, "include", "maed_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [CLANG, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-I", HERE, "-Wno-unused-value"]
-    for s in srcs:
-        cmd += ["-x", "c++", s]
-    cmd += ["-o", OUT]
-    subprocess.run(cmd, check=True)
+    flags = [CLANG, "-std=c++20", "-O1", "-fPIC", "-pthread", "-I", HERE, "-Wno-unused-value"]
+
+    def compile_one(src):     # one object per source, in parallel (the whole library is ~14 translation units)
+        obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
+        hdrs = deps[len(srcs):]
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + hdrs):
+            subprocess.run(flags + ["-c", "-x", "c++", src, "-o", obj], check=True)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    subprocess.run([CLANG, "-shared", "-pthread", "-o", OUT] + objs, check=True)
     return OUT
 
 
