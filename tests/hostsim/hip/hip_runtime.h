@@ -72,29 +72,35 @@ extern thread_local void* t_dyn_lds;
 
 template <typename K, typename... Args>
 void launch(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, Args... args) {
+    // one host thread per GPU thread of a workgroup, created ONCE per launch; the threads walk the workgroups of the grid one after
+    // another (function-local `static` LDS arrays mean only one workgroup may be alive at a time), separated by a full barrier
     const int nthr = (int)(block.x * block.y * block.z);
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    if (nblocks == 0 || nthr == 0) return;
     std::vector<double> dyn((dyn_lds + 7) / 8 + 2);   // dynamic LDS of the workgroup (16-B aligned)
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                BlockCtx ctx(nthr);
-                std::vector<std::thread> th;
-                th.reserve(nthr);
-                for (int t = 0; t < nthr; ++t)
-                    th.emplace_back([&, t]() {
-                        t_threadIdx = Idx{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
-                        t_blockIdx = Idx{bx, by, bz};
-                        t_blockDim = Idx{block.x, block.y, block.z};
-                        t_gridDim = Idx{grid.x, grid.y, grid.z};
-                        t_block = &ctx;
-                        t_tid = t;
-                        t_dyn_lds = (void*)(((uintptr_t)dyn.data() + 15) & ~(uintptr_t)15);
-                        kernel(args...);
-                        ctx.waves[t / 64]->bar.arrive_and_drop();
-                        ctx.bar.arrive_and_drop();
-                    });
-                for (auto& t : th) t.join();
+    std::unique_ptr<BlockCtx> ctx;
+    std::barrier<> between(nthr);
+    std::vector<std::thread> th;
+    th.reserve(nthr);
+    for (int t = 0; t < nthr; ++t)
+        th.emplace_back([&, t]() {
+            t_threadIdx = Idx{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+            t_blockDim = Idx{block.x, block.y, block.z};
+            t_gridDim = Idx{grid.x, grid.y, grid.z};
+            t_tid = t;
+            t_dyn_lds = (void*)(((uintptr_t)dyn.data() + 15) & ~(uintptr_t)15);
+            for (size_t b = 0; b < nblocks; ++b) {
+                if (t == 0) ctx.reset(new BlockCtx(nthr));          // fresh barriers: exited lanes drop out of them
+                between.arrive_and_wait();
+                t_blockIdx = Idx{(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y))};
+                t_block = ctx.get();
+                kernel(args...);
+                ctx->waves[t / 64]->bar.arrive_and_drop();
+                ctx->bar.arrive_and_drop();
+                between.arrive_and_wait();                          // nobody still uses this workgroup's context / LDS
             }
+        });
+    for (auto& t : th) t.join();
 }
 }  // namespace hostsim
 
