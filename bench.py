@@ -180,6 +180,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, not a benchmark step: the first pass through the model makes MIOpen search its convolution algorithms (~20 s) and
+    # loads every code object; it is kept out of the W warm-up steps so that a small --warmup cannot put it next to the timed region
+    t1 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    log(f"setup pass (MIOpen algorithm search, code-object loading): {time.perf_counter() - t1:.3f}s")
     for i in range(args.warmup):
         t1 = time.perf_counter()
         step()
