@@ -5,6 +5,8 @@
 // HBM-bound (arithmetic intensity ~T/2 flop/B): thread per (n,h,p,t) query row, the T key/value rows
 // of the same (n,h,p) are shared by T neighbouring threads through L1.  fp32 math for both dtypes.
 #include "common.cuh"
+#include "attn_mfma.cuh"
+#include <stdlib.h>
 
 #define D HEAD_DIM
 
@@ -343,6 +345,357 @@ static bool launch_tm_bwd_lds(const void* qkv, const void* o, const void* d_o, c
     return true;
 }
 
+// ==================================================================================================
+// MFMA forward (bf16): temporal attention as block-diagonal attention over a VIRTUAL sequence.
+// A workgroup owns one (clip n, head h, group of G tokens): its L = G*T rows r = g*T + t are the T frames of G tokens
+// (G = max(1, 32/T): with T = 16 two tokens fill one 32-row MFMA tile; with T = 64 one token is two tiles).  Row r lives at
+// frame n*T + t, token tg*G + g of the (F,P,3C) qkv tensor.  S^T = K Q^T runs on v_mfma_f32_32x32x16_bf16 exactly as in the
+// spatial kernel (lane = query, 16 keys per lane per tile); keys of a different token (or padding) are masked to -inf,
+// the softmax is lane-local, O^T = V^T P^T consumes the exponentiated scores as the MFMA B fragment.  The thread-per-row
+// kernels above spend ~2100 VALU instructions per query row on the dot products; this spends 8 MFMAs per 32x32 score tile.
+// ==================================================================================================
+__global__ __launch_bounds__(1024) void attn_tm_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
+                                                         int P, int H, int Tn, int G, int ngroups, float scale_log2e) {
+    MAED_DYN_SHARED(unsigned short, smem);
+    const int L = G * Tn, Lk = (L + 31) & ~31, VLD = Lk + 4;
+    unsigned short* Ks = smem;                      // [Lk][64], 16-B chunk index XOR-swizzled with (row>>1)&7
+    unsigned short* Vt = smem + (size_t)Lk * 64;    // [64][VLD]
+    const int C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    const int tg = bid % ngroups; bid /= ngroups;
+    const int h = bid % H, n = bid / H;
+    const int p0 = tg * G;
+    // row r -> element offset of its (frame, token) row in qkv (q part, this head); rows beyond L or tokens beyond P are invalid
+#define TM_ROW_OK(r) ((r) < L && p0 + (r) / Tn < P)
+#define TM_ROW_OFF(r) ((((int64_t)n * Tn + (r) % Tn) * P + p0 + (r) / Tn) * ld + h * D)
+    const int q = wave * 32 + l31;
+    const bool q_ok = TM_ROW_OK(q);
+    const int qg = q / Tn;
+    bf16x8_t qf[4];
+    {
+        const int qc = q_ok ? q : 0;                // row 0 of the group always exists
+        const bf16* qp = qkv + TM_ROW_OFF(qc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8_t*>(qp + t * 16 + hi * 8);
+    }
+    // stage K (swizzled rows) and V^T; invalid rows are staged as zeros (their scores are masked, 0 * finite = 0 in the PV product)
+    for (int idx = tid; idx < Lk * 8; idx += nthr) {
+        const int r = idx >> 3, c8 = (idx & 7) * 8;
+        uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
+        if (TM_ROW_OK(r)) {
+            const bf16* rp = qkv + TM_ROW_OFF(r);
+            kv = *reinterpret_cast<const uint4*>(rp + C + c8);
+            vv = *reinterpret_cast<const uint4*>(rp + 2 * C + c8);
+        }
+        *reinterpret_cast<uint4*>(Ks + r * 64 + (((c8 >> 3) ^ ((r >> 1) & 7)) << 3)) = kv;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Vt[(c8 + 2 * j) * VLD + r] = (unsigned short)(w[j] & 0xffffu);
+            Vt[(c8 + 2 * j + 1) * VLD + r] = (unsigned short)(w[j] >> 16);
+        }
+    }
+    for (int i = tid; i < D * 4; i += nthr) Vt[(i >> 2) * VLD + Lk + (i & 3)] = 0;   // the 4 pad columns of every V^T row
+    __syncthreads();
+
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const int nkt = Lk / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16_t s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const int krow = kt * 32 + l31;
+        const unsigned short* kp = Ks + krow * 64;
+        const int swz = (krow >> 1) & 7;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + (((2 * t + hi) ^ swz) << 3));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s, 0, 0, 0);
+        }
+        // lane holds keys k(r) = kt*32 + (r&3) + 8*(r>>2) + 4*hi of its query: keep the keys of the query's own token
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool ok = TM_ROW_OK(k) && (k / Tn == qg);
+            s[r] = ok ? s[r] : -INFINITY;
+            any |= ok;
+        }
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+        const float mn = fmaxf(m, mt);
+        // a tile may hold no key of this query's token (mn stays -inf until the first one does): keep everything at zero then
+        const float msafe = (mn == -INFINITY) ? 0.f : mn;
+        const float alpha = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - msafe);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -msafe)); ps += s[r]; }
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            union { bf16x8_t v; uint32_t u[4]; } pf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf2(s[8 * st + 2 * j], s[8 * st + 2 * j + 1]);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                const unsigned short* vp = Vt + (et * 32 + l31) * VLD + kt * 32 + 16 * st + 4 * hi;
+                union { bf16x8_t v; uint2 u[2]; } vf;
+                vf.u[0] = *reinterpret_cast<const uint2*>(vp);
+                vf.u[1] = *reinterpret_cast<const uint2*>(vp + 8);
+                oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[et], 0, 0, 0);
+            }
+        }
+        (void)any;
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (q_ok) {
+        const float inv = 1.f / l;
+        const int t = q % Tn, p = p0 + qg;
+        const int64_t f = (int64_t)n * Tn + t;
+        bf16* orow = o + (f * P + p) * C + h * D;
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int e0 = et * 32 + 8 * g + 4 * hi;
+                const uint2 w = make_uint2(pack_bf2(oacc[et][4 * g] * inv, oacc[et][4 * g + 1] * inv),
+                                           pack_bf2(oacc[et][4 * g + 2] * inv, oacc[et][4 * g + 3] * inv));
+                *reinterpret_cast<uint2*>(orow + e0) = w;
+            }
+        if (hi == 0) lse[(f * H + h) * P + p] = (m + log2f(l)) * 0.69314718055994530942f;
+    }
+#undef TM_ROW_OK
+#undef TM_ROW_OFF
+}
+
+// ==================================================================================================
+// MFMA backward (bf16) over the same virtual sequences: ONE kernel produces dQ, dK and dV of a workgroup's L rows.
+// Q, K, V, dO are staged once (row-major images for the S / dP products, transposed images for the dQ / dK / dV
+// products), then every wave runs the query-side pass (lane = query: dS from S^T = K Q^T and dP^T = V dO^T, dQ^T += K^T dS^T)
+// and the key-side pass (lane = key: P and dS from S = Q K^T, dV^T += dO^T P, dK^T += Q^T dS) for its own 32 rows --
+// flash-style recompute from the saved log-sum-exp, block-diagonal mask as in the forward.
+// ==================================================================================================
+__global__ __launch_bounds__(1024) void attn_tm_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+                                                         const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int P, int H,
+                                                         int Tn, int G, int ngroups, float scale) {
+    MAED_DYN_SHARED(unsigned short, smem);
+    const int L = G * Tn, Lk = (L + 31) & ~31, VLD = Lk + 4;
+    unsigned short* Qs = smem;
+    unsigned short* Ks = Qs + (size_t)Lk * KLD;
+    unsigned short* Vs = Ks + (size_t)Lk * KLD;
+    unsigned short* dOs = Vs + (size_t)Lk * KLD;
+    unsigned short* Qt = dOs + (size_t)Lk * KLD;
+    unsigned short* Kt = Qt + (size_t)D * VLD;
+    unsigned short* dOt = Kt + (size_t)D * VLD;
+    float* Ls = reinterpret_cast<float*>(dOt + (size_t)D * VLD);
+    float* Ds = Ls + Lk;
+    const int C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    const int tg = bid % ngroups; bid /= ngroups;
+    const int h = bid % H, n = bid / H;
+    const int p0 = tg * G;
+#define TM_ROW_OK(r) ((r) < L && p0 + (r) / Tn < P)
+#define TM_TOK(r) (((int64_t)n * Tn + (r) % Tn) * P + p0 + (r) / Tn)          /* flattened (frame, token) index of row r */
+    const float l2e = 1.44269504088896340736f;
+    for (int idx = tid; idx < Lk * 8; idx += nthr) {
+        const int r = idx >> 3, c8 = (idx & 7) * 8;
+        uint4 qv = make_uint4(0u, 0u, 0u, 0u), kv = qv, vv = qv, gv = qv;
+        if (TM_ROW_OK(r)) {
+            const int64_t tok = TM_TOK(r);
+            const bf16* rp = qkv + tok * ld + h * D;
+            qv = *reinterpret_cast<const uint4*>(rp + c8);
+            kv = *reinterpret_cast<const uint4*>(rp + C + c8);
+            vv = *reinterpret_cast<const uint4*>(rp + 2 * C + c8);
+            gv = *reinterpret_cast<const uint4*>(d_o + tok * C + h * D + c8);
+        }
+        *reinterpret_cast<uint4*>(Qs + r * KLD + c8) = qv;
+        *reinterpret_cast<uint4*>(Ks + r * KLD + c8) = kv;
+        *reinterpret_cast<uint4*>(Vs + r * KLD + c8) = vv;
+        *reinterpret_cast<uint4*>(dOs + r * KLD + c8) = gv;
+        const uint32_t wq[4] = {qv.x, qv.y, qv.z, qv.w}, wk[4] = {kv.x, kv.y, kv.z, kv.w}, wg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e0 = (c8 + 2 * j) * VLD + r, e1 = (c8 + 2 * j + 1) * VLD + r;
+            Qt[e0] = (unsigned short)(wq[j] & 0xffffu); Qt[e1] = (unsigned short)(wq[j] >> 16);
+            Kt[e0] = (unsigned short)(wk[j] & 0xffffu); Kt[e1] = (unsigned short)(wk[j] >> 16);
+            dOt[e0] = (unsigned short)(wg[j] & 0xffffu); dOt[e1] = (unsigned short)(wg[j] >> 16);
+        }
+    }
+    for (int i = tid; i < D * 4; i += nthr) {       // the 4 pad columns of the transposed images
+        const int e = (i >> 2) * VLD + Lk + (i & 3);
+        Qt[e] = 0; Kt[e] = 0; dOt[e] = 0;
+    }
+    for (int r = tid; r < Lk; r += nthr) {
+        float dsum = 0.f, Lv = 0.f;
+        if (TM_ROW_OK(r)) {
+            const int64_t tok = TM_TOK(r);
+#pragma unroll
+            for (int c = 0; c < D; c += 8) {
+                float a[8], b[8];
+                ld8(d_o + tok * C + h * D + c, a); ld8(o + tok * C + h * D + c, b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum = fmaf(a[j], b[j], dsum);
+            }
+            Lv = lse[(((int64_t)n * Tn + r % Tn) * H + h) * P + p0 + r / Tn] * l2e;
+        }
+        Ds[r] = dsum; Ls[r] = Lv;
+    }
+    __syncthreads();
+
+    const int row = wave * 32 + l31;                // this lane's row: a query in pass A, a key in pass B
+    const bool row_ok = TM_ROW_OK(row);
+    const int rg = row / Tn;
+    const float sl2e = scale * l2e;
+    const int nt = Lk / 32;
+    bf16* drow = dqkv + (row_ok ? TM_TOK(row) : 0) * ld + h * D;
+    // ---- pass A: lane = query ------------------------------------------------------------------------------
+    {
+        bf16x8_t qf[4], dof[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            qf[t] = *reinterpret_cast<const bf16x8_t*>(Qs + row * KLD + t * 16 + hi * 8);
+            dof[t] = *reinterpret_cast<const bf16x8_t*>(dOs + row * KLD + t * 16 + hi * 8);
+        }
+        const float Dq = Ds[row], L2 = Ls[row];
+        f32x16_t dq[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+        for (int kt = 0; kt < nt; ++kt) {
+            f32x16_t sa, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+            const int krow = kt * 32 + l31;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + krow * KLD + t * 16 + hi * 8);
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + krow * KLD + t * 16 + hi * 8);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[t], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool ok = row_ok && TM_ROW_OK(k) && (k / Tn == rg);
+                const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], sl2e, -L2)) : 0.f;
+                sa[r] = pr * (dp[r] - Dq) * scale;  // dS
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8_t dsf = pack_frag(sa, st);
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    const bf16x8_t ktf = lds_frag_tr(Kt + (et * 32 + l31) * VLD + kt * 32 + 16 * st + 4 * hi);
+                    dq[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[et], 0, 0, 0);
+                }
+            }
+        }
+        if (row_ok) store_rowT(drow, dq, hi, accumulate);
+    }
+    // ---- pass B: lane = key ------------------------------------------------------------------------------------
+    {
+        bf16x8_t kf[4], vf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            kf[t] = *reinterpret_cast<const bf16x8_t*>(Ks + row * KLD + t * 16 + hi * 8);
+            vf[t] = *reinterpret_cast<const bf16x8_t*>(Vs + row * KLD + t * 16 + hi * 8);
+        }
+        f32x16_t dk[2], dv[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+        for (int qt = 0; qt < nt; ++qt) {
+            f32x16_t sb, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dp[r] = 0.f; }
+            const int qrow = qt * 32 + l31;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8_t qfr = *reinterpret_cast<const bf16x8_t*>(Qs + qrow * KLD + t * 16 + hi * 8);
+                const bf16x8_t dofr = *reinterpret_cast<const bf16x8_t*>(dOs + qrow * KLD + t * 16 + hi * 8);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[t], sb, 0, 0, 0);     // D[q][k]: lane = key
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[t], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool ok = row_ok && TM_ROW_OK(qq) && (qq / Tn == rg);
+                const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sb[r], sl2e, -Ls[qq])) : 0.f;
+                dp[r] = pr * (dp[r] - Ds[qq]) * scale;  // dS
+                sb[r] = pr;                             // P
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8_t pf = pack_frag(sb, st), dsf = pack_frag(dp, st);
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    const int off = (et * 32 + l31) * VLD + qt * 32 + 16 * st + 4 * hi;
+                    dv[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(dOt + off), pf, dv[et], 0, 0, 0);
+                    dk[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Qt + off), dsf, dk[et], 0, 0, 0);
+                }
+            }
+        }
+        if (row_ok) {
+            store_rowT(drow + C, dk, hi, accumulate);
+            store_rowT(drow + 2 * C, dv, hi, accumulate);
+        }
+    }
+#undef TM_ROW_OK
+#undef TM_TOK
+}
+
+// bf16 default; MAED_TEMPORAL_MFMA=0 falls back to the LDS-staged thread-per-row kernels (measurement knob).
+// Measured on MI355X (profiles/r01_attn_temporal_mfma_ab.txt): cfg3 (T=16) forward 61.8 -> 27.7 us, backward 133.8 -> 123.3 us;
+// cfg5 (T=64) forward 251 -> 62 us, backward 578 -> 304 us.
+static bool tm_mfma_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* ev = getenv("MAED_TEMPORAL_MFMA"); on = (ev && atoi(ev) == 0) ? 0 : 1; }
+    return on != 0;
+}
+
+static bool launch_tm_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int P, int H,
+                               int Tn, float scale, hipStream_t s) {
+    if (!tm_mfma_enabled()) return false;
+    const int G = Tn >= 32 ? 1 : 32 / Tn;
+    const int L = G * Tn, Lk = (L + 31) & ~31;
+    if (Lk / 32 > 16) return false;
+    const size_t lds = ((size_t)4 * Lk * KLD + (size_t)3 * D * (Lk + 4)) * 2 + (size_t)2 * Lk * sizeof(float);
+    if (lds > 160 * 1024) return false;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)attn_tm_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const int ngroups = (P + G - 1) / G;
+    hipLaunchKernelGGL(attn_tm_bwd_mfma, dim3((unsigned)((F / Tn) * H * ngroups)), dim3(64 * (Lk / 32)), lds, s, (const bf16*)qkv, (const bf16*)o,
+                       (const bf16*)d_o, lse, (bf16*)dqkv, accumulate, P, H, Tn, G, ngroups, scale);
+    return true;
+}
+
+static bool launch_tm_fwd_mfma(const void* qkv, void* o, float* lse, int F, int P, int H, int Tn, float scale, hipStream_t s) {
+    if (!tm_mfma_enabled()) return false;
+    const int G = Tn >= 32 ? 1 : 32 / Tn;
+    const int L = G * Tn, Lk = (L + 31) & ~31;
+    if (Lk / 32 > 16) return false;                                   // at most 16 waves per workgroup
+    const size_t lds = ((size_t)Lk * 64 + (size_t)D * (Lk + 4)) * 2;
+    if (lds > 160 * 1024) return false;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)attn_tm_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const int ngroups = (P + G - 1) / G;
+    hipLaunchKernelGGL(attn_tm_fwd_mfma, dim3((unsigned)((F / Tn) * H * ngroups)), dim3(64 * (Lk / 32)), lds, s, (const bf16*)qkv, (bf16*)o, lse, P, H,
+                       Tn, G, ngroups, scale * 1.44269504088896340736f);
+    return true;
+}
+
 extern "C" int maed_attn_temporal_fwd(const void* qkv, void* o, float* lse, int F, int P, int H, int T, float scale, int dtype,
                                       void* stream) {
     MAED_CHECK_ARG(qkv && o && lse, MAED_ERR_ARG, "attn_temporal_fwd: null pointer");
@@ -351,6 +704,7 @@ extern "C" int maed_attn_temporal_fwd(const void* qkv, void* o, float* lse, int 
     const int64_t total = (int64_t)F * H * P;
     if (total == 0) return MAED_OK;
     dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == MAED_BF16 && launch_tm_fwd_mfma(qkv, o, lse, F, P, H, T, scale, (hipStream_t)stream)) { MAED_CHECK_LAUNCH("attn_temporal_fwd"); return MAED_OK; }
     MAED_DISPATCH_DTYPE(dtype, TT, {
         if (!launch_tm_fwd_lds<TT>(qkv, o, lse, F, P, H, T, scale, (hipStream_t)stream))
             hipLaunchKernelGGL((attn_tm_fwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, (TT*)o, lse, total, P, H, T, scale);
@@ -366,6 +720,10 @@ extern "C" int maed_attn_temporal_bwd(const void* qkv, const void* o, const void
     const int64_t total = (int64_t)F * H * P;
     if (total == 0) return MAED_OK;
     dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == MAED_BF16 && launch_tm_bwd_mfma(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, T, scale, (hipStream_t)stream)) {
+        MAED_CHECK_LAUNCH("attn_temporal_bwd");
+        return MAED_OK;
+    }
     MAED_DISPATCH_DTYPE(dtype, TT, {
         if (!launch_tm_bwd_lds<TT>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, T, scale, (hipStream_t)stream))
             hipLaunchKernelGGL((attn_tm_bwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, (const TT*)o, (const TT*)d_o, lse,
