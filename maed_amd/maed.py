@@ -7,7 +7,8 @@
 Extra keyword arguments (defaults = the reference's hard-coded values): embed_dim=768, max_seqlen=16,
 img_size=224, compute_dtype=torch.bfloat16 (torch.float32 = parity mode), impl, smpl_arrays
 (dict with the SMPL model arrays; None -> deterministic synthetic stand-in, see maed_amd/smpl.py).
-Only encoder='ste' / decoder='ktd' (the configured pair, configs/config_stage2.yaml:70-78) exist.
+encoder='ste' only ('cnn' is the stage-1 torchvision ResNet-50); decoder 'ktd' (configured, config_stage2.yaml:70-78)
+or 'iterative' (spin.py Regressor; extra kwarg smpl_mean_params).
 """
 import torch
 import torch.nn as nn
@@ -29,9 +30,14 @@ class MAED(nn.Module):
         self.encoder = vit_custom_resnet50_224_in21k(num_blocks, num_heads, st_mode, embed_dim=embed_dim, img_size=img_size,
                                                      max_seqlen=max_seqlen, compute_dtype=compute_dtype, impl=impl)
         self.decoder_type = decoder
-        if decoder.lower() != 'ktd':
-            raise NotImplementedError(decoder)       # maed.py:29 ('iterative' SPIN regressor: SURVEY 8(f) rank 3)
-        self.decoder = KTD(feat_dim=self.encoder.num_features, hidden_dim=hidden_dim, smpl_arrays=smpl_arrays)
+        if decoder.lower() == 'ktd':                 # maed.py:24-29
+            self.decoder = KTD(feat_dim=self.encoder.num_features, hidden_dim=hidden_dim, smpl_arrays=smpl_arrays)
+        elif decoder.lower() == 'iterative':
+            from .iterative import Regressor
+            self.decoder = Regressor(feat_dim=self.encoder.num_features, hidden_dim=hidden_dim, smpl_arrays=smpl_arrays,
+                                     smpl_mean_params=kwargs.get('smpl_mean_params'))
+        else:
+            raise NotImplementedError(decoder)
 
     def extract_feature(self, x):
         batch_size, seqlen = x.shape[:2]

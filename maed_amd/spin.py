@@ -1,6 +1,15 @@
-"""Weak-perspective camera projection (reference: lib/models/spin.py:113-157).  ATen version for the
-training graph; inference uses maed_smpl_joints_project_fwd."""
+"""lib/models/spin.py: weak-perspective camera projection (:113-157; ATen version for CPU tensors and a
+differentiable J_regressor override -- the GPU paths use maed_smpl_joints_project_fwd / tail.SmplTailFn) and the
+iterative `Regressor` (:17-110), which lives in maed_amd/iterative.py and is re-exported here lazily because it
+builds on KTD, which imports this module."""
 import torch
+
+
+def __getattr__(name):
+    if name == "Regressor":
+        from .iterative import Regressor
+        return Regressor
+    raise AttributeError(name)
 
 
 def projection(pred_joints, pred_camera):

@@ -121,3 +121,42 @@ def test_g10_cfg1_full(golden):
     close(o["kp_2d"], fx["kp_2d"], rtol=1e-3, atol=1e-3)
     close(o["verts"][:, :, ::53], fx["verts_sub"], rtol=1e-3, atol=1e-4)
     close(o17["kp_3d"], fx["kp_3d_h36m"], rtol=1e-3, atol=1e-4)
+
+
+# ---- the other st_modes and decoder='iterative' --------------------------------------------------
+MODES = ["series", "vanilla", "temporal", "coupling"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_g13_attention_and_block_modes(golden, mode):
+    fx, g1, g2 = golden("g13_st_modes"), golden("g1_attention"), golden("g2_block")
+    x, H, T = t(g1["x"]), int(g1["heads"]), int(g1["seqlen"])
+    close(R.attention_mode(x, sd(g1, "sd."), "", H, T, mode), fx[f"{mode}.att.out"])
+    close(R.block(x, sd(g2, "sd."), "", H, T, mode), fx[f"{mode}.blk.out"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_g13_vit_tiny_modes(golden, mode):
+    fx, g4 = golden("g13_st_modes"), golden("g4_vit_tiny")
+    p = sd(g4, "sd.")
+    if not bool(fx[f"{mode}.vit.has_temp_embed"]):
+        del p["temp_embed"]                      # the reference has no such parameter in 'vanilla'/'temporal' (:363)
+    layers = tuple(int(v) for v in g4["layers"])
+    out = R.ste_forward_features(t(g4["img"]), p, "", int(g4["depth"]), int(g4["heads"]), int(g4["seqlen"]), layers, mode)
+    close(out, fx[f"{mode}.vit.out"], rtol=1e-4, atol=1e-4)
+
+
+def test_g12_iterative(golden):
+    fx = golden("g12_iterative")
+    p = sd(fx, "sd.")
+    sp = R.make_synthetic_smpl(int(fx["smpl_seed"]))
+    pose, shape, cam = R.iterative_head(t(fx["x"]), p, "", t(fx["mean_pose"])[None], t(fx["mean_shape"])[None], t(fx["mean_cam"])[None])
+    close(pose, fx["pose6d"])
+    close(shape, fx["shape"])
+    close(cam, fx["cam"])
+    o = R.ktd_get_output(pose, shape, cam, sp)
+    for k in ("theta", "kp_2d", "kp_3d", "rotmat"):
+        close(o[k], fx[k], rtol=1e-4, atol=1e-4)
+    close(o["verts"][:, ::53], fx["verts_sub"], rtol=1e-4, atol=1e-4)
+    o17 = R.ktd_get_output(pose, shape, cam, sp, J_regressor=sp["J_regressor_h36m"])
+    close(o17["kp_3d"], fx["kp_3d_h36m"], rtol=1e-4, atol=1e-4)
