@@ -1,0 +1,195 @@
+"""STE Block for the ablation st_modes 'series', 'vanilla', 'temporal' and 'coupling' (reference:
+lib/models/vision_transformer.py:136-178, 244-261).
+
+The configured mode ('parallel') runs as ONE fused library call per direction (ops.STEBlockFn); the other modes are not on
+the benchmarked path and are composed here from the same libmaed_hip kernels, one autograd Function per stage:
+
+    LayerNormFn        maed_layernorm_fwd / _bwd                fp32 residual stream -> compute-dtype rows
+    LinearTokFn        maed_gemm_nt (+ maed_gemm_tn_wgrad)       nn.Linear on (rows, C); compute-dtype or fp32 output
+    SpatialAttnFn      maed_attn_spatial_fwd / _bwd             reads q/k/v in place from the (F,P,3C) qkv rows
+    TemporalAttnFn     maed_attn_temporal_fwd / _bwd
+    TokenMeanFn        maed_st_colmean                          'temporal' mode's mean over the tokens of a frame
+    MlpFn              fc1+GELU and fc2 with the fused epilogues (GELU', bias) of the fused block
+
+'coupling' attends over the T*P tokens of a clip.  Frames of a clip are contiguous rows, and the reference's reshape_T
+(:180-189) orders a clip's tokens (t, p), i.e. exactly the row-major order of the (T, P, 3C) qkv rows of that clip -- so
+coupling is the spatial kernel on the VIEW (N, T*P, 3C), no data movement.  The spatial kernels keep one (frame, head)'s K/V
+in LDS, which bounds T*P (<= 512 forward / 320 backward on the MFMA path): tiny clips only; the long-sequence K/V-tiled
+kernel this mode needs at 16 x 197 tokens is future work and the library reports MAED_ERR_SHAPE until then.
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def _wgrad(dy, x, need_bias):
+    """(dW fp32 [N,K], db fp32 [N] or None) for y = x W^T + b; dy (M,N), x (M,K) in the same compute dtype"""
+    N, K = dy.shape[1], x.shape[1]
+    db = torch.zeros(N, dtype=torch.float32, device=dy.device) if need_bias else None
+    if dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0:
+        dW = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
+        ops.gemm_tn_wgrad(dy, x, dW, db)
+        return dW, db
+    dyt, _ = ops.transpose_cast(dy, dy.dtype, colsum=db)
+    xt, _ = ops.transpose_cast(x, x.dtype)
+    tiles = max(1, ((N + 127) // 128) * ((K + 127) // 128))
+    dW = ops.gemm_nt(dyt, xt, L.EPI_ATOMIC_F32, splitk=max(1, min(dyt.shape[1] // 256, 1024 // tiles)))
+    return dW, db
+
+
+def _as(t, dtype):
+    """contiguous copy-free view of t in `dtype` (casts only when needed)"""
+    t = t if t.dtype == dtype else t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class LayerNormFn(torch.autograd.Function):
+    """fp32 rows (R,C) -> LayerNorm rows in `out_dtype` (vision_transformer.py:259-260 norm1/norm2)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype):
+        x = _as(x, torch.float32)
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, out_dtype, eps=eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.layernorm_bwd(dy, x, gamma, mean, rstd)
+        return dx.view_as(x), dgamma, dbeta, None, None
+
+
+class LinearTokFn(torch.autograd.Function):
+    """y = x W^T + b on (M,K) rows in the compute dtype; `out_f32` writes fp32 (the branch outputs that join the residual)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache, out_f32):
+        (wc, wt), = cache.get([weight], x.dtype)
+        x = _as(x, x.dtype)
+        ctx.save_for_backward(x)
+        ctx.wt, ctx.has_bias = wt, bias is not None
+        return ops.gemm_nt(x, wc, L.EPI_STORE_F32 if out_f32 else L.EPI_STORE, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = _as(dy, x.dtype)
+        dW, db = _wgrad(dy, x, ctx.has_bias) if ctx.needs_input_grad[1] else (None, None)
+        dx = ops.gemm_nt(dy, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
+        return dx, dW, db, None, None
+
+
+class MlpFn(torch.autograd.Function):
+    """fc2(GELU_erf(fc1(h))) (vision_transformer.py:96-112); h compute dtype (M,C) -> fp32 (M,C)"""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2, cache):
+        (w1c, w1t), (w2c, w2t) = cache.get([w1, w2], h.dtype)
+        h = _as(h, h.dtype)
+        act, pre = ops.gemm_nt(h, w1c, L.EPI_GELU, bias=b1)
+        y = ops.gemm_nt(act, w2c, L.EPI_STORE_F32, bias=b2)
+        ctx.save_for_backward(h, act, pre)
+        ctx.wts = (w1t, w2t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, act, pre = ctx.saved_tensors
+        w1t, w2t = ctx.wts
+        dy = _as(dy, h.dtype)
+        dW2, db2 = _wgrad(dy, act, True)
+        dpre = ops.gemm_nt(dy, w2t, L.EPI_MUL_DGELU, aux=pre)            # (dy W2) * GELU'(fc1 pre-activation)
+        dW1, db1 = _wgrad(dpre, h, True)
+        dh = ops.gemm_nt(dpre, w1t, L.EPI_STORE) if ctx.needs_input_grad[0] else None
+        return dh, dW1, db1, dW2, db2, None
+
+
+class SpatialAttnFn(torch.autograd.Function):
+    """per (frame, head) softmax(q k^T d^-0.5) v over the P tokens (vision_transformer.py:206-214); qkv (F,P,3C) -> (F,P,C)"""
+
+    @staticmethod
+    def forward(ctx, qkv, H, impl):
+        qkv = _as(qkv, qkv.dtype)
+        o, lse = ops.attn_spatial_fwd(qkv, H, impl)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.H, ctx.impl = H, impl
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, lse = ctx.saved_tensors
+        return ops.attn_spatial_bwd(qkv, o, _as(d_o, qkv.dtype), lse, ctx.H, impl=ctx.impl), None, None
+
+
+class TemporalAttnFn(torch.autograd.Function):
+    """attention across the T frames of a clip at the same token position (vision_transformer.py:216-228)"""
+
+    @staticmethod
+    def forward(ctx, qkv, H, T):
+        qkv = _as(qkv, qkv.dtype)
+        if qkv.shape[0] % T:
+            raise ValueError(f"{qkv.shape[0]} frames are not a whole number of clips of seqlen={T}")
+        o, lse = ops.attn_temporal_fwd(qkv, H, T)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.H, ctx.T = H, T
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, lse = ctx.saved_tensors
+        return ops.attn_temporal_bwd(qkv, o, _as(d_o, qkv.dtype), lse, ctx.H, ctx.T), None, None
+
+
+class TokenMeanFn(torch.autograd.Function):
+    """x.mean(dim=1, keepdim=True) (vision_transformer.py:169) with fp32 accumulation"""
+
+    @staticmethod
+    def forward(ctx, x):
+        Fr, P, C_ = x.shape
+        ctx.P = P
+        x = _as(x, x.dtype)
+        return ops.st_colmean(x, x)[:, :C_].reshape(Fr, 1, C_)
+
+    @staticmethod
+    def backward(ctx, dm):
+        return (dm / ctx.P).expand(-1, ctx.P, -1)
+
+
+def attention(attn, h, seqlen, compute_dtype, impl):
+    """Attention.forward for mode != 'parallel': h (F,P,C) compute dtype -> fp32 (F,P,C), or (F,1,C) in 'temporal' mode"""
+    Fr, P, C_ = h.shape
+    H, mode = attn.num_heads, attn.mode
+    cache = attn._cache
+
+    def qkv_of(t):
+        return LinearTokFn.apply(t.reshape(-1, C_), attn.qkv.weight, attn.qkv.bias, cache, False).view(t.shape[0], t.shape[1], 3 * C_)
+
+    if mode == 'series':          # :139-145  (the SAME qkv projection before each stage)
+        o = SpatialAttnFn.apply(qkv_of(h), H, impl)
+        o = TemporalAttnFn.apply(qkv_of(o), H, seqlen)
+    elif mode == 'vanilla':       # :164-167
+        o = SpatialAttnFn.apply(qkv_of(h), H, impl)
+    elif mode == 'temporal':      # :168-173
+        o = TemporalAttnFn.apply(qkv_of(TokenMeanFn.apply(h)), H, seqlen)
+    elif mode == 'coupling':      # :160-163, 180-204
+        if Fr % seqlen:
+            raise ValueError(f"{Fr} frames are not a whole number of clips of seqlen={seqlen}")
+        o = SpatialAttnFn.apply(qkv_of(h).view(Fr // seqlen, seqlen * P, 3 * C_), H, impl).view(Fr, P, C_)
+    else:
+        raise NotImplementedError(mode)
+    out = LinearTokFn.apply(o.reshape(-1, C_), attn.proj.weight, attn.proj.bias, cache, True)
+    return out.view(Fr, o.shape[1], C_)
+
+
+def block(blk, x, seqlen):
+    """Block.forward (vision_transformer.py:258-261) for mode != 'parallel'; x fp32 (F,P,C)"""
+    Fr, P, C_ = x.shape
+    cd = blk.compute_dtype
+    x = x.float()
+    h = LayerNormFn.apply(x.reshape(-1, C_), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, cd).view(Fr, P, C_)
+    x = x + attention(blk.attn, h, seqlen, cd, blk.impl)          # 'temporal': (F,1,C) broadcasts over the tokens
+    h = LayerNormFn.apply(x.reshape(-1, C_), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, cd)
+    m = MlpFn.apply(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.mlp._cache)
+    return x + m.view(Fr, P, C_)

@@ -10,7 +10,8 @@ operands are in `compute_dtype` (torch.bfloat16 for throughput, torch.float32 fo
 
 Extra keyword arguments relative to the reference (defaults = the reference's hard-coded values,
 SURVEY.md section 0): `embed_dim`, `max_seqlen`, `img_size`, `compute_dtype`, `impl`.
-Only st_mode='parallel' (the configured mode, configs/config_stage2.yaml:75) is implemented.
+st_mode='parallel' (the configured mode, configs/config_stage2.yaml:75) is the fused path; the ablation modes 'series',
+'vanilla', 'temporal', 'coupling' are composed from the same kernels in maed_amd/ste_modes.py.
 """
 from collections import OrderedDict
 from functools import partial
@@ -21,7 +22,10 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import ops
+from . import ste_modes
 from .resnetv2 import ResNetV2
+
+ST_MODES = ('parallel', 'series', 'vanilla', 'temporal', 'coupling')
 
 
 def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
@@ -59,12 +63,13 @@ class Mlp(nn.Module):
 
 
 class Attention(nn.Module):
-    """vision_transformer.py:115-240, st_mode='parallel' (:146-158,176)."""
+    """vision_transformer.py:115-240.  st_mode='parallel' (:146-158,176) is what Block fuses; the other modes
+    (:139-145,160-173) run through ste_modes.attention."""
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., st_mode='vanilla'):
         super().__init__()
-        if st_mode != 'parallel':
-            raise NotImplementedError(f"st_mode={st_mode!r}: only 'parallel' is implemented (SURVEY.md 8(f) rank 3)")
+        if st_mode not in ST_MODES:
+            raise NotImplementedError(st_mode)       # the reference raises at forward time (:175)
         if dim != 64 * num_heads:
             raise NotImplementedError(f"head dim must be 64 (dim={dim}, heads={num_heads})")
         if qk_scale is not None or attn_drop or proj_drop:
@@ -73,14 +78,18 @@ class Attention(nn.Module):
         self.scale = (dim // num_heads) ** -0.5
         self.proj = nn.Linear(dim, dim)
         self.mode = st_mode
-        self.ts_attn = nn.Linear(dim * 2, dim * 2)
+        if st_mode == 'parallel':                    # the only mode with the attentive-addition weights (:126-128)
+            self.ts_attn = nn.Linear(dim * 2, dim * 2)
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj_drop = nn.Dropout(proj_drop)
         self._cache = ops.WeightCache()
 
     def forward(self, x, seqlen=1, compute_dtype=torch.float32, impl=L.IMPL_AUTO, return_parts=False):
-        """Stand-alone (inference) use; inside a Block attention runs fused in maed_ste_block_fwd."""
+        """Stand-alone use.  'parallel': inference only (inside a Block it runs fused in maed_ste_block_fwd);
+        the other modes are differentiable here."""
+        if self.mode != 'parallel':
+            return ste_modes.attention(self, x.to(compute_dtype), seqlen, compute_dtype, impl)
         if _needs_grad(x, self.qkv.weight):
             raise NotImplementedError("Attention: the differentiable path is Block.forward (fused)")
         Fr, P, C_ = x.shape
@@ -99,7 +108,8 @@ class Attention(nn.Module):
 
 
 class Block(nn.Module):
-    """vision_transformer.py:244-261.  forward = one fused call (ops.STEBlockFn)."""
+    """vision_transformer.py:244-261.  forward = one fused call (ops.STEBlockFn) in 'parallel' mode, the staged
+    composition of ste_modes.block otherwise."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
                  drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, st_mode='vanilla',
@@ -118,6 +128,7 @@ class Block(nn.Module):
         self._cache = ops.WeightCache()
         self._pending_backwards = 0
         self.grads_ready = None  # callback(block) set by the data-parallel gradient bucketer
+        self.fused = st_mode == 'parallel'
 
     # ---- C structs for the fused kernels -------------------------------------------------------
     def _linears(self):
@@ -154,10 +165,15 @@ class Block(nn.Module):
         return g
 
     def fused_parameters(self):
+        """parameters whose gradients the fused backward writes straight into .grad (none in the staged modes: autograd owns them)"""
+        if not self.fused:
+            return []
         return [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias] + \
                [t for l in self._linears() for t in (l.weight, l.bias) if t is not None]
 
     def forward(self, x, seqlen=1):
+        if not self.fused:
+            return ste_modes.block(self, x, seqlen)
         Fr, P, C_ = x.shape
         dims = (Fr, P, C_, self.num_heads, seqlen, self.hidden, ops.dt_code(self.compute_dtype), self.impl, self.norm1.eps)
         return ops.STEBlockFn.apply(x.float(), self, dims, self.num_heads, seqlen, *self.fused_parameters())
@@ -189,7 +205,7 @@ class HybridEmbed(nn.Module):
 
 
 class VisionTransformer(nn.Module):
-    """vision_transformer.py:314-413 (hybrid input stage, st_mode='parallel')."""
+    """vision_transformer.py:314-413 (hybrid input stage)."""
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, representation_size=None,
@@ -222,8 +238,11 @@ class VisionTransformer(nn.Module):
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
         trunc_normal_(self.pos_embed, std=.02)
         trunc_normal_(self.cls_token, std=.02)
-        self.temp_embed = nn.Parameter(torch.zeros(1, max_seqlen, 1, embed_dim))  # reference: 16 slots (:364)
-        trunc_normal_(self.temp_embed, std=.02)
+        if st_mode in ('coupling', 'parallel', 'series'):                             # :363-365
+            self.temp_embed = nn.Parameter(torch.zeros(1, max_seqlen, 1, embed_dim))  # reference: 16 slots (:364)
+            trunc_normal_(self.temp_embed, std=.02)
+        else:   # 'vanilla' / 'temporal' add no temporal embedding (:396): the embed kernel gets one all-zero slot
+            self.register_buffer('_no_temp_embed', torch.zeros(1, 1, 1, embed_dim), persistent=False)
         self.apply(self._init_weights)
         self._cache = ops.WeightCache()
 
@@ -238,10 +257,13 @@ class VisionTransformer(nn.Module):
 
     def forward_tokens(self, x, seqlen=1):
         """everything up to (and including) the last Block: (F,3,S,S) -> fp32 tokens (F,P,C)"""
-        if seqlen > self.temp_embed.shape[1]:
-            raise ValueError(f"seqlen={seqlen} exceeds max_seqlen={self.temp_embed.shape[1]}")
         patch = self.patch_embed(x)
-        tok = ops.EmbedAddFn.apply(patch, self.cls_token, self.pos_embed, self.temp_embed, seqlen)
+        if hasattr(self, 'temp_embed'):
+            if seqlen > self.temp_embed.shape[1]:
+                raise ValueError(f"seqlen={seqlen} exceeds max_seqlen={self.temp_embed.shape[1]}")
+            tok = ops.EmbedAddFn.apply(patch, self.cls_token, self.pos_embed, self.temp_embed, seqlen)
+        else:
+            tok = ops.EmbedAddFn.apply(patch, self.cls_token, self.pos_embed, self._no_temp_embed, 1)
         for blk in self.blocks:
             tok = blk(tok, seqlen)
         return tok
