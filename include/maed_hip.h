@@ -326,6 +326,26 @@ int maed_comm_wait(void* compute_stream);
 int maed_comm_world(void);
 int maed_comm_destroy(void);
 
+/* ---- evaluation metrics on the device ----------------------------------------------------
+ * Replace the numpy / torch-CPU post-processing of lib/core/evaluate.py:135-166 and lib/utils/eval_utils.py.  fp32 in/out.
+ *
+ * maed_eval_pose_errors: per frame n of pred (N,J,3) / target (N,J,4 = x,y,z,visibility), 4 <= J <= 64:
+ *   both sides * visibility (evaluate.py:142-146), minus their pelvis = midpoint of joints 2 and 3 (:151-155);
+ *   mpjpe[n]    = mean_j ||pred - target||                                   (:158)
+ *   pa_mpjpe[n] = the same after the similarity transform (s, R, t) of eval_utils.py:201-252
+ *                 (batch_compute_similarity_transform_torch; the 3x3 SVD is solved in-kernel)   (:159-160)
+ *   pred_centred / target_centred (N,J,3), optional: the masked, centred joints (inputs of the acceleration metrics). */
+int maed_eval_pose_errors(const float* pred, const float* target, int N, int J, float* mpjpe, float* pa_mpjpe,
+                          float* pred_centred, float* target_centred, void* stream);
+/* eval_utils.py:201-252 batch_compute_similarity_transform_torch on (N,J,3) point sets, J <= 64:
+ * S1_hat[n] = s R S1[n] + t, the similarity transform of S1[n] closest to S2[n] (det R = +1). */
+int maed_similarity_transform(const float* S1, const float* S2, int N, int J, float* S1_hat, void* stream);
+/* out[n] = mean_j ||a[n] - 2 a[n+1] + a[n+2]||, n < N-2; a = joints (N,J,3) (eval_utils.py:10-21 compute_accel), or
+ * joints - joints_gt when joints_gt != NULL (eval_utils.py:24-52 compute_error_accel with vis=None). */
+int maed_eval_accel(const float* joints, const float* joints_gt, int N, int J, float* out, void* stream);
+/* out[n] = mean_v ||pred_verts[n,v] - target_verts[n,v]||, (N,V,3) each (eval_utils.py:88-90 compute_error_verts). */
+int maed_eval_vertex_error(const float* pred_verts, const float* target_verts, int N, int V, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,10 @@ SIGNATURES = {
     "maed_comm_wait": (i32, [vp]),
     "maed_comm_world": (i32, []),
     "maed_comm_destroy": (i32, []),
+    "maed_eval_pose_errors": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "maed_similarity_transform": (i32, [vp, vp, i32, i32, vp, vp]),
+    "maed_eval_accel": (i32, [vp, vp, i32, i32, vp, vp]),
+    "maed_eval_vertex_error": (i32, [vp, vp, i32, i32, vp, vp]),
     "maed_maxpool3s2_same_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "maed_maxpool3s2_same_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "maed_weight_refresh": (i32, [vp, i32, i32, i32, vp]),

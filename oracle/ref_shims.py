@@ -71,7 +71,16 @@ def install(smpl_seed=0):
             self.faces = np.zeros((13776, 3), dtype=np.int64)
 
         def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=True, get_skin=True, **k):
-            assert pose2rot is False
+            if pose2rot:    # smplx.lbs.batch_rodrigues on the (F,72) axis-angle pose: R = I + sin(a) K + (1 - cos(a)) K^2
+                aa = torch.cat([global_orient, body_pose], dim=1).reshape(-1, 3)
+                ang = torch.norm(aa + 1e-8, dim=1, keepdim=True)
+                ax = aa / ang
+                Kx = torch.zeros(aa.shape[0], 3, 3, dtype=aa.dtype)
+                Kx[:, 0, 1], Kx[:, 0, 2], Kx[:, 1, 0] = -ax[:, 2], ax[:, 1], ax[:, 2]
+                Kx[:, 1, 2], Kx[:, 2, 0], Kx[:, 2, 1] = -ax[:, 0], -ax[:, 1], ax[:, 0]
+                s, c = torch.sin(ang)[:, :, None], torch.cos(ang)[:, :, None]
+                rot = (torch.eye(3, dtype=aa.dtype)[None] + s * Kx + (1 - c) * (Kx @ Kx)).reshape(-1, 24, 3, 3)
+                global_orient, body_pose = rot[:, :1], rot[:, 1:]
             rot = torch.cat([global_orient, body_pose], dim=1)
             verts, posed = maed_ref.smpl_lbs(betas, rot, sp)
             j45 = torch.cat([posed, verts[:, sp["extra_vertex_ids"]]], dim=1)

@@ -123,6 +123,24 @@ static inline float __shfl_xor(float v, int mask, int /*width*/ = 64) {
     return r;
 }
 
+static inline int __shfl_xor(int v, int mask, int width = 64) {
+    return __builtin_bit_cast(int, __shfl_xor(__builtin_bit_cast(float, v), mask, width));
+}
+static inline float __shfl(float v, int src_lane, int /*width*/ = 64) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    w.fx[lane] = v;
+    w.bar.arrive_and_wait();
+    const float r = w.fx[src_lane & 63];
+    w.bar.arrive_and_wait();
+    return r;
+}
+static inline int __double2loint(double d) { return (int)(uint32_t)(__builtin_bit_cast(uint64_t, d) & 0xffffffffu); }
+static inline int __double2hiint(double d) { return (int)(uint32_t)(__builtin_bit_cast(uint64_t, d) >> 32); }
+static inline double __hiloint2double(int hi, int lo) {
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+
 typedef float hostsim_f32x16 __attribute__((ext_vector_type(16)));
 // v_mfma_f32_32x32x2_f32: A[i][k] from lane k*32+i, B[k][j] from lane k*32+j, D[(r&3)+8*(r>>2)+4*(lane>>5)][lane&31] in reg r
 static inline hostsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hostsim_f32x16 acc, int, int, int) {
