@@ -1,0 +1,331 @@
+// Long-sequence attention on MFMA (bf16): K/V-tiled flash forward and the two-pass recompute backward.
+//
+// Why: st_mode='coupling' (reference lib/models/vision_transformer.py:160-163,180-204) attends over the T*P tokens of a
+// clip -- 16 x 197 = 3152 at cfg3 -- and the whole-head kernels of attn_spatial.hip keep one head's K/V (or Q/dO) resident in
+// LDS, which stops at 512 (forward) / 320 (backward) tokens.  Same arithmetic, same operand orientation, same fragment tricks
+// as those kernels (S^T = K Q^T so softmax statistics are per lane; P^T / dS packed straight from the accumulators as the
+// next MFMA's B operand), but the resident side is streamed through LDS in 64-row tiles and a workgroup owns 128 rows
+// (4 waves x 32) of the other side, so the grid is (sequence / 128) x (items x heads) workgroups of 256 threads at 18-36 KB
+// of LDS each instead of items x heads workgroups of up to 1024 threads.
+//
+//   attn_long_fwd_mfma     wave = 32 queries; K tile row-major + V tile transposed in LDS; online softmax
+//   attn_long_bwd_dq_mfma  wave = 32 queries; K (row-major + transposed) and V tiles in LDS
+//   attn_long_bwd_dkv_mfma wave = 32 keys;    Q and dO tiles (row-major + transposed), lse and delta = rowsum(dO*O) in LDS
+//
+// Data layout is the spatial kernels': qkv (items, L, 3C) with q|k|v channel blocks and head-major channels, o / d_o (items, L, C),
+// lse (items, H, L) natural log, dqkv like qkv.  Selected by maed_attn_spatial_{fwd,bwd} when the sequence does not fit the
+// whole-head kernels, or explicitly with impl = MAED_IMPL_MFMA_LONG.  Single-buffered staging (two barriers per tile): the first
+// correct version; software pipelining is left to a round with a GPU to measure it on.
+#include "attn_mfma.cuh"
+
+#define D HEAD_DIM
+
+namespace {
+
+constexpr int LT = 64;          // rows of the streamed side per LDS tile (two 32-row MFMA sub-tiles)
+constexpr int LVLD = LT + 4;    // row stride of transposed images: 34 dwords = 2 * odd -> conflict-free ds_read_b64
+constexpr int WG_ROWS = 128;    // rows of the owning side per workgroup (4 waves x 32)
+
+// consecutive logical workgroups (the row tiles of one (item, head), then the next head ...) on ONE XCD: they stream the same
+// K/V (or Q/dO) tiles, which then stay in that XCD's L2
+__device__ __forceinline__ int long_xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// rows [r0, r0+64) of src (64 bf16 per row, row stride ld elements; rows past L-1 replicate row L-1: finite filler that the
+// callers mask) -> row-major image (stride KLD) and/or transposed image (stride LVLD).  256 threads x 2 chunks of 16 B.
+__device__ __forceinline__ void stage_tile(unsigned short* rows, unsigned short* tr, const bf16* src, int64_t ld, int r0, int L, int tid) {
+    uint4 reg[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        int row = r0 + (idx >> 3);
+        if (row > L - 1) row = L - 1;
+        reg[i] = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + (idx & 7) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        const int p = idx >> 3, c8 = (idx & 7) * 8;
+        if (rows) *reinterpret_cast<uint4*>(rows + p * KLD + c8) = reg[i];
+        if (tr) {
+            const uint32_t w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tr[(c8 + 2 * j) * LVLD + p] = (unsigned short)(w[j] & 0xffffu);
+                tr[(c8 + 2 * j + 1) * LVLD + p] = (unsigned short)(w[j] >> 16);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_long_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
+                                                          int L, int H, int ntile, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[LT * KLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[D * LVLD];
+    const int bid = long_xcd_remap(blockIdx.x, gridDim.x);
+    const int item = bid / ntile, tile = bid - item * ntile;
+    const int f = item / H, h = item - f * H, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16* base = qkv + (int64_t)f * L * ld + h * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int q0 = tile * WG_ROWS + wave * 32, q = q0 + l31;
+    const bool active = q0 < L;                     // wave-uniform; inactive waves still stage tiles and meet the barriers
+    const int qc = q < L ? q : L - 1;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8_t*>(base + (int64_t)qc * ld + t * 16 + hi * 8);
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const int nkt = (L + LT - 1) / LT;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                            // every wave is done with the previous tile
+        stage_tile(Ks, nullptr, base + C, ld, kt * LT, L, tid);
+        stage_tile(nullptr, Vt, base + 2 * C, ld, kt * LT, L, tid);
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int k0 = kt * LT + sub * 32;
+            if (k0 >= L) break;
+            f32x16_t s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const unsigned short* kp = Ks + (sub * 32 + l31) * KLD + hi * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(kp + t * 16), qf[t], s, 0, 0, 0);
+            // lane holds keys k0 + (r&3) + 8*(r>>2) + 4*hi of its query; only the sequence's last sub-tile has padding keys
+            if (k0 + 32 > L) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (k0 + (r & 3) + 8 * (r >> 2) + 4 * hi < L) ? s[r] : -INFINITY;
+            }
+            float mt = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
+            const float mn = fmaxf(m, mt);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -mn)); ps += s[r]; }
+            l = l * alpha + ps;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {        // O^T += V^T P^T, 16 keys per step
+                const bf16x8_t pf = pack_frag(s, st);
+#pragma unroll
+                for (int et = 0; et < 2; ++et)
+                    oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Vt + (et * 32 + l31) * LVLD + sub * 32 + 16 * st + 4 * hi), pf,
+                                                                       oacc[et], 0, 0, 0);
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (active && q < L) {
+        const float inv = 1.f / l;
+        bf16* orow = o + ((int64_t)f * L + q) * C + h * D;
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 w = make_uint2(pack_bf2(oacc[et][4 * g] * inv, oacc[et][4 * g + 1] * inv),
+                                           pack_bf2(oacc[et][4 * g + 2] * inv, oacc[et][4 * g + 3] * inv));
+                *reinterpret_cast<uint2*>(orow + et * 32 + 8 * g + 4 * hi) = w;
+            }
+        if (hi == 0) lse[((int64_t)f * H + h) * L + q] = (m + log2f(l)) * 0.69314718055994530942f;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_long_bwd_dq_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+                                                             const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int L, int H,
+                                                             int ntile, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[LT * KLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[LT * KLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Kt[D * LVLD];
+    const int bid = long_xcd_remap(blockIdx.x, gridDim.x);
+    const int item = bid / ntile, tile = bid - item * ntile;
+    const int f = item / H, h = item - f * H, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16* base = qkv + (int64_t)f * L * ld + h * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int q0 = tile * WG_ROWS + wave * 32, q = q0 + l31;
+    const bool active = q0 < L;
+    const int qc = q < L ? q : L - 1;
+    const bf16* orow = o + ((int64_t)f * L + qc) * C + h * D;
+    const bf16* dorow = d_o + ((int64_t)f * L + qc) * C + h * D;
+    bf16x8_t qf[4], dof[4];
+    float Dq = 0.f;                                 // delta = rowsum(dO * O) of this lane's query
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        qf[t] = *reinterpret_cast<const bf16x8_t*>(base + (int64_t)qc * ld + t * 16 + hi * 8);
+        dof[t] = *reinterpret_cast<const bf16x8_t*>(dorow + t * 16 + hi * 8);
+        float a[8], b[8];
+        ld8(dorow + t * 16 + hi * 8, a); ld8(orow + t * 16 + hi * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Dq = fmaf(a[j], b[j], Dq);
+    }
+    Dq += __shfl_xor(Dq, 32, 64);
+    const float l2e = 1.44269504088896340736f;
+    const float L2 = lse[((int64_t)f * H + h) * L + qc] * l2e, sl2e = scale * l2e;
+    f32x16_t dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    const int nkt = (L + LT - 1) / LT;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_tile(Ks, Kt, base + C, ld, kt * LT, L, tid);
+        stage_tile(Vs, nullptr, base + 2 * C, ld, kt * LT, L, tid);
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int k0 = kt * LT + sub * 32;
+            if (k0 >= L) break;
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            const int off = (sub * 32 + l31) * KLD + hi * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Ks + off + t * 16), qf[t], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Vs + off + t * 16), dof[t], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float p = (k < L) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, -L2)) : 0.f;
+                s[r] = p * (dp[r] - Dq) * scale;    // dS^T
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {        // dQ^T += K^T dS^T
+                const bf16x8_t dsf = pack_frag(s, st);
+#pragma unroll
+                for (int et = 0; et < 2; ++et)
+                    dq[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Kt + (et * 32 + l31) * LVLD + sub * 32 + 16 * st + 4 * hi), dsf,
+                                                                     dq[et], 0, 0, 0);
+            }
+        }
+    }
+    if (active && q < L) store_rowT(dqkv + ((int64_t)f * L + q) * ld + h * D, dq, hi, accumulate);
+}
+
+__global__ __launch_bounds__(256) void attn_long_bwd_dkv_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+                                                              const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int L, int H,
+                                                              int ntile, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[LT * KLD];
+    __shared__ __attribute__((aligned(16))) unsigned short dOs[LT * KLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Qt[D * LVLD];
+    __shared__ __attribute__((aligned(16))) unsigned short dOt[D * LVLD];
+    __shared__ float Ls[LT], Ds[LT];
+    const int bid = long_xcd_remap(blockIdx.x, gridDim.x);
+    const int item = bid / ntile, tile = bid - item * ntile;
+    const int f = item / H, h = item - f * H, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16* base = qkv + (int64_t)f * L * ld + h * D;
+    const bf16* obase = o + (int64_t)f * L * C + h * D;
+    const bf16* dobase = d_o + (int64_t)f * L * C + h * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int k0w = tile * WG_ROWS + wave * 32, k = k0w + l31;
+    const bool active = k0w < L;
+    const int kc = k < L ? k : L - 1;
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        kf[t] = *reinterpret_cast<const bf16x8_t*>(base + C + (int64_t)kc * ld + t * 16 + hi * 8);
+        vf[t] = *reinterpret_cast<const bf16x8_t*>(base + 2 * C + (int64_t)kc * ld + t * 16 + hi * 8);
+    }
+    const float l2e = 1.44269504088896340736f, sl2e = scale * l2e;
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+    const int nqt = (L + LT - 1) / LT;
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+        stage_tile(Qs, Qt, base, ld, qt * LT, L, tid);
+        stage_tile(dOs, dOt, dobase, C, qt * LT, L, tid);
+        if (tid < LT) {                             // lse (in log2 units) and delta of the tile's 64 queries
+            int qi = qt * LT + tid;
+            if (qi > L - 1) qi = L - 1;
+            float dsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; c += 8) {
+                float a[8], b[8];
+                ld8(dobase + (int64_t)qi * C + c, a); ld8(obase + (int64_t)qi * C + c, b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum = fmaf(a[j], b[j], dsum);
+            }
+            Ds[tid] = dsum;
+            Ls[tid] = lse[((int64_t)f * H + h) * L + qi] * l2e;
+        }
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int q0 = qt * LT + sub * 32;
+            if (q0 >= L) break;
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            const int off = (sub * 32 + l31) * KLD + hi * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Qs + off + t * 16), kf[t], s, 0, 0, 0);      // D[q][k]: lane = key
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(dOs + off + t * 16), vf[t], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;         // row within the tile
+                const float p = (qt * LT + ql < L) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, -Ls[ql])) : 0.f;
+                dp[r] = p * (dp[r] - Ds[ql]) * scale;   // dS
+                s[r] = p;                               // P
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8_t pf = pack_frag(s, st), dsf = pack_frag(dp, st);
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    const int toff = (et * 32 + l31) * LVLD + sub * 32 + 16 * st + 4 * hi;
+                    dv[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(dOt + toff), pf, dv[et], 0, 0, 0);    // dV^T += dO^T P
+                    dk[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Qt + toff), dsf, dk[et], 0, 0, 0);    // dK^T += Q^T dS
+                }
+            }
+        }
+    }
+    if (active && k < L) {
+        bf16* drow = dqkv + ((int64_t)f * L + k) * ld + h * D;
+        store_rowT(drow + C, dk, hi, accumulate);
+        store_rowT(drow + 2 * C, dv, hi, accumulate);
+    }
+}
+
+}  // namespace
+
+// entry points used by maed_attn_spatial_{fwd,bwd} (attn_spatial.hip); arguments as there, bf16 only
+int maed_attn_long_fwd_launch(const void* qkv, void* o, float* lse, int F, int L, int H, float scale, hipStream_t s) {
+    const int ntile = (L + WG_ROWS - 1) / WG_ROWS;
+    MAED_CHECK_ARG((int64_t)F * H * ntile < (1ll << 31), MAED_ERR_SHAPE, "attn_long_fwd: grid too large");
+    hipLaunchKernelGGL(attn_long_fwd_mfma, dim3((unsigned)(F * H * ntile)), dim3(256), 0, s, (const bf16*)qkv, (bf16*)o, lse, L, H, ntile,
+                       scale * 1.44269504088896340736f);
+    MAED_CHECK_LAUNCH("attn_long_fwd");
+    return MAED_OK;
+}
+
+int maed_attn_long_bwd_launch(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int L, int H,
+                              float scale, hipStream_t s) {
+    const int ntile = (L + WG_ROWS - 1) / WG_ROWS;
+    MAED_CHECK_ARG((int64_t)F * H * ntile < (1ll << 31), MAED_ERR_SHAPE, "attn_long_bwd: grid too large");
+    const dim3 grid((unsigned)(F * H * ntile));
+    hipLaunchKernelGGL(attn_long_bwd_dq_mfma, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, accumulate,
+                       L, H, ntile, scale);
+    hipLaunchKernelGGL(attn_long_bwd_dkv_mfma, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, accumulate,
+                       L, H, ntile, scale);
+    MAED_CHECK_LAUNCH("attn_long_bwd");
+    return MAED_OK;
+}

@@ -546,6 +546,11 @@ __global__ __launch_bounds__(640) void attn_sp_bwd_dkv_mfma(const bf16* __restri
     }
 }
 
+// long-sequence (K/V-tiled) kernels: attn_long.hip
+int maed_attn_long_fwd_launch(const void* qkv, void* o, float* lse, int F, int L, int H, float scale, hipStream_t s);
+int maed_attn_long_bwd_launch(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int L, int H,
+                              float scale, hipStream_t s);
+
 // ==================================================================================================
 static size_t valu_lds_bytes(int P, bool bwd_dkv) { return ((size_t)2 * P * LDF + (bwd_dkv ? 2 * P : 0)) * sizeof(float); }
 
@@ -557,7 +562,10 @@ extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F
     if (F == 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool use_mfma = (dtype == MAED_BF16) && (impl != MAED_IMPL_VALU);
-    MAED_CHECK_ARG(!(impl == MAED_IMPL_MFMA && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED, "attn_spatial_fwd: MFMA path is bf16 only");
+    MAED_CHECK_ARG(!((impl == MAED_IMPL_MFMA || impl == MAED_IMPL_MFMA_LONG) && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED,
+                   "attn_spatial_fwd: MFMA path is bf16 only");
+    // sequences that do not fit one workgroup's LDS (st_mode='coupling': T*P tokens), or on request: the K/V-tiled kernels
+    if (use_mfma && (impl == MAED_IMPL_MFMA_LONG || P > 512)) return maed_attn_long_fwd_launch(qkv, o, lse, F, P, H, scale, s);
     if (use_mfma) {
         const int Pk = (P + 31) & ~31;
         MAED_CHECK_ARG(Pk / 32 <= 16, MAED_ERR_SHAPE, "attn_spatial_fwd(mfma): P=%d > 512 tokens per frame", P);
@@ -597,11 +605,14 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
                                      int accumulate, int F, int P, int H, float scale, int dtype, int impl, void* stream) {
     MAED_CHECK_ARG(qkv && o && d_o && lse && dqkv, MAED_ERR_ARG, "attn_spatial_bwd: null pointer");
     MAED_CHECK_ARG(F >= 0 && P > 0 && H > 0, MAED_ERR_SHAPE, "attn_spatial_bwd: bad extents");
-    MAED_CHECK_ARG(valu_lds_bytes(P, true) <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_bwd: P=%d too large for LDS", P);
-    MAED_CHECK_ARG(!(impl == MAED_IMPL_MFMA && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED, "attn_spatial_bwd: MFMA path is bf16 only");
+    MAED_CHECK_ARG(!((impl == MAED_IMPL_MFMA || impl == MAED_IMPL_MFMA_LONG) && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED,
+                   "attn_spatial_bwd: MFMA path is bf16 only");
     if (F == 0) return MAED_OK;
     const bool mfma_fits = ((P + 31) / 32) <= 10;  // 640-thread workgroups (register budget 168/lane)
-    MAED_CHECK_ARG(!(impl == MAED_IMPL_MFMA && !mfma_fits), MAED_ERR_SHAPE, "attn_spatial_bwd(mfma): P=%d > 320", P);
+    // sequences beyond the whole-head kernels (MFMA: 320 tokens, VALU: LDS), or on request: the tiled two-pass backward
+    if (dtype == MAED_BF16 && impl != MAED_IMPL_VALU &&
+        (impl == MAED_IMPL_MFMA_LONG || (!mfma_fits && (impl == MAED_IMPL_MFMA || valu_lds_bytes(P, true) > 160 * 1024))))
+        return maed_attn_long_bwd_launch(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     if (dtype == MAED_BF16 && impl != MAED_IMPL_VALU && mfma_fits) {
         const int Pk = (P + 31) & ~31;
         const size_t lds_dq = ((size_t)2 * P * KLD + (size_t)D * (Pk + 4)) * 2;
@@ -621,6 +632,7 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
         MAED_CHECK_LAUNCH("attn_spatial_bwd(mfma)");
         return MAED_OK;
     }
+    MAED_CHECK_ARG(valu_lds_bytes(P, true) <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_bwd(valu): P=%d too large for LDS", P);
     if (dtype == MAED_F32) launch_bwd_valu<float>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     else if (dtype == MAED_BF16) launch_bwd_valu<bf16>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     else { maed_set_error("attn_spatial_bwd: bad dtype"); return MAED_ERR_ARG; }

@@ -13,9 +13,9 @@ the benchmarked path and are composed here from the same libmaed_hip kernels, on
 
 'coupling' attends over the T*P tokens of a clip.  Frames of a clip are contiguous rows, and the reference's reshape_T
 (:180-189) orders a clip's tokens (t, p), i.e. exactly the row-major order of the (T, P, 3C) qkv rows of that clip -- so
-coupling is the spatial kernel on the VIEW (N, T*P, 3C), no data movement.  The spatial kernels keep one (frame, head)'s K/V
-in LDS, which bounds T*P (<= 512 forward / 320 backward on the MFMA path): tiny clips only; the long-sequence K/V-tiled
-kernel this mode needs at 16 x 197 tokens is future work and the library reports MAED_ERR_SHAPE until then.
+coupling is the spatial entry point on the VIEW (N, T*P, 3C), no data movement.  Past the whole-head kernels' limits (512
+tokens forward, 320 backward; 16 x 197 = 3152 at cfg3) the library switches to the K/V-tiled long-sequence kernels of
+csrc/attn_long.hip (bf16); the f32 parity mode is limited to sequences whose K/V fit one workgroup's LDS (~300 tokens).
 """
 import torch
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "maed_amd", "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 OUT = os.path.join(OUT_DIR, "libmaed_hostsim.so")
-SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip"]
+SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip", "attn_long.hip"]
 CLANG = os.environ.get("MAED_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 

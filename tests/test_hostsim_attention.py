@@ -89,3 +89,63 @@ def test_ste_block_forward_backward_vs_oracle(dtype, impl):
         scale = max(ref.abs().max().item(), 1e-3)
         assert prm.grad is not None, name
         close(prm.grad, ref, rtol=1e-3 if f32 else 5e-2, atol=(1e-4 if f32 else 3e-2) * scale)
+
+
+# ---- long-sequence (K/V-tiled) kernels: attn_long.hip ------------------------------------------------------------------
+@pytest.mark.parametrize("Fr,L_,H,impl", [
+    (2, 5, 2, L.IMPL_MFMA_LONG),          # one partial tile, one partially filled wave
+    (1, 197, 2, L.IMPL_MFMA_LONG),        # spatial shape of cfg3 through the tiled kernels: 2 row tiles x 4 streamed tiles, ragged ends
+    (1, 64, 1, L.IMPL_MFMA_LONG),         # exactly one full tile (no masking anywhere)
+    (1, 530, 1, L.IMPL_AUTO),             # beyond every whole-head limit: AUTO must pick the tiled kernels (fwd > 512, bwd > 320)
+])
+def test_attn_long_fwd_bwd(Fr, L_, H, impl):
+    dtype = torch.bfloat16
+    qkv = q(rnd(Fr, L_, 3 * 64 * H, seed=L_), dtype)
+    do = q(rnd(Fr, L_, 64 * H, seed=4), dtype)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_spatial(qq, kk, vv, 64 ** -0.5)
+    lse_ref = torch.logsumexp((qq @ kk.transpose(-2, -1)) * 64 ** -0.5, dim=-1)
+    oref.backward(do.double())
+    with patched():
+        o, lse = ops.attn_spatial_fwd(qkv.to(dtype), H, impl)
+        dqkv = ops.attn_spatial_bwd(qkv.to(dtype), o, do.to(dtype), lse, H, impl=impl)
+        acc = ops.attn_spatial_bwd(qkv.to(dtype), o, do.to(dtype), lse, H, dqkv=dqkv.clone(), accumulate=True, impl=impl)
+    close(o.float(), oref.detach(), **tol(dtype))
+    close(lse, lse_ref.detach(), rtol=1e-4, atol=2e-2)
+    close(dqkv.float(), x.grad, **tol(dtype, 0.5))
+    close(acc.float(), 2 * x.grad, **tol(dtype, 1.0))            # accumulate=1 adds into the existing gradient
+
+
+def test_attn_long_agrees_with_whole_head_kernels():
+    """same inputs through the whole-head MFMA kernels and the tiled ones: identical math up to the online-softmax rescaling order"""
+    dtype = torch.bfloat16
+    qkv = q(rnd(2, 150, 3 * 64, seed=9), dtype).to(dtype)
+    do = q(rnd(2, 150, 64, seed=10), dtype).to(dtype)
+    with patched():
+        o1, l1 = ops.attn_spatial_fwd(qkv, 1, L.IMPL_MFMA)
+        o2, l2 = ops.attn_spatial_fwd(qkv, 1, L.IMPL_MFMA_LONG)
+        g1 = ops.attn_spatial_bwd(qkv, o1, do, l1, 1, impl=L.IMPL_MFMA)
+        g2 = ops.attn_spatial_bwd(qkv, o1, do, l1, 1, impl=L.IMPL_MFMA_LONG)
+    close(o2.float(), o1.float(), rtol=1e-2, atol=1e-2)
+    close(l2, l1, rtol=1e-5, atol=1e-5)
+    close(g2.float(), g1.float(), rtol=1e-2, atol=1e-2)
+
+
+def test_coupling_mode_at_a_sequence_beyond_the_whole_head_limit():
+    """st_mode='coupling' with T*P = 8 * 70 = 560 tokens per clip (vision_transformer.py:160-163): the reshape-free view of the
+    qkv rows + the tiled kernels against the oracle's explicit reshape_T formulation, forward and backward"""
+    from maed_amd import ste_modes
+    N, T, P, H = 1, 8, 70, 1
+    dtype = torch.bfloat16
+    qkv = q(rnd(N * T, P, 3 * 64 * H, seed=21), dtype)
+    do = q(rnd(N * T, P, 64 * H, seed=22), dtype)
+    x = qkv.double().requires_grad_(True)
+    oref = R.attention_coupling(*R.split_qkv(x, H), T, 64 ** -0.5)
+    oref.backward(do.double())
+    xg = qkv.to(dtype).requires_grad_(True)
+    with patched():
+        o = ste_modes.SpatialAttnFn.apply(xg.view(N, T * P, 3 * 64 * H), H, L.IMPL_AUTO).view(N * T, P, 64 * H)
+        o.backward(do.to(dtype))
+    close(o.float(), oref.detach(), **tol(dtype))
+    close(xg.grad.float(), x.grad, **tol(dtype, 0.5))
