@@ -8,3 +8,5 @@ from .ktd import KTD  # noqa: F401
 from .vision_transformer import VisionTransformer, Block, Attention, Mlp, vit_custom_resnet50_224_in21k  # noqa: F401
 from .resnetv2 import ResNetV2  # noqa: F401
 from .smpl import SMPL  # noqa: F401
+from .iterative import Regressor  # noqa: F401
+from .evaluate import Evaluator  # noqa: F401

@@ -22,7 +22,6 @@ import torch.distributed as dist
 
 from . import _lib as L
 from . import ops
-from .vision_transformer import Block
 
 ALIGN = 64  # elements: every view starts 256-B aligned
 

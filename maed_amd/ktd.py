@@ -9,11 +9,8 @@ Training on the GPU runs the same forward kernels inside two autograd Functions 
 is ~10 hand-written launches; fc1/fc2 + Dropout stay ATen (two plain GEMMs and the framework's RNG).  The
 ATen composition of the whole tail is kept for CPU tensors and for a differentiable J_regressor override.
 """
-import ctypes as C
-
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib as L
 from . import ops

@@ -12,7 +12,6 @@ or 'iterative' (spin.py Regressor; extra kwarg smpl_mean_params).
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib as L
 from .ktd import KTD

@@ -15,7 +15,6 @@ Module / parameter names match the reference so its checkpoints load unchanged.
 import math
 import os
 from collections import OrderedDict
-from functools import partial
 
 import torch
 import torch.nn as nn

@@ -1,7 +1,7 @@
 """STE spatial-attention forward at the cfg3 shape (F=128, P=197, H=8, bf16) in isolation: event timing and a
 clean target for `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE` (HBM traffic per launch).  Inputs are ~N(0,1) random
 (never zero-filled: DVFS / softmax work depend on the data)."""
-import os, sys, time
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maed_amd import ops
