@@ -127,3 +127,37 @@ def test_vit_tiny_modes_match_reference(golden, mode):
 def test_unknown_mode_rejected():
     with pytest.raises(NotImplementedError):
         Attention(128, num_heads=2, st_mode="bogus")
+
+
+def test_staged_block_trains_through_arena_bucketer_and_fused_adam():
+    """a staged Block has no kernel-written gradients (fused_parameters() == []): every parameter must reach the gradient arena
+    through autograd's accumulate hooks, complete its bucket, and take the same Adam step as torch.optim.Adam"""
+    import copy
+    from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+    torch.manual_seed(0)
+    blk = Block(128, 2, mlp_ratio=2, qkv_bias=True, norm_layer=LN, st_mode="series", compute_dtype=torch.float32)
+    ref = copy.deepcopy(blk)
+    x, dy = rnd(4, 5, 128, seed=3), rnd(4, 5, 128, seed=4)
+    with patched():
+        arena = ParamArena(blk, device=torch.device("cpu"))
+        bucketer = GradBucketer(arena, blk, bucket_bytes=64 << 10)
+        assert len(bucketer.buckets) > 1 and not bucketer._fused
+        opt = FusedAdam(arena, lr=1e-2, weight_decay=1e-3, bucketer=bucketer, model=blk)
+        topt = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-3)
+        for step in range(2):
+            opt.zero_grad()
+            (blk(x, 2) * dy).sum().backward()
+            assert all(bucketer._launched), "every bucket must have completed during backward"
+            topt.zero_grad()
+            (ref(x, 2) * dy).sum().backward()
+            for (n, p), q_ in zip(blk.named_parameters(), ref.parameters()):
+                assert p.grad.data_ptr() == arena.grad[arena.offsets[arena.index[id(p)]]:].data_ptr(), n      # accumulated IN the arena
+                if step == 0:
+                    torch.testing.assert_close(p.grad, q_.grad, rtol=1e-4, atol=1e-5, msg=n)
+                # (softmax is invariant to the key bias: that gradient is pure rounding noise, which Adam's 1/sqrt(v) would turn
+                #  into O(lr) differences) -> both optimizers step on the SAME gradients
+                q_.grad.copy_(p.grad)
+            opt.step()
+            topt.step()
+    for (n, p), q_ in zip(blk.named_parameters(), ref.parameters()):
+        torch.testing.assert_close(p, q_, rtol=1e-5, atol=1e-6, msg=n)
