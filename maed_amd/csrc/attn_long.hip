@@ -305,9 +305,185 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_mfma(const bf16* __rest
     }
 }
 
+// ==================================================================================================
+// Exact-arithmetic (VALU) variants for the f32 parity mode: thread per row, the streamed side in fp32 LDS tiles.
+// Same decomposition as the whole-head VALU kernels of attn_spatial.hip; correctness path, not a throughput path.
+// ==================================================================================================
+constexpr int VT = 64;          // streamed rows per tile
+constexpr int VLDF = 65;        // padded fp32 LDS row
+constexpr int VROWS = 256;      // rows owned by a workgroup (one per thread)
+
+template <typename T>
+__device__ __forceinline__ void stage_tile_f32(float* dst, const T* src, int64_t ld, int r0, int L, int tid) {
+    for (int idx = tid; idx < VT * (D / 4); idx += 256) {
+        const int p = idx / (D / 4), c = (idx % (D / 4)) * 4;
+        int row = r0 + p;
+        if (row > L - 1) row = L - 1;
+        float v[4];
+        ld4(src + (int64_t)row * ld + c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[p * VLDF + c + j] = v[j];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_long_fwd_valu(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse, int L, int H,
+                                                          int ntile, float scale) {
+    __shared__ float Ks[VT * VLDF], Vs[VT * VLDF];
+    const int item = blockIdx.x / ntile, tile = blockIdx.x - item * ntile;
+    const int f = item / H, h = item - f * H, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)f * L * ld + h * D;
+    const int tid = threadIdx.x, q = tile * VROWS + tid;
+    const int qc = q < L ? q : L - 1;
+    float qv[D], acc[D];
+#pragma unroll
+    for (int c = 0; c < D; c += 4) { float v[4]; ld4(base + (int64_t)qc * ld + c, v); qv[c] = v[0]; qv[c + 1] = v[1]; qv[c + 2] = v[2]; qv[c + 3] = v[3]; }
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < L; k0 += VT) {
+        __syncthreads();
+        stage_tile_f32(Ks, base + C, ld, k0, L, tid);
+        stage_tile_f32(Vs, base + 2 * C, ld, k0, L, tid);
+        __syncthreads();
+        const int kn = (L - k0 < VT) ? L - k0 : VT;
+        for (int k = 0; k < kn; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) s = fmaf(qv[c], Ks[k * VLDF + c], s);
+            s *= scale;
+            const float mn = fmaxf(m, s);
+            const float a = __expf(m - mn), p = __expf(s - mn);
+            l = l * a + p;
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] = fmaf(p, Vs[k * VLDF + c], acc[c] * a);
+            m = mn;
+        }
+    }
+    if (q < L) {
+        const float inv = 1.f / l;
+        T* orow = o + ((int64_t)f * L + q) * C + h * D;
+#pragma unroll
+        for (int c = 0; c < D; c += 4) { float v[4] = {acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv}; st4(orow + c, v); }
+        lse[((int64_t)f * H + h) * L + q] = m + __logf(l);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_row_acc(T* dst, const float (&acc)[D], int accumulate) {
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        float v[4] = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+        if (accumulate) { float old[4]; ld4(dst + c, old); v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3]; }
+        st4(dst + c, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_long_bwd_dq_valu(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
+                                                             const float* __restrict__ lse, T* __restrict__ dqkv, int accumulate, int L, int H,
+                                                             int ntile, float scale) {
+    __shared__ float Ks[VT * VLDF], Vs[VT * VLDF];
+    const int item = blockIdx.x / ntile, tile = blockIdx.x - item * ntile;
+    const int f = item / H, h = item - f * H, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)f * L * ld + h * D;
+    const int tid = threadIdx.x, q = tile * VROWS + tid;
+    const int qc = q < L ? q : L - 1;
+    const T* orow = o + ((int64_t)f * L + qc) * C + h * D;
+    const T* dorow = d_o + ((int64_t)f * L + qc) * C + h * D;
+    float qv[D], dov[D], dq[D];
+    float Dq = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        float v[4], w[4], u[4];
+        ld4(base + (int64_t)qc * ld + c, v); ld4(dorow + c, w); ld4(orow + c, u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { qv[c + j] = v[j]; dov[c + j] = w[j]; Dq = fmaf(w[j], u[j], Dq); dq[c + j] = 0.f; }
+    }
+    const float Lq = lse[((int64_t)f * H + h) * L + qc];
+    for (int k0 = 0; k0 < L; k0 += VT) {
+        __syncthreads();
+        stage_tile_f32(Ks, base + C, ld, k0, L, tid);
+        stage_tile_f32(Vs, base + 2 * C, ld, k0, L, tid);
+        __syncthreads();
+        const int kn = (L - k0 < VT) ? L - k0 : VT;
+        for (int k = 0; k < kn; ++k) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) { s = fmaf(qv[c], Ks[k * VLDF + c], s); dp = fmaf(dov[c], Vs[k * VLDF + c], dp); }
+            const float ds = __expf(s * scale - Lq) * (dp - Dq) * scale;
+#pragma unroll
+            for (int c = 0; c < D; ++c) dq[c] = fmaf(ds, Ks[k * VLDF + c], dq[c]);
+        }
+    }
+    if (q < L) store_row_acc(dqkv + ((int64_t)f * L + q) * ld + h * D, dq, accumulate);
+}
+
+// thread per key; SWEEP 0: dV[k] = sum_q p dO[q]; SWEEP 1: dK[k] = sum_q dS Q[q]  (two sweeps over the query tiles to stay in registers)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_long_bwd_dkv_valu(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ d_o,
+                                                              const float* __restrict__ lse, T* __restrict__ dqkv, int accumulate, int L, int H,
+                                                              int ntile, float scale) {
+    __shared__ float Qs[VT * VLDF], dOs[VT * VLDF], Ls[VT], Ds[VT];
+    const int item = blockIdx.x / ntile, tile = blockIdx.x - item * ntile;
+    const int f = item / H, h = item - f * H, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const T* base = qkv + (int64_t)f * L * ld + h * D;
+    const T* obase = o + (int64_t)f * L * C + h * D;
+    const T* dobase = d_o + (int64_t)f * L * C + h * D;
+    const int tid = threadIdx.x, k = tile * VROWS + tid;
+    const int kc = k < L ? k : L - 1;
+    float kv[D], vv[D], acc[D];
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        float a[4], b[4];
+        ld4(base + C + (int64_t)kc * ld + c, a); ld4(base + 2 * C + (int64_t)kc * ld + c, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kv[c + j] = a[j]; vv[c + j] = b[j]; }
+    }
+    for (int sweep = 0; sweep < 2; ++sweep) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = 0.f;
+        for (int q0 = 0; q0 < L; q0 += VT) {
+            __syncthreads();
+            stage_tile_f32(Qs, base, ld, q0, L, tid);
+            stage_tile_f32(dOs, dobase, (int64_t)C, q0, L, tid);
+            if (tid < VT) {
+                int qi = q0 + tid;
+                if (qi > L - 1) qi = L - 1;
+                float dsum = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; c += 4) {
+                    float a[4], b[4];
+                    ld4(dobase + (int64_t)qi * C + c, a); ld4(obase + (int64_t)qi * C + c, b);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dsum = fmaf(a[j], b[j], dsum);
+                }
+                Ds[tid] = dsum;
+                Ls[tid] = lse[((int64_t)f * H + h) * L + qi];
+            }
+            __syncthreads();
+            const int qn = (L - q0 < VT) ? L - q0 : VT;
+            for (int qq = 0; qq < qn; ++qq) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) { s = fmaf(Qs[qq * VLDF + c], kv[c], s); dp = fmaf(dOs[qq * VLDF + c], vv[c], dp); }
+                const float p = __expf(s * scale - Ls[qq]);
+                const float w = sweep == 0 ? p : p * (dp - Ds[qq]) * scale;
+                const float* src = sweep == 0 ? dOs + qq * VLDF : Qs + qq * VLDF;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc[c] = fmaf(w, src[c], acc[c]);
+            }
+        }
+        if (k < L) store_row_acc(dqkv + ((int64_t)f * L + k) * ld + (sweep == 0 ? 2 * C : C) + h * D, acc, accumulate);
+    }
+}
+
 }  // namespace
 
-// entry points used by maed_attn_spatial_{fwd,bwd} (attn_spatial.hip); arguments as there, bf16 only
+// entry points used by maed_attn_spatial_{fwd,bwd} (attn_spatial.hip); arguments as there.  *_launch: bf16 MFMA; *_valu_launch: exact VALU
 int maed_attn_long_fwd_launch(const void* qkv, void* o, float* lse, int F, int L, int H, float scale, hipStream_t s) {
     const int ntile = (L + WG_ROWS - 1) / WG_ROWS;
     MAED_CHECK_ARG((int64_t)F * H * ntile < (1ll << 31), MAED_ERR_SHAPE, "attn_long_fwd: grid too large");
@@ -327,5 +503,27 @@ int maed_attn_long_bwd_launch(const void* qkv, const void* o, const void* d_o, c
     hipLaunchKernelGGL(attn_long_bwd_dkv_mfma, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, accumulate,
                        L, H, ntile, scale);
     MAED_CHECK_LAUNCH("attn_long_bwd");
+    return MAED_OK;
+}
+
+int maed_attn_long_fwd_valu_launch(const void* qkv, void* o, float* lse, int F, int L, int H, float scale, int dtype, hipStream_t s) {
+    const int ntile = (L + VROWS - 1) / VROWS;
+    const dim3 grid((unsigned)(F * H * ntile));
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((attn_long_fwd_valu<T>), grid, dim3(256), 0, s, (const T*)qkv, (T*)o, lse, L, H, ntile, scale));
+    MAED_CHECK_LAUNCH("attn_long_fwd(valu)");
+    return MAED_OK;
+}
+
+int maed_attn_long_bwd_valu_launch(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int L,
+                                   int H, float scale, int dtype, hipStream_t s) {
+    const int ntile = (L + VROWS - 1) / VROWS;
+    const dim3 grid((unsigned)(F * H * ntile));
+    MAED_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((attn_long_bwd_dq_valu<T>), grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, accumulate, L, H,
+                           ntile, scale);
+        hipLaunchKernelGGL((attn_long_bwd_dkv_valu<T>), grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)d_o, lse, (T*)dqkv, accumulate, L, H,
+                           ntile, scale);
+    });
+    MAED_CHECK_LAUNCH("attn_long_bwd(valu)");
     return MAED_OK;
 }

@@ -550,6 +550,9 @@ __global__ __launch_bounds__(640) void attn_sp_bwd_dkv_mfma(const bf16* __restri
 int maed_attn_long_fwd_launch(const void* qkv, void* o, float* lse, int F, int L, int H, float scale, hipStream_t s);
 int maed_attn_long_bwd_launch(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int L, int H,
                               float scale, hipStream_t s);
+int maed_attn_long_fwd_valu_launch(const void* qkv, void* o, float* lse, int F, int L, int H, float scale, int dtype, hipStream_t s);
+int maed_attn_long_bwd_valu_launch(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int L,
+                                   int H, float scale, int dtype, hipStream_t s);
 
 // ==================================================================================================
 static size_t valu_lds_bytes(int P, bool bwd_dkv) { return ((size_t)2 * P * LDF + (bwd_dkv ? 2 * P : 0)) * sizeof(float); }
@@ -577,7 +580,7 @@ extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F
                            scale * 1.44269504088896340736f);
     } else {
         const size_t lds = valu_lds_bytes(P, false);
-        MAED_CHECK_ARG(lds <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_fwd(valu): P=%d needs %zu B LDS", P, lds);
+        if (lds > 160 * 1024) return maed_attn_long_fwd_valu_launch(qkv, o, lse, F, P, H, scale, dtype, s);   // K/V do not fit: tiled
         if (dtype == MAED_F32) {
             hipFuncSetAttribute((const void*)attn_sp_fwd_valu<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((attn_sp_fwd_valu<float>), dim3(F * H), dim3(256), lds, s, (const float*)qkv, (float*)o, lse, P, H, scale);
@@ -632,7 +635,8 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
         MAED_CHECK_LAUNCH("attn_spatial_bwd(mfma)");
         return MAED_OK;
     }
-    MAED_CHECK_ARG(valu_lds_bytes(P, true) <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_bwd(valu): P=%d too large for LDS", P);
+    if (valu_lds_bytes(P, true) > 160 * 1024)      // Q/dO do not fit one workgroup's LDS: tiled exact kernels
+        return maed_attn_long_bwd_valu_launch(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, dtype, (hipStream_t)stream);
     if (dtype == MAED_F32) launch_bwd_valu<float>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     else if (dtype == MAED_BF16) launch_bwd_valu<bf16>(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     else { maed_set_error("attn_spatial_bwd: bad dtype"); return MAED_ERR_ARG; }

@@ -15,7 +15,7 @@ the benchmarked path and are composed here from the same libmaed_hip kernels, on
 (:180-189) orders a clip's tokens (t, p), i.e. exactly the row-major order of the (T, P, 3C) qkv rows of that clip -- so
 coupling is the spatial entry point on the VIEW (N, T*P, 3C), no data movement.  Past the whole-head kernels' limits (512
 tokens forward, 320 backward; 16 x 197 = 3152 at cfg3) the library switches to the K/V-tiled long-sequence kernels of
-csrc/attn_long.hip (bf16); the f32 parity mode is limited to sequences whose K/V fit one workgroup's LDS (~300 tokens).
+csrc/attn_long.hip: MFMA flash forward / two-pass backward in bf16, exact VALU tiles in the f32 parity mode.
 """
 import torch
 

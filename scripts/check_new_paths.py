@@ -178,6 +178,15 @@ def long_attention():
             g = ops.attn_spatial_bwd(qkv.to(DEV), o, do.to(DEV), lse, H, impl=impl)
         check(f"long attention F{Fr} L{L_} H{H} impl{impl} forward vs fp64 oracle", rel(o, oref), 2e-2)
         check(f"long attention F{Fr} L{L_} H{H} impl{impl} dqkv vs fp64 oracle", rel(g, x.grad), 3e-2)
+    qkv, do = rnd(1, 330, 3 * 64, seed=330), rnd(1, 330, 64, seed=4)          # f32 parity mode past the whole-head LDS limit: exact tiled kernels
+    x = qkv.double().requires_grad_(True)
+    oref = R.attention_spatial(*R.split_qkv(x, 1), 64 ** -0.5)
+    oref.backward(do.double())
+    with patched():
+        o, lse = ops.attn_spatial_fwd(qkv.to(DEV), 1, L.IMPL_AUTO)
+        g = ops.attn_spatial_bwd(qkv.to(DEV), o, do.to(DEV), lse, 1)
+    check("long attention f32 (exact VALU tiles) L330 forward vs fp64 oracle", rel(o, oref), 2e-5)
+    check("long attention f32 (exact VALU tiles) L330 dqkv vs fp64 oracle", rel(g, x.grad), 5e-5)
     N, T, P, H = 1, 8, 70, 1
     qkv, do = rnd(N * T, P, 3 * 64 * H, seed=21).bfloat16(), rnd(N * T, P, 64 * H, seed=22).bfloat16()
     x = qkv.double().requires_grad_(True)

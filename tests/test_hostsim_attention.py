@@ -149,3 +149,24 @@ def test_coupling_mode_at_a_sequence_beyond_the_whole_head_limit():
         o.backward(do.to(dtype))
     close(o.float(), oref.detach(), **tol(dtype))
     close(xg.grad.float(), x.grad, **tol(dtype, 0.5))
+
+
+@pytest.mark.parametrize("dtype,impl", [(torch.float32, L.IMPL_AUTO), (torch.bfloat16, L.IMPL_VALU)])
+def test_attn_long_exact_valu_kernels(dtype, impl):
+    """f32 parity mode (and bf16 with the VALU kernels forced) past the whole-head LDS limit of ~310 tokens: tiled exact kernels"""
+    Fr, L_, H = 1, 330, 2
+    qkv = q(rnd(Fr, L_, 3 * 64 * H, seed=L_), dtype)
+    do = q(rnd(Fr, L_, 64 * H, seed=4), dtype)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_spatial(qq, kk, vv, 64 ** -0.5)
+    lse_ref = torch.logsumexp((qq @ kk.transpose(-2, -1)) * 64 ** -0.5, dim=-1)
+    oref.backward(do.double())
+    with patched():
+        o, lse = ops.attn_spatial_fwd(qkv.to(dtype), H, impl)
+        dqkv = ops.attn_spatial_bwd(qkv.to(dtype), o, do.to(dtype), lse, H, impl=impl)
+        acc = ops.attn_spatial_bwd(qkv.to(dtype), o, do.to(dtype), lse, H, dqkv=dqkv.clone(), accumulate=True, impl=impl)
+    close(o.float(), oref.detach(), **tol(dtype))
+    close(lse, lse_ref.detach(), rtol=1e-4, atol=1e-3 if dtype == torch.float32 else 2e-2)
+    close(dqkv.float(), x.grad, **tol(dtype, 0.5))
+    close(acc.float(), 2 * x.grad, **tol(dtype, 1.0))
