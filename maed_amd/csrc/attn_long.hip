@@ -14,8 +14,9 @@
 //
 // Data layout is the spatial kernels': qkv (items, L, 3C) with q|k|v channel blocks and head-major channels, o / d_o (items, L, C),
 // lse (items, H, L) natural log, dqkv like qkv.  Selected by maed_attn_spatial_{fwd,bwd} when the sequence does not fit the
-// whole-head kernels, or explicitly with impl = MAED_IMPL_MFMA_LONG.  Single-buffered staging (two barriers per tile): the first
-// correct version; software pipelining is left to a round with a GPU to measure it on.
+// whole-head kernels, or explicitly with impl = MAED_IMPL_MFMA_LONG.  One LDS buffer, two barriers per tile; the next tile's global
+// loads are issued into registers before the current tile is consumed (register prefetch), so only the LDS write sits between the
+// barriers.  Not yet measured on hardware (written after the round-1 GPU budget was spent; scripts/attn_long_micro.py).
 #include "attn_mfma.cuh"
 
 #define D HEAD_DIM
@@ -34,31 +35,36 @@ __device__ __forceinline__ int long_xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-// rows [r0, r0+64) of src (64 bf16 per row, row stride ld elements; rows past L-1 replicate row L-1: finite filler that the
-// callers mask) -> row-major image (stride KLD) and/or transposed image (stride LVLD).  256 threads x 2 chunks of 16 B.
-__device__ __forceinline__ void stage_tile(unsigned short* rows, unsigned short* tr, const bf16* src, int64_t ld, int r0, int L, int tid) {
-    uint4 reg[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 256;
-        int row = r0 + (idx >> 3);
-        if (row > L - 1) row = L - 1;
-        reg[i] = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + (idx & 7) * 8);
+// One streamed tile = rows [r0, r0+64) of src (64 bf16 per row, row stride ld elements; rows past L-1 replicate row L-1: finite
+// filler that the callers mask).  256 threads x 2 chunks of 16 B.  Split in two so that the NEXT tile's global loads are in
+// flight while the current tile is consumed: tile_load() right after the barrier that publishes the current tile, tile_store()
+// (row-major image with stride KLD and/or transposed image with stride LVLD) after the barrier that retires it.
+// (two named uint4 per tile rather than an array: arrays that live across the loop's conditional reload get demoted to scratch)
+struct TileRegs { uint4 a, b; };
+
+__device__ __forceinline__ uint4 tile_load1(const bf16* src, int64_t ld, int r0, int L, int idx) {
+    int row = r0 + (idx >> 3);
+    if (row > L - 1) row = L - 1;
+    return *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + (idx & 7) * 8);
+}
+__device__ __forceinline__ void tile_load(TileRegs& t, const bf16* src, int64_t ld, int r0, int L, int tid) {
+    t.a = tile_load1(src, ld, r0, L, tid);
+    t.b = tile_load1(src, ld, r0, L, tid + 256);
+}
+
+__device__ __forceinline__ void tile_store1(const uint4 v, unsigned short* rows, unsigned short* tr, int idx) {
+    const int p = idx >> 3, c8 = (idx & 7) * 8;
+    if (rows) *reinterpret_cast<uint4*>(rows + p * KLD + c8) = v;
+    if (tr) {
+        tr[(c8 + 0) * LVLD + p] = (unsigned short)(v.x & 0xffffu); tr[(c8 + 1) * LVLD + p] = (unsigned short)(v.x >> 16);
+        tr[(c8 + 2) * LVLD + p] = (unsigned short)(v.y & 0xffffu); tr[(c8 + 3) * LVLD + p] = (unsigned short)(v.y >> 16);
+        tr[(c8 + 4) * LVLD + p] = (unsigned short)(v.z & 0xffffu); tr[(c8 + 5) * LVLD + p] = (unsigned short)(v.z >> 16);
+        tr[(c8 + 6) * LVLD + p] = (unsigned short)(v.w & 0xffffu); tr[(c8 + 7) * LVLD + p] = (unsigned short)(v.w >> 16);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 256;
-        const int p = idx >> 3, c8 = (idx & 7) * 8;
-        if (rows) *reinterpret_cast<uint4*>(rows + p * KLD + c8) = reg[i];
-        if (tr) {
-            const uint32_t w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tr[(c8 + 2 * j) * LVLD + p] = (unsigned short)(w[j] & 0xffffu);
-                tr[(c8 + 2 * j + 1) * LVLD + p] = (unsigned short)(w[j] >> 16);
-            }
-        }
-    }
+}
+__device__ __forceinline__ void tile_store(const TileRegs& t, unsigned short* rows, unsigned short* tr, int tid) {
+    tile_store1(t.a, rows, tr, tid);
+    tile_store1(t.b, rows, tr, tid + 256);
 }
 
 __global__ __launch_bounds__(256) void attn_long_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
@@ -82,11 +88,18 @@ __global__ __launch_bounds__(256) void attn_long_fwd_mfma(const bf16* __restrict
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
     float m = -INFINITY, l = 0.f;
     const int nkt = (L + LT - 1) / LT;
+    TileRegs kreg, vreg;
+    tile_load(kreg, base + C, ld, 0, L, tid);
+    tile_load(vreg, base + 2 * C, ld, 0, L, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                            // every wave is done with the previous tile
-        stage_tile(Ks, nullptr, base + C, ld, kt * LT, L, tid);
-        stage_tile(nullptr, Vt, base + 2 * C, ld, kt * LT, L, tid);
+        tile_store(kreg, Ks, nullptr, tid);
+        tile_store(vreg, nullptr, Vt, tid);
         __syncthreads();
+        if (kt + 1 < nkt) {                         // next tile's loads fly while this one is consumed
+            tile_load(kreg, base + C, ld, (kt + 1) * LT, L, tid);
+            tile_load(vreg, base + 2 * C, ld, (kt + 1) * LT, L, tid);
+        }
         if (!active) continue;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -178,11 +191,18 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_mfma(const bf16* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
     const int nkt = (L + LT - 1) / LT;
+    TileRegs kreg, vreg;
+    tile_load(kreg, base + C, ld, 0, L, tid);
+    tile_load(vreg, base + 2 * C, ld, 0, L, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        stage_tile(Ks, Kt, base + C, ld, kt * LT, L, tid);
-        stage_tile(Vs, nullptr, base + 2 * C, ld, kt * LT, L, tid);
+        tile_store(kreg, Ks, Kt, tid);
+        tile_store(vreg, Vs, nullptr, tid);
         __syncthreads();
+        if (kt + 1 < nkt) {
+            tile_load(kreg, base + C, ld, (kt + 1) * LT, L, tid);
+            tile_load(vreg, base + 2 * C, ld, (kt + 1) * LT, L, tid);
+        }
         if (!active) continue;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -246,10 +266,13 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_mfma(const bf16* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
     const int nqt = (L + LT - 1) / LT;
+    TileRegs qreg, doreg;
+    tile_load(qreg, base, ld, 0, L, tid);
+    tile_load(doreg, dobase, C, 0, L, tid);
     for (int qt = 0; qt < nqt; ++qt) {
         __syncthreads();
-        stage_tile(Qs, Qt, base, ld, qt * LT, L, tid);
-        stage_tile(dOs, dOt, dobase, C, qt * LT, L, tid);
+        tile_store(qreg, Qs, Qt, tid);
+        tile_store(doreg, dOs, dOt, tid);
         if (tid < LT) {                             // lse (in log2 units) and delta of the tile's 64 queries
             int qi = qt * LT + tid;
             if (qi > L - 1) qi = L - 1;
@@ -265,6 +288,10 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dkv_mfma(const bf16* __rest
             Ls[tid] = lse[((int64_t)f * H + h) * L + qi] * l2e;
         }
         __syncthreads();
+        if (qt + 1 < nqt) {
+            tile_load(qreg, base, ld, (qt + 1) * LT, L, tid);
+            tile_load(doreg, dobase, C, (qt + 1) * LT, L, tid);
+        }
         if (!active) continue;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
