@@ -67,7 +67,9 @@ __device__ __forceinline__ void tile_store(const TileRegs& t, unsigned short* ro
     tile_store1(t.b, rows, tr, tid + 256);
 }
 
-__global__ __launch_bounds__(256) void attn_long_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
+// (occupancy hints: without them the 512-register budget of a 256-thread workgroup makes the compiler park the MFMA accumulators in
+// AGPRs and copy all 32 of them to VGPRs and back around every softmax rescale -- 159 v_accvgpr_read + 159 write in this kernel)
+__global__ __launch_bounds__(256, 4) void attn_long_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
                                                           int L, int H, int ntile, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[LT * KLD];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[D * LVLD];
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_long_fwd_mfma(const bf16* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void attn_long_bwd_dq_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+__global__ __launch_bounds__(256, 3) void attn_long_bwd_dq_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
                                                              const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int L, int H,
                                                              int ntile, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[LT * KLD];
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_long_bwd_dq_mfma(const bf16* __restr
     if (active && q < L) store_rowT(dqkv + ((int64_t)f * L + q) * ld + h * D, dq, hi, accumulate);
 }
 
-__global__ __launch_bounds__(256) void attn_long_bwd_dkv_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+__global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
                                                               const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int L, int H,
                                                               int ntile, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[LT * KLD];

@@ -486,7 +486,11 @@ __global__ __launch_bounds__(1024) void attn_tm_fwd_mfma(const bf16* __restrict_
 // and the key-side pass (lane = key: P and dS from S = Q K^T, dV^T += dO^T P, dK^T += Q^T dS) for its own 32 rows --
 // flash-style recompute from the saved log-sum-exp, block-diagonal mask as in the forward.
 // ==================================================================================================
-__global__ __launch_bounds__(1024) void attn_tm_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+// Register budget: the workgroup is ONE wave at T = 16 and two at T = 64, so the common case is compiled for <= 256 threads at two
+// workgroups per CU (166 VGPRs, nothing spilled); under the 1024-thread bound (128 VGPRs) the same code spills 40 VGPRs to scratch
+// inside the loops.  The 1024-thread instantiation stays for virtual sequences longer than 128 rows.
+template <int MAX_THREADS, int MIN_BLOCKS>
+__global__ __launch_bounds__(MAX_THREADS, MIN_BLOCKS) void attn_tm_bwd_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
                                                          const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int P, int H,
                                                          int Tn, int G, int ngroups, float scale) {
     MAED_DYN_SHARED(unsigned short, smem);
@@ -674,10 +678,23 @@ static bool launch_tm_bwd_mfma(const void* qkv, const void* o, const void* d_o, 
     const size_t lds = ((size_t)4 * Lk * KLD + (size_t)3 * D * (Lk + 4)) * 2 + (size_t)2 * Lk * sizeof(float);
     if (lds > 160 * 1024) return false;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)attn_tm_bwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+        hipFuncSetAttribute((const void*)attn_tm_bwd_mfma<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)attn_tm_bwd_mfma<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     const int ngroups = (P + G - 1) / G;
-    hipLaunchKernelGGL(attn_tm_bwd_mfma, dim3((unsigned)((F / Tn) * H * ngroups)), dim3(64 * (Lk / 32)), lds, s, (const bf16*)qkv, (const bf16*)o,
-                       (const bf16*)d_o, lse, (bf16*)dqkv, accumulate, P, H, Tn, G, ngroups, scale);
+    const dim3 grid((unsigned)((F / Tn) * H * ngroups)), block(64 * (Lk / 32));
+    // the spill-free instantiation was written after the round-1 GPU budget was spent: opt-in (MAED_TM_BWD_WIDE_REGS=1) until it has
+    // been timed against the measured default on hardware (scripts/attn_tm_micro.py)
+    static int wide = -1;
+    if (wide < 0) { const char* ev = getenv("MAED_TM_BWD_WIDE_REGS"); wide = (ev && atoi(ev) != 0) ? 1 : 0; }
+    if (wide && Lk / 32 <= 4)
+        hipLaunchKernelGGL((attn_tm_bwd_mfma<256, 2>), grid, block, lds, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv,
+                           accumulate, P, H, Tn, G, ngroups, scale);
+    else
+        hipLaunchKernelGGL((attn_tm_bwd_mfma<1024, 1>), grid, block, lds, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv,
+                           accumulate, P, H, Tn, G, ngroups, scale);
     return true;
 }
 

@@ -6,3 +6,5 @@ set -x
 mkdir -p gpurun_out
 timeout 900 python scripts/check_new_paths.py 2>&1 | tee gpurun_out/r02_new_paths_on_gpu.log
 timeout 300 python scripts/attn_long_micro.py 20 2>&1 | tee gpurun_out/r02_attn_long_micro.txt
+# temporal backward: measured default (1024-thread register budget, 40 VGPRs spilled) vs the spill-free instantiation
+for w in 0 1; do MAED_TM_BWD_WIDE_REGS=$w MAED_TEMPORAL_MFMA=1 timeout 120 python scripts/attn_tm_micro.py 30 2>&1 | sed "s/^/wide_regs=$w /" | tee -a gpurun_out/r02_attn_tm_wide_regs.txt; done
