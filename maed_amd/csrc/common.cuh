@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "../../include/maed_hip.h"
 
 #define HEAD_DIM 64
@@ -36,6 +37,12 @@ void maed_set_error(const char* fmt, ...);
 #define MAED_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
     maed_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return MAED_ERR_LAUNCH; } } while (0)
 #define MAED_PROPAGATE(expr) do { int rc__ = (expr); if (rc__ != MAED_OK) return rc__; } while (0)
+
+// opt-in/opt-out switches read once from the environment (measurement knobs, documented in README.md)
+static inline bool maed_env_flag(const char* name, bool dflt) {
+    const char* ev = getenv(name);
+    return ev ? atoi(ev) != 0 : dflt;
+}
 
 static inline bool is_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 

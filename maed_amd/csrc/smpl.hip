@@ -27,10 +27,44 @@ __global__ void ktd_chain_kernel(const float* __restrict__ base, const float* __
     for (int i = 0; i < NJ * 6; ++i) pose[(int64_t)f * NJ * 6 + i] = ps[i];
 }
 
+// The same recurrence with the 6 outputs of a joint on 6 lanes (8 lanes per frame, 8 frames per 64-thread workgroup) and the pose in
+// LDS instead of a 576-B private array in scratch: every output keeps the serial kernel's fmaf chain (bit-identical results), the
+// dependent chain per frame drops from 3420 to 570 FMAs.  The thread-per-frame kernel above puts 128 frames on two waves.
+#define KC_FPB 8
+__global__ __launch_bounds__(64) void ktd_chain_par_kernel(const float* __restrict__ base, const float* __restrict__ w_anc, float* __restrict__ pose, int F) {
+    __shared__ float ps[KC_FPB][NJ * 6];
+    const int o = threadIdx.x & 7, fs = threadIdx.x >> 3;
+    const int f = blockIdx.x * KC_FPB + fs, fc = f < F ? f : F - 1;
+    for (int i = o; i < NJ * 6; i += 8) ps[fs][i] = base[(int64_t)fc * NJ * 6 + i];
+    __syncthreads();
+    for (int j = 1; j < NJ; ++j) {
+        if (o < 6) {
+            const int na = c_anc_cnt[j];
+            const float* W = w_anc + 36 * c_anc_start[j] + o * 6 * na;
+            float s = ps[fs][j * 6 + o];
+            for (int sl = 0; sl < na; ++sl) {
+                const int a = c_anc[c_anc_start[j] + sl];
+                for (int i = 0; i < 6; ++i) s = fmaf(W[sl * 6 + i], ps[fs][a * 6 + i], s);
+            }
+            ps[fs][j * 6 + o] = s;          // nobody else reads element (j, o) in this step: ancestors have smaller indices
+        }
+        __syncthreads();
+    }
+    if (f < F)
+        for (int i = o; i < NJ * 6; i += 8) pose[(int64_t)f * NJ * 6 + i] = ps[fs][i];
+}
+
+// MAED_TAIL_PARALLEL=1 selects the lane-parallel chain kernels (written after the round-1 GPU budget was spent; bit-identical to the
+// serial ones on the host simulator, not yet timed on hardware)
+static bool tail_parallel() { return maed_env_flag("MAED_TAIL_PARALLEL", false); }   // read per call: a getenv, three times per step
+
 extern "C" int maed_ktd_chain_fwd(const float* base, const float* w_anc, float* pose, int F, void* stream) {
     MAED_CHECK_ARG(base && w_anc && pose, MAED_ERR_ARG, "ktd_chain_fwd: null pointer");
     if (F <= 0) return MAED_OK;
-    hipLaunchKernelGGL(ktd_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, base, w_anc, pose, F);
+    if (tail_parallel())
+        hipLaunchKernelGGL(ktd_chain_par_kernel, dim3((F + KC_FPB - 1) / KC_FPB), dim3(64), 0, (hipStream_t)stream, base, w_anc, pose, F);
+    else
+        hipLaunchKernelGGL(ktd_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, base, w_anc, pose, F);
     MAED_CHECK_LAUNCH("ktd_chain_fwd");
     return MAED_OK;
 }
@@ -135,6 +169,51 @@ __global__ void lbs_chain_kernel(maed_smpl_params sp, const float* __restrict__ 
     }
 }
 
+// lane-parallel variant (MAED_TAIL_PARALLEL=1): 16 lanes per frame, 4 frames per workgroup, J / Rw / tw in LDS.  The 72 rest-pose
+// joint coordinates, the 12 outputs of each joint's transform and the 24 x 15 outputs are spread over the lanes; every scalar is
+// produced by the same expression as in lbs_chain_kernel (bit-identical), the tree is still walked joint by joint (any parent table).
+#define LC_FPB 4
+__global__ __launch_bounds__(64) void lbs_chain_par_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
+                                                           float* __restrict__ joints24, float* __restrict__ A, int F) {
+    __shared__ float sJ[LC_FPB][NJ][3], sRw[LC_FPB][NJ][9], stw[LC_FPB][NJ][3];
+    const int l = threadIdx.x & 15, fs = threadIdx.x >> 4;
+    const int f = blockIdx.x * LC_FPB + fs, fc = f < F ? f : F - 1;
+    const float* b = betas + (int64_t)fc * 10;
+    for (int t = l; t < NJ * 3; t += 16) {
+        float s = sp.J_template[t];
+        for (int k = 0; k < 10; ++k) s = fmaf(sp.J_shapedirs[t * 10 + k], b[k], s);
+        sJ[fs][t / 3][t % 3] = s;
+    }
+    __syncthreads();
+    const float* R = rotmat + (int64_t)fc * NJ * 9;
+    for (int j = 0; j < NJ; ++j) {
+        const int p = sp.parents[j];
+        const float* Rj = R + j * 9;
+        if (l < 12) {
+            if (p < 0) {
+                if (l < 9) sRw[fs][j][l] = Rj[l];
+                else stw[fs][j][l - 9] = sJ[fs][j][l - 9];
+            } else if (l < 9) {
+                const int r = l / 3, c = l % 3;
+                sRw[fs][j][l] = sRw[fs][p][r * 3 + 0] * Rj[0 * 3 + c] + sRw[fs][p][r * 3 + 1] * Rj[1 * 3 + c] + sRw[fs][p][r * 3 + 2] * Rj[2 * 3 + c];
+            } else {
+                const int r = l - 9;
+                const float rel[3] = {sJ[fs][j][0] - sJ[fs][p][0], sJ[fs][j][1] - sJ[fs][p][1], sJ[fs][j][2] - sJ[fs][p][2]};
+                stw[fs][j][r] = sRw[fs][p][r * 3 + 0] * rel[0] + sRw[fs][p][r * 3 + 1] * rel[1] + sRw[fs][p][r * 3 + 2] * rel[2] + stw[fs][p][r];
+            }
+        }
+        __syncthreads();
+    }
+    if (f >= F) return;
+    for (int t = l; t < NJ * 3; t += 16) {
+        const int j = t / 3, r = t % 3;
+        float* Aj = A + ((int64_t)f * NJ + j) * 12;
+        for (int c = 0; c < 3; ++c) Aj[r * 4 + c] = sRw[fs][j][r * 3 + c];
+        Aj[r * 4 + 3] = stw[fs][j][r] - (sRw[fs][j][r * 3 + 0] * sJ[fs][j][0] + sRw[fs][j][r * 3 + 1] * sJ[fs][j][1] + sRw[fs][j][r * 3 + 2] * sJ[fs][j][2]);
+        joints24[((int64_t)f * NJ + j) * 3 + r] = stw[fs][j][r];
+    }
+}
+
 // kernel B: thread per vertex, LBS_FB frames per workgroup so posedirs (17 MB) is streamed once per LBS_FB frames
 #define LBS_FB 4
 __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
@@ -210,7 +289,10 @@ extern "C" int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas,
                    MAED_ERR_ARG, "smpl_lbs_fwd: null SMPL parameter");
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(lbs_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
+    if (tail_parallel())
+        hipLaunchKernelGGL(lbs_chain_par_kernel, dim3((F + LC_FPB - 1) / LC_FPB), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
+    else
+        hipLaunchKernelGGL(lbs_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
     hipLaunchKernelGGL(lbs_skin_kernel, dim3((NV + 255) / 256, (F + LBS_FB - 1) / LBS_FB), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
     MAED_CHECK_LAUNCH("smpl_lbs_fwd");
     return MAED_OK;

@@ -333,6 +333,36 @@ __global__ void ktd_chain_bwd_kernel(const float* __restrict__ w_anc, const floa
     for (int i = 0; i < 3; ++i) o[154 + i] = d_cam ? d_cam[(int64_t)f * 3 + i] : 0.f;
 }
 
+// lane-parallel variant (MAED_TAIL_PARALLEL=1): 16 lanes per frame, 4 frames per workgroup, g in LDS.  The 6*n_anc(j) gradient
+// elements joint j feeds (distinct (ancestor, i) pairs) are updated by different lanes with the serial kernel's fmaf chain over o.
+#define KB_FPB 4
+__global__ __launch_bounds__(64) void ktd_chain_bwd_par_kernel(const float* __restrict__ w_anc, const float* __restrict__ d_pose,
+                                                               const float* __restrict__ d_shape, const float* __restrict__ d_cam,
+                                                               float* __restrict__ d_out, int64_t ld, int F) {
+    __shared__ float g[KB_FPB][NJ * 6];
+    const int l = threadIdx.x & 15, fs = threadIdx.x >> 4;
+    const int f = blockIdx.x * KB_FPB + fs, fc = f < F ? f : F - 1;
+    for (int i = l; i < NJ * 6; i += 16) g[fs][i] = d_pose[(int64_t)fc * NJ * 6 + i];
+    __syncthreads();
+    for (int j = NJ - 1; j >= 1; --j) {
+        const int na = c_anc_cnt[j];
+        const float* W = w_anc + 36 * c_anc_start[j];
+        for (int t = l; t < 6 * na; t += 16) {
+            const int sl = t / 6, i = t % 6;
+            const int a = c_anc[c_anc_start[j] + sl];
+            float s = g[fs][a * 6 + i];
+            for (int o = 0; o < 6; ++o) s = fmaf(W[o * 6 * na + sl * 6 + i], g[fs][j * 6 + o], s);
+            g[fs][a * 6 + i] = s;
+        }
+        __syncthreads();
+    }
+    if (f >= F) return;
+    float* o = d_out + (int64_t)f * ld;
+    for (int i = l; i < NJ * 6; i += 16) o[i] = g[fs][i];
+    if (l < 10) o[144 + l] = d_shape ? d_shape[(int64_t)f * 10 + l] : 0.f;
+    if (l < 3) o[154 + l] = d_cam ? d_cam[(int64_t)f * 3 + l] : 0.f;
+}
+
 // thread per ancestor-weight element: dW_j[o][6*slot+i] = sum_f d_base[f][6j+o] pose[f][6*anc+i]; the last 157 threads
 // produce the bias gradient (column sums of d_out)
 __global__ void ktd_wanc_bwd_kernel(const float* __restrict__ pose, const float* __restrict__ d_out, int64_t ld, float* __restrict__ d_w_anc,
@@ -361,7 +391,10 @@ extern "C" int maed_ktd_chain_bwd(const float* pose, const float* w_anc, const f
     MAED_CHECK_ARG(pose && w_anc && d_pose && d_out && d_w_anc && d_b_feat, MAED_ERR_ARG, "ktd_chain_bwd: null pointer");
     MAED_CHECK_ARG(ld_out >= KTD_OUT, MAED_ERR_SHAPE, "ktd_chain_bwd: ld_out=%lld < 157", (long long)ld_out);
     hipStream_t s = (hipStream_t)stream;
-    if (F > 0)
+    const bool parallel = maed_env_flag("MAED_TAIL_PARALLEL", false);
+    if (F > 0 && parallel)
+        hipLaunchKernelGGL(ktd_chain_bwd_par_kernel, dim3((F + KB_FPB - 1) / KB_FPB), dim3(64), 0, s, w_anc, d_pose, d_shape, d_cam, d_out, ld_out, F);
+    else if (F > 0)
         hipLaunchKernelGGL(ktd_chain_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, s, w_anc, d_pose, d_shape, d_cam, d_out, ld_out, F);
     hipLaunchKernelGGL(ktd_wanc_bwd_kernel, dim3((MAED_KTD_W_ANC + KTD_OUT + 127) / 128), dim3(128), 0, s, pose, d_out, ld_out, d_w_anc, d_b_feat, F);
     MAED_CHECK_LAUNCH("ktd_chain_bwd");

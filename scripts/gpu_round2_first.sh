@@ -8,3 +8,6 @@ timeout 900 python scripts/check_new_paths.py 2>&1 | tee gpurun_out/r02_new_path
 timeout 300 python scripts/attn_long_micro.py 20 2>&1 | tee gpurun_out/r02_attn_long_micro.txt
 # temporal backward: measured default (1024-thread register budget, 40 VGPRs spilled) vs the spill-free instantiation
 for w in 0 1; do MAED_TM_BWD_WIDE_REGS=$w MAED_TEMPORAL_MFMA=1 timeout 120 python scripts/attn_tm_micro.py 30 2>&1 | sed "s/^/wide_regs=$w /" | tee -a gpurun_out/r02_attn_tm_wide_regs.txt; done
+# decoder tail: thread-per-frame chain kernels (measured) vs the lane-parallel ones (bit-identical on the simulator)
+for w in 0 1; do MAED_TAIL_PARALLEL=$w timeout 300 python -m pytest tests/test_gpu_tail.py -q -x 2>&1 | tail -2 | sed "s/^/tail_parallel=$w /" | tee -a gpurun_out/r02_tail_parallel.txt; done
+for w in 0 1; do MAED_TAIL_PARALLEL=$w timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('tail_parallel=$w', d['ms_per_step'], 'ms/step')" | tee -a gpurun_out/r02_tail_parallel.txt; done

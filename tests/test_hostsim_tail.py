@@ -119,3 +119,27 @@ def test_grads_ready_protocol_and_fused_parameter_list():
     fused = {id(p) for p in ktd.fused_parameters()}
     assert len(fused) == 52 and all(p.grad is not None for p in ktd.fused_parameters())
     assert id(ktd.fc1.weight) not in fused and ktd.fc1.weight.grad is not None      # fc1/fc2 travel through autograd
+
+
+def test_lane_parallel_chain_kernels_are_bit_identical_to_the_serial_ones(monkeypatch):
+    """MAED_TAIL_PARALLEL=1 (ktd_chain_par / ktd_chain_bwd_par / lbs_chain_par): same fmaf chains, spread over lanes -> torch.equal.
+    (End-to-end gradients are not compared bitwise: the skinning backward reduces with LDS atomics in thread-arrival order.)"""
+    from maed_amd import _lib as L, ops
+    ktd = make_ktd(seed=5)
+    F_ = 11                                                      # ragged last workgroup for every frames-per-workgroup choice
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(F_, 48, generator=g)
+    w_anc = torch.randn(L.KTD_W_ANC, generator=g) * 0.2
+    pose_in, d_pose = torch.randn(F_, 144, generator=g), torch.randn(F_, 144, generator=g)
+    d_shape, d_cam = torch.randn(F_, 10, generator=g), torch.randn(F_, 3, generator=g)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MAED_TAIL_PARALLEL", flag)
+        with patched() as lib, torch.no_grad():
+            inf = ktd.get_output(*ktd._head_hip(x), None, hip=True)          # ktd_chain_fwd + lbs_chain (+ everything downstream)
+            d_out, d_w, d_b = torch.empty(F_, 160), torch.empty(L.KTD_W_ANC), torch.empty(157)
+            L.check(lib.maed_ktd_chain_bwd(ops._p(pose_in), ops._p(w_anc), ops._p(d_pose), ops._p(d_shape), ops._p(d_cam), ops._p(d_out), 160,
+                                           ops._p(d_w), ops._p(d_b), F_, None), "ktd_chain_bwd")
+        outs[flag] = [inf[k] for k in ("theta", "verts", "kp_3d", "kp_2d", "rotmat")] + [d_out[:, :157].clone(), d_w, d_b]
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
