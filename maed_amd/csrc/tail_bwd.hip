@@ -222,14 +222,110 @@ __global__ void smpl_chain_bwd_kernel(maed_smpl_params sp, const float* __restri
     }
 }
 
+// lane-parallel variant (MAED_TAIL_PARALLEL=1): 32 lanes per frame, 2 frames per workgroup, all chain state in LDS (2.9 KB per frame
+// that the kernel above keeps in scratch).  Every scalar is produced by the expression the serial kernel uses, joints are still
+// visited one after another where the recurrence requires it (children accumulate into their parent in the same order), so the
+// results are bit-identical; what runs in parallel are the independent outputs of each step.
+#define SC_FPB 2
+__global__ __launch_bounds__(64) void smpl_chain_bwd_par_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
+                                                                const float* __restrict__ dA, const float* __restrict__ d_j24,
+                                                                const float* __restrict__ dpf_dbeta, const float* __restrict__ d_rot_in,
+                                                                const float* __restrict__ d_betas_in, int64_t betas_in_stride,
+                                                                float* __restrict__ d_rotmat, float* __restrict__ d_betas, int F) {
+    __shared__ float J[SC_FPB][NJ][3], Rw[SC_FPB][NJ][9], tw[SC_FPB][NJ][3], gRw[SC_FPB][NJ][9], gtw[SC_FPB][NJ][3], gJ[SC_FPB][NJ][3];
+    const int l = threadIdx.x & 31, fs = threadIdx.x >> 5;
+    const int f = blockIdx.x * SC_FPB + fs, fc = f < F ? f : F - 1;
+    const float* b = betas + (int64_t)fc * 10;
+    for (int t = l; t < NJ * 3; t += 32) {
+        float s = sp.J_template[t];
+        for (int k = 0; k < 10; ++k) s = fmaf(sp.J_shapedirs[t * 10 + k], b[k], s);
+        J[fs][t / 3][t % 3] = s;
+    }
+    __syncthreads();
+    const float* R = rotmat + (int64_t)fc * NJ * 9;
+    for (int j = 0; j < NJ; ++j) {                               // forward chain, 12 outputs per joint
+        const int p = sp.parents[j];
+        const float* Rj = R + j * 9;
+        if (l < 12) {
+            if (p < 0) {
+                if (l < 9) Rw[fs][j][l] = Rj[l];
+                else tw[fs][j][l - 9] = J[fs][j][l - 9];
+            } else if (l < 9) {
+                const int r = l / 3, c = l % 3;
+                Rw[fs][j][l] = Rw[fs][p][r * 3 + 0] * Rj[0 * 3 + c] + Rw[fs][p][r * 3 + 1] * Rj[1 * 3 + c] + Rw[fs][p][r * 3 + 2] * Rj[2 * 3 + c];
+            } else {
+                const int r = l - 9;
+                const float rel[3] = {J[fs][j][0] - J[fs][p][0], J[fs][j][1] - J[fs][p][1], J[fs][j][2] - J[fs][p][2]};
+                tw[fs][j][r] = Rw[fs][p][r * 3 + 0] * rel[0] + Rw[fs][p][r * 3 + 1] * rel[1] + Rw[fs][p][r * 3 + 2] * rel[2] + tw[fs][p][r];
+            }
+        }
+        __syncthreads();
+    }
+    if (l < NJ) {                                                // outputs -> chain variables: one joint per lane, serial code per joint
+        const int j = l;
+        const float* g = dA + ((int64_t)fc * NJ + j) * 12;
+        const float* gj = d_j24 + ((int64_t)fc * NJ + j) * 3;
+        for (int c = 0; c < 3; ++c) gJ[fs][j][c] = 0.f;
+        for (int r = 0; r < 3; ++r) {
+            const float gt = g[r * 4 + 3];
+            for (int c = 0; c < 3; ++c) {
+                gRw[fs][j][r * 3 + c] = g[r * 4 + c] - gt * J[fs][j][c];
+                gJ[fs][j][c] -= Rw[fs][j][r * 3 + c] * gt;
+            }
+            gtw[fs][j][r] = gt + gj[r];
+        }
+    }
+    __syncthreads();
+    float* gR = d_rotmat + (int64_t)fc * NJ * 9;
+    const float* gin = d_rot_in ? d_rot_in + (int64_t)fc * NJ * 9 : nullptr;
+    const float* gpf = dpf_dbeta + (int64_t)fc * 217;
+    const bool live = f < F;
+    for (int j = NJ - 1; j >= 1; --j) {                          // leaves -> root; lanes 0-8 dR_j, 9-17 gRw[p], 18-20 gJ, 21-23 gtw[p]
+        const int p = sp.parents[j];
+        const float* Rj = R + j * 9;
+        if (l < 9) {
+            const int a = l / 3, c = l % 3;
+            const float s = Rw[fs][p][0 * 3 + a] * gRw[fs][j][0 * 3 + c] + Rw[fs][p][1 * 3 + a] * gRw[fs][j][1 * 3 + c] + Rw[fs][p][2 * 3 + a] * gRw[fs][j][2 * 3 + c];
+            if (live) gR[j * 9 + a * 3 + c] = s + gpf[(j - 1) * 9 + a * 3 + c] + (gin ? gin[j * 9 + a * 3 + c] : 0.f);
+        } else if (l < 18) {
+            const int r = (l - 9) / 3, a = (l - 9) % 3;
+            const float rel_a = J[fs][j][a] - J[fs][p][a];
+            gRw[fs][p][r * 3 + a] += gRw[fs][j][r * 3 + 0] * Rj[a * 3 + 0] + gRw[fs][j][r * 3 + 1] * Rj[a * 3 + 1] + gRw[fs][j][r * 3 + 2] * Rj[a * 3 + 2]
+                                     + gtw[fs][j][r] * rel_a;
+        } else if (l < 21) {
+            const int a = l - 18;
+            const float grel = Rw[fs][p][0 * 3 + a] * gtw[fs][j][0] + Rw[fs][p][1 * 3 + a] * gtw[fs][j][1] + Rw[fs][p][2 * 3 + a] * gtw[fs][j][2];
+            gJ[fs][j][a] += grel; gJ[fs][p][a] -= grel;
+        } else if (l < 24) {
+            const int r = l - 21;
+            gtw[fs][p][r] += gtw[fs][j][r];
+        }
+        __syncthreads();
+    }
+    if (live && l < 9) gR[l] = gRw[fs][0][l] + (gin ? gin[l] : 0.f);
+    if (l < 3) gJ[fs][0][l] += gtw[fs][0][l];
+    __syncthreads();
+    if (live && l < 10) {
+        const float* bi = d_betas_in ? d_betas_in + (int64_t)f * betas_in_stride : nullptr;
+        float s = gpf[207 + l] + (bi ? bi[l] : 0.f);
+        for (int j = 0; j < NJ; ++j)
+            for (int c = 0; c < 3; ++c) s = fmaf(sp.J_shapedirs[(j * 3 + c) * 10 + l], gJ[fs][j][c], s);
+        d_betas[(int64_t)f * 10 + l] = s;
+    }
+}
+
 extern "C" int maed_smpl_chain_bwd(const maed_smpl_params* sp, const float* betas, const float* rotmat, const float* dA,
                                    const float* d_joints24, const float* dpf_dbeta, const float* d_rotmat_in, const float* d_betas_in,
                                    int64_t betas_in_stride, float* d_rotmat, float* d_betas, int F, void* stream) {
     MAED_CHECK_ARG(sp && betas && rotmat && dA && d_joints24 && dpf_dbeta && d_rotmat && d_betas, MAED_ERR_ARG, "smpl_chain_bwd: null pointer");
     MAED_CHECK_ARG(sp->J_template && sp->J_shapedirs && sp->parents, MAED_ERR_ARG, "smpl_chain_bwd: null SMPL parameter");
     if (F <= 0) return MAED_OK;
-    hipLaunchKernelGGL(smpl_chain_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, *sp, betas, rotmat, dA, d_joints24, dpf_dbeta,
-                       d_rotmat_in, d_betas_in, betas_in_stride, d_rotmat, d_betas, F);
+    if (maed_env_flag("MAED_TAIL_PARALLEL", false))
+        hipLaunchKernelGGL(smpl_chain_bwd_par_kernel, dim3((F + SC_FPB - 1) / SC_FPB), dim3(64), 0, (hipStream_t)stream, *sp, betas, rotmat, dA,
+                           d_joints24, dpf_dbeta, d_rotmat_in, d_betas_in, betas_in_stride, d_rotmat, d_betas, F);
+    else
+        hipLaunchKernelGGL(smpl_chain_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, *sp, betas, rotmat, dA, d_joints24, dpf_dbeta,
+                           d_rotmat_in, d_betas_in, betas_in_stride, d_rotmat, d_betas, F);
     MAED_CHECK_LAUNCH("smpl_chain_bwd");
     return MAED_OK;
 }
