@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
                                                             const double* __restrict__ sums, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ ab /* [N][C][2] */,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int HW, int C, float eps, int rows_per_wg) {
+                                                            int HW, int C, float eps, int rows_per_wg, int defer_affine) {
     MAED_DYN_SHARED(float, lpart);   // [256/cbn][C][2] = 16 KB
     __shared__ float lmu[GN_G], lrs[GN_G];
     const int n = blockIdx.y;
@@ -273,8 +273,21 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         float t = 0.f;
         for (int k = 0; k < rstep; ++k) t += lpart[(size_t)k * 2 * C + i];
         atomicAdd(ab + (int64_t)n * C * 2 + i, t);
-        atomicAdd(((i & 1) ? dgamma : dbeta) + (i >> 1), t);
+        if (!defer_affine) atomicAdd(((i & 1) ? dgamma : dbeta) + (i >> 1), t);
     }
+}
+
+// dgamma[c] += sum_n ab[n][c][1], dbeta[c] += sum_n ab[n][c][0]: the affine gradients are the frame sums of the per-frame partials the
+// reduction pass leaves in `ab` anyway.  Used with MAED_GN_DEFER_AFFINE=1 instead of the 2C atomics every workgroup of the reduction
+// pass otherwise sends to the same 2C addresses (~768 workgroups per layer: on the 14x14 and 28x28 layers the serialised atomics,
+// not HBM, set that pass's ~23 us floor -- profiles/r01_rocprofv3_last_step_kernel_sequence_v9.txt).
+__global__ __launch_bounds__(256) void gn_affine_grad_kernel(const float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    float t = 0.f;
+    for (int n = 0; n < N; ++n) t += ab[(int64_t)n * C * 2 + i];
+    float* dst = ((i & 1) ? dgamma : dbeta) + (i >> 1);
+    *dst += t;                                   // single writer per element; the arena accumulates across micro-batches
 }
 
 // ---- backward pass 2: dx = rstd * (gamma*dy_eff - m1 - xhat*m2); optional d_res = dy_eff ------------------------
@@ -376,12 +389,14 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
     if (!ab_zeroed) hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
     const bool ymask = relu && dres;
+    const int defer = maed_env_flag("MAED_GN_DEFER_AFFINE", false) ? 1 : 0;     // opt-in until timed on hardware (written without GPU access)
 #define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, relu_mask, (const T*)dy, \
-        sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows)
+        sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows, defer)
 #define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
     MAED_DISPATCH_DTYPE(dtype, T, {
         if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);
+        if (defer) hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, ab_scratch, dgamma, dbeta, N, C);
         if (dres && relu) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);
     });
 #undef GN_RED
