@@ -95,6 +95,14 @@ ScratchLayout scratch_layout(const maed_block_dims& d) {
     return s;
 }
 
+}  // namespace
+// layernorm.hip: dgamma/dbeta through per-workgroup partials + a column sum instead of contended atomics
+size_t maed_layernorm_bwd_partials_bytes(int64_t rows, int C);
+int maed_layernorm_bwd_ws(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres_in, float* dx_out, void* dx_twin, float* dgamma, float* dbeta, int64_t rows, int C, float* partials,
+                          void* stream);
+namespace {
+
 int check_dims(const maed_block_dims* d, const char* who) {
     MAED_CHECK_ARG(d, MAED_ERR_ARG, "%s: null dims", who);
     MAED_CHECK_ARG(d->dtype == MAED_F32 || d->dtype == MAED_BF16, MAED_ERR_ARG, "%s: bad dtype %d", who, d->dtype);
@@ -185,8 +193,12 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         MAED_PROPAGATE(maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, stream));
         MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
-        MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
-                                          dx_out, dxmid, dxmid_tw, g->ln2_g, g->ln2_b, M, C, stream));
+        // MAED_LN_DEFER_AFFINE=1: LayerNorm dgamma/dbeta via partials in the (bf16-mode-unused) transpose slot -- opt-in until timed on hardware
+        const size_t big_t_bytes = (size_t)(Hd > 3 * C ? Hd : 3 * C) * (size_t)Mp * dtype_size(dt);      // S.bigT: only the f32 path transposes into it
+        float* ln_part = (maed_env_flag("MAED_LN_DEFER_AFFINE", false) && maed_layernorm_bwd_partials_bytes(M, C) <= big_t_bytes)
+                             ? (float*)(sc + S.bigT) : nullptr;
+        MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
+                                             dx_out, dxmid, dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream));
         // attention: x_mid = x_in + proj(mix(x_s, x_t))
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dt, stream));
         MAED_PROPAGATE(maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
@@ -199,8 +211,8 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
                                                      MAED_IMPL_AUTO, stream));
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, 3 * C, sv + L.ln1, C, M, 3 * C, C, g->w_qkv, C, g->b_qkv, dt, stream));
         MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
-        MAED_PROPAGATE(maed_layernorm_bwd(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in, dx_in_twin,
-                                          g->ln1_g, g->ln1_b, M, C, stream));
+        MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in,
+                                             dx_in_twin, g->ln1_g, g->ln1_b, M, C, ln_part, stream));
         return MAED_OK;
     }
     // ---- f32 parity mode (and impl = VALU): NT GEMMs on transposed copies ---------------------------------------

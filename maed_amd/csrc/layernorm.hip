@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // are combined across the 4 waves through LDS and leave the workgroup as one atomicAdd per column.
 #define LN_ROWS_PER_WG 32
 
-template <typename T, int NV>
+// PARTIALS: instead of 2C atomics per workgroup onto the same 2C addresses (788 workgroups at cfg3: ~25k atomics per cache line, a
+// serial tail of ~20 us after ~31 us of streaming), every workgroup stores its column sums to row blockIdx.x of `dg` ([nwg][2C],
+// dgamma | dbeta) and ln_affine_finish_kernel adds the column totals to the gradients.  Opt-in (MAED_LN_DEFER_AFFINE=1, block.hip).
+template <typename T, int NV, bool PARTIALS = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ g, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ dres,
@@ -121,9 +124,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int c = threadIdx.x; c < C; c += 256) {
         const float sg = (lds[c] + lds[C + c]) + (lds[2 * C + c] + lds[3 * C + c]);
         const float sb = (lds[4 * C + c] + lds[5 * C + c]) + (lds[6 * C + c] + lds[7 * C + c]);
-        atomicAdd(dg + c, sg);
-        atomicAdd(db + c, sb);
+        if constexpr (PARTIALS) {
+            dg[(int64_t)blockIdx.x * 2 * C + c] = sg;
+            dg[(int64_t)blockIdx.x * 2 * C + C + c] = sb;
+        } else {
+            atomicAdd(dg + c, sg);
+            atomicAdd(db + c, sb);
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void ln_affine_finish_kernel(const float* __restrict__ partials, int nwg, int C, float* __restrict__ dg,
+                                                               float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    float t = 0.f;
+    for (int w = 0; w < nwg; ++w) t += partials[(int64_t)w * 2 * C + i];
+    float* dst = i < C ? dg + i : db + (i - C);
+    *dst += t;                                    // single writer per element; += because the gradient arena accumulates
 }
 
 extern "C" int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
@@ -141,9 +159,24 @@ extern "C" int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const fl
     return MAED_OK;
 }
 
+size_t maed_layernorm_bwd_partials_bytes(int64_t rows, int C) {
+    return (size_t)((rows + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG) * 2 * C * sizeof(float);
+}
+
+// internal (block.hip): `partials` (maed_layernorm_bwd_partials_bytes, or null) selects the store-then-sum form of dgamma/dbeta
+int maed_layernorm_bwd_ws(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma,
+                          const float* mean, const float* rstd, const float* dres_in, float* dx_out, void* dx_twin,
+                          float* dgamma, float* dbeta, int64_t rows, int C, float* partials, void* stream);
+
 extern "C" int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma,
                                   const float* mean, const float* rstd, const float* dres_in, float* dx_out, void* dx_twin,
                                   float* dgamma, float* dbeta, int64_t rows, int C, void* stream) {
+    return maed_layernorm_bwd_ws(dy, dtype, x, x_row_stride, gamma, mean, rstd, dres_in, dx_out, dx_twin, dgamma, dbeta, rows, C, nullptr, stream);
+}
+
+int maed_layernorm_bwd_ws(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma,
+                          const float* mean, const float* rstd, const float* dres_in, float* dx_out, void* dx_twin,
+                          float* dgamma, float* dbeta, int64_t rows, int C, float* partials, void* stream) {
     MAED_CHECK_ARG(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta, MAED_ERR_ARG, "layernorm_bwd: null pointer");
     MAED_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXV, MAED_ERR_SHAPE, "layernorm_bwd: C=%d unsupported", C);
     MAED_CHECK_ARG(x_row_stride % 4 == 0 && is_aligned(x, 16) && is_aligned(dy, 8) && is_aligned(dx_out, 16), MAED_ERR_ALIGN, "layernorm_bwd: alignment");
@@ -152,7 +185,15 @@ extern "C" int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int
     const size_t lds = (size_t)8 * C * sizeof(float);
 #define LN_BWD(NV_) hipLaunchKernelGGL((ln_bwd_kernel<T, NV_>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)dy, x, x_row_stride, gamma, mean, \
                                       rstd, dres_in, dx_out, (T*)dx_twin, dgamma, dbeta, rows, C)
-    MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_BWD(2); else if (C <= 768) LN_BWD(3); else if (C <= 1024) LN_BWD(4); else LN_BWD(8); });
+#define LN_BWD_P(NV_) hipLaunchKernelGGL((ln_bwd_kernel<T, NV_, true>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)dy, x, x_row_stride, gamma, \
+                                        mean, rstd, dres_in, dx_out, (T*)dx_twin, partials, (float*)nullptr, rows, C)
+    if (partials) {
+        MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_BWD_P(2); else if (C <= 768) LN_BWD_P(3); else if (C <= 1024) LN_BWD_P(4); else LN_BWD_P(8); });
+        hipLaunchKernelGGL(ln_affine_finish_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, (int)grid.x, C, dgamma, dbeta);
+    } else {
+        MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_BWD(2); else if (C <= 768) LN_BWD(3); else if (C <= 1024) LN_BWD(4); else LN_BWD(8); });
+    }
+#undef LN_BWD_P
 #undef LN_BWD
     MAED_CHECK_LAUNCH("layernorm_bwd");
     return MAED_OK;

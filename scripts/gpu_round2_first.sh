@@ -12,7 +12,7 @@ for w in 0 1; do MAED_TM_BWD_WIDE_REGS=$w MAED_TEMPORAL_MFMA=1 timeout 120 pytho
 for w in 0 1; do MAED_TAIL_PARALLEL=$w timeout 300 python -m pytest tests/test_gpu_tail.py -q -x 2>&1 | tail -2 | sed "s/^/tail_parallel=$w /" | tee -a gpurun_out/r02_tail_parallel.txt; done
 for w in 0 1; do MAED_TAIL_PARALLEL=$w timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('tail_parallel=$w', d['ms_per_step'], 'ms/step')" | tee -a gpurun_out/r02_tail_parallel.txt; done
 # GroupNorm backward: per-workgroup dgamma/dbeta atomics (measured) vs deferred frame sums; then every opt-in together
-for flags in "MAED_GN_DEFER_AFFINE=1" "MAED_GN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_WIDE_REGS=1"; do
+for flags in "MAED_GN_DEFER_AFFINE=1" "MAED_LN_DEFER_AFFINE=1" "MAED_GN_DEFER_AFFINE=1 MAED_LN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_WIDE_REGS=1"; do
   env $flags timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$flags', d['ms_per_step'], 'ms/step')" | tee -a gpurun_out/r02_optin_flags.txt
 done
-env MAED_GN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_WIDE_REGS=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee -a gpurun_out/r02_optin_flags.txt
+env MAED_GN_DEFER_AFFINE=1 MAED_LN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_WIDE_REGS=1 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee -a gpurun_out/r02_optin_flags.txt

@@ -58,13 +58,15 @@ def test_attn_temporal_fwd_bwd(dtype, N, T, P, H):
     close(dqkv.float(), x.grad, **tol(dtype, 0.5))
 
 
-@pytest.mark.parametrize("dtype,impl", [(torch.float32, 0), (torch.bfloat16, 0)])      # f32 parity mode, bf16 MFMA throughput mode
-def test_ste_block_forward_backward_vs_oracle(dtype, impl):
-    """one whole Block through maed_ste_block_fwd/bwd (vision_transformer.py:244-261) incl. every parameter gradient"""
+@pytest.mark.parametrize("dtype,impl,ln_defer", [(torch.float32, 0, "0"), (torch.bfloat16, 0, "0"), (torch.bfloat16, 0, "1")])
+def test_ste_block_forward_backward_vs_oracle(dtype, impl, ln_defer, monkeypatch):
+    """one whole Block through maed_ste_block_fwd/bwd (vision_transformer.py:244-261) incl. every parameter gradient; f32 parity mode,
+    bf16 MFMA throughput mode, and the latter with LayerNorm dgamma/dbeta through per-workgroup partials (MAED_LN_DEFER_AFFINE=1)"""
+    monkeypatch.setenv("MAED_LN_DEFER_AFFINE", ln_defer)
     from functools import partial
     import torch.nn as nn
     from maed_amd.vision_transformer import Block
-    N, T, P, H = 1, 2, 9, 2
+    N, T, P, H = 1, 2, (40 if ln_defer == "1" else 9), 2          # 80 rows = 3 LayerNorm workgroups of 32 rows for the partials path
     C, Fr = 64 * H, N * T
     p = {k[len("encoder.blocks.0."):]: v for k, v in R.make_params(embed_dim=C, depth=1, hidden_dim=64, layers=(1, 1, 1), n_tokens=P, seed=3).items()
          if k.startswith("encoder.blocks.0.")}
