@@ -327,6 +327,15 @@ int maed_comm_wait(void* compute_stream);
 int maed_comm_world(void);
 int maed_comm_destroy(void);
 
+/* ---- 3x3 convolution as an implicit GEMM (resnetv2.py:74-93 StdConv2dSame, kernel 3; bf16, channels_last) -----------------
+ * y (F,Ho,Wo,Cout) = conv(x (F,H,W,Cin), w) with TF-SAME zero padding (pad_top / pad_left rows / columns in front; the rest behind),
+ * any stride; w_taps is the weight as (Cout, 3, 3, Cin) = (Cout, 9*Cin) row-major (maed_weight_std_fwd's output order).
+ * zero_page: >= 128 bytes of zeros in device memory (source of every out-of-image tap).  add (optional, (F,Ho,Wo,Cout)): y = conv + add.
+ * The input gradient of a stride-1 convolution is this entry point on dY with the flipped, transposed weight image
+ * w'[ci][2-ky][2-kx][co].  Needs Cin % 64 == 0, Cout % 8 == 0.  Opt-in path (maed_amd/resnetv2.py MAED_CONV3X3=own). */
+int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* zero_page, void* y, int F, int H, int W, int Cin, int Cout,
+                     int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int dtype, void* stream);
+
 /* ---- evaluation metrics on the device ----------------------------------------------------
  * Replace the numpy / torch-CPU post-processing of lib/core/evaluate.py:135-166 and lib/utils/eval_utils.py.  fp32 in/out.
  *

@@ -453,6 +453,132 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 convolution as an implicit GEMM on the same tile / LDS image / epilogue as gemm_nt_glds_bf16_kernel<EPI, 1>
+// (resnetv2.py:74-93 StdConv2dSame 3x3: 16 of the backbone's 53 convolutions; today they run on MIOpen).
+//   out[m][co] = sum_{tap, ci} X[pixel(m) shifted by tap][ci] * Wt[co][tap*Cin + ci]      m = (f, oy, ox), channels_last
+// A-operand rows are GATHERED: every lane of the LDS-DMA computes its own source address, so "im2col" costs nothing -- for K tile
+// kt the tap is (kt*64)/Cin (Cin % 64 == 0: a K tile never straddles taps), and a lane whose shifted pixel falls outside the image
+// points at a 128-byte page of zeros instead (TF-SAME zero padding, any stride).  The input gradient of a stride-1 convolution is
+// the same kernel on dY with the flipped, transposed weight image.  Opt-in (MAED_CONV3X3=own in resnetv2.py): written after the
+// round-1 GPU budget was spent, verified on the host simulator only.
+// ------------------------------------------------------------------------------------------------
+struct Conv3x3Dims { int F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left; };
+
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt, const bf16* __restrict__ zero_page,
+                                                                   Conv3x3Dims d, int64_t M, int64_t N, int tiles_n, EpiArgs e) {
+    constexpr int kTileElems = 2 * GM_BM * GM_BK, kStageElems = 4 * 32 * GL_ST * 2;
+    __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kTileElems > kStageElems ? kTileElems : kStageElems];
+    unsigned short (*lds)[GM_BM * GM_BK] = reinterpret_cast<unsigned short (*)[GM_BM * GM_BK]>(lds_raw);     // [A|B][128*64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(id / tiles_n) * GM_BM, n0 = (int64_t)(id % tiles_n) * GM_BN;
+    const int64_t ldb = 9 * (int64_t)d.Cin;
+    const int nkt = (int)(ldb / GM_BK);
+    const int srow = wave * 8 + (lane >> 3);
+    const int schunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    // per staging round i: the output pixel of this lane's A row (top-left input tap, element offset of it) and its B row
+#define CV_PTRS(i)                                                                                        \
+    int iy##i, ix##i; int64_t aoff##i; const bf16* gbp##i;                                                \
+    {                                                                                                     \
+        const int row = srow + 32 * i;                                                                    \
+        const int64_t m = (m0 + row < M) ? m0 + row : M - 1;                                              \
+        const int ox = (int)(m % d.Wo), oy = (int)((m / d.Wo) % d.Ho);                                    \
+        const int64_t f = m / ((int64_t)d.Wo * d.Ho);                                                     \
+        iy##i = oy * d.stride - d.pad_top; ix##i = ox * d.stride - d.pad_left;                            \
+        aoff##i = ((f * d.H + iy##i) * d.W + ix##i) * (int64_t)d.Cin + schunk * 8;                        \
+        const int64_t br = (n0 + row < N) ? n0 + row : N - 1;                                             \
+        gbp##i = Wt + br * ldb + schunk * 8;                                                              \
+    }
+    CV_PTRS(0) CV_PTRS(1) CV_PTRS(2) CV_PTRS(3)
+#define CV_ISSUE1(i, ty_, tx_, toff_, k0_)                                                                                            \
+    {                                                                                                                                 \
+        const bool ok = (unsigned)(iy##i + ty_) < (unsigned)d.H && (unsigned)(ix##i + tx_) < (unsigned)d.W;                           \
+        const bf16* src = ok ? X + aoff##i + toff_ : zero_page + schunk * 8;                                                          \
+        __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)&lds[0][(4 * i + wave) * 8 * GM_BK], 16, 0, 0);               \
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gbp##i + k0_), (lds_void_t*)&lds[1][(4 * i + wave) * 8 * GM_BK], 16, 0, 0);   \
+    }
+    f32x16_t acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    const int fsw = (l31 >> 1) & 7;
+    int ty = 0, tx = 0, c0 = 0;                                     // K tile -> (tap, channel chunk), advanced incrementally (wave-uniform)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * GM_BK;
+        const int64_t toff = ((int64_t)ty * d.W + tx) * d.Cin + c0;
+        CV_ISSUE1(0, ty, tx, toff, k0) CV_ISSUE1(1, ty, tx, toff, k0) CV_ISSUE1(2, ty, tx, toff, k0) CV_ISSUE1(3, ty, tx, toff, k0)
+        MAED_WAIT_VMCNT0();
+        __syncthreads();
+        {
+            const unsigned short* As = &lds[0][(wr * 64 + l31) * GM_BK];
+            const unsigned short* Bs = &lds[1][(wc * 64 + l31) * GM_BK];
+#pragma unroll
+            for (int kk = 0; kk < GM_BK / 16; ++kk) {
+                const int co = ((kk * 2 + hi) ^ fsw) * 8;
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(As + co);
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(As + 32 * GM_BK + co);
+                const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(Bs + co);
+                const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(Bs + 32 * GM_BK + co);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc00, 0, 0, 0);     // transposed tiles: lane = output row (pixel)
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc11, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        c0 += GM_BK;
+        if (c0 == d.Cin) { c0 = 0; if (++tx == 3) { tx = 0; ++ty; } }
+    }
+#undef CV_PTRS
+#undef CV_ISSUE1
+    // LDS-shuffled epilogue, exactly as in gemm_nt_glds_bf16_kernel
+    const bool vec_ok = (e.ldo % 8 == 0) && (e.ldaux % 8 == 0);
+    float* stg = reinterpret_cast<float*>(lds_raw) + wave * 32 * GL_ST;
+    const int rr = lane >> 3, cc = (lane & 7) * 8;
+#define CV_SHUFFLE_HALF(accA_, accB_, i_)                                                                              \
+    __syncthreads();                                                                                                   \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                    \
+        *reinterpret_cast<float4*>(stg + l31 * GL_ST + 8 * g + 4 * hi) = make_float4(accA_[4 * g], accA_[4 * g + 1], accA_[4 * g + 2], accA_[4 * g + 3]);      \
+        *reinterpret_cast<float4*>(stg + l31 * GL_ST + 32 + 8 * g + 4 * hi) = make_float4(accB_[4 * g], accB_[4 * g + 1], accB_[4 * g + 2], accB_[4 * g + 3]); \
+    }                                                                                                                  \
+    __syncthreads();                                                                                                   \
+    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                                 \
+        const int lr = ps * 8 + rr;                                                                                    \
+        const int64_t row = m0 + wr * 64 + (i_) * 32 + lr, c0 = n0 + wc * 64 + cc;                                     \
+        float v8[8];                                                                                                   \
+        ld8(stg + lr * GL_ST + cc, v8);                                                                                \
+        if (row < M && c0 < N) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);                                  \
+    }
+    CV_SHUFFLE_HALF(acc00, acc01, 0)
+    CV_SHUFFLE_HALF(acc10, acc11, 1)
+#undef CV_SHUFFLE_HALF
+}
+
+extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* zero_page, void* y, int F, int H, int W, int Cin, int Cout,
+                                int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int dtype, void* stream) {
+    MAED_CHECK_ARG(x && w_taps && zero_page && y, MAED_ERR_ARG, "conv3x3_fwd: null pointer");
+    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_fwd: bf16 only (the f32 parity mode keeps the library convolution)");
+    MAED_CHECK_ARG(F >= 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride >= 1 && pad_top >= 0 && pad_left >= 0, MAED_ERR_SHAPE, "conv3x3_fwd: bad extents");
+    MAED_CHECK_ARG(Cin % GM_BK == 0 && Cout % 8 == 0, MAED_ERR_SHAPE, "conv3x3_fwd: need Cin %% 64 == 0 and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    MAED_CHECK_ARG((Ho - 1) * stride - pad_top + 2 < H + 2 && (Wo - 1) * stride - pad_left + 2 < W + 2, MAED_ERR_SHAPE, "conv3x3_fwd: output extent exceeds the padded input");
+    MAED_CHECK_ARG(is_aligned(x, 16) && is_aligned(w_taps, 16) && is_aligned(zero_page, 16) && is_aligned(y, 16), MAED_ERR_ALIGN, "conv3x3_fwd: 16-B alignment");
+    if (F == 0) return MAED_OK;
+    const int64_t M = (int64_t)F * Ho * Wo, N = Cout;
+    const int tm = (int)((M + GM_BM - 1) / GM_BM), tn = (int)((N + GM_BN - 1) / GM_BN);
+    const Conv3x3Dims d{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left};
+    EpiArgs e{nullptr, y, (int64_t)Cout, nullptr, add, (int64_t)Cout};
+    if (add)
+        hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<MAED_EPI_ADD>), dim3((unsigned)(tm * tn)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)w_taps, (const bf16*)zero_page, d, M, N, tn, e);
+    else
+        hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<MAED_EPI_STORE>), dim3((unsigned)(tm * tn)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)w_taps, (const bf16*)zero_page, d, M, N, tn, e);
+    MAED_CHECK_LAUNCH("conv3x3_fwd");
+    return MAED_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int EPI, typename T>
 static int launch_valu(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                        const EpiArgs& e, int splitk, hipStream_t s) {

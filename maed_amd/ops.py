@@ -626,3 +626,71 @@ class Conv1x1Fn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+
+
+_ZERO_PAGE = {}
+
+
+def _zero_page(device):
+    """>= 128 bytes of zeros: the source of every out-of-image tap of the implicit-GEMM 3x3 convolution"""
+    key = str(device)
+    if key not in _ZERO_PAGE:
+        _ZERO_PAGE[key] = _aligned_bytes(256, device).zero_()
+    return _ZERO_PAGE[key]
+
+
+def conv3x3(x, w_taps, stride=1, add=None):
+    """y = conv3x3_SAME(x, w) on channels_last bf16 tensors through maed_conv3x3_fwd.  x (N,Cin,H,W) channels_last,
+    w_taps: storage (Cout, 3, 3, Cin) contiguous (any view of it).  TF-SAME padding from the input size (resnetv2.py:51-59)."""
+    N, I, H, W = x.shape
+    x = x.contiguous(memory_format=torch.channels_last)
+    O = w_taps.numel() // (9 * I)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw = max((Ho - 1) * stride + 3 - H, 0), max((Wo - 1) * stride + 3 - W, 0)
+    y = torch.empty(N, O, Ho, Wo, dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    if add is not None:
+        add = add.contiguous(memory_format=torch.channels_last)
+    check(L.lib().maed_conv3x3_fwd(_p(x), _p(w_taps), _p(_zero_page(x.device)), _p(y), N, H, W, I, O, stride, ph // 2, pw // 2, Ho, Wo, _p(add),
+                                   dt_code(x.dtype), _stream()), "conv3x3_fwd")
+    return y
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """StdConv2dSame 3x3 (resnetv2.py:74-93) on the library's implicit-GEMM kernel: forward for any stride, input gradient for
+    stride 1 (the same kernel on dY with the flipped, transposed weight image); the weight gradient -- and the input gradient of
+    the three stride-2 convolutions -- stay on the framework's convolution backward.  w: the standardised weight as WeightStdFn
+    hands it out, logical (O, I, 3, 3) over (O, 3, 3, I) storage."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        x = x.contiguous(memory_format=torch.channels_last)
+        w_taps = w.permute(0, 2, 3, 1)
+        w_taps = w_taps if w_taps.is_contiguous() else w_taps.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return conv3x3(x, w_taps, stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        s = ctx.stride
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        N, I, H, W = x.shape
+        Ho, Wo = dy.shape[-2:]
+        ph, pw = max((Ho - 1) * s + 3 - H, 0), max((Wo - 1) * s + 3 - W, 0)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = dw = None
+        own_dx = need_x and s == 1 and w.shape[0] % 64 == 0      # (the gathered operand's channel count is O here)
+        if own_dx:                                  # dX = conv3x3(dY, w'), w'[ci][ky][kx][co] = w[co][ci][2-ky][2-kx]
+            w_flip = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()       # storage (I, 3, 3, O)
+            dx = conv3x3(dy, w_flip, 1)
+        if need_w or (need_x and not own_dx):
+            sym = ph % 2 == 0 and pw % 2 == 0
+            xin = x if sym else torch.nn.functional.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+            pad = (ph // 2, pw // 2) if sym else (0, 0)
+            gx, gw, _ = torch.ops.aten.convolution_backward(dy, xin, w, None, (s, s), pad, (1, 1), False, (0, 0), 1,
+                                                            (need_x and not own_dx, need_w, False))
+            dw = gw
+            if need_x and not own_dx:
+                dx = gx if sym else gx[:, :, ph // 2:ph // 2 + H, pw // 2:pw // 2 + W]
+        return dx, dw, None

@@ -200,8 +200,30 @@ def long_attention():
     check("coupling (8 x 70 tokens) dqkv vs fp64 oracle", rel(xg.grad, x.grad), 3e-2)
 
 
+def conv3x3():
+    import torch.nn.functional as F
+    from maed_amd.resnetv2 import _same_pad
+    bf = torch.bfloat16
+    for N, I, O, H, W, stride in [(2, 64, 64, 6, 5, 1), (2, 64, 136, 8, 8, 2), (1, 64, 64, 7, 7, 2), (2, 128, 128, 28, 28, 1)]:
+        x = rnd(N, I, H, W, seed=H).to(bf).float()
+        w = (rnd(O, I, 3, 3, seed=W) * (1.0 / (3 * I ** 0.5))).to(bf).float()
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = F.conv2d(_same_pad(xr, 3, stride), wr, None, stride)
+        dy = rnd(*ref.shape, seed=3).to(bf).float()
+        ref.backward(dy)
+        xs = x.to(bf).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ws = w.to(bf).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)
+        with patched():
+            y = ops.Conv3x3Fn.apply(xs, ws, stride)
+            y.backward(dy.to(bf).to(DEV).contiguous(memory_format=torch.channels_last))
+        tag = f"conv3x3 N{N} I{I} O{O} {H}x{W} stride {stride}"
+        check(tag + " forward vs fp32 conv", rel(y, ref), 1e-2)
+        check(tag + " input gradient", rel(xs.grad, xr.grad), 1e-2)
+        check(tag + " weight gradient", rel(ws.grad, wr.grad), 2e-2)
+
+
 if __name__ == "__main__":
-    for part in (long_attention, modes, iterative, evaluation):
+    for part in (conv3x3, long_attention, modes, iterative, evaluation):
         print(f"--- {part.__name__} ({'host simulator' if SIM else 'GPU'}) ---", flush=True)
         part()
     print("ALL NEW PATHS OK")

@@ -10,10 +10,12 @@ bench_ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(s
 
 timeout 600 python scripts/check_new_paths.py 2>&1 | tee gpurun_out/r02_new_paths_on_gpu.log
 timeout 200 python scripts/attn_long_micro.py 20 2>&1 | tee gpurun_out/r02_attn_long_micro.txt
+timeout 200 python scripts/conv3x3_micro.py 10 2>&1 | tee gpurun_out/r02_conv3x3_micro.txt
 for w in 0 1; do MAED_TM_BWD_WIDE_REGS=$w MAED_TEMPORAL_MFMA=1 timeout 120 python scripts/attn_tm_micro.py 30 2>&1 | sed "s/^/wide_regs=$w /" | tee -a gpurun_out/r02_attn_tm_wide_regs.txt; done
 
 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | bench_ms "default" | tee gpurun_out/r02_optin_flags.txt
 env $OPTIN timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | bench_ms "all-opt-in" | tee -a gpurun_out/r02_optin_flags.txt
+env MAED_CONV3X3=own timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | bench_ms "MAED_CONV3X3=own" | tee -a gpurun_out/r02_optin_flags.txt
 for one in MAED_GN_DEFER_AFFINE MAED_LN_DEFER_AFFINE MAED_TAIL_PARALLEL; do
   env $one=1 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | bench_ms "$one" | tee -a gpurun_out/r02_optin_flags.txt
 done

@@ -94,3 +94,27 @@ def test_weight_standardisation_batched_matches_aten():
     for o, r, w, wr in zip(outs, outs_ref, ws, refs):
         assert torch.allclose(o.detach(), r.detach(), rtol=1e-4, atol=1e-5)
         assert torch.allclose(w.grad, wr.grad, rtol=1e-3, atol=1e-4), (w.grad - wr.grad).abs().max()
+
+
+@pytest.mark.parametrize("N,I,O,H,W,stride", [(2, 64, 64, 6, 5, 1), (1, 128, 72, 7, 9, 1), (2, 64, 136, 8, 8, 2), (1, 64, 64, 7, 7, 2), (1, 64, 64, 14, 14, 1)])
+def test_conv3x3_implicit_gemm_matches_aten(N, I, O, H, W, stride):
+    """maed_conv3x3_fwd (gathered A rows, zero page for out-of-image taps) and Conv3x3Fn's input gradient against F.conv2d with the
+    reference's TF-SAME padding (resnetv2.py:51-59: pad//2 in front), odd and even sizes, stride 1 and 2, ragged row / column tiles"""
+    from maed_amd.resnetv2 import _same_pad
+    g = torch.Generator().manual_seed(H * 100 + W)
+    bf = torch.bfloat16
+    x = torch.randn(N, I, H, W, generator=g).to(bf).float()
+    w = (torch.randn(O, I, 3, 3, generator=g) * (1.0 / (3 * I ** 0.5))).to(bf).float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(_same_pad(xr, 3, stride), wr, None, stride)
+    dy = torch.randn(ref.shape, generator=g).to(bf).float()
+    ref.backward(dy)
+    xs = cl(x.to(bf)).requires_grad_(True)
+    ws = w.to(bf).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)       # (O,I,3,3) over (O,3,3,I) storage
+    with patched():
+        y = ops.Conv3x3Fn.apply(xs, ws, stride)
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        y.backward(cl(dy.to(bf)))
+    assert torch.allclose(y.float(), ref.detach(), rtol=2e-2, atol=2e-2), (y.float() - ref).abs().max()
+    assert torch.allclose(xs.grad.float(), xr.grad, rtol=2e-2, atol=2e-2), (xs.grad.float() - xr.grad).abs().max()
+    assert torch.allclose(ws.grad.float(), wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max()))
