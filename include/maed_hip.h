@@ -336,6 +336,13 @@ int maed_comm_destroy(void);
 int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* zero_page, void* y, int F, int H, int W, int Cin, int Cout,
                      int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int dtype, void* stream);
 
+/* weight gradient of the stride-1 3x3 SAME convolution: dW (Cout, 9*Cin) fp32 += sum over pixels of dy (F,H,W,Cout) x shifted x (F,H,W,Cin)
+ * (a TN GEMM over gathered rows on maed_gemm_tn_wgrad's kernel).  tapmask: F*H*W uint16 rounded up to a multiple of 64, filled once per
+ * (F,H,W) by maed_conv3x3_tapmask; zero_page as for maed_conv3x3_fwd.  Needs F*H*W % 64 == 0, Cin % 8 == 0, Cout % 8 == 0. */
+int maed_conv3x3_tapmask(void* tapmask, int F, int H, int W, void* stream);
+int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tapmask, const void* zero_page, float* dW, int F, int H, int W, int Cin,
+                       int Cout, int dtype, void* stream);
+
 /* ---- evaluation metrics on the device ----------------------------------------------------
  * Replace the numpy / torch-CPU post-processing of lib/core/evaluate.py:135-166 and lib/utils/eval_utils.py.  fp32 in/out.
  *

@@ -18,9 +18,18 @@
 __device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }  // {b.lo16, a.lo16}
 __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }  // {b.hi16, a.hi16}
 
+// CONV = true: the weight gradient of a stride-1 3x3 SAME convolution (resnetv2.py:74-93) as the same TN GEMM over GATHERED X rows:
+//   dW[co][tap*Cin + ci] += sum_m dY[m][co] * X[m + shift(tap)][ci] * inside(m, tap)         m = (f, y, x), K = 9*Cin
+// a thread's 8 K-columns lie in ONE tap (Cin % 8 == 0), so the tap's row shift is a constant folded into its loop-invariant lane
+// offsets; whether the shifted pixel is inside the image comes from a per-pixel 9-bit mask (maed_conv3x3_tapmask, computed once per
+// feature-map size), and a masked row loads a page of zeros instead.  Needs M % 64 == 0 (no ragged tile).  Opt-in path.
+struct TnConv { const uint16_t* tapmask; const bf16* zero_page; int Cin, Wimg; };
+
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* __restrict__ Y, int64_t ldy, const bf16* __restrict__ X,
                                                                    int64_t ldx, int64_t M, int N, int K, float* __restrict__ dW,
-                                                                   int64_t ldw, float* __restrict__ dbias, int tiles_k, int mtiles_per_split) {
+                                                                   int64_t ldw, float* __restrict__ dbias, int tiles_k, int mtiles_per_split,
+                                                                   TnConv cv) {
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][128 * TN_LD];  // [buf][Y^T | X^T][row n|k][m]
     __shared__ float lcs[8][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,7 +69,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     for (int j = 0; j < 8; ++j) cs[j] = 0.f;
     // lanes whose columns lie beyond N / K load column 0 instead (always valid), never store, and their LDS rows are zeroed once
     const int ldi = (int)lds_src;
-    const int vo0 = (mg * 8) * ldi + (col_ok ? c0 : 0), vo1 = vo0 + ldi, vo2 = vo1 + ldi, vo3 = vo2 + ldi, vo4 = vo3 + ldi, vo5 = vo4 + ldi,
+    int tap = 0, col_in = col_ok ? c0 : 0;                    // CONV, X side: K column -> (tap, channel); the tap's pixel shift in rows
+    int shift = 0;
+    if constexpr (CONV) {
+        if (side) { tap = col_in / cv.Cin; col_in -= tap * cv.Cin; shift = (tap / 3 - 1) * cv.Wimg + (tap % 3 - 1); }
+    }
+    const int vo0 = (mg * 8 + shift) * ldi + col_in, vo1 = vo0 + ldi, vo2 = vo1 + ldi, vo3 = vo2 + ldi, vo4 = vo3 + ldi, vo5 = vo4 + ldi,
               vo6 = vo5 + ldi, vo7 = vo6 + ldi;               // fits 32 bits: the launcher checks ld < 2^24
     if (!col_ok) {
 #pragma unroll
@@ -72,9 +86,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
 
     uint4 r0_0, r0_1, r0_2, r0_3, r0_4, r0_5, r0_6, r0_7, r1_0, r1_1, r1_2, r1_3, r1_4, r1_5, r1_6, r1_7;
 #define TN_LD1(S, i, tb_) r##S##_##i = *reinterpret_cast<const uint4*>((tb_) + vo##i);
+    // CONV, X side: row i of the 8-row group is taken from the image only if bit `tap` of its pixel's mask is set, else from the zero page
+#define TN_LD1M(S, i, tb_, mw_) r##S##_##i = *reinterpret_cast<const uint4*>(((((mw_) >> (((i) & 1) * 16 + tap)) & 1u) ? (tb_) + vo##i : cv.zero_page));
 #define TN_LOAD(S, mt_) { int mtc__ = (mt_); if (mtc__ > mt_endf - 1) mtc__ = mt_endf - 1; \
         const bf16* tb__ = src + (int64_t)mtc__ * TN_BM * lds_src; \
-        TN_LD1(S, 0, tb__) TN_LD1(S, 1, tb__) TN_LD1(S, 2, tb__) TN_LD1(S, 3, tb__) TN_LD1(S, 4, tb__) TN_LD1(S, 5, tb__) TN_LD1(S, 6, tb__) TN_LD1(S, 7, tb__) }
+        bool masked__ = false; \
+        if constexpr (CONV) masked__ = side != 0; \
+        if (masked__) { \
+            const uint4 mk__ = *reinterpret_cast<const uint4*>(cv.tapmask + (int64_t)mtc__ * TN_BM + mg * 8); \
+            TN_LD1M(S, 0, tb__, mk__.x) TN_LD1M(S, 1, tb__, mk__.x) TN_LD1M(S, 2, tb__, mk__.y) TN_LD1M(S, 3, tb__, mk__.y) \
+            TN_LD1M(S, 4, tb__, mk__.z) TN_LD1M(S, 5, tb__, mk__.z) TN_LD1M(S, 6, tb__, mk__.w) TN_LD1M(S, 7, tb__, mk__.w) \
+        } else { \
+            TN_LD1(S, 0, tb__) TN_LD1(S, 1, tb__) TN_LD1(S, 2, tb__) TN_LD1(S, 3, tb__) TN_LD1(S, 4, tb__) TN_LD1(S, 5, tb__) TN_LD1(S, 6, tb__) TN_LD1(S, 7, tb__) } }
     // ragged tile: rows >= M contribute zeros
 #define TN_LD1C(S, i, tb_, mrow0) r##S##_##i = ((mrow0) + mg * 8 + i < M) ? *reinterpret_cast<const uint4*>((tb_) + vo##i) : make_uint4(0u, 0u, 0u, 0u);
 #define TN_LOAD_TAIL(S) { const int64_t mrow0__ = (int64_t)n_full * TN_BM; const bf16* tb__ = src + mrow0__ * lds_src; \
@@ -176,8 +199,56 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     if (splits < 1) splits = 1;
     const int per = (nmt + splits - 1) / splits;
     const int z = (nmt + per - 1) / per;
-    hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
-                       N, K, dW, ldw, dbias, tk, per);
+    hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
+                       N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0});
     MAED_CHECK_LAUNCH("gemm_tn_wgrad");
+    return MAED_OK;
+}
+
+// bit t of mask[m] = 1 iff the input pixel (y + t/3 - 1, x + t%3 - 1) of output pixel m = (f, y, x) lies inside the H x W image
+__global__ __launch_bounds__(256) void conv_tapmask_kernel(uint16_t* __restrict__ mask, int64_t M, int64_t Mpad, int H, int W) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= Mpad) return;
+    unsigned bits = 0;
+    if (m < M) {
+        const int x = (int)(m % W), y = (int)((m / W) % H);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            bits |= ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W ? 1u : 0u) << t;
+        }
+    }
+    mask[m] = (uint16_t)bits;
+}
+
+extern "C" int maed_conv3x3_tapmask(void* mask, int F, int H, int W, void* stream) {
+    MAED_CHECK_ARG(mask, MAED_ERR_ARG, "conv3x3_tapmask: null pointer");
+    MAED_CHECK_ARG(F > 0 && H > 0 && W > 0, MAED_ERR_SHAPE, "conv3x3_tapmask: bad extents");
+    const int64_t M = (int64_t)F * H * W, Mpad = (M + TN_BM - 1) / TN_BM * TN_BM;
+    hipLaunchKernelGGL(conv_tapmask_kernel, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)mask, M, Mpad, H, W);
+    MAED_CHECK_LAUNCH("conv3x3_tapmask");
+    return MAED_OK;
+}
+
+extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tapmask, const void* zero_page, float* dW, int F, int H, int W, int Cin,
+                                  int Cout, int dtype, void* stream) {
+    MAED_CHECK_ARG(dy && x && tapmask && zero_page && dW, MAED_ERR_ARG, "conv3x3_wgrad: null pointer");
+    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_wgrad: bf16 only");
+    const int64_t M = (int64_t)F * H * W;
+    const int N = Cout, K = 9 * Cin;
+    MAED_CHECK_ARG(M > 0 && M % TN_BM == 0, MAED_ERR_SHAPE, "conv3x3_wgrad: F*H*W = %lld must be a multiple of 64", (long long)M);
+    MAED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && Cin < (1 << 20) && W + 1 < (1 << 10), MAED_ERR_SHAPE, "conv3x3_wgrad: need Cin, Cout multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
+    MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16) && is_aligned(tapmask, 16) && is_aligned(zero_page, 16), MAED_ERR_ALIGN, "conv3x3_wgrad: 16-B alignment");
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    const int nmt = (int)(M / TN_BM);
+    int splits = (384 + tn * tk - 1) / (tn * tk);
+    if (splits > (nmt + 3) / 4) splits = (nmt + 3) / 4;
+    if (splits < 1) splits = 1;
+    const int per = (nmt + splits - 1) / splits;
+    const int z = (nmt + per - 1) / per;
+    hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<true>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (int64_t)Cout,
+                       (const bf16*)x, (int64_t)Cin, M, N, K, dW, (int64_t)K, (float*)nullptr, tk, per,
+                       TnConv{(const uint16_t*)tapmask, (const bf16*)zero_page, Cin, W});
+    MAED_CHECK_LAUNCH("conv3x3_wgrad");
     return MAED_OK;
 }

@@ -655,10 +655,34 @@ def conv3x3(x, w_taps, stride=1, add=None):
     return y
 
 
+_TAPMASKS = {}
+
+
+def _tapmask(N, H, W, device):
+    """per-pixel 9-bit 'tap inside the image' mask of the 3x3 weight-gradient kernel; depends only on the feature-map size: cached"""
+    key = (N, H, W, str(device))
+    if key not in _TAPMASKS:
+        n = (N * H * W + 63) // 64 * 64
+        m = _aligned_bytes(2 * n, device)
+        check(L.lib().maed_conv3x3_tapmask(_p(m), N, H, W, _stream()), "conv3x3_tapmask")
+        _TAPMASKS[key] = m
+    return _TAPMASKS[key]
+
+
+def conv3x3_wgrad(dy, x):
+    """fp32 dW (O, 3, 3, I) of the stride-1 3x3 SAME convolution from channels_last bf16 dy (N,O,H,W) and x (N,I,H,W)"""
+    N, I, H, W = x.shape
+    O = dy.shape[1]
+    dW = torch.zeros(O, 3, 3, I, dtype=torch.float32, device=x.device)
+    check(L.lib().maed_conv3x3_wgrad(_p(dy), _p(x), _p(_tapmask(N, H, W, x.device)), _p(_zero_page(x.device)), _p(dW), N, H, W, I, O,
+                                     dt_code(x.dtype), _stream()), "conv3x3_wgrad")
+    return dW
+
+
 class Conv3x3Fn(torch.autograd.Function):
     """StdConv2dSame 3x3 (resnetv2.py:74-93) on the library's implicit-GEMM kernel: forward for any stride, input gradient for
-    stride 1 (the same kernel on dY with the flipped, transposed weight image); the weight gradient -- and the input gradient of
-    the three stride-2 convolutions -- stay on the framework's convolution backward.  w: the standardised weight as WeightStdFn
+    stride 1 (the same kernel on dY with the flipped, transposed weight image), weight gradient for stride 1 (maed_conv3x3_wgrad: the TN
+    weight-gradient kernel over gathered rows); the three stride-2 convolutions keep the framework's convolution backward.  w: the standardised weight as WeightStdFn
     hands it out, logical (O, I, 3, 3) over (O, 3, 3, I) storage."""
 
     @staticmethod
@@ -684,13 +708,17 @@ class Conv3x3Fn(torch.autograd.Function):
         if own_dx:                                  # dX = conv3x3(dY, w'), w'[ci][ky][kx][co] = w[co][ci][2-ky][2-kx]
             w_flip = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()       # storage (I, 3, 3, O)
             dx = conv3x3(dy, w_flip, 1)
+        own_dw = need_w and s == 1 and (N * H * W) % 64 == 0 and I % 8 == 0 and w.shape[0] % 8 == 0
+        if own_dw:                                  # TN GEMM over gathered rows; fp32, in the (O,3,3,I) order of w's storage
+            dw = conv3x3_wgrad(dy, x).permute(0, 3, 1, 2)
+            need_w = False
         if need_w or (need_x and not own_dx):
             sym = ph % 2 == 0 and pw % 2 == 0
             xin = x if sym else torch.nn.functional.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
             pad = (ph // 2, pw // 2) if sym else (0, 0)
             gx, gw, _ = torch.ops.aten.convolution_backward(dy, xin, w, None, (s, s), pad, (1, 1), False, (0, 0), 1,
                                                             (need_x and not own_dx, need_w, False))
-            dw = gw
+            dw = gw if need_w else dw
             if need_x and not own_dx:
                 dx = gx if sym else gx[:, :, ph // 2:ph // 2 + H, pw // 2:pw // 2 + W]
         return dx, dw, None

@@ -204,7 +204,8 @@ def conv3x3():
     import torch.nn.functional as F
     from maed_amd.resnetv2 import _same_pad
     bf = torch.bfloat16
-    for N, I, O, H, W, stride in [(2, 64, 64, 6, 5, 1), (2, 64, 136, 8, 8, 2), (1, 64, 64, 7, 7, 2), (2, 128, 128, 28, 28, 1)]:
+    for N, I, O, H, W, stride in [(2, 64, 64, 6, 5, 1), (2, 64, 136, 8, 8, 2), (1, 64, 64, 7, 7, 2), (2, 128, 128, 28, 28, 1),
+                                       (4, 64, 64, 14, 14, 1), (1, 64, 136, 8, 16, 1)]:     # last two: F*H*W % 64 == 0 -> own weight-gradient kernel
         x = rnd(N, I, H, W, seed=H).to(bf).float()
         w = (rnd(O, I, 3, 3, seed=W) * (1.0 / (3 * I ** 0.5))).to(bf).float()
         xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)

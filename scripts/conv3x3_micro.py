@@ -25,7 +25,7 @@ def timeit(fn):
     return 1e3 * e0.elapsed_time(e1) / iters
 
 
-tot = dict(fwd_miopen=0.0, fwd_own=0.0, dgrad_miopen=0.0, dgrad_own=0.0)
+tot = dict(fwd_miopen=0.0, fwd_own=0.0, dgrad_miopen=0.0, dgrad_own=0.0, wgrad_miopen=0.0, wgrad_own=0.0)
 for H, C, s, cnt in shapes:
     x = torch.randn(Fr, C, H, H, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(C, C, 3, 3, device="cuda") * (9 * C) ** -0.5).bfloat16().contiguous(memory_format=torch.channels_last)
@@ -48,5 +48,11 @@ for H, C, s, cnt in shapes:
         gerr = ((ops.conv3x3(dy, w_flip, 1).float() - gref.float()).abs().max() / gref.float().abs().max()).item()
         line += f" | dgrad miopen {dm:7.1f} own {do:7.1f} us  rel err {gerr:.1e}"
         tot["dgrad_miopen"] += cnt * dm; tot["dgrad_own"] += cnt * do
+        wm = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1])
+        wo = timeit(lambda: ops.conv3x3_wgrad(dy, x))
+        wref = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1].float()
+        werr = ((ops.conv3x3_wgrad(dy, x).permute(0, 3, 1, 2) - wref).abs().max() / wref.abs().max()).item()
+        line += f" | wgrad miopen {wm:7.1f} own {wo:7.1f} us  rel err {werr:.1e}"
+        tot["wgrad_miopen"] += cnt * wm; tot["wgrad_own"] += cnt * wo
     print(line, flush=True)
 print("backbone totals (ms): " + "  ".join(f"{k} {v / 1e3:.2f}" for k, v in tot.items()))

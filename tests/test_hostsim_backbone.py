@@ -96,11 +96,15 @@ def test_weight_standardisation_batched_matches_aten():
         assert torch.allclose(w.grad, wr.grad, rtol=1e-3, atol=1e-4), (w.grad - wr.grad).abs().max()
 
 
-@pytest.mark.parametrize("N,I,O,H,W,stride", [(2, 64, 64, 6, 5, 1), (1, 128, 72, 7, 9, 1), (2, 64, 136, 8, 8, 2), (1, 64, 64, 7, 7, 2), (1, 64, 64, 14, 14, 1)])
-def test_conv3x3_implicit_gemm_matches_aten(N, I, O, H, W, stride):
+@pytest.mark.parametrize("N,I,O,H,W,stride", [(2, 64, 64, 6, 5, 1), (1, 128, 72, 7, 9, 1), (2, 64, 136, 8, 8, 2), (1, 64, 64, 7, 7, 2), (1, 64, 64, 14, 14, 1),
+                                              (2, 64, 64, 8, 4, 1), (4, 128, 64, 4, 8, 1), (1, 64, 136, 8, 16, 1), (2, 64, 64, 16, 12, 1)])
+def test_conv3x3_implicit_gemm_matches_aten(N, I, O, H, W, stride, monkeypatch):
     """maed_conv3x3_fwd (gathered A rows, zero page for out-of-image taps) and Conv3x3Fn's input gradient against F.conv2d with the
     reference's TF-SAME padding (resnetv2.py:51-59: pad//2 in front), odd and even sizes, stride 1 and 2, ragged row / column tiles"""
     from maed_amd.resnetv2 import _same_pad
+    own_wgrad = []
+    real = ops.conv3x3_wgrad
+    monkeypatch.setattr(ops, "conv3x3_wgrad", lambda dy_, x_: (own_wgrad.append(1), real(dy_, x_))[1])
     g = torch.Generator().manual_seed(H * 100 + W)
     bf = torch.bfloat16
     x = torch.randn(N, I, H, W, generator=g).to(bf).float()
@@ -118,3 +122,5 @@ def test_conv3x3_implicit_gemm_matches_aten(N, I, O, H, W, stride):
     assert torch.allclose(y.float(), ref.detach(), rtol=2e-2, atol=2e-2), (y.float() - ref).abs().max()
     assert torch.allclose(xs.grad.float(), xr.grad, rtol=2e-2, atol=2e-2), (xs.grad.float() - xr.grad).abs().max()
     assert torch.allclose(ws.grad.float(), wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max()))
+    # the library's own weight-gradient kernel (TN GEMM over gathered rows + tap mask) runs for stride 1 when F*H*W % 64 == 0
+    assert bool(own_wgrad) == (stride == 1 and (N * H * W) % 64 == 0)
