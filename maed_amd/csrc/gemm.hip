@@ -464,16 +464,18 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
 // ------------------------------------------------------------------------------------------------
 struct Conv3x3Dims { int F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left; };
 
-template <int EPI>
+// NARROW: 128 x 64 output tile for Cout <= 64 (stage 1 of the R50: a 128-wide tile would spend half its MFMAs on duplicated weight rows):
+// the four waves take 32 pixel rows each and both 32-column halves; only 64 weight rows are staged.
+template <int EPI, bool NARROW>
 __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt, const bf16* __restrict__ zero_page,
                                                                    Conv3x3Dims d, int64_t M, int64_t N, int tiles_n, EpiArgs e) {
     constexpr int kTileElems = 2 * GM_BM * GM_BK, kStageElems = 4 * 32 * GL_ST * 2;
     __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kTileElems > kStageElems ? kTileElems : kStageElems];
     unsigned short (*lds)[GM_BM * GM_BK] = reinterpret_cast<unsigned short (*)[GM_BM * GM_BK]>(lds_raw);     // [A|B][128*64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int wr = NARROW ? wave : wave >> 1, wc = NARROW ? 0 : wave & 1, l31 = lane & 31, hi = lane >> 5;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(id / tiles_n) * GM_BM, n0 = (int64_t)(id % tiles_n) * GM_BN;
+    const int64_t m0 = (int64_t)(id / tiles_n) * GM_BM, n0 = (int64_t)(id % tiles_n) * (NARROW ? 64 : GM_BN);
     const int64_t ldb = 9 * (int64_t)d.Cin;
     const int nkt = (int)(ldb / GM_BK);
     const int srow = wave * 8 + (lane >> 3);
@@ -497,7 +499,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
         const bool ok = (unsigned)(iy##i + ty_) < (unsigned)d.H && (unsigned)(ix##i + tx_) < (unsigned)d.W;                           \
         const bf16* src = ok ? X + aoff##i + toff_ : zero_page + schunk * 8;                                                          \
         __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)&lds[0][(4 * i + wave) * 8 * GM_BK], 16, 0, 0);               \
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(gbp##i + k0_), (lds_void_t*)&lds[1][(4 * i + wave) * 8 * GM_BK], 16, 0, 0);   \
+        if (!NARROW || i < 2)                                                                                                         \
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gbp##i + k0_), (lds_void_t*)&lds[1][(4 * i + wave) * 8 * GM_BK], 16, 0, 0); \
     }
     f32x16_t acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -511,19 +514,21 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
         MAED_WAIT_VMCNT0();
         __syncthreads();
         {
-            const unsigned short* As = &lds[0][(wr * 64 + l31) * GM_BK];
+            const unsigned short* As = &lds[0][(wr * (NARROW ? 32 : 64) + l31) * GM_BK];
             const unsigned short* Bs = &lds[1][(wc * 64 + l31) * GM_BK];
 #pragma unroll
             for (int kk = 0; kk < GM_BK / 16; ++kk) {
                 const int co = ((kk * 2 + hi) ^ fsw) * 8;
                 const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(As + co);
-                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(As + 32 * GM_BK + co);
                 const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(Bs + co);
                 const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(Bs + 32 * GM_BK + co);
                 acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc00, 0, 0, 0);     // transposed tiles: lane = output row (pixel)
                 acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc11, 0, 0, 0);
+                if constexpr (!NARROW) {
+                    const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(As + 32 * GM_BK + co);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc11, 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -545,13 +550,13 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
     __syncthreads();                                                                                                   \
     _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                                 \
         const int lr = ps * 8 + rr;                                                                                    \
-        const int64_t row = m0 + wr * 64 + (i_) * 32 + lr, c0 = n0 + wc * 64 + cc;                                     \
+        const int64_t row = m0 + wr * (NARROW ? 32 : 64) + (i_) * 32 + lr, c0 = n0 + wc * 64 + cc;                     \
         float v8[8];                                                                                                   \
         ld8(stg + lr * GL_ST + cc, v8);                                                                                \
         if (row < M && c0 < N) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);                                  \
     }
     CV_SHUFFLE_HALF(acc00, acc01, 0)
-    CV_SHUFFLE_HALF(acc10, acc11, 1)
+    if constexpr (!NARROW) { CV_SHUFFLE_HALF(acc10, acc11, 1) }
 #undef CV_SHUFFLE_HALF
 }
 
@@ -565,15 +570,16 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
     MAED_CHECK_ARG(is_aligned(x, 16) && is_aligned(w_taps, 16) && is_aligned(zero_page, 16) && is_aligned(y, 16), MAED_ERR_ALIGN, "conv3x3_fwd: 16-B alignment");
     if (F == 0) return MAED_OK;
     const int64_t M = (int64_t)F * Ho * Wo, N = Cout;
-    const int tm = (int)((M + GM_BM - 1) / GM_BM), tn = (int)((N + GM_BN - 1) / GM_BN);
+    const bool narrow = N <= 64;
+    const int tm = (int)((M + GM_BM - 1) / GM_BM), tn = narrow ? 1 : (int)((N + GM_BN - 1) / GM_BN);
     const Conv3x3Dims d{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left};
     EpiArgs e{nullptr, y, (int64_t)Cout, nullptr, add, (int64_t)Cout};
-    if (add)
-        hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<MAED_EPI_ADD>), dim3((unsigned)(tm * tn)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                           (const bf16*)w_taps, (const bf16*)zero_page, d, M, N, tn, e);
-    else
-        hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<MAED_EPI_STORE>), dim3((unsigned)(tm * tn)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                           (const bf16*)w_taps, (const bf16*)zero_page, d, M, N, tn, e);
+    const dim3 grid((unsigned)(tm * tn));
+#define CV_LAUNCH(EPI_, NARROW_) hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<EPI_, NARROW_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, \
+                                                   (const bf16*)w_taps, (const bf16*)zero_page, d, M, N, tn, e)
+    if (add) { if (narrow) CV_LAUNCH(MAED_EPI_ADD, true); else CV_LAUNCH(MAED_EPI_ADD, false); }
+    else { if (narrow) CV_LAUNCH(MAED_EPI_STORE, true); else CV_LAUNCH(MAED_EPI_STORE, false); }
+#undef CV_LAUNCH
     MAED_CHECK_LAUNCH("conv3x3_fwd");
     return MAED_OK;
 }
