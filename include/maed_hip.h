@@ -331,10 +331,12 @@ int maed_comm_destroy(void);
  * y (F,Ho,Wo,Cout) = conv(x (F,H,W,Cin), w) with TF-SAME zero padding (pad_top / pad_left rows / columns in front; the rest behind),
  * any stride; w_taps is the weight as (Cout, 3, 3, Cin) = (Cout, 9*Cin) row-major (maed_weight_std_fwd's output order).
  * zero_page: >= 128 bytes of zeros in device memory (source of every out-of-image tap).  add (optional, (F,Ho,Wo,Cout)): y = conv + add.
- * The input gradient of a stride-1 convolution is this entry point on dY with the flipped, transposed weight image
- * w'[ci][2-ky][2-kx][co].  Needs Cin % 64 == 0, Cout % 8 == 0.  Opt-in path (maed_amd/resnetv2.py MAED_CONV3X3=own). */
+ * The input gradient of a stride-1 convolution is this entry point on dY (Cin := forward Cout, Cout := forward Cin) with either the
+ * flipped, transposed weight w'[ci][2-ky][2-kx][co] (w_layout 0) or, copy-free, the transposed image (3,3,Cin_f,Cout_f) that
+ * maed_weight_std_fwd writes next to the forward image (w_layout 1: the tap flip becomes a negative tap stride).
+ * Needs Cin % 64 == 0, Cout % 8 == 0.  Opt-in path (maed_amd/resnetv2.py MAED_CONV3X3=own). */
 int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* zero_page, void* y, int F, int H, int W, int Cin, int Cout,
-                     int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int dtype, void* stream);
+                     int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int w_layout, int dtype, void* stream);
 
 /* weight gradient of the stride-1 3x3 SAME convolution: dW (Cout, 9*Cin) fp32 += sum over pixels of dy (F,H,W,Cout) x shifted x (F,H,W,Cin)
  * (a TN GEMM over gathered rows on maed_gemm_tn_wgrad's kernel).  tapmask: F*H*W uint16 rounded up to a multiple of 64, filled once per

@@ -462,7 +462,8 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
 // the same kernel on dY with the flipped, transposed weight image.  Opt-in (MAED_CONV3X3=own in resnetv2.py): written after the
 // round-1 GPU budget was spent, verified on the host simulator only.
 // ------------------------------------------------------------------------------------------------
-struct Conv3x3Dims { int F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left; };
+// B (weight) addressing: element (n, tap, c) of the GEMM's B operand lives at Wt[b_base + tap * b_tap + n * b_row + c]
+struct Conv3x3Dims { int F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left; int64_t b_row, b_tap, b_base; };
 
 // NARROW: 128 x 64 output tile for Cout <= 64 (stage 1 of the R50: a 128-wide tile would spend half its MFMAs on duplicated weight rows):
 // the four waves take 32 pixel rows each and both 32-column halves; only 64 weight rows are staged.
@@ -476,8 +477,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
     const int wr = NARROW ? wave : wave >> 1, wc = NARROW ? 0 : wave & 1, l31 = lane & 31, hi = lane >> 5;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(id / tiles_n) * GM_BM, n0 = (int64_t)(id % tiles_n) * (NARROW ? 64 : GM_BN);
-    const int64_t ldb = 9 * (int64_t)d.Cin;
-    const int nkt = (int)(ldb / GM_BK);
+    const int nkt = 9 * d.Cin / GM_BK;
     const int srow = wave * 8 + (lane >> 3);
     const int schunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
     // per staging round i: the output pixel of this lane's A row (top-left input tap, element offset of it) and its B row
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
         iy##i = oy * d.stride - d.pad_top; ix##i = ox * d.stride - d.pad_left;                            \
         aoff##i = ((f * d.H + iy##i) * d.W + ix##i) * (int64_t)d.Cin + schunk * 8;                        \
         const int64_t br = (n0 + row < N) ? n0 + row : N - 1;                                             \
-        gbp##i = Wt + br * ldb + schunk * 8;                                                              \
+        gbp##i = Wt + d.b_base + br * d.b_row + schunk * 8;                                               \
     }
     CV_PTRS(0) CV_PTRS(1) CV_PTRS(2) CV_PTRS(3)
 #define CV_ISSUE1(i, ty_, tx_, toff_, k0_)                                                                                            \
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
     const int fsw = (l31 >> 1) & 7;
     int ty = 0, tx = 0, c0 = 0;                                     // K tile -> (tap, channel chunk), advanced incrementally (wave-uniform)
     for (int kt = 0; kt < nkt; ++kt) {
-        const int k0 = kt * GM_BK;
+        const int64_t k0 = (int64_t)(ty * 3 + tx) * d.b_tap + c0;     // B offset of this K tile
         const int64_t toff = ((int64_t)ty * d.W + tx) * d.Cin + c0;
         CV_ISSUE1(0, ty, tx, toff, k0) CV_ISSUE1(1, ty, tx, toff, k0) CV_ISSUE1(2, ty, tx, toff, k0) CV_ISSUE1(3, ty, tx, toff, k0)
         MAED_WAIT_VMCNT0();
@@ -561,7 +561,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
 }
 
 extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* zero_page, void* y, int F, int H, int W, int Cin, int Cout,
-                                int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int dtype, void* stream) {
+                                int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int w_layout, int dtype, void* stream) {
+    MAED_CHECK_ARG(w_layout == 0 || w_layout == 1, MAED_ERR_ARG, "conv3x3_fwd: w_layout must be 0 (Cout,3,3,Cin) or 1 (transposed image of the forward weight)");
     MAED_CHECK_ARG(x && w_taps && zero_page && y, MAED_ERR_ARG, "conv3x3_fwd: null pointer");
     MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_fwd: bf16 only (the f32 parity mode keeps the library convolution)");
     MAED_CHECK_ARG(F >= 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride >= 1 && pad_top >= 0 && pad_left >= 0, MAED_ERR_SHAPE, "conv3x3_fwd: bad extents");
@@ -572,7 +573,12 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
     const int64_t M = (int64_t)F * Ho * Wo, N = Cout;
     const bool narrow = N <= 64;
     const int tm = (int)((M + GM_BM - 1) / GM_BM), tn = narrow ? 1 : (int)((N + GM_BN - 1) / GM_BN);
-    const Conv3x3Dims d{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left};
+    // layout 0: w_taps[co][tap][ci].  layout 1 (input gradient from the forward weight's transposed image Wt[tap_f][c_f][o_f], as
+    // maed_weight_std_fwd writes it next to the forward image): here Cin = O_f, Cout = I_f, and element (n = c_f, tap, c = o_f) is
+    // Wt[(8 - tap)][n][c] -- the tap flip is a negative tap stride, nothing is copied.
+    const Conv3x3Dims d = w_layout == 0
+        ? Conv3x3Dims{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left, 9 * (int64_t)Cin, (int64_t)Cin, 0}
+        : Conv3x3Dims{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left, (int64_t)Cin, -(int64_t)Cout * Cin, 8 * (int64_t)Cout * Cin};
     EpiArgs e{nullptr, y, (int64_t)Cout, nullptr, add, (int64_t)Cout};
     const dim3 grid((unsigned)(tm * tn));
 #define CV_LAUNCH(EPI_, NARROW_) hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<EPI_, NARROW_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, \

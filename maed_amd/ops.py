@@ -440,7 +440,9 @@ class WeightStdFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, dtype, eps, *weights):
         weights = [_c(w) for w in weights]
-        gemm = set(getattr(owner, "_gemm_convs", ()) or ()) if dtype != torch.float32 else set()
+        # convolutions that run on the library's own kernels: they also get the transposed image and an fp32 dW slice
+        direct = getattr(owner, "_direct_convs", None)
+        gemm = set((direct if direct is not None else getattr(owner, "_gemm_convs", ())) or ()) if dtype != torch.float32 else set()
         tab, _, nf, total, t_offs = _ws_table(weights, transposed=gemm)
         dev = weights[0].device
         out = torch.empty(total, dtype=dtype, device=dev)
@@ -455,7 +457,8 @@ class WeightStdFn(torch.autograd.Function):
             O, I, kh, kw = w.shape
             views.append(out[off:off + w.numel()].view(O, kh, kw, I).permute(0, 3, 1, 2))
             off += w.numel()
-        owner._w_std_t = {i: out[o:o + weights[i].numel()].view(weights[i].shape[1], weights[i].shape[0]) for i, o in t_offs.items()}
+        # (I, O) for the 1x1 convolutions, (9*I, O) = (3,3,I,O) for the 3x3 ones
+        owner._w_std_t = {i: out[o:o + weights[i].numel()].view(-1, weights[i].shape[0]) for i, o in t_offs.items()}
         # fp32 weight-gradient arena of the GEMM convolutions (maed_gemm_tn_wgrad accumulates with atomics: zero it once per step)
         owner._dw_arena, owner._dw_slices = None, {}
         if gemm and any(ctx.needs_input_grad[3:]):   # (grad mode is off inside Function.forward: ask autograd, not torch.is_grad_enabled)
@@ -463,7 +466,7 @@ class WeightStdFn(torch.autograd.Function):
             owner._dw_arena = torch.zeros(n, dtype=torch.float32, device=dev)
             o = 0
             for i in sorted(gemm):
-                owner._dw_slices[i] = owner._dw_arena[o:o + weights[i].numel()].view(weights[i].shape[0], weights[i].shape[1])
+                owner._dw_slices[i] = owner._dw_arena[o:o + weights[i].numel()].view(weights[i].shape[0], -1)     # (O, I) / (O, 9*I)
                 o += weights[i].numel()
         ctx.dw_slices = owner._dw_slices
         return tuple(views)
@@ -639,9 +642,10 @@ def _zero_page(device):
     return _ZERO_PAGE[key]
 
 
-def conv3x3(x, w_taps, stride=1, add=None):
+def conv3x3(x, w_taps, stride=1, add=None, w_layout=0):
     """y = conv3x3_SAME(x, w) on channels_last bf16 tensors through maed_conv3x3_fwd.  x (N,Cin,H,W) channels_last,
-    w_taps: storage (Cout, 3, 3, Cin) contiguous (any view of it).  TF-SAME padding from the input size (resnetv2.py:51-59)."""
+    w_taps: storage (Cout, 3, 3, Cin) contiguous (w_layout 0), or the transposed image (3, 3, Cout, Cin) of the FORWARD convolution whose
+    input gradient this call computes (w_layout 1).  TF-SAME padding from the input size (resnetv2.py:51-59)."""
     N, I, H, W = x.shape
     x = x.contiguous(memory_format=torch.channels_last)
     O = w_taps.numel() // (9 * I)
@@ -651,7 +655,7 @@ def conv3x3(x, w_taps, stride=1, add=None):
     if add is not None:
         add = add.contiguous(memory_format=torch.channels_last)
     check(L.lib().maed_conv3x3_fwd(_p(x), _p(w_taps), _p(_zero_page(x.device)), _p(y), N, H, W, I, O, stride, ph // 2, pw // 2, Ho, Wo, _p(add),
-                                   dt_code(x.dtype), _stream()), "conv3x3_fwd")
+                                   w_layout, dt_code(x.dtype), _stream()), "conv3x3_fwd")
     return y
 
 
@@ -669,11 +673,12 @@ def _tapmask(N, H, W, device):
     return _TAPMASKS[key]
 
 
-def conv3x3_wgrad(dy, x):
-    """fp32 dW (O, 3, 3, I) of the stride-1 3x3 SAME convolution from channels_last bf16 dy (N,O,H,W) and x (N,I,H,W)"""
+def conv3x3_wgrad(dy, x, out=None):
+    """fp32 dW (O, 3, 3, I) of the stride-1 3x3 SAME convolution from channels_last bf16 dy (N,O,H,W) and x (N,I,H,W); accumulates
+    into `out` (any (O, 9*I)-sized contiguous fp32 tensor) when given"""
     N, I, H, W = x.shape
     O = dy.shape[1]
-    dW = torch.zeros(O, 3, 3, I, dtype=torch.float32, device=x.device)
+    dW = torch.zeros(O, 3, 3, I, dtype=torch.float32, device=x.device) if out is None else out
     check(L.lib().maed_conv3x3_wgrad(_p(dy), _p(x), _p(_tapmask(N, H, W, x.device)), _p(_zero_page(x.device)), _p(dW), N, H, W, I, O,
                                      dt_code(x.dtype), _stream()), "conv3x3_wgrad")
     return dW
@@ -681,36 +686,45 @@ def conv3x3_wgrad(dy, x):
 
 class Conv3x3Fn(torch.autograd.Function):
     """StdConv2dSame 3x3 (resnetv2.py:74-93) on the library's implicit-GEMM kernel: forward for any stride, input gradient for
-    stride 1 (the same kernel on dY with the flipped, transposed weight image), weight gradient for stride 1 (maed_conv3x3_wgrad: the TN
-    weight-gradient kernel over gathered rows); the three stride-2 convolutions keep the framework's convolution backward.  w: the standardised weight as WeightStdFn
-    hands it out, logical (O, I, 3, 3) over (O, 3, 3, I) storage."""
+    stride 1 (the same kernel on dY), weight gradient for stride 1 (maed_conv3x3_wgrad: the TN weight-gradient kernel over gathered
+    rows); the three stride-2 convolutions keep the framework's convolution backward.
+    w: the standardised weight as WeightStdFn hands it out, logical (O, I, 3, 3) over (O, 3, 3, I) storage.
+    wt / dw (optional, both from WeightStdFn like Conv1x1Fn's): the transposed image (3,3,I,O) -- the input gradient then reads it in
+    place (no flipped copy) -- and the fp32 (O, 9*I) slice the weight gradient accumulates into (autograd then carries no dW)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride):
+    def forward(ctx, x, w, stride, wt=None, dw=None):
         x = x.contiguous(memory_format=torch.channels_last)
         w_taps = w.permute(0, 2, 3, 1)
         w_taps = w_taps if w_taps.is_contiguous() else w_taps.contiguous()
         ctx.save_for_backward(x, w)
-        ctx.stride = stride
+        ctx.stride, ctx.wt, ctx.dw = stride, wt, dw
         return conv3x3(x, w_taps, stride)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        s = ctx.stride
+        s, wt, dw_slice = ctx.stride, ctx.wt, ctx.dw
         dy = dy.contiguous(memory_format=torch.channels_last)
         N, I, H, W = x.shape
+        O = w.shape[0]
         Ho, Wo = dy.shape[-2:]
         ph, pw = max((Ho - 1) * s + 3 - H, 0), max((Wo - 1) * s + 3 - W, 0)
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1] or dw_slice is not None
         dx = dw = None
-        own_dx = need_x and s == 1 and w.shape[0] % 64 == 0      # (the gathered operand's channel count is O here)
-        if own_dx:                                  # dX = conv3x3(dY, w'), w'[ci][ky][kx][co] = w[co][ci][2-ky][2-kx]
-            w_flip = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()       # storage (I, 3, 3, O)
-            dx = conv3x3(dy, w_flip, 1)
-        own_dw = need_w and s == 1 and (N * H * W) % 64 == 0 and I % 8 == 0 and w.shape[0] % 8 == 0
-        if own_dw:                                  # TN GEMM over gathered rows; fp32, in the (O,3,3,I) order of w's storage
-            dw = conv3x3_wgrad(dy, x).permute(0, 3, 1, 2)
+        own_dx = need_x and s == 1 and O % 64 == 0               # (the gathered operand's channel count is O here)
+        if own_dx:
+            if wt is not None:                                   # in place from the transposed image: tap flip = negative tap stride
+                dx = conv3x3(dy, wt, 1, w_layout=1)
+            else:                                                # dX = conv3x3(dY, w'), w'[ci][ky][kx][co] = w[co][ci][2-ky][2-kx]
+                dx = conv3x3(dy, w.flip(2, 3).permute(1, 2, 3, 0).contiguous(), 1)
+        own_dw = need_w and s == 1 and (N * H * W) % 64 == 0 and I % 8 == 0 and O % 8 == 0
+        if own_dw:                                               # TN GEMM over gathered rows; fp32, (O,3,3,I) like w's storage
+            if dw_slice is not None:
+                conv3x3_wgrad(dy, x, out=dw_slice)
+            else:
+                dw = conv3x3_wgrad(dy, x).permute(0, 3, 1, 2)
             need_w = False
         if need_w or (need_x and not own_dx):
             sym = ph % 2 == 0 and pw % 2 == 0
@@ -718,7 +732,11 @@ class Conv3x3Fn(torch.autograd.Function):
             pad = (ph // 2, pw // 2) if sym else (0, 0)
             gx, gw, _ = torch.ops.aten.convolution_backward(dy, xin, w, None, (s, s), pad, (1, 1), False, (0, 0), 1,
                                                             (need_x and not own_dx, need_w, False))
-            dw = gw if need_w else dw
+            if need_w:
+                if dw_slice is not None:
+                    dw_slice.view(O, 3, 3, I).add_(gw.permute(0, 2, 3, 1))
+                else:
+                    dw = gw
             if need_x and not own_dx:
                 dx = gx if sym else gx[:, :, ph // 2:ph // 2 + H, pw // 2:pw // 2 + W]
-        return dx, dw, None
+        return dx, dw, None, None, None

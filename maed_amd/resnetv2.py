@@ -56,7 +56,7 @@ class StdConv2dSame(nn.Conv2d):
     def forward(self, x, fork=False):
         """fork=True (GEMM convolutions only): returns (conv(x), alias of x) -- see ops.Conv1x1Fn"""
         w = self._w_std
-        if w is not None and self._w_t is not None:
+        if w is not None and self._w_t is not None and self.kernel_size == (1, 1):
             # 1x1, stride 1, bf16: three GEMMs on libmaed_hip instead of MIOpen's implicit-GEMM solvers (which zero-fill the
             # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
             return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork)
@@ -64,7 +64,8 @@ class StdConv2dSame(nn.Conv2d):
         if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and x.is_cuda and x.dtype == torch.bfloat16
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and self.dilation == (1, 1) and self.groups == 1):
             # opt-in (MAED_CONV3X3=own): implicit-GEMM forward / stride-1 input gradient on libmaed_hip instead of MIOpen
-            return ops.Conv3x3Fn.apply(x, w, self.stride[0])
+            # (_w_t / _dw: transposed image and fp32 dW slice from WeightStdFn for the stride-1 ones, see ResNetV2._own3x3)
+            return ops.Conv3x3Fn.apply(x, w, self.stride[0], self._w_t, self._dw)
         if w is None:  # stand-alone use / CPU: per-conv ATen composition
             w = self.get_weight().to(x.dtype)
             if x.is_cuda:
@@ -202,6 +203,10 @@ class ResNetV2(nn.Module):
                             and c.in_channels % 64 == 0 and c.out_channels % 64 == 0]
         if os.environ.get("MAED_GEMM_CONVS", "1") == "0":      # measurement knob: every convolution on MIOpen
             self._gemm_convs = []
+        # MAED_CONV3X3=own: the stride-1 3x3 convolutions hand their weights / weight gradients over like the GEMM convolutions
+        self._own3x3 = [i for i, c in enumerate(self._convs) if _OWN_CONV3X3 and c.kernel_size == (3, 3) and c.stride == (1, 1)
+                        and c.in_channels % 64 == 0 and c.out_channels % 64 == 0]
+        self._direct_convs = self._gemm_convs + self._own3x3
         self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
         self._pending_backwards = 0
         self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer

@@ -96,6 +96,47 @@ def test_weight_standardisation_batched_matches_aten():
         assert torch.allclose(w.grad, wr.grad, rtol=1e-3, atol=1e-4), (w.grad - wr.grad).abs().max()
 
 
+def test_weight_standardisation_direct_convs_get_transposed_images_and_fp32_slices():
+    """bf16 mode, convolutions on the library's own kernels (owner._direct_convs: 1x1 GEMM convolutions and, with MAED_CONV3X3=own, the
+    stride-1 3x3 ones): ws_fwd also writes the (kh,kw,I,O) transposed image, ws_bwd reads their weight gradient from an fp32 (O, kh*kw*I) slice"""
+    torch.manual_seed(3)
+
+    class Owner:
+        _pending_backwards = 0
+        grads_ready = None
+        _direct_convs = [1, 2]
+
+        def __init__(self, ws):
+            self._ws = ws
+
+        def conv_weights(self):
+            return self._ws
+    shapes = [(8, 3, 7, 7), (16, 8, 1, 1), (8, 16, 3, 3)]
+    ws = [torch.randn(s, requires_grad=True) for s in shapes]
+    refs = [w.detach().clone().requires_grad_(True) for w in ws]
+    owner = Owner(ws)
+    cots = [torch.randn(s) for s in shapes]
+    outs_ref = []
+    for w in refs:
+        std, mean = torch.std_mean(w, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        outs_ref.append((w - mean) / (std + 1e-5))
+    sum((o * c).sum() for o, c in zip(outs_ref, cots)).backward()
+    with patched():
+        outs = ops.WeightStdFn.apply(owner, torch.bfloat16, 1e-5, *ws)
+        for i in (1, 2):
+            O, I, kh, kw = shapes[i]
+            wt = owner._w_std_t[i]
+            assert wt.shape == (kh * kw * I, O) and owner._dw_slices[i].shape == (O, kh * kw * I)
+            assert torch.allclose(wt.float(), outs_ref[i].detach().permute(2, 3, 1, 0).reshape(kh * kw * I, O), rtol=1e-2, atol=1e-2)
+            owner._dw_slices[i].copy_(cots[i].permute(0, 2, 3, 1).reshape(O, -1))          # what Conv1x1Fn / Conv3x3Fn leave there
+        (outs[0].float() * cots[0]).sum().backward()                                        # conv 0 through autograd (bf16 gradient)
+    for i, (o, r) in enumerate(zip(outs, outs_ref)):
+        assert torch.allclose(o.float(), r.detach(), rtol=1e-2, atol=1e-2)
+    for i in (1, 2):
+        assert torch.allclose(ws[i].grad, refs[i].grad, rtol=1e-3, atol=1e-4), (i, (ws[i].grad - refs[i].grad).abs().max())
+    assert torch.allclose(ws[0].grad, refs[0].grad, rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("N,I,O,H,W,stride", [(2, 64, 64, 6, 5, 1), (1, 128, 72, 7, 9, 1), (2, 64, 136, 8, 8, 2), (1, 64, 64, 7, 7, 2), (1, 64, 64, 14, 14, 1),
                                               (2, 64, 64, 8, 4, 1), (4, 128, 64, 4, 8, 1), (1, 64, 136, 8, 16, 1), (2, 64, 64, 16, 12, 1)])
 def test_conv3x3_implicit_gemm_matches_aten(N, I, O, H, W, stride, monkeypatch):
@@ -124,3 +165,30 @@ def test_conv3x3_implicit_gemm_matches_aten(N, I, O, H, W, stride, monkeypatch):
     assert torch.allclose(ws.grad.float(), wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max()))
     # the library's own weight-gradient kernel (TN GEMM over gathered rows + tap mask) runs for stride 1 when F*H*W % 64 == 0
     assert bool(own_wgrad) == (stride == 1 and (N * H * W) % 64 == 0)
+
+
+@pytest.mark.parametrize("N,I,O,H,W", [(2, 64, 64, 8, 4), (1, 128, 64, 8, 16), (1, 64, 128, 6, 5)])
+def test_conv3x3_with_transposed_image_and_direct_dw_slice(N, I, O, H, W):
+    """the hand-over used inside the backbone: input gradient read in place from the (3,3,I,O) transposed image WeightStdFn writes
+    (tap flip = negative tap stride), weight gradient accumulated into an fp32 (O, 9*I) slice (also when it falls back to the framework
+    because F*H*W is not a multiple of 64)"""
+    g = torch.Generator().manual_seed(N * 10 + W)
+    bf = torch.bfloat16
+    x = torch.randn(N, I, H, W, generator=g).to(bf).float()
+    w = (torch.randn(O, I, 3, 3, generator=g) * (1.0 / (3 * I ** 0.5))).to(bf).float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, 1, 1)
+    dy = torch.randn(ref.shape, generator=g).to(bf).float()
+    ref.backward(dy)
+    xs = cl(x.to(bf)).requires_grad_(True)
+    ws = w.to(bf).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)                 # no grad: the slice carries dW
+    wt = w.to(bf).permute(2, 3, 1, 0).contiguous()                                     # (3,3,I,O): what ws_fwd's dst_t image holds
+    prior = torch.randn(O, 9 * I, generator=g)
+    dw = prior.clone()
+    with patched():
+        y = ops.Conv3x3Fn.apply(xs, ws, 1, wt, dw)
+        y.backward(cl(dy.to(bf)))
+    assert torch.allclose(y.float(), ref.detach(), rtol=2e-2, atol=2e-2)
+    assert torch.allclose(xs.grad.float(), xr.grad, rtol=2e-2, atol=2e-2), (xs.grad.float() - xr.grad).abs().max()
+    got = (dw - prior).view(O, 3, 3, I).permute(0, 3, 1, 2)
+    assert torch.allclose(got, wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max())), (got - wr.grad).abs().max()
