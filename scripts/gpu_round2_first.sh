@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 OPTIN="MAED_GN_DEFER_AFFINE=1 MAED_LN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_WIDE_REGS=1"
 bench_ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], d['ms_per_step'], 'ms/step', {k: v['avg_us'] for k, v in d['kernels'].items()})" "$1"; }
 
-timeout 600 python scripts/check_new_paths.py 2>&1 | tee gpurun_out/r02_new_paths_on_gpu.log
+MAED_RUN_UNVERIFIED_GPU_TESTS=1 timeout 600 python -m pytest tests/test_gpu_unverified.py -m gpu -q -s 2>&1 | tee gpurun_out/r02_new_paths_on_gpu.log
 timeout 200 python scripts/attn_long_micro.py 20 2>&1 | tee gpurun_out/r02_attn_long_micro.txt
 timeout 200 python scripts/conv3x3_micro.py 10 2>&1 | tee gpurun_out/r02_conv3x3_micro.txt
 for w in 0 1; do MAED_TM_BWD_WIDE_REGS=$w MAED_TEMPORAL_MFMA=1 timeout 120 python scripts/attn_tm_micro.py 30 2>&1 | sed "s/^/wide_regs=$w /" | tee -a gpurun_out/r02_attn_tm_wide_regs.txt; done
