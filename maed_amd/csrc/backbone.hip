@@ -282,12 +282,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
 // pass otherwise sends to the same 2C addresses (~768 workgroups per layer: on the 14x14 and 28x28 layers the serialised atomics,
 // not HBM, set that pass's ~23 us floor -- profiles/r01_rocprofv3_last_step_kernel_sequence_v9.txt).
 __global__ __launch_bounds__(256) void gn_affine_grad_kernel(const float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
-    float t = 0.f;
-    for (int n = 0; n < N; ++n) t += ab[(int64_t)n * C * 2 + i];
-    float* dst = ((i & 1) ? dgamma : dbeta) + (i >> 1);
-    *dst += t;                                   // single writer per element; the arena accumulates across micro-batches
+    colsum_add(ab, N, 2 * C, [=](int i) { return ((i & 1) ? dgamma : dbeta) + (i >> 1); });      // ab[n][c][0|1] = (dbeta, dgamma) partials
 }
 
 // ---- backward pass 2: dx = rstd * (gamma*dy_eff - m1 - xhat*m2); optional d_res = dy_eff ------------------------
@@ -396,7 +391,7 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
         sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
     MAED_DISPATCH_DTYPE(dtype, T, {
         if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);
-        if (defer) hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, ab_scratch, dgamma, dbeta, N, C);
+        if (defer) hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 63) / 64, (N + 63) / 64), dim3(256), 0, s, ab_scratch, dgamma, dbeta, N, C);
         if (dres && relu) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);
     });
 #undef GN_RED

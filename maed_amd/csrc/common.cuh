@@ -109,6 +109,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// dst[c] += sum_r src[r][c] for a small (rows x cols) fp32 matrix of partial sums (closing step of the deferred dgamma/dbeta paths).
+// 64 columns x 4 row lanes per workgroup, <= 64 rows per workgroup (grid.y row chunks): at most 16 independent, coalesced loads per
+// thread, one LDS fold, one atomic per column and row chunk -- a handful per address, unlike the per-workgroup atomics it replaces.
+// dst_of(c) maps a column to its destination (dgamma / dbeta are separate or interleaved depending on the producer).
+template <typename DstOf>
+__device__ __forceinline__ void colsum_add(const float* __restrict__ src, int rows, int cols, DstOf dst_of) {
+    __shared__ float fold[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 64, r1 = min(rows, r0 + 64);
+    float t = 0.f;
+    if (c < cols)
+        for (int r = r0 + rl; r < r1; r += 4) t += src[(int64_t)r * cols + c];
+    fold[rl][threadIdx.x & 63] = t;
+    __syncthreads();
+    if (rl == 0 && c < cols) atomicAdd(dst_of(c), (fold[0][threadIdx.x] + fold[1][threadIdx.x]) + (fold[2][threadIdx.x] + fold[3][threadIdx.x]));
+}
+
 // ---- math ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_erf(float x) {

@@ -136,12 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 __global__ __launch_bounds__(256) void ln_affine_finish_kernel(const float* __restrict__ partials, int nwg, int C, float* __restrict__ dg,
                                                                float* __restrict__ db) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
-    float t = 0.f;
-    for (int w = 0; w < nwg; ++w) t += partials[(int64_t)w * 2 * C + i];
-    float* dst = i < C ? dg + i : db + (i - C);
-    *dst += t;                                    // single writer per element; += because the gradient arena accumulates
+    colsum_add(partials, nwg, 2 * C, [=](int i) { return i < C ? dg + i : db + (i - C); });       // rows = [dgamma (C) | dbeta (C)]
 }
 
 extern "C" int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
@@ -189,7 +184,8 @@ int maed_layernorm_bwd_ws(const void* dy, int dtype, const float* x, int64_t x_r
                                         mean, rstd, dres_in, dx_out, (T*)dx_twin, partials, (float*)nullptr, rows, C)
     if (partials) {
         MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_BWD_P(2); else if (C <= 768) LN_BWD_P(3); else if (C <= 1024) LN_BWD_P(4); else LN_BWD_P(8); });
-        hipLaunchKernelGGL(ln_affine_finish_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, (int)grid.x, C, dgamma, dbeta);
+        hipLaunchKernelGGL(ln_affine_finish_kernel, dim3((2 * C + 63) / 64, (grid.x + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, (int)grid.x, C,
+                           dgamma, dbeta);
     } else {
         MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_BWD(2); else if (C <= 768) LN_BWD(3); else if (C <= 1024) LN_BWD(4); else LN_BWD(8); });
     }
