@@ -90,7 +90,12 @@ void launch(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, Args..
             t_tid = t;
             t_dyn_lds = (void*)(((uintptr_t)dyn.data() + 15) & ~(uintptr_t)15);
             for (size_t b = 0; b < nblocks; ++b) {
-                if (t == 0) ctx.reset(new BlockCtx(nthr));          // fresh barriers: exited lanes drop out of them
+                if (t == 0) {
+                    ctx.reset(new BlockCtx(nthr));                  // fresh barriers: exited lanes drop out of them
+                    // LDS content is undefined at workgroup start on hardware: poison the dynamic region (NaN bit patterns for fp32 and
+                    // bf16) so that a kernel reading LDS it never wrote fails its parity test here instead of passing on zeros
+                    memset(dyn.data(), 0xFF, dyn.size() * sizeof(double));
+                }
                 between.arrive_and_wait();
                 t_blockIdx = Idx{(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y))};
                 t_block = ctx.get();
