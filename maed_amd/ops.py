@@ -25,6 +25,13 @@ def bump_weight_epoch():
     WEIGHT_EPOCH += 1
 
 
+def on_library_device(t):
+    """True for tensors the library can address: GPU tensors -- and host tensors while the test suite has swapped in the host simulator
+    (tests/_hostsim.patched: the simulator library reports a negative maed_version()), so that module-level code paths that are
+    otherwise GPU-only can be exercised without a GPU.  Never loads a library itself."""
+    return t.is_cuda or (L._lib is not None and L._lib.maed_version() < 0)
+
+
 def dt_code(dtype):
     if dtype == torch.float32:
         return F32

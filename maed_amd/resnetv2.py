@@ -61,14 +61,14 @@ class StdConv2dSame(nn.Conv2d):
             # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
             return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork)
         assert not fork
-        if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and x.is_cuda and x.dtype == torch.bfloat16
+        if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and x.dtype == torch.bfloat16
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and self.dilation == (1, 1) and self.groups == 1):
             # opt-in (MAED_CONV3X3=own): implicit-GEMM forward / stride-1 input gradient on libmaed_hip instead of MIOpen
             # (_w_t / _dw: transposed image and fp32 dW slice from WeightStdFn for the stride-1 ones, see ResNetV2._own3x3)
             return ops.Conv3x3Fn.apply(x, w, self.stride[0], self._w_t, self._dw)
         if w is None:  # stand-alone use / CPU: per-conv ATen composition
             w = self.get_weight().to(x.dtype)
-            if x.is_cuda:
+            if ops.on_library_device(x):
                 w = w.contiguous(memory_format=torch.channels_last)
         k, s = self.kernel_size[0], self.stride[0]
         ih, iw = x.shape[-2:]
@@ -94,7 +94,7 @@ class GroupNormAct(nn.GroupNorm):
     def forward(self, x, residual=None, relu=None):
         """y = act(GN(x) [+ residual]); relu defaults to the layer's own activation flag"""
         relu = self.apply_act if relu is None else relu
-        if x.is_cuda and self.num_groups == 32:
+        if ops.on_library_device(x) and self.num_groups == 32:
             return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad, self._sums_buf, self._ab_buf)
         x = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
         if residual is not None:
@@ -110,7 +110,7 @@ class MaxPool2dSame(nn.Module):
         self.kernel_size, self.stride = kernel_size, stride
 
     def forward(self, x):
-        if x.is_cuda and self.kernel_size == 3 and self.stride == 2 and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16):
+        if ops.on_library_device(x) and self.kernel_size == 3 and self.stride == 2 and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16):
             return ops.MaxPool3s2SameFn.apply(x)
         return F.max_pool2d(_same_pad(x, self.kernel_size, self.stride, value=-float("inf")), self.kernel_size, self.stride, 0)
 
@@ -220,7 +220,7 @@ class ResNetV2(nn.Module):
         return self.conv_weights() + [t for m in self._norms for t in (m.weight, m.bias)]
 
     def forward_features(self, x):
-        if not x.is_cuda:
+        if not ops.on_library_device(x):
             return self.stages(self.stem(x))
         x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
         ws = ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
