@@ -1,6 +1,7 @@
 """The st_modes other than 'parallel' (maed_amd/ste_modes.py; reference lib/models/vision_transformer.py:136-178) with the
 kernels running on the host simulator: against the fixture the reference's own Attention / Block / VisionTransformer produced
 (tests/golden/g13_st_modes.npz, f32 parity mode) and against fp64 autograd through the CPU oracle (bf16 mode)."""
+import os
 from functools import partial
 
 import numpy as np
@@ -161,3 +162,26 @@ def test_staged_block_trains_through_arena_bucketer_and_fused_adam():
             topt.step()
     for (n, p), q_ in zip(blk.named_parameters(), ref.parameters()):
         torch.testing.assert_close(p, q_, rtol=1e-5, atol=1e-6, msg=n)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4),
+                                       pytest.param(torch.bfloat16, 6e-2, marks=pytest.mark.skipif(os.environ.get("MAED_SLOW_TESTS") != "1",
+                                                                                                   reason="40 s on the simulator: MAED_SLOW_TESTS=1"))])
+def test_vit_tiny_parallel_mode_whole_gpu_path_matches_reference(golden, dtype, tol):
+    """the benchmarked configuration (st_mode='parallel', fused STE blocks) with the BACKBONE also on its library path (batched weight
+    standardisation, fused GroupNorm, max-pool kernels; GEMM convolutions in bf16), against the reference's own output (g4)"""
+    g4 = golden("g4_vit_tiny")
+    layers = tuple(int(v) for v in g4["layers"])
+    bb = ResNetV2(layers=layers, channels=(128, 256, 512), in_chans=3, compute_dtype=dtype)
+    vit = VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=int(g4["depth"]), num_heads=int(g4["heads"]), hybrid_backbone=bb,
+                            mlp_ratio=4, qkv_bias=True, representation_size=128, norm_layer=LN, st_mode="parallel", num_classes=-1,
+                            compute_dtype=dtype)
+    vit.load_state_dict(sd(g4, drop=()))                              # strict: every key of the reference, ts_attn and temp_embed included
+    vit.eval()
+    seen = {}
+    bb.register_forward_hook(lambda m, i, o: seen.__setitem__("feat", o))
+    with patched(), torch.no_grad():
+        out = vit(t(g4["img"]), seqlen=int(g4["seqlen"]))              # on_library_device -> the HIP backbone path, not ATen
+    assert seen["feat"].dtype == dtype
+    assert rel(seen["feat"].float(), g4["backbone_out"]) < (1e-4 if dtype == torch.float32 else 5e-2)
+    assert rel(out, g4["out"]) < tol
