@@ -29,7 +29,10 @@ def on_library_device(t):
     """True for tensors the library can address: GPU tensors -- and host tensors while the test suite has swapped in the host simulator
     (tests/_hostsim.patched: the simulator library reports a negative maed_version()), so that module-level code paths that are
     otherwise GPU-only can be exercised without a GPU.  Never loads a library itself."""
-    return t.is_cuda or (L._lib is not None and L._lib.maed_version() < 0)
+    return t.is_cuda or (SIM_MODULE_PATHS and L._lib is not None and L._lib.maed_version() < 0)
+
+
+SIM_MODULE_PATHS = True     # tests may switch the simulator's module-level paths off (tests/_hostsim.patched(module_paths=False))
 
 
 def dt_code(dtype):

@@ -23,14 +23,18 @@ def load():
 
 
 @contextlib.contextmanager
-def patched():
+def patched(module_paths=True):
+    """module_paths=False: only explicit library calls run on the simulator; module-level gates (ops.on_library_device: the backbone's
+    kernel path) stay on their ATen CPU path -- for tests about something else that should not pay for ~700 simulated workgroups per
+    weight-standardisation launch"""
     from maed_amd import _lib as L
     from maed_amd import ops
-    saved = (L._lib, ops._p, ops._stream)
+    saved = (L._lib, ops._p, ops._stream, ops.SIM_MODULE_PATHS)
     L._lib = load()
     ops._p = lambda t: None if t is None else t.data_ptr()
     ops._stream = lambda: None
+    ops.SIM_MODULE_PATHS = module_paths
     try:
         yield L._lib
     finally:
-        L._lib, ops._p, ops._stream = saved
+        L._lib, ops._p, ops._stream, ops.SIM_MODULE_PATHS = saved
