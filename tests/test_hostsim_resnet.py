@@ -56,3 +56,62 @@ def test_backbone_gpu_path_on_simulator_matches_aten(own3x3, monkeypatch):
     print(f"own3x3={own3x3}: worst parameter-gradient cosine {worst:.4f}, library 3x3 calls {calls}")
     # two stride-1 3x3 convolutions: forward + input gradient each on maed_conv3x3_fwd, weight gradients on maed_conv3x3_wgrad
     assert calls == ({"conv3x3": 4, "wgrad": 2} if own3x3 else {"conv3x3": 0, "wgrad": 0})
+
+
+class _BackboneToy(torch.nn.Module):
+    """tiny hybrid backbone on its library path + an autograd-managed head: the two kinds of parameters the bucketer tracks in the real
+    model's patch_embed (kernel-written conv / GroupNorm gradients reported through ResNetV2.grads_ready, autograd hooks for the rest)"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.backbone = ResNetV2(layers=(1,), channels=(256,), in_chans=3, compute_dtype=torch.bfloat16)
+        self.head = torch.nn.Linear(256, 8)
+
+    def forward(self, x):
+        return self.head(self.backbone(x).float().mean(dim=(2, 3)))
+
+
+def _backbone_ddp_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    from maed_amd.ddp import GradBucketer, ParamArena
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with patched():
+            model = _BackboneToy()
+            arena = ParamArena(model, device=torch.device("cpu"))
+            bucketer = GradBucketer(arena, model, bucket_bytes=64 << 10)
+            bucketer.broadcast_parameters(0)
+            assert len(bucketer.buckets) > 3 and len(bucketer._fused) == len(model.backbone.fused_parameters())
+            x = torch.randn(4, 3, 16, 16, generator=torch.Generator().manual_seed(5))
+            shard = slice(rank * 2, rank * 2 + 2)
+            for _ in range(2):                                   # two steps: the readiness counters must reset
+                arena.zero_grad()
+                (model(x[shard]) ** 2).sum().backward()
+                assert all(bucketer._launched), "every bucket must have been reduced during backward"
+                bucketer.finish()
+            out[rank] = arena.grad.clone()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_backbone_fused_gradients_through_the_bucketer_gloo_world2():
+    """2 gloo ranks x 2 images on the simulator == one process x 4 images (GroupNorm is per sample): the kernel-written backbone
+    gradients land in the arena, every bucket completes during backward via ResNetV2.grads_ready, and the all-reduced sum matches"""
+    import torch.multiprocessing as mp
+    from maed_amd.ddp import ParamArena
+    world, port = 2, 31533 + os.getpid() % 1000
+    out = mp.Manager().dict()
+    mp.spawn(_backbone_ddp_worker, args=(world, port, out), nprocs=world, join=True)
+    assert torch.equal(out[0], out[1])
+    with patched():
+        ref = _BackboneToy()
+        arena = ParamArena(ref, device=torch.device("cpu"))
+        x = torch.randn(4, 3, 16, 16, generator=torch.Generator().manual_seed(5))
+        (ref(x) ** 2).sum().backward()
+    for n, o in zip(arena.names, arena.offsets):
+        p = dict(ref.named_parameters())[n]
+        a, b = out[0][o:o + p.numel()], arena.grad[o:o + p.numel()]
+        assert cos(a, b) > 0.999, (n, cos(a, b))                 # same bf16 kernels; only the summation order differs
