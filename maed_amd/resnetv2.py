@@ -28,6 +28,39 @@ from . import ops
 _OWN_CONV3X3 = os.environ.get("MAED_CONV3X3", "miopen") == "own"
 
 
+# MAED_WS_PER_STAGE=1: weight standardisation launched per backbone stage, right before the stage runs, instead of once for all 53
+# convolutions.  Single-GPU cost: two more (tiny) launches per direction.  Purpose: data-parallel overlap -- a stage's convolution
+# weight gradients become final, and its gradient bucket starts its all-reduce, as soon as THAT stage's backward is done; with one
+# batched launch the whole backbone (47 MB at cfg3) is reported only by the very last kernel of the backward and reduced un-overlapped.
+# Written without GPU access: opt-in until it has run on hardware (logic covered on the simulator + gloo, tests/test_hostsim_resnet.py).
+_WS_PER_STAGE = os.environ.get("MAED_WS_PER_STAGE", "0") == "1"
+
+
+class _WsGroup:
+    """the convolutions / norms of one backbone stage as the `owner` ops.WeightStdFn talks to (same protocol as ResNetV2 itself)"""
+
+    def __init__(self, parent, conv_idx, norms):
+        self.parent, self.conv_idx, self.norms = parent, list(conv_idx), list(norms)
+        self._pending_backwards = 0
+        self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
+
+    def conv_weights(self):
+        return [self.parent._convs[i].weight for i in self.conv_idx]
+
+    def fused_parameters(self):
+        return self.conv_weights() + [t for m in self.norms for t in (m.weight, m.bias)]
+
+    @property
+    def _direct_convs(self):
+        pos = {ci: k for k, ci in enumerate(self.conv_idx)}
+        return [pos[i] for i in self.parent._direct_convs if i in pos]
+
+    @property
+    def grads_ready(self):
+        cb = self.parent.grads_ready
+        return None if cb is None else (lambda _owner: cb(self))          # the bucketer marks exactly this stage's parameters
+
+
 def _same_pad(x, k, s, value=0.0):
     """TF 'SAME' padding computed from the input size (resnetv2.py:51-59): left = pad//2."""
     ih, iw = x.shape[-2:]
@@ -210,6 +243,11 @@ class ResNetV2(nn.Module):
         self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
         self._pending_backwards = 0
         self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
+        # per-stage groups (MAED_WS_PER_STAGE): the stem rides with stage 0
+        conv_pos = {id(c): i for i, c in enumerate(self._convs)}
+        parts = [[self.stem, self.stages[0]]] + [[st] for st in list(self.stages)[1:]]
+        self._ws_groups = [_WsGroup(self, [conv_pos[id(m)] for part in ps for m in part.modules() if isinstance(m, StdConv2dSame)],
+                                    [m for part in ps for m in part.modules() if isinstance(m, GroupNormAct)]) for ps in parts]
 
     def conv_weights(self):
         return [c.weight for c in self._convs]
@@ -223,7 +261,7 @@ class ResNetV2(nn.Module):
         if not ops.on_library_device(x):
             return self.stages(self.stem(x))
         x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
-        ws = ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
+        ws = None if _WS_PER_STAGE else ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
         # GroupNorm scratch for all layers of this pass: ONE zero-fill each instead of a memset per layer and direction
         N = x.shape[0]
         sums = torch.zeros(len(self._norms), N, 32, 2, dtype=torch.float64, device=x.device)
@@ -231,8 +269,9 @@ class ResNetV2(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in (self._norms[0].weight, self._convs[0].weight)):
             ab = torch.zeros(N * 2 * sum(m.num_channels for m in self._norms), dtype=torch.float32, device=x.device)
         try:
-            for i, (c, w) in enumerate(zip(self._convs, ws)):
-                c._w_std, c._w_t, c._dw = w, self._w_std_t.get(i), self._dw_slices.get(i)
+            if ws is not None:
+                for i, (c, w) in enumerate(zip(self._convs, ws)):
+                    c._w_std, c._w_t, c._dw = w, self._w_std_t.get(i), self._dw_slices.get(i)
             off = 0
             for i, m in enumerate(self._norms):
                 m._sums_buf = sums[i]
@@ -240,7 +279,15 @@ class ResNetV2(nn.Module):
                     n = N * 2 * m.num_channels
                     m._ab_buf = ab[off:off + n].view(N, m.num_channels, 2)
                     off += n
-            return self.stages(self.stem(x))
+            if ws is not None:
+                return self.stages(self.stem(x))
+            for gi, g in enumerate(self._ws_groups):       # standardise a stage's weights right before it runs: its autograd node
+                wg = ops.WeightStdFn.apply(g, self.compute_dtype, self._convs[0].eps, *g.conv_weights())   # then fires right after its backward
+                for k, (ci, w) in enumerate(zip(g.conv_idx, wg)):
+                    c = self._convs[ci]
+                    c._w_std, c._w_t, c._dw = w, g._w_std_t.get(k), g._dw_slices.get(k)
+                x = self.stages[0](self.stem(x)) if gi == 0 else self.stages[gi](x)
+            return x
         finally:
             for c in self._convs:
                 c._w_std = c._w_t = c._dw = None

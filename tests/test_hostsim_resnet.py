@@ -115,3 +115,37 @@ def test_backbone_fused_gradients_through_the_bucketer_gloo_world2():
         p = dict(ref.named_parameters())[n]
         a, b = out[0][o:o + p.numel()], arena.grad[o:o + p.numel()]
         assert cos(a, b) > 0.999, (n, cos(a, b))                 # same bf16 kernels; only the summation order differs
+
+
+def test_per_stage_weight_standardisation_reports_readiness_stage_by_stage(monkeypatch):
+    """MAED_WS_PER_STAGE: the backbone's gradients are reported to the bucketer in two steps -- the last stage first, as soon as its
+    backward is done -- instead of once after the very last backward kernel; numbers as on the ATen path (and, with MAED_SLOW_TESTS=1,
+    equal to the single batched launch)"""
+    torch.manual_seed(0)
+    base = ResNetV2(layers=(1, 1), channels=(256, 256), in_chans=3, compute_dtype=torch.bfloat16)
+    x = torch.randn(2, 3, 16, 16)
+    gout = torch.randn(2, 256, 2, 2)
+    ref = copy.deepcopy(base)
+    ref.compute_dtype = torch.float32
+    (ref(x) * gout).sum().backward()                                         # ATen fp32 path (CPU tensors outside patched())
+
+    def run(per_stage):
+        monkeypatch.setattr(resnetv2, "_WS_PER_STAGE", per_stage)
+        m = copy.deepcopy(base)
+        reports = []
+        m.grads_ready = lambda owner: reports.append(owner)
+        with patched():
+            (m(x).float() * gout).sum().backward()
+        return [p.grad.clone() for p in m.parameters()], reports, m
+
+    g1, rep1, m1 = run(True)
+    assert rep1 == [m1._ws_groups[1], m1._ws_groups[0]]                      # last stage first, then stem + stage 0
+    fused = [id(p) for grp in rep1 for p in grp.fused_parameters()]
+    assert sorted(fused) == sorted(id(p) for p in m1.fused_parameters()) and len(set(fused)) == len(fused)      # every parameter exactly once
+    for a, q, (n, _) in zip(g1, ref.parameters(), base.named_parameters()):
+        assert cos(a, q.grad) > 0.93, (n, cos(a, q.grad))
+    if os.environ.get("MAED_SLOW_TESTS") == "1":
+        g0, rep0, m0 = run(False)
+        assert rep0 == [m0]                                                  # one report, after the batched backward
+        for a, b, (n, _) in zip(g0, g1, base.named_parameters()):
+            assert cos(a, b) > 0.9999, (n, cos(a, b))
