@@ -5,7 +5,7 @@
 # (4) runs the GPU suite with the switches on.   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash scripts/gpu_round2_first.sh'
 set -x
 mkdir -p gpurun_out
-OPTIN="MAED_GN_DEFER_AFFINE=1 MAED_LN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_WIDE_REGS=1"
+OPTIN="MAED_GN_DEFER_AFFINE=1 MAED_LN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_WIDE_REGS=1 MAED_WS_PER_STAGE=1"
 bench_ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], d['ms_per_step'], 'ms/step', {k: v['avg_us'] for k, v in d['kernels'].items()})" "$1"; }
 
 MAED_RUN_UNVERIFIED_GPU_TESTS=1 timeout 600 python -m pytest tests/test_gpu_unverified.py -m gpu -q -s 2>&1 | tee gpurun_out/r02_new_paths_on_gpu.log
