@@ -79,7 +79,15 @@ void launch(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, Args..
     if (nblocks == 0 || nthr == 0) return;
     std::vector<double> dyn((dyn_lds + 7) / 8 + 2);   // dynamic LDS of the workgroup (16-B aligned)
     std::unique_ptr<BlockCtx> ctx;
-    std::barrier<> between(nthr);
+    // ONE full barrier per workgroup boundary; its completion step (run by the last thread to arrive, while the others are parked) gives
+    // the next workgroup fresh block / wave barriers (exited lanes drop out of them) and poisons the dynamic LDS region: LDS content is
+    // undefined at workgroup start on hardware, so a kernel reading LDS it never wrote fails its parity test here instead of passing on zeros
+    auto next_block = [&]() noexcept {
+        ctx.reset(new BlockCtx(nthr));
+        memset(dyn.data(), 0xFF, dyn.size() * sizeof(double));
+    };
+    next_block();
+    std::barrier<decltype(next_block)> between(nthr, next_block);
     std::vector<std::thread> th;
     th.reserve(nthr);
     for (int t = 0; t < nthr; ++t)
@@ -90,19 +98,12 @@ void launch(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, Args..
             t_tid = t;
             t_dyn_lds = (void*)(((uintptr_t)dyn.data() + 15) & ~(uintptr_t)15);
             for (size_t b = 0; b < nblocks; ++b) {
-                if (t == 0) {
-                    ctx.reset(new BlockCtx(nthr));                  // fresh barriers: exited lanes drop out of them
-                    // LDS content is undefined at workgroup start on hardware: poison the dynamic region (NaN bit patterns for fp32 and
-                    // bf16) so that a kernel reading LDS it never wrote fails its parity test here instead of passing on zeros
-                    memset(dyn.data(), 0xFF, dyn.size() * sizeof(double));
-                }
-                between.arrive_and_wait();
                 t_blockIdx = Idx{(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y))};
                 t_block = ctx.get();
                 kernel(args...);
                 ctx->waves[t / 64]->bar.arrive_and_drop();
                 ctx->bar.arrive_and_drop();
-                between.arrive_and_wait();                          // nobody still uses this workgroup's context / LDS
+                between.arrive_and_wait();                          // nobody still uses this workgroup's context / LDS; completion sets up the next
             }
         });
     for (auto& t : th) t.join();
