@@ -50,10 +50,13 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 namespace hostsim {
 struct WaveCtx {
     std::barrier<> bar;
-    float fx[64];
-    float fa[64], fb[64];
-    float ha[64][8], hb[64][8];     // bf16 MFMA operands, widened
-    uint64_t u64[64];               // ballot / readfirstlane / LDS-DMA base exchange
+    // every exchange area exists twice: lane-exchange k uses copy k & 1 and needs ONE barrier (write, barrier, read) -- a lane can be at
+    // most one exchange ahead of the slowest lane of its wave (it cannot pass barrier k+1 before everybody arrived there, i.e. finished
+    // reading copy k & 1), and exchange k+1 writes the other copy
+    float fx[2][64];
+    float fa[2][64], fb[2][64];
+    float ha[2][64][8], hb[2][64][8];   // bf16 MFMA operands, widened
+    uint64_t u64[2][64];                // readfirstlane / LDS-DMA base exchange
     int live;                       // threads of this wave that exist (the last wave of a block may be partial)
     explicit WaveCtx(int n) : bar(n), live(n) {}
 };
@@ -68,6 +71,7 @@ struct Idx { unsigned x, y, z; };
 extern thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local BlockCtx* t_block;
 extern thread_local int t_tid;
+extern thread_local unsigned t_wop;     // wave-exchange counter of this lane (same sequence in every lane of a wave)
 extern thread_local void* t_dyn_lds;
 
 template <typename K, typename... Args>
@@ -100,6 +104,7 @@ void launch(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, Args..
             for (size_t b = 0; b < nblocks; ++b) {
                 t_blockIdx = Idx{(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y))};
                 t_block = ctx.get();
+                t_wop = 0;
                 kernel(args...);
                 ctx->waves[t / 64]->bar.arrive_and_drop();
                 ctx->bar.arrive_and_drop();
@@ -122,11 +127,10 @@ static inline void __syncthreads() { hostsim::t_block->bar.arrive_and_wait(); }
 static inline float __shfl_xor(float v, int mask, int /*width*/ = 64) {
     hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
     const int lane = hostsim::t_tid % 64;
-    w.fx[lane] = v;
+    const unsigned p = hostsim::t_wop++ & 1u;
+    w.fx[p][lane] = v;
     w.bar.arrive_and_wait();
-    const float r = w.fx[lane ^ mask];
-    w.bar.arrive_and_wait();
-    return r;
+    return w.fx[p][lane ^ mask];
 }
 
 static inline int __shfl_xor(int v, int mask, int width = 64) {
@@ -135,11 +139,10 @@ static inline int __shfl_xor(int v, int mask, int width = 64) {
 static inline float __shfl(float v, int src_lane, int /*width*/ = 64) {
     hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
     const int lane = hostsim::t_tid % 64;
-    w.fx[lane] = v;
+    const unsigned p = hostsim::t_wop++ & 1u;
+    w.fx[p][lane] = v;
     w.bar.arrive_and_wait();
-    const float r = w.fx[src_lane & 63];
-    w.bar.arrive_and_wait();
-    return r;
+    return w.fx[p][src_lane & 63];
 }
 static inline int __double2loint(double d) { return (int)(uint32_t)(__builtin_bit_cast(uint64_t, d) & 0xffffffffu); }
 static inline int __double2hiint(double d) { return (int)(uint32_t)(__builtin_bit_cast(uint64_t, d) >> 32); }
@@ -152,14 +155,14 @@ typedef float hostsim_f32x16 __attribute__((ext_vector_type(16)));
 static inline hostsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hostsim_f32x16 acc, int, int, int) {
     hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
     const int lane = hostsim::t_tid % 64;
-    w.fa[lane] = a; w.fb[lane] = b;
+    const unsigned p = hostsim::t_wop++ & 1u;
+    w.fa[p][lane] = a; w.fb[p][lane] = b;
     w.bar.arrive_and_wait();
     const int j = lane & 31, hi = lane >> 5;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        acc[r] = fmaf(w.fa[32 + i], w.fb[32 + j], fmaf(w.fa[i], w.fb[j], acc[r]));
+        acc[r] = fmaf(w.fa[p][32 + i], w.fb[p][32 + j], fmaf(w.fa[p][i], w.fb[p][j], acc[r]));
     }
-    w.bar.arrive_and_wait();
     return acc;
 }
 
@@ -168,17 +171,17 @@ typedef __bf16 hostsim_bf16x8 __attribute__((ext_vector_type(8)));
 static inline hostsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hostsim_bf16x8 a, hostsim_bf16x8 b, hostsim_f32x16 acc, int, int, int) {
     hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
     const int lane = hostsim::t_tid % 64;
-    for (int e = 0; e < 8; ++e) { w.ha[lane][e] = (float)a[e]; w.hb[lane][e] = (float)b[e]; }
+    const unsigned p = hostsim::t_wop++ & 1u;
+    for (int e = 0; e < 8; ++e) { w.ha[p][lane][e] = (float)a[e]; w.hb[p][lane][e] = (float)b[e]; }
     w.bar.arrive_and_wait();
     const int j = lane & 31, hi = lane >> 5;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float s = acc[r];
         for (int kg = 0; kg < 2; ++kg)
-            for (int e = 0; e < 8; ++e) s = fmaf(w.ha[kg * 32 + i][e], w.hb[kg * 32 + j][e], s);
+            for (int e = 0; e < 8; ++e) s = fmaf(w.ha[p][kg * 32 + i][e], w.hb[p][kg * 32 + j][e], s);
         acc[r] = s;
     }
-    w.bar.arrive_and_wait();
     return acc;
 }
 
@@ -186,20 +189,19 @@ static inline hostsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hostsim_bf1
 static inline int __builtin_amdgcn_readfirstlane(int v) {
     hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
     const int lane = hostsim::t_tid % 64;
-    if (lane == 0) w.u64[0] = (uint64_t)(uint32_t)v;
+    const unsigned p = hostsim::t_wop++ & 1u;
+    if (lane == 0) w.u64[p][0] = (uint64_t)(uint32_t)v;
     w.bar.arrive_and_wait();
-    const int r = (int)(uint32_t)w.u64[0];
-    w.bar.arrive_and_wait();
-    return r;
+    return (int)(uint32_t)w.u64[p][0];
 }
 // global_load_lds_dwordx4: every lane's 16 bytes land at (lane 0's LDS pointer) + lane * size
 static inline void __builtin_amdgcn_global_load_lds(const void* gptr, void* lds_ptr, unsigned size, int offset, unsigned) {
     hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
     const int lane = hostsim::t_tid % 64;
-    if (lane == 0) w.u64[1] = (uint64_t)(uintptr_t)lds_ptr;
+    const unsigned p = hostsim::t_wop++ & 1u;
+    if (lane == 0) w.u64[p][1] = (uint64_t)(uintptr_t)lds_ptr;
     w.bar.arrive_and_wait();
-    memcpy((char*)(uintptr_t)w.u64[1] + (size_t)lane * size + offset, (const char*)gptr + offset, size);
-    w.bar.arrive_and_wait();
+    memcpy((char*)(uintptr_t)w.u64[p][1] + (size_t)lane * size + offset, (const char*)gptr + offset, size);   // visible to readers after the kernel's own barrier
 }
 // v_perm_b32: byte select from the 8-byte pool {src0 (bytes 7..4), src1 (bytes 3..0)}; selector values 0..7 only (what the kernels use)
 static inline uint32_t __builtin_amdgcn_perm(uint32_t src0, uint32_t src1, uint32_t sel) {

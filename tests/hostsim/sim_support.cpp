@@ -4,6 +4,7 @@ namespace hostsim {
 thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local BlockCtx* t_block = nullptr;
 thread_local int t_tid = 0;
+thread_local unsigned t_wop = 0;
 thread_local void* t_dyn_lds = nullptr;
 }
 
