@@ -110,10 +110,10 @@ class KTD(nn.Module):
         return pose, out[:, 144:154].contiguous(), out[:, 154:157].contiguous()
 
     def _use_hip(self, x):
-        return x.is_cuda and not self.training and not (torch.is_grad_enabled() and (x.requires_grad or self.fc1.weight.requires_grad))
+        return ops.on_library_device(x) and not self.training and not (torch.is_grad_enabled() and (x.requires_grad or self.fc1.weight.requires_grad))
 
     def _use_hip_train(self, x, J_regressor):
-        return x.is_cuda and J_regressor is None and not self._use_hip(x)
+        return ops.on_library_device(x) and J_regressor is None and not self._use_hip(x)
 
     def forward(self, x, seqlen, J_regressor=None, return_shape_cam=False, **kwargs):
         hip = self._use_hip(x)

@@ -33,6 +33,11 @@ def batch_rodrigues(axisang):
                         2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1)
 
 
+def _on_dev(t):
+    from . import ops
+    return ops.on_library_device(t)
+
+
 class _LossBase(nn.Module):
     def __init__(self, device='cuda'):
         super().__init__()
@@ -144,7 +149,7 @@ class LossVideo(_LossBase):
             n2 = 0
             gt_j2d = data_3d['kp_2d']
         w_smpl = data_3d['w_smpl'].type(torch.bool)
-        if preds['kp_2d'].is_cuda and not self.e_smpl_accl_loss > 0:
+        if _on_dev(preds['kp_2d']) and not self.e_smpl_accl_loss > 0:
             T = preds['kp_3d'].shape[1]
             return self._terms_fused(preds['kp_2d'], gt_j2d, preds['kp_3d'], data_3d['kp_3d'], preds['theta'], data_3d['theta'], w_smpl,
                                      n2 * T, self.e_3d_loss_weight)
@@ -169,7 +174,7 @@ class LossImage(_LossBase):
         gt_j3d = target['kp_3d'] if 'kp_3d' in target else None
         pred_j2d, pred_j3d, pred_theta = preds['kp_2d'].squeeze(1), preds['kp_3d'].squeeze(1), preds['theta'].squeeze(1)
         w_smpl = target['w_smpl'].type(torch.bool)
-        if pred_j2d.is_cuda:
+        if _on_dev(pred_j2d):
             return self._terms_fused(pred_j2d, target['kp_2d'], pred_j3d, gt_j3d, pred_theta, target['theta'], w_smpl, 0, self.e_3d_loss_weight)
         return self._terms_aten(pred_j2d, target['kp_2d'], pred_j3d, gt_j3d, pred_theta, target['theta'], w_smpl, self.e_3d_loss_weight)
 

@@ -181,7 +181,7 @@ class SMPL(nn.Module):
             raise NotImplementedError('pose2rot=True is not used on the MAED path (ktd.py:104)')
         rot = torch.cat([global_orient, body_pose], dim=1)
         needs_grad = torch.is_grad_enabled() and (betas.requires_grad or rot.requires_grad)
-        if needs_grad or not betas.is_cuda:  # ATen composition = the training graph (device-agnostic)
+        if needs_grad or not ops.on_library_device(betas):  # ATen composition = the training graph (device-agnostic)
             verts, j24 = self.lbs_torch(betas, rot)
             joints = self.joints49_torch(verts, j24)
         else:

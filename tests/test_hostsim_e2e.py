@@ -1,0 +1,64 @@
+"""One whole data-parallel train step of the default configuration -- hybrid backbone on its kernels, fused parallel-mode STE blocks,
+KTD head + SMPL tail, the fused LossVideo objective, gradient arena + bucketer (world 1), FusedAdam -- end to end on the host simulator
+with a tiny backbone.  A smoke test of the module-level wiring for rounds without GPU time (every piece has its own parity test)."""
+import os
+from functools import partial
+
+import pytest
+import torch
+import torch.nn as nn
+
+from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+from maed_amd.ktd import KTD
+from maed_amd.loss import Loss
+from maed_amd.resnetv2 import ResNetV2
+from maed_amd.trainer import TrainStep
+from maed_amd.vision_transformer import VisionTransformer
+
+from _hostsim import patched
+
+pytestmark = pytest.mark.skipif(os.environ.get("MAED_SLOW_TESTS") != "1", reason="~2 min on the simulator: MAED_SLOW_TESTS=1")
+
+
+class TinyMAED(nn.Module):
+    """maed_amd.MAED (lib/models/maed.py:52-67) with a (1,1,1) backbone at 32x32 instead of the R50 at 224x224"""
+
+    def __init__(self, dtype):
+        super().__init__()
+        bb = ResNetV2(layers=(1, 1, 1), channels=(128, 256, 512), in_chans=3, compute_dtype=dtype)
+        self.encoder = VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, hybrid_backbone=bb, mlp_ratio=4,
+                                         qkv_bias=True, representation_size=128, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                         st_mode="parallel", num_classes=-1, compute_dtype=dtype)
+        self.decoder = KTD(feat_dim=128, hidden_dim=64)
+
+    def forward(self, x, J_regressor=None):
+        n, t = x.shape[:2]
+        out = self.decoder(self.encoder(x.reshape(-1, *x.shape[2:]), seqlen=t), seqlen=t, J_regressor=J_regressor)
+        return {k: v.reshape(n, t, *v.shape[1:]) for k, v in out.items()}
+
+
+def test_train_steps_end_to_end_on_the_simulator():
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+    model = TinyMAED(torch.bfloat16).train()
+    N, T = 2, 2
+    clip = torch.randn(N, T, 3, 32, 32, generator=g)
+    tgt = dict(images=clip, kp_2d=torch.cat([torch.randn(N, T, 49, 2, generator=g) * 0.3, torch.rand(N, T, 49, 1, generator=g)], -1),
+               kp_3d=torch.cat([torch.randn(N, T, 49, 3, generator=g) * 0.3, torch.ones(N, T, 49, 1)], -1),
+               theta=torch.cat([torch.randn(N, T, 3, generator=g) * 0.1, torch.randn(N, T, 72, generator=g) * 0.2, torch.randn(N, T, 10, generator=g)], -1),
+               w_smpl=torch.ones(N, T))
+    with patched():
+        arena = ParamArena(model, device=torch.device("cpu"))
+        bucketer = GradBucketer(arena, model, bucket_bytes=256 << 10)
+        opt = FusedAdam(arena, lr=1e-3, bucketer=bucketer, model=model)
+        step = TrainStep(model, Loss(e_loss_weight=300.0, e_3d_loss_weight=600.0, e_pose_loss_weight=60.0, e_shape_loss_weight=0.06,
+                                     e_smpl_norm_loss=1.0, e_smpl_accl_loss=0.0, device="cpu"), opt)
+        totals = []
+        for _ in range(3):
+            total, terms = step(target_3d=tgt)
+            totals.append(float(total.detach()))
+    assert all(torch.isfinite(torch.tensor(totals))), totals
+    assert totals[-1] < totals[0], totals                              # three Adam steps on one batch must reduce its loss
+    assert bool(torch.isfinite(arena.flat).all())
+    dead = [n for n, p in model.named_parameters() if p.grad is None or float(p.grad.abs().max()) == 0.0]
+    assert not [n for n in dead if "smpl" not in n], dead              # every trainable tensor received a gradient
