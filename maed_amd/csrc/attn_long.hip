@@ -123,15 +123,23 @@ __global__ __launch_bounds__(256, 4) void attn_long_fwd_mfma(const bf16* __restr
 #pragma unroll
             for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2e;
-            const float mn = fmaxf(m, mt);
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            // lazy rescaling: the softmax reference m of a query moves only when its running maximum grew by more than 2^8 -- the
+            // probabilities are then at most 256 (exact in fp32 / bf16 all the same; o = acc / l uses the same reference), and after the
+            // first tile or two no lane of the wave qualifies any more, so the 32 accumulator multiplies, the exp2 of the correction
+            // and the bookkeeping are skipped wave-uniformly for most tiles (they are ~a fifth of the VALU work per tile)
+            const bool grow = mt > m + 8.0f;
+            if (__any(grow)) {
+                const float mn = grow ? mt : m;
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);     // 1 for the lanes that stay
+                l *= alpha;
+                m = mn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+            }
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -mn)); ps += s[r]; }
-            l = l * alpha + ps;
-            m = mn;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m)); ps += s[r]; }
+            l += ps;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {        // O^T += V^T P^T, 16 keys per step
                 const bf16x8_t pf = pack_frag(s, st);

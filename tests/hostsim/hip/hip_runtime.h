@@ -144,6 +144,17 @@ static inline float __shfl(float v, int src_lane, int /*width*/ = 64) {
     w.bar.arrive_and_wait();
     return w.fx[p][src_lane & 63];
 }
+// wave vote: true if the predicate holds in any live lane
+static inline int __any(int pred) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    const unsigned p = hostsim::t_wop++ & 1u;
+    w.fx[p][lane] = pred ? 1.0f : 0.0f;
+    w.bar.arrive_and_wait();
+    int r = 0;
+    for (int l = 0; l < w.live; ++l) r |= (w.fx[p][l] != 0.0f);
+    return r;
+}
 static inline int __double2loint(double d) { return (int)(uint32_t)(__builtin_bit_cast(uint64_t, d) & 0xffffffffu); }
 static inline int __double2hiint(double d) { return (int)(uint32_t)(__builtin_bit_cast(uint64_t, d) >> 32); }
 static inline double __hiloint2double(int hi, int lo) {
