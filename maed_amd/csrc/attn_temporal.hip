@@ -660,6 +660,138 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_BLOCKS) void attn_tm_bwd_mfma(cons
 #undef TM_TOK
 }
 
+// ==================================================================================================
+// The same backward specialised for virtual sequences of ONE 32-row tile (T <= 32: cfg3's T = 16 packs two tokens per workgroup) --
+// a one-wave workgroup.  With a single tile the "other side's" rows of both passes ARE the wave's own rows, so every row-major MFMA
+// operand (Q, K, V, dO fragments) is loaded straight from global memory in fragment layout and only the three TRANSPOSED images
+// (Q^T, K^T, dO^T: the A operands of the dQ / dK / dV products) go through LDS: 13.8 KB per workgroup instead of 32.5 KB, i.e. 11
+// resident one-wave workgroups per CU instead of 4 (the general kernel runs at one wave per SIMD at T = 16), and no row-major LDS
+// stores.  Opt-in (MAED_TM_BWD_L32=1): written without GPU access, parity-green on the host simulator.
+// ==================================================================================================
+__global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+                                                               const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int P, int H,
+                                                               int Tn, int G, int ngroups, float scale) {
+    constexpr int VLD = 36;                          // 32 rows + 4 pad: conflict-free ds_read_b64 of the transposed images
+    __shared__ __attribute__((aligned(16))) unsigned short Qt[D * VLD], Kt[D * VLD], dOt[D * VLD];
+    __shared__ float Ls[32], Ds[32];
+    const int L = G * Tn, C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    const int tg = bid % ngroups; bid /= ngroups;
+    const int h = bid % H, n = bid / H;
+    const int p0 = tg * G;
+#define TM_ROW_OK(r) ((r) < L && p0 + (r) / Tn < P)
+#define TM_TOK(r) (((int64_t)n * Tn + (r) % Tn) * P + p0 + (r) / Tn)
+    const int row = l31;
+    const bool row_ok = TM_ROW_OK(row);
+    const int64_t tok = row_ok ? TM_TOK(row) : 0;
+    const bf16* rp = qkv + tok * ld + h * D;
+    const bf16* gp = d_o + tok * C + h * D;
+    const bf16* op = o + tok * C + h * D;
+    const float l2e = 1.44269504088896340736f;
+    // this lane's half of row `row`: elements t*16 + hi*8 .. +7, t = 0..3 (exactly the MFMA row-fragment layout)
+    union Frag { bf16x8_t v; uint4 u; };
+    Frag qf[4], kf[4], vf[4], dof[4];
+    float dsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e0 = t * 16 + hi * 8;
+        qf[t].u = kf[t].u = vf[t].u = dof[t].u = make_uint4(0u, 0u, 0u, 0u);
+        if (row_ok) {
+            qf[t].u = *reinterpret_cast<const uint4*>(rp + e0);
+            kf[t].u = *reinterpret_cast<const uint4*>(rp + C + e0);
+            vf[t].u = *reinterpret_cast<const uint4*>(rp + 2 * C + e0);
+            dof[t].u = *reinterpret_cast<const uint4*>(gp + e0);
+            float a[8], b[8];
+            ld8(gp + e0, a); ld8(op + e0, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum = fmaf(a[j], b[j], dsum);
+        }
+        const uint32_t wq[4] = {qf[t].u.x, qf[t].u.y, qf[t].u.z, qf[t].u.w}, wk[4] = {kf[t].u.x, kf[t].u.y, kf[t].u.z, kf[t].u.w},
+                       wg[4] = {dof[t].u.x, dof[t].u.y, dof[t].u.z, dof[t].u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                // transposed images: element (e, row)
+            const int a0 = (e0 + 2 * j) * VLD + row, a1 = a0 + VLD;
+            Qt[a0] = (unsigned short)(wq[j] & 0xffffu); Qt[a1] = (unsigned short)(wq[j] >> 16);
+            Kt[a0] = (unsigned short)(wk[j] & 0xffffu); Kt[a1] = (unsigned short)(wk[j] >> 16);
+            dOt[a0] = (unsigned short)(wg[j] & 0xffffu); dOt[a1] = (unsigned short)(wg[j] >> 16);
+        }
+    }
+    for (int i = lane; i < D * 4; i += 64) {         // the 4 pad columns
+        const int e = (i >> 2) * VLD + 32 + (i & 3);
+        Qt[e] = 0; Kt[e] = 0; dOt[e] = 0;
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    const float Dq = dsum;
+    const float L2 = row_ok ? lse[(((int64_t)n * Tn + row % Tn) * H + h) * P + p0 + row / Tn] * l2e : 0.f;
+    if (hi == 0) { Ds[row] = Dq; Ls[row] = L2; }
+    __syncthreads();
+
+    const int rg = row / Tn;
+    const float sl2e = scale * l2e;
+    bf16* drow = dqkv + tok * ld + h * D;
+    {   // ---- pass A: lane = query;  S^T = K Q^T, dP^T = V dO^T (rows = keys = the wave's own rows) ----
+        f32x16_t sa, dp, dq[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; dq[0][r] = 0.f; dq[1][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t].v, qf[t].v, sa, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t].v, dof[t].v, dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool ok = row_ok && TM_ROW_OK(k) && (k / Tn == rg);
+            const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], sl2e, -L2)) : 0.f;
+            sa[r] = pr * (dp[r] - Dq) * scale;       // dS
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8_t dsf = pack_frag(sa, st);
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+                dq[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Kt + (et * 32 + l31) * VLD + 16 * st + 4 * hi), dsf, dq[et], 0, 0, 0);
+        }
+        if (row_ok) store_rowT(drow, dq, hi, accumulate);
+    }
+    {   // ---- pass B: lane = key;  S = Q K^T, dP = dO V^T (rows = queries = the wave's own rows) ----
+        f32x16_t sb, dp, dk[2], dv[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dp[r] = 0.f; dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[t].v, kf[t].v, sb, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof[t].v, vf[t].v, dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool ok = row_ok && TM_ROW_OK(qq) && (qq / Tn == rg);
+            const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sb[r], sl2e, -Ls[qq])) : 0.f;
+            dp[r] = pr * (dp[r] - Ds[qq]) * scale;   // dS
+            sb[r] = pr;                              // P
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8_t pf = pack_frag(sb, st), dsf = pack_frag(dp, st);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                const int off = (et * 32 + l31) * VLD + 16 * st + 4 * hi;
+                dv[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(dOt + off), pf, dv[et], 0, 0, 0);
+                dk[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Qt + off), dsf, dk[et], 0, 0, 0);
+            }
+        }
+        if (row_ok) {
+            store_rowT(drow + C, dk, hi, accumulate);
+            store_rowT(drow + 2 * C, dv, hi, accumulate);
+        }
+    }
+#undef TM_ROW_OK
+#undef TM_TOK
+}
+
 // bf16 default; MAED_TEMPORAL_MFMA=0 falls back to the LDS-staged thread-per-row kernels (measurement knob).
 // Measured on MI355X (profiles/r01_attn_temporal_mfma_ab.txt): cfg3 (T=16) forward 61.8 -> 27.7 us, backward 133.8 -> 123.3 us;
 // cfg5 (T=64) forward 251 -> 62 us, backward 578 -> 304 us.
@@ -685,6 +817,11 @@ static bool launch_tm_bwd_mfma(const void* qkv, const void* o, const void* d_o, 
     }
     const int ngroups = (P + G - 1) / G;
     const dim3 grid((unsigned)((F / Tn) * H * ngroups)), block(64 * (Lk / 32));
+    if (Lk == 32 && maed_env_flag("MAED_TM_BWD_L32", false)) {      // one-tile specialisation (see above): opt-in until timed on hardware
+        hipLaunchKernelGGL(attn_tm_bwd_mfma_l32, grid, dim3(64), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, accumulate,
+                           P, H, Tn, G, ngroups, scale);
+        return true;
+    }
     // the spill-free instantiation was written after the round-1 GPU budget was spent: opt-in (MAED_TM_BWD_WIDE_REGS=1) until it has
     // been timed against the measured default on hardware (scripts/attn_tm_micro.py)
     static int wide = -1;

@@ -5,13 +5,14 @@
 # (4) runs the GPU suite with the switches on.   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash scripts/gpu_round2_first.sh'
 set -x
 mkdir -p gpurun_out
-OPTIN="MAED_GN_DEFER_AFFINE=1 MAED_LN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_WIDE_REGS=1 MAED_WS_PER_STAGE=1"
+OPTIN="MAED_GN_DEFER_AFFINE=1 MAED_LN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_TM_BWD_L32=1 MAED_TM_BWD_WIDE_REGS=1 MAED_WS_PER_STAGE=1"
 bench_ms() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], d['ms_per_step'], 'ms/step', {k: v['avg_us'] for k, v in d['kernels'].items()})" "$1"; }
 
 MAED_RUN_UNVERIFIED_GPU_TESTS=1 timeout 600 python -m pytest tests/test_gpu_unverified.py -m gpu -q -s 2>&1 | tee gpurun_out/r02_new_paths_on_gpu.log
 timeout 200 python scripts/attn_long_micro.py 20 2>&1 | tee gpurun_out/r02_attn_long_micro.txt
 timeout 200 python scripts/conv3x3_micro.py 10 2>&1 | tee gpurun_out/r02_conv3x3_micro.txt
 for w in 0 1; do MAED_TM_BWD_WIDE_REGS=$w MAED_TEMPORAL_MFMA=1 timeout 120 python scripts/attn_tm_micro.py 30 2>&1 | sed "s/^/wide_regs=$w /" | tee -a gpurun_out/r02_attn_tm_wide_regs.txt; done
+MAED_TM_BWD_L32=1 MAED_TEMPORAL_MFMA=1 timeout 120 python scripts/attn_tm_micro.py 30 2>&1 | sed "s/^/one_tile_kernel /" | tee -a gpurun_out/r02_attn_tm_wide_regs.txt
 
 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | bench_ms "default" | tee gpurun_out/r02_optin_flags.txt
 env $OPTIN timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | bench_ms "all-opt-in" | tee -a gpurun_out/r02_optin_flags.txt

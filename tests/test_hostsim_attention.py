@@ -41,9 +41,13 @@ def test_attn_spatial_fwd_bwd(name, dtype, impl, Fr, P, H):
     close(dqkv.float(), x.grad, **tol(dtype, 0.5))
 
 
+@pytest.mark.parametrize("l32", ["0", "1"])          # MAED_TM_BWD_L32: one-tile specialisation of the MFMA backward (T <= 32)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,T,P,H", [(2, 3, 5, 2), (1, 16, 9, 1), (1, 64, 3, 1)])
-def test_attn_temporal_fwd_bwd(dtype, N, T, P, H):
+def test_attn_temporal_fwd_bwd(dtype, N, T, P, H, l32, monkeypatch):
+    if l32 == "1" and (dtype != torch.bfloat16 or T > 32):
+        pytest.skip("the specialisation only exists for bf16 sequences of one 32-row tile")
+    monkeypatch.setenv("MAED_TM_BWD_L32", l32)
     Fr = N * T
     qkv = q(rnd(Fr, P, 3 * 64 * H, seed=5), dtype)
     do = q(rnd(Fr, P, 64 * H, seed=6), dtype)
