@@ -239,7 +239,6 @@ class ResNetV2(nn.Module):
         # MAED_CONV3X3=own: the stride-1 3x3 convolutions hand their weights / weight gradients over like the GEMM convolutions
         self._own3x3 = [i for i, c in enumerate(self._convs) if _OWN_CONV3X3 and c.kernel_size == (3, 3) and c.stride == (1, 1)
                         and c.in_channels % 64 == 0 and c.out_channels % 64 == 0]
-        self._direct_convs = self._gemm_convs + self._own3x3
         self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
         self._pending_backwards = 0
         self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
@@ -251,6 +250,12 @@ class ResNetV2(nn.Module):
 
     def conv_weights(self):
         return [c.weight for c in self._convs]
+
+    @property
+    def _direct_convs(self):
+        """convolutions on the library's own kernels (transposed weight image + fp32 dW slice from WeightStdFn); computed on access so that
+        switching `_gemm_convs` off at run time (tests/test_gpu_model.py's all-MIOpen variant) keeps its meaning"""
+        return list(self._gemm_convs) + list(self._own3x3)
 
     def fused_parameters(self):
         """parameters whose gradients the HIP kernels write directly into .grad: conv weights (batched

@@ -149,3 +149,13 @@ def test_per_stage_weight_standardisation_reports_readiness_stage_by_stage(monke
         assert rep0 == [m0]                                                  # one report, after the batched backward
         for a, b, (n, _) in zip(g0, g1, base.named_parameters()):
             assert cos(a, b) > 0.9999, (n, cos(a, b))
+
+
+def test_switching_gemm_convs_off_at_run_time_also_drops_their_direct_hand_over():
+    """tests/test_gpu_model.py's all-MIOpen variant sets `net._gemm_convs = []` on a live model: WeightStdFn must then stop producing
+    transposed images / fp32 slices for them (it reads `_direct_convs`, which therefore has to follow `_gemm_convs`)"""
+    net = ResNetV2(layers=(1, 2, 1), channels=(256, 512, 1024), compute_dtype=torch.bfloat16)
+    assert len(net._gemm_convs) == 9 and net._direct_convs == net._gemm_convs + net._own3x3
+    net._gemm_convs = []
+    assert net._direct_convs == net._own3x3
+    assert all(g._direct_convs == [] for g in net._ws_groups) or bool(net._own3x3)
