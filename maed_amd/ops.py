@@ -661,7 +661,7 @@ def conv3x3(x, w_taps, stride=1, add=None, w_layout=0):
     O = w_taps.numel() // (9 * I)
     Ho, Wo = -(-H // stride), -(-W // stride)
     ph, pw = max((Ho - 1) * stride + 3 - H, 0), max((Wo - 1) * stride + 3 - W, 0)
-    y = torch.empty(N, O, Ho, Wo, dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    y = torch.empty(N, O, Ho, Wo, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     if add is not None:
         add = add.contiguous(memory_format=torch.channels_last)
     check(L.lib().maed_conv3x3_fwd(_p(x), _p(w_taps), _p(_zero_page(x.device)), _p(y), N, H, W, I, O, stride, ph // 2, pw // 2, Ho, Wo, _p(add),
