@@ -70,12 +70,12 @@ class _LossBase(nn.Module):
         return (conf * (pred - gt) ** 2).mean()
 
     def smpl_losses(self, pred_pose, pred_shape, gt_pose, gt_shape, w_smpl):
-        """loss.py:64-92: MSE on rotation matrices and betas over the frames whose SMPL labels are valid"""
+        """loss.py:64-92: MSE on rotation matrices and betas.  Video input (N,T,.) keeps only the frames whose SMPL labels are
+        valid (:77-82); image input (N,.) is NOT masked by the reference (w_smpl is ignored there) and neither is it here."""
         if pred_pose.dim() > 2:
             w_smpl = w_smpl.reshape(-1)
-            pred_pose, pred_shape = pred_pose.reshape(-1, pred_pose.shape[-1]), pred_shape.reshape(-1, pred_shape.shape[-1])
-            gt_pose, gt_shape = gt_pose.reshape(-1, gt_pose.shape[-1]), gt_shape.reshape(-1, gt_shape.shape[-1])
-        pred_pose, pred_shape, gt_pose, gt_shape = pred_pose[w_smpl], pred_shape[w_smpl], gt_pose[w_smpl], gt_shape[w_smpl]
+            pred_pose, pred_shape = pred_pose.reshape(-1, pred_pose.shape[-1])[w_smpl], pred_shape.reshape(-1, pred_shape.shape[-1])[w_smpl]
+            gt_pose, gt_shape = gt_pose.reshape(-1, gt_pose.shape[-1])[w_smpl], gt_shape.reshape(-1, gt_shape.shape[-1])[w_smpl]
         if len(pred_pose) == 0:
             return self._zero(pred_pose), self._zero(pred_pose)
         pred_rot = batch_rodrigues(pred_pose.reshape(-1, 3)).reshape(-1, 24, 3, 3)
@@ -175,7 +175,9 @@ class LossImage(_LossBase):
         pred_j2d, pred_j3d, pred_theta = preds['kp_2d'].squeeze(1), preds['kp_3d'].squeeze(1), preds['theta'].squeeze(1)
         w_smpl = target['w_smpl'].type(torch.bool)
         if _on_dev(pred_j2d):
-            return self._terms_fused(pred_j2d, target['kp_2d'], pred_j3d, gt_j3d, pred_theta, target['theta'], w_smpl, 0, self.e_3d_loss_weight)
+            # the reference's smpl_losses masks by w_smpl for video input only (loss.py:77): every image counts here
+            return self._terms_fused(pred_j2d, target['kp_2d'], pred_j3d, gt_j3d, pred_theta, target['theta'], torch.ones_like(w_smpl), 0,
+                                     self.e_3d_loss_weight)
         return self._terms_aten(pred_j2d, target['kp_2d'], pred_j3d, gt_j3d, pred_theta, target['theta'], w_smpl, self.e_3d_loss_weight)
 
 

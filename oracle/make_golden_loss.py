@@ -105,6 +105,10 @@ def main():
     fx["merge.total"] = lm.detach().numpy()
     for k, v in dm.items():
         fx["merge.term." + k] = v.detach().numpy()
+    # image loss on a mixed batch: some images without SMPL labels -- the reference's smpl_losses does NOT mask image input (loss.py:77)
+    preds, d3, _ = make_case(g, 0, 6, 1, image=True)
+    d3 = dict(d3, w_smpl=torch.tensor([1., 0., 1., 0., 1., 1.]))
+    put("image_mixed", preds, d3, None, run(front.loss_image, preds, d3))
     save("g11_loss", **fx)
 
 

@@ -76,7 +76,7 @@ def test_tail_joint_gather_backward_is_scatter_add():
     report("joint_map scatter-add backward (integer cotangents)", got, ref, rtol=0, atol=0)
 
 
-CASES = ["video_2d3d", "video_3d", "video_novalid", "image"]
+CASES = ["video_2d3d", "video_3d", "video_novalid", "image", "image_mixed"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -87,7 +87,7 @@ def test_fused_loss_matches_reference_golden(name):
     leaves = {k: t(f"{name}.pred.{k}").requires_grad_(True) for k in ("kp_2d", "kp_3d", "theta")}
     d3 = {k: t(f"{name}.d3.{k}") for k in ("kp_2d", "kp_3d", "theta", "w_smpl")}
     d2 = {"kp_2d": t(f"{name}.d2.kp_2d")} if f"{name}.d2.kp_2d" in fx else None
-    if name == "image":
+    if name.startswith("image"):
         total, terms = mloss.Loss().loss_image(leaves, d3)
     else:
         total, terms = mloss.LossVideo()(leaves, d3, d2)

@@ -10,7 +10,7 @@ from maed_amd import loss as mloss
 from oracle import loss_ref
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["video_2d3d", "video_3d", "video_accl", "video_novalid", "image"]
+CASES = ["video_2d3d", "video_3d", "video_accl", "video_novalid", "image", "image_mixed"]   # image_mixed: w_smpl has zeros (not masked, loss.py:77)
 ACCL_KW = dict(e_loss_weight=5., e_3d_loss_weight=7., e_pose_loss_weight=2., e_shape_loss_weight=0.5, e_smpl_norm_loss=0.25, e_smpl_accl_loss=3.)
 
 
@@ -46,7 +46,7 @@ def test_oracle_matches_reference(name):
     fx = np.load(os.path.join(GOLD, "g11_loss.npz"))
     preds, d3, d2 = load_case(fx, name, torch.float64)
     leaves = {k: v.clone().requires_grad_(True) for k, v in preds.items()}
-    if name == "image":
+    if name.startswith("image"):
         total, terms = loss_ref.loss_image(leaves, d3, w3d=30.)       # Loss() hands its e_3d_loss_weight=30 to LossImage
     elif name == "video_accl":
         total, terms = loss_ref.loss_video(leaves, d3, d2, 5., 7., 2., 0.5, 0.25, 3.)
@@ -57,7 +57,7 @@ def test_oracle_matches_reference(name):
 
 
 def _module_for(name):
-    if name == "image":
+    if name.startswith("image"):
         return mloss.Loss(device="cpu").loss_image
     return mloss.LossVideo(device="cpu", **(ACCL_KW if name == "video_accl" else {}))
 
@@ -68,7 +68,7 @@ def test_host_mirror_matches_reference(name):
     preds, d3, d2 = load_case(fx, name)
     leaves = {k: v.clone().requires_grad_(True) for k, v in preds.items()}
     mod = _module_for(name)
-    total, terms = mod(leaves, d3) if name == "image" else mod(leaves, d3, d2)
+    total, terms = mod(leaves, d3) if name.startswith("image") else mod(leaves, d3, d2)
     total.backward()
     check(fx, name, total, terms, {k: v.grad for k, v in leaves.items()}, rtol=2e-5, atol=2e-6)
 
@@ -87,7 +87,7 @@ def test_front_end_and_merge():
     assert front(pv) == (0, {})
 
 
-@pytest.mark.parametrize("name", ["video_2d3d", "video_3d", "video_novalid", "image"])
+@pytest.mark.parametrize("name", ["video_2d3d", "video_3d", "video_novalid", "image", "image_mixed"])
 def test_fused_kernels_on_host_simulator(name, monkeypatch):
     """maed_loss_fwd_bwd (maed_amd/csrc/loss.hip) compiled for x86 against tests/hostsim: values AND gradients vs the
     reference's.  The fused path is selected by .is_cuda in the module, so call its back end directly."""
@@ -96,10 +96,8 @@ def test_fused_kernels_on_host_simulator(name, monkeypatch):
     preds, d3, d2 = load_case(fx, name)
     leaves = {k: v.clone().requires_grad_(True) for k, v in preds.items()}
     with patched():
-        if name == "image":
-            mod = mloss.Loss(device="cpu").loss_image
-            total, terms = mod._terms_fused(leaves["kp_2d"].squeeze(1), d3["kp_2d"], leaves["kp_3d"].squeeze(1), d3["kp_3d"],
-                                            leaves["theta"].squeeze(1), d3["theta"], d3["w_smpl"].bool(), 0, mod.e_3d_loss_weight)
+        if name.startswith("image"):
+            total, terms = mloss.Loss(device="cpu").loss_image(leaves, d3)       # on_library_device: the simulator counts as the device
         else:
             mod = mloss.LossVideo(device="cpu")
             n2 = d2["kp_2d"].shape[0] if d2 else 0
