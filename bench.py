@@ -27,6 +27,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MAED_SYNTHETIC_SMPL_OK", "1")     # the licensed SMPL model file is unavailable: synthetic stand-in, stated in the JSON
 
 CFG = dict(clips=8, T=16, img=224, depth=6, heads=8, dim=512, hidden=1024)
 _T0 = time.perf_counter()

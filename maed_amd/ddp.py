@@ -138,9 +138,11 @@ class GradBucketer:
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._fused = set()
+        self._fused_modules = []
         for m in model.modules():  # modules whose kernels write parameter gradients directly (STE Block, ResNetV2)
             if hasattr(m, "fused_parameters") and hasattr(m, "grads_ready"):
                 m.grads_ready = self._block_ready
+                self._fused_modules.append(m)
                 self._fused.update(id(p) for p in m.fused_parameters())
         for p in arena.params:
             if id(p) not in self._fused:
@@ -186,6 +188,8 @@ class GradBucketer:
             self.comm.wait()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        for m in self._fused_modules:       # a backward that never ran (an exception, a detached output) must not poison the next step
+            m._pending_backwards = 0
 
     def broadcast_parameters(self, src=0):
         """train.py:113 DDP construction broadcasts rank 0's parameters once."""

@@ -361,7 +361,23 @@ _TWIN = [None, None]
 TWIN_HITS = [0, 0]   # [hits, misses] -- diagnostics
 
 
-class STEBlockFn(torch.autograd.Function):
+class ReportingFn(torch.autograd.Function):
+    """Base of the Functions whose backward writes parameter gradients itself and reports through owner.grads_ready: the owner's
+    _pending_backwards counts forwards whose backward WILL run.  Inside Function.forward grad mode is always off and
+    ctx.needs_input_grad ignores torch.no_grad(), so the mode is sampled at apply() time."""
+    _grad_mode_at_apply = True
+
+    @classmethod
+    def apply(cls, *args):
+        ReportingFn._grad_mode_at_apply = torch.is_grad_enabled()
+        return super().apply(*args)
+
+    @staticmethod
+    def will_run_backward(ctx):
+        return ReportingFn._grad_mode_at_apply and any(ctx.needs_input_grad)
+
+
+class STEBlockFn(ReportingFn):
     """One STE Block through maed_ste_block_{fwd,bwd}.  Parameter gradients are accumulated by the
     kernels directly into p.grad (fp32, allocated on demand); autograd sees None for them, and the
     module's `grads_ready` hook tells the data-parallel bucketer when they are final."""
@@ -377,7 +393,8 @@ class STEBlockFn(torch.autograd.Function):
         check(lib.maed_ste_block_fwd(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _stream()), "ste_block_fwd")
         ctx.block, ctx.dims = block, dims
         ctx.save_for_backward(x, saved)
-        block._pending_backwards += 1
+        if ReportingFn.will_run_backward(ctx):        # a forward under no_grad has no backward to pair with
+            block._pending_backwards += 1
         return y
 
     @staticmethod
@@ -438,7 +455,7 @@ def _ws_table(weights, grads=None, gouts=None, transposed=None, gout_f32=None):
     return tab, off, fstart, total, t_offs
 
 
-class WeightStdFn(torch.autograd.Function):
+class WeightStdFn(ReportingFn):
     """All StdConv2dSame weights of a backbone standardised in ONE launch (forward) / ONE launch (backward).
     Outputs are channels_last-strided (O,I,kh,kw) views of one arena in the compute dtype.  Like STEBlockFn
     the backward accumulates straight into p.grad and reports through owner.grads_ready.
@@ -461,7 +478,8 @@ class WeightStdFn(torch.autograd.Function):
         check(L.lib().maed_weight_std_fwd(_p(tab_dev), len(weights), nf, _p(out), dt_code(dtype), _p(stats), eps, _stream()), "weight_std_fwd")
         ctx.owner, ctx.dtype, ctx.eps, ctx.stats, ctx.nf = owner, dtype, eps, stats, nf
         ctx.weights = weights
-        owner._pending_backwards += 1
+        if ReportingFn.will_run_backward(ctx):
+            owner._pending_backwards += 1
         views, off = [], 0
         for w in weights:
             O, I, kh, kw = w.shape
@@ -471,7 +489,7 @@ class WeightStdFn(torch.autograd.Function):
         owner._w_std_t = {i: out[o:o + weights[i].numel()].view(-1, weights[i].shape[0]) for i, o in t_offs.items()}
         # fp32 weight-gradient arena of the GEMM convolutions (maed_gemm_tn_wgrad accumulates with atomics: zero it once per step)
         owner._dw_arena, owner._dw_slices = None, {}
-        if gemm and any(ctx.needs_input_grad[3:]):   # (grad mode is off inside Function.forward: ask autograd, not torch.is_grad_enabled)
+        if gemm and ReportingFn.will_run_backward(ctx):
             n = sum(weights[i].numel() for i in gemm)
             owner._dw_arena = torch.zeros(n, dtype=torch.float32, device=dev)
             o = 0

@@ -11,6 +11,8 @@ lib/models/ktd.py:100-105 and returns an object with .vertices and .joints (49 j
 joint_map, smpl.py:97-99).
 """
 import ctypes as C
+import os
+import warnings
 from collections import namedtuple
 
 import torch
@@ -87,6 +89,10 @@ class SMPL(nn.Module):
         super().__init__()
         a = model_arrays if model_arrays is not None else synthetic_smpl_arrays(0)
         self.synthetic = model_arrays is None
+        if self.synthetic and os.environ.get("MAED_SYNTHETIC_SMPL_OK") != "1":
+            warnings.warn("maed_amd.SMPL: no model arrays given -- using the deterministic synthetic stand-in (SMPL-shaped random parameters). "
+                          "Pass smpl_arrays= (or load a state_dict that carries decoder.smpl.*) for real meshes; set MAED_SYNTHETIC_SMPL_OK=1 "
+                          "to silence this in tests and benchmarks.", stacklevel=3)
         f = lambda k: torch.as_tensor(a[k], dtype=torch.float32).contiguous()
         self.register_buffer('v_template', f('v_template'))
         self.register_buffer('shapedirs', f('shapedirs')[:, :, :10].contiguous())
@@ -97,14 +103,34 @@ class SMPL(nn.Module):
         self.register_buffer('parents', torch.tensor(SMPL_PARENTS, dtype=torch.int32), persistent=False)
         self.register_buffer('extra_vertex_ids', torch.tensor(SMPL_EXTRA_VERTEX_IDS, dtype=torch.long), persistent=False)
         self.register_buffer('joint_map', torch.tensor([JOINT_MAP[n] for n in JOINT_NAMES], dtype=torch.long), persistent=False)
-        # rest-pose joint regression folded once: J = J_regressor (v_template + shapedirs beta)
+        # rest-pose joint regression folded once: J = J_regressor (v_template + shapedirs beta).  DERIVED from the persistent buffers:
+        # refreshed whenever those change (load_state_dict of a reference checkpoint carrying decoder.smpl.*, in-place edits, .to())
         self.register_buffer('J_template', self.J_regressor @ self.v_template, persistent=False)
         self.register_buffer('J_shapedirs', torch.einsum('jv,vcl->jcl', self.J_regressor, self.shapedirs).contiguous(), persistent=False)
         self.faces = None
         self._ps_t = None
+        self._derived_key = self._base_key()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_derived(force=True))
+
+    def _base_key(self):
+        return tuple((t.data_ptr(), t._version) for t in (self.v_template, self.shapedirs, self.posedirs, self.J_regressor))
+
+    def refresh_derived(self, force=False):
+        """J_template, J_shapedirs and the backward's GEMM operand follow v_template / shapedirs / posedirs / J_regressor"""
+        key = self._base_key()
+        changed = key != self._derived_key
+        if force or changed:
+            with torch.no_grad():
+                self.J_template = self.J_regressor @ self.v_template
+                self.J_shapedirs = torch.einsum('jv,vcl->jcl', self.J_regressor, self.shapedirs).contiguous()
+            self._ps_t = None
+            self._derived_key = self._base_key()
+            if changed:
+                self.synthetic = False
 
     def pose_shape_dirs_t(self):
         """(20670, 207+10) = [posedirs ; shapedirs^T]^T: the one GEMM operand of the LBS backward (tail.SmplTailFn)"""
+        self.refresh_derived()
         if self._ps_t is None or self._ps_t.device != self.posedirs.device:
             self._ps_t = torch.cat([self.posedirs, self.shapedirs.reshape(-1, 10).t()], dim=0).t().contiguous()
         return self._ps_t
@@ -116,6 +142,7 @@ class SMPL(nn.Module):
     _LEVELS = [[0], [1, 2, 3], [4, 5, 6], [7, 8, 9], [10, 11, 12, 13, 14], [15, 16, 17], [18, 19], [20, 21], [22, 23]]
 
     def lbs_torch(self, betas, rotmat):
+        self.refresh_derived()
         Fr = betas.shape[0]
         v_shaped = self.v_template.reshape(1, -1) + betas @ self.shapedirs.reshape(-1, 10).t()          # (F, 20670)
         J = (self.J_template.reshape(1, -1) + betas @ self.J_shapedirs.reshape(-1, 10).t()).reshape(Fr, 24, 3)
@@ -154,6 +181,7 @@ class SMPL(nn.Module):
 
     # ---- HIP path (inference) ----------------------------------------------------------------------------
     def _c_params(self):
+        self.refresh_derived()
         sp = L.SmplParams()
         for k in ['v_template', 'shapedirs', 'posedirs', 'J_template', 'J_shapedirs', 'lbs_weights', 'parents']:
             setattr(sp, k, getattr(self, k).data_ptr())

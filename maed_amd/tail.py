@@ -31,7 +31,7 @@ def _off(t, elems):
     return None if t is None else ops._p(t) + 4 * elems
 
 
-class KtdChainFn(torch.autograd.Function):
+class KtdChainFn(ops.ReportingFn):
     @staticmethod
     def forward(ctx, h2, ktd, *params):
         lib = L.lib()
@@ -50,7 +50,8 @@ class KtdChainFn(torch.autograd.Function):
         ctx.save_for_backward(h2, pose, w_feat, w_anc)
         ctx.ktd = ktd
         ctx.set_materialize_grads(False)
-        ktd._pending_backwards += 1
+        if ops.ReportingFn.will_run_backward(ctx):
+            ktd._pending_backwards += 1
         return pose, out[:, 144:154].contiguous(), out[:, 154:157].contiguous()
 
     @staticmethod

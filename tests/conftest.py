@@ -8,6 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("MAED_SYNTHETIC_SMPL_OK", "1")     # tests run on the synthetic SMPL stand-in on purpose (maed_amd/smpl.py)
 
 
 def pytest_configure(config):

@@ -334,3 +334,37 @@ def test_full_ddp_train_steps_gloo_world2_match_single_process_adam():
             opt.step()
     # Adam divides by sqrt(v): an element whose gradient is ~0 amplifies summation-order noise -> absolute tolerance of 1% of one lr step
     torch.testing.assert_close(out[0], arena.flat, rtol=1e-3, atol=1e-4)
+
+
+def test_smpl_derived_tables_follow_a_loaded_state_dict():
+    """the reference's Trainer.resume_pretrained loads checkpoints that carry decoder.smpl.* with strict=True
+    (lib/core/trainer.py:358); the joint tables folded from J_regressor / v_template / shapedirs and the backward's GEMM operand
+    must follow the loaded arrays, not stay on the construction-time (synthetic) ones."""
+    from maed_amd.smpl import SMPL, synthetic_smpl_arrays
+    a, b = SMPL(synthetic_smpl_arrays(0)), SMPL(synthetic_smpl_arrays(7))
+    assert not torch.allclose(a.J_template, b.J_template)
+    ps_old = a.pose_shape_dirs_t().clone()
+    a.load_state_dict(b.state_dict(), strict=True)
+    assert torch.equal(a.J_template, b.J_template) and torch.equal(a.J_shapedirs, b.J_shapedirs)
+    assert torch.equal(a.pose_shape_dirs_t(), b.pose_shape_dirs_t()) and not torch.equal(a.pose_shape_dirs_t(), ps_old)
+    g = torch.Generator().manual_seed(1)
+    betas, rot = torch.randn(2, 10, generator=g), torch.eye(3).expand(2, 24, 3, 3).contiguous()
+    va, _ = a.lbs_torch(betas, rot)
+    vb, _ = b.lbs_torch(betas, rot)
+    assert torch.equal(va, vb)
+    # in-place edits of a base array are picked up lazily as well
+    with torch.no_grad():
+        a.v_template.mul_(2.0)
+    a.refresh_derived()
+    assert torch.allclose(a.J_template, 2.0 * b.J_template, rtol=1e-5, atol=1e-6)
+    # the stand-in announces itself unless a test / benchmark opted out
+    import os, warnings
+    old = os.environ.pop("MAED_SYNTHETIC_SMPL_OK", None)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            s = SMPL()
+        assert s.synthetic and any("synthetic stand-in" in str(x.message) for x in w)
+    finally:
+        if old is not None:
+            os.environ["MAED_SYNTHETIC_SMPL_OK"] = old

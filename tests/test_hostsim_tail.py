@@ -121,6 +121,23 @@ def test_grads_ready_protocol_and_fused_parameter_list():
     assert id(ktd.fc1.weight) not in fused and ktd.fc1.weight.grad is not None      # fc1/fc2 travel through autograd
 
 
+def test_forward_without_backward_does_not_block_the_readiness_report():
+    """a validation forward on the training model (lib/core/trainer.py validates every epoch, under no_grad) must not leave
+    _pending_backwards raised: the next training backward still reports through grads_ready"""
+    ktd = make_ktd()
+    fired = []
+    ktd.grads_ready = lambda m: fired.append(m)
+    x = torch.randn(2, 48, requires_grad=True)
+    with patched():
+        with torch.no_grad():
+            ktd._head_train(x)
+        assert ktd._pending_backwards == 0
+        pose, shape, cam = ktd._head_train(x)
+        assert ktd._pending_backwards == 1
+        (pose.sum() + shape.sum() + cam.sum()).backward()
+    assert fired == [ktd] and ktd._pending_backwards == 0
+
+
 def test_lane_parallel_chain_kernels_are_bit_identical_to_the_serial_ones(monkeypatch):
     """MAED_TAIL_PARALLEL=1 (ktd_chain_par / ktd_chain_bwd_par / lbs_chain_par): same fmaf chains, spread over lanes -> torch.equal.
     (End-to-end gradients are not compared bitwise: the skinning backward reduces with LDS atomics in thread-arrival order.)"""
