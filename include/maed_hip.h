@@ -58,7 +58,8 @@ typedef enum {
 /* kernel implementation selector for ops that have both */
 typedef enum { MAED_IMPL_AUTO = 0, MAED_IMPL_VALU = 1, MAED_IMPL_MFMA = 2,
                MAED_IMPL_MFMA_GLDS1 = 3, MAED_IMPL_MFMA_GLDS2 = 4, /* gemm_nt only: direct global->LDS staging, 1 or 2 LDS buffers */
-               MAED_IMPL_MFMA_LONG = 5 /* attn_spatial only: K/V-tiled long-sequence kernels (chosen automatically past 512 / 320 tokens) */ } maed_impl;
+               MAED_IMPL_MFMA_LONG = 5, /* attn_spatial only: K/V-tiled long-sequence kernels (chosen automatically past 512 / 320 tokens) */
+               MAED_IMPL_MFMA_256 = 6 /* gemm_nt only: 256x256 tiles, counted-vmcnt LDS-DMA pipeline (csrc/gemm256.hip) */ } maed_impl;
 
 const char* maed_last_error(void);
 int maed_version(void);

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MAED_HIP_LIB") or os.path.join(HERE, "libmaed_hip.so"
 F32, BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID_F32, EPI_MUL_DGELU, EPI_ATOMIC_F32, EPI_STORE_F32, EPI_TANH, EPI_ADD = range(8)
 IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
+IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmaed_hip.so")
-SOURCES = ["layernorm.hip", "gemm.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "elementwise.hip", "block.hip", "smpl.hip", "backbone.hip", "tail_bwd.hip", "loss.hip", "comm.hip", "eval_metrics.hip", "attn_long.hip"]
+SOURCES = ["layernorm.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "elementwise.hip", "block.hip", "smpl.hip", "backbone.hip", "tail_bwd.hip", "loss.hip", "comm.hip", "eval_metrics.hip", "attn_long.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -33,7 +33,7 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.cuh"), os.path.join(os.path.dirname(HERE), "include", "maed_hip.h")]
+    headers = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "gemm_epilogue.cuh"), os.path.join(os.path.dirname(HERE), "include", "maed_hip.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

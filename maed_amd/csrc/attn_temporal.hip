@@ -666,7 +666,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_BLOCKS) void attn_tm_bwd_mfma(cons
 // operand (Q, K, V, dO fragments) is loaded straight from global memory in fragment layout and only the three TRANSPOSED images
 // (Q^T, K^T, dO^T: the A operands of the dQ / dK / dV products) go through LDS: 13.8 KB per workgroup instead of 32.5 KB, i.e. 11
 // resident one-wave workgroups per CU instead of 4 (the general kernel runs at one wave per SIMD at T = 16), and no row-major LDS
-// stores.  Opt-in (MAED_TM_BWD_L32=1): written without GPU access, parity-green on the host simulator.
+// stores.  Default for one-tile problems since it was timed on MI355X (profiles/r02_call1_attn_tm_wide_regs.txt: cfg3 backward 123.0 -> 73.8 us);
+// MAED_TM_BWD_L32=0 switches back to the general kernel (A/B knob).
 // ==================================================================================================
 __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int P, int H,
@@ -817,15 +818,15 @@ static bool launch_tm_bwd_mfma(const void* qkv, const void* o, const void* d_o, 
     }
     const int ngroups = (P + G - 1) / G;
     const dim3 grid((unsigned)((F / Tn) * H * ngroups)), block(64 * (Lk / 32));
-    if (Lk == 32 && maed_env_flag("MAED_TM_BWD_L32", false)) {      // one-tile specialisation (see above): opt-in until timed on hardware
+    if (Lk == 32 && maed_env_flag("MAED_TM_BWD_L32", true)) {       // one-tile specialisation (see above)
         hipLaunchKernelGGL(attn_tm_bwd_mfma_l32, grid, dim3(64), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, accumulate,
                            P, H, Tn, G, ngroups, scale);
         return true;
     }
-    // the spill-free instantiation was written after the round-1 GPU budget was spent: opt-in (MAED_TM_BWD_WIDE_REGS=1) until it has
-    // been timed against the measured default on hardware (scripts/attn_tm_micro.py)
+    // up to four waves per workgroup: the spill-free instantiation (166 VGPRs; measured on MI355X, profiles/r02_call1_attn_tm_wide_regs.txt:
+    // cfg5 T = 64 backward 305.8 -> 215.9 us, cfg3 123.0 -> 90.6 us); MAED_TM_BWD_WIDE_REGS=0 switches back (A/B knob)
     static int wide = -1;
-    if (wide < 0) { const char* ev = getenv("MAED_TM_BWD_WIDE_REGS"); wide = (ev && atoi(ev) != 0) ? 1 : 0; }
+    if (wide < 0) { const char* ev = getenv("MAED_TM_BWD_WIDE_REGS"); wide = (ev && atoi(ev) == 0) ? 0 : 1; }
     if (wide && Lk / 32 <= 4)
         hipLaunchKernelGGL((attn_tm_bwd_mfma<256, 2>), grid, block, lds, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv,
                            accumulate, P, H, Tn, G, ngroups, scale);

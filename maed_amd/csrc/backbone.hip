@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // dgamma[c] += sum_n ab[n][c][1], dbeta[c] += sum_n ab[n][c][0]: the affine gradients are the frame sums of the per-frame partials the
-// reduction pass leaves in `ab` anyway.  Used with MAED_GN_DEFER_AFFINE=1 instead of the 2C atomics every workgroup of the reduction
+// reduction pass leaves in `ab` anyway.  Used (default; MAED_GN_DEFER_AFFINE=0 switches it off) instead of the 2C atomics every workgroup of the reduction
 // pass otherwise sends to the same 2C addresses (~768 workgroups per layer: on the 14x14 and 28x28 layers the serialised atomics,
 // not HBM, set that pass's ~23 us floor -- profiles/r01_rocprofv3_last_step_kernel_sequence_v9.txt).
 __global__ __launch_bounds__(256) void gn_affine_grad_kernel(const float* __restrict__ ab, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C) {
@@ -384,7 +384,9 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
     if (!ab_zeroed) hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
     const bool ymask = relu && dres;
-    const int defer = maed_env_flag("MAED_GN_DEFER_AFFINE", false) ? 1 : 0;     // opt-in until timed on hardware (written without GPU access)
+    // default since it was timed on MI355X (profiles/r02_call2_steady_*.csv: reduction passes 2.15 -> 1.42 ms per step + 0.31 ms closing kernels);
+    // MAED_GN_DEFER_AFFINE=0 switches back to the atomics (A/B knob)
+    const int defer = maed_env_flag("MAED_GN_DEFER_AFFINE", true) ? 1 : 0;
 #define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows, defer)
 #define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, relu_mask, (const T*)dy, \

@@ -193,9 +193,10 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         MAED_PROPAGATE(maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, stream));
         MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
-        // MAED_LN_DEFER_AFFINE=1: LayerNorm dgamma/dbeta via partials in the (bf16-mode-unused) transpose slot -- opt-in until timed on hardware
+        // LayerNorm dgamma/dbeta via partials in the (bf16-mode-unused) transpose slot (measured on MI355X, profiles/r02_call2_steady_*.csv:
+        // 0.629 -> 0.503 + 0.080 ms per step); MAED_LN_DEFER_AFFINE=0 switches back to the atomics (A/B knob)
         const size_t big_t_bytes = (size_t)(Hd > 3 * C ? Hd : 3 * C) * (size_t)Mp * dtype_size(dt);      // S.bigT: only the f32 path transposes into it
-        float* ln_part = (maed_env_flag("MAED_LN_DEFER_AFFINE", false) && maed_layernorm_bwd_partials_bytes(M, C) <= big_t_bytes)
+        float* ln_part = (maed_env_flag("MAED_LN_DEFER_AFFINE", true) && maed_layernorm_bwd_partials_bytes(M, C) <= big_t_bytes)
                              ? (float*)(sc + S.bigT) : nullptr;
         MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
                                              dx_out, dxmid, dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream));

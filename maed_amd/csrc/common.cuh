@@ -12,10 +12,22 @@
 // the two places where kernels speak raw ISA; tests/hostsim (x86 build of the same sources) substitutes no-ops / plain pointers
 #ifdef MAED_HOSTSIM
 #define MAED_WAIT_VMCNT0() do { } while (0)
+#define MAED_WAIT_VMCNT(n) do { } while (0)
+#define MAED_WAIT_LGKMCNT0() do { } while (0)
+#define MAED_LDS_DMA16(base_, voff_, lds_ptr_) __builtin_amdgcn_global_load_lds((const char*)(base_) + (voff_), (void*)(lds_ptr_), 16, 0, 0)
 typedef void maed_lds_void_t;
 typedef const void maed_glb_void_t;
 #else
 #define MAED_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MAED_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")      // counted: the n most recent VMEM operations stay in flight
+#define MAED_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// one LDS-DMA of 16 B per lane in its cheapest form: wave-uniform 64-bit base in SGPRs + 32-bit lane offset, LDS destination = the
+// wave-uniform byte address in M0 (+ lane * 16).  Through the builtin hipcc keeps 64-bit lane pointers (two v_lshl_add_u64 per DMA)
+// and may route the LDS base through v_readfirstlane.  M0 is written in the statement that reads it (it is compiler-reserved and not
+// preserved across statements); hipcc does not count this load: every consumer waits with MAED_WAIT_VMCNT + a barrier.
+#define MAED_LDS_DMA16(base_, voff_, lds_ptr_)                                                                                   \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"                                                 \
+                 :: "v"((uint32_t)(voff_)), "s"((uint32_t)(uintptr_t)(lds_ptr_)), "s"((const char*)(base_)) : "memory")
 typedef __attribute__((address_space(3))) void maed_lds_void_t;
 typedef const __attribute__((address_space(1))) void maed_glb_void_t;
 #endif

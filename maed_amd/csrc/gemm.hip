@@ -10,129 +10,7 @@
 //  * f32 (parity mode): 64x64x16 LDS-tiled VALU kernel, exact fp32 FMA chains.
 // Split-K (grid.z) is available for the atomic weight-gradient epilogue.
 #include "common.cuh"
-
-struct EpiArgs {
-    const float* bias;
-    void* out; int64_t ldo;
-    void* out2;
-    const void* aux; int64_t ldaux;
-};
-
-template <int EPI, typename T>
-__device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int64_t c, float acc) {
-    if constexpr (EPI == MAED_EPI_STORE) {
-        stf((T*)e.out + r * e.ldo + c, acc + (e.bias ? e.bias[c] : 0.f));
-    } else if constexpr (EPI == MAED_EPI_GELU) {
-        const float pre = acc + (e.bias ? e.bias[c] : 0.f);
-        stf((T*)e.out2 + r * e.ldo + c, pre);
-        stf((T*)e.out + r * e.ldo + c, gelu_fwd<T>(round_to<T>(pre)));  // activation of the STORED (rounded) pre-activation
-    } else if constexpr (EPI == MAED_EPI_RESID_F32) {
-        ((float*)e.out)[r * e.ldo + c] = ((const float*)e.aux)[r * e.ldaux + c] + (acc + (e.bias ? e.bias[c] : 0.f));
-    } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
-        stf((T*)e.out + r * e.ldo + c, acc * gelu_bwd<T>(ldf((const T*)e.aux + r * e.ldaux + c)));
-    } else if constexpr (EPI == MAED_EPI_ATOMIC_F32) {
-        atomicAdd((float*)e.out + r * e.ldo + c, acc);
-    } else if constexpr (EPI == MAED_EPI_STORE_F32) {
-        ((float*)e.out)[r * e.ldo + c] = acc + (e.bias ? e.bias[c] : 0.f);
-    } else if constexpr (EPI == MAED_EPI_TANH) {
-        stf((T*)e.out + r * e.ldo + c, tanhf(acc + (e.bias ? e.bias[c] : 0.f)));
-    } else if constexpr (EPI == MAED_EPI_ADD) {
-        stf((T*)e.out + r * e.ldo + c, ldf((const T*)e.aux + r * e.ldaux + c) + acc + (e.bias ? e.bias[c] : 0.f));
-    }
-}
-
-// four consecutive columns c0..c0+3 of one row (c0 % 4 == 0): 8/16-byte accesses when the row base is aligned
-template <int EPI, typename T>
-__device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int64_t c0, int64_t N, const float (&acc)[4], bool vec_ok) {
-    if (!(vec_ok && c0 + 4 <= N)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (c0 + j < N) epilogue_store<EPI, T>(e, r, c0 + j, acc[j]);
-        return;
-    }
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    if constexpr (EPI == MAED_EPI_ATOMIC_F32) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd((float*)e.out + r * e.ldo + c0 + j, v[j]);
-        return;
-    }
-    if constexpr (EPI != MAED_EPI_MUL_DGELU) {
-        if (e.bias) { float b[4]; ld4(e.bias + c0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
-    }
-    if constexpr (EPI == MAED_EPI_STORE) {
-        st4((T*)e.out + r * e.ldo + c0, v);
-    } else if constexpr (EPI == MAED_EPI_GELU) {
-        st4((T*)e.out2 + r * e.ldo + c0, v);
-        // activation of the STORED (rounded) pre-activation, as the backward sees it -- rounded in registers, not read back
-        float a[4] = {gelu_fwd<T>(round_to<T>(v[0])), gelu_fwd<T>(round_to<T>(v[1])), gelu_fwd<T>(round_to<T>(v[2])), gelu_fwd<T>(round_to<T>(v[3]))};
-        st4((T*)e.out + r * e.ldo + c0, a);
-    } else if constexpr (EPI == MAED_EPI_RESID_F32) {
-        float x[4]; ld4((const float*)e.aux + r * e.ldaux + c0, x);
-        float o[4] = {x[0] + v[0], x[1] + v[1], x[2] + v[2], x[3] + v[3]};
-        st4((float*)e.out + r * e.ldo + c0, o);
-    } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
-        float x[4]; ld4((const T*)e.aux + r * e.ldaux + c0, x);
-        float o[4] = {v[0] * gelu_bwd<T>(x[0]), v[1] * gelu_bwd<T>(x[1]), v[2] * gelu_bwd<T>(x[2]), v[3] * gelu_bwd<T>(x[3])};
-        st4((T*)e.out + r * e.ldo + c0, o);
-    } else if constexpr (EPI == MAED_EPI_STORE_F32) {
-        st4((float*)e.out + r * e.ldo + c0, v);
-    } else if constexpr (EPI == MAED_EPI_TANH) {
-        float o[4] = {tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
-        st4((T*)e.out + r * e.ldo + c0, o);
-    } else if constexpr (EPI == MAED_EPI_ADD) {
-        float x[4]; ld4((const T*)e.aux + r * e.ldaux + c0, x);
-        float o[4] = {x[0] + v[0], x[1] + v[1], x[2] + v[2], x[3] + v[3]};
-        st4((T*)e.out + r * e.ldo + c0, o);
-    }
-}
-
-// eight consecutive columns c0..c0+7 of one row (c0 % 8 == 0): 16/32-byte accesses (the LDS-shuffled epilogue of the
-// direct-to-LDS kernels: 8 lanes cover a 64-column row segment = one or two full cache lines per row)
-template <int EPI, typename T>
-__device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int64_t c0, int64_t N, const float (&acc)[8], bool vec_ok) {
-    if (!(vec_ok && c0 + 8 <= N)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (c0 + j < N) epilogue_store<EPI, T>(e, r, c0 + j, acc[j]);
-        return;
-    }
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = acc[j];
-    if constexpr (EPI != MAED_EPI_MUL_DGELU) {
-        if (e.bias) { float b[8]; ld8(e.bias + c0, b);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += b[j]; }
-    }
-    if constexpr (EPI == MAED_EPI_STORE) {
-        st8((T*)e.out + r * e.ldo + c0, v);
-    } else if constexpr (EPI == MAED_EPI_GELU) {
-        st8((T*)e.out2 + r * e.ldo + c0, v);
-        float a[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = gelu_fwd<T>(round_to<T>(v[j]));   // activation of the STORED (rounded) pre-activation
-        st8((T*)e.out + r * e.ldo + c0, a);
-    } else if constexpr (EPI == MAED_EPI_RESID_F32) {
-        float x[8]; ld8((const float*)e.aux + r * e.ldaux + c0, x);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] += v[j];
-        st8((float*)e.out + r * e.ldo + c0, x);
-    } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
-        float x[8]; ld8((const T*)e.aux + r * e.ldaux + c0, x);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = v[j] * gelu_bwd<T>(x[j]);
-        st8((T*)e.out + r * e.ldo + c0, x);
-    } else if constexpr (EPI == MAED_EPI_STORE_F32) {
-        st8((float*)e.out + r * e.ldo + c0, v);
-    } else if constexpr (EPI == MAED_EPI_TANH) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = tanhf(v[j]);
-        st8((T*)e.out + r * e.ldo + c0, v);
-    } else if constexpr (EPI == MAED_EPI_ADD) {
-        float x[8]; ld8((const T*)e.aux + r * e.ldaux + c0, x);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] += v[j];
-        st8((T*)e.out + r * e.ldo + c0, x);
-    }
-}
+#include "gemm_epilogue.cuh"
 
 // ------------------------------------------------------------------------------------------------
 // VALU kernel (any T; used for f32 and as the cross-check for the MFMA kernel)
@@ -192,13 +70,6 @@ __global__ __launch_bounds__(256) void gemm_nt_valu_kernel(const T* __restrict__
 #define GM_BN 128
 #define GM_BK 64
 #define GM_LD 72  // padded LDS row (elements): 144 B = 9 x 16-B slots, 9 coprime with 16 -> conflict-free b128
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // bijective remap: blocks that the dispatcher places on XCD x (bid % 8 == x) get a contiguous id range
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (bid >> 3);
-}
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* __restrict__ A, int64_t lda,
@@ -325,20 +196,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* _
 //   NBUF == 1: 32 KB LDS, <=128 VGPRs -> 4 workgroups per CU, latency hidden by the other workgroups
 //   NBUF == 2: 64 KB LDS, tile t+1 lands while tile t is multiplied, one barrier per K tile
 // ------------------------------------------------------------------------------------------------
-#define GL_ST 68   // fp32 row stride of the epilogue staging area: 272 B -> conflict-free ds_write_b128 per 16-lane group
-typedef maed_lds_void_t lds_void_t;
-typedef maed_glb_void_t glb_void_t;
 
 template <int EPI, int NBUF>
 __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                                      const bf16* __restrict__ B, int64_t ldb, int64_t M,
                                                                                      int64_t N, int64_t K, int tiles_n,
-                                                                                     int ktiles_per_split, EpiArgs e) {
+                                                                                     int ktiles_per_split, EpiArgs e
+#ifdef MAED_GEMM_ABLATE
+                                                                                     , int ablate    // diagnostic build only (scripts/gemm_ablate.sh): 1 no stores, 2 no loads, 4 no MFMA
+#endif
+                                                                                     ) {
+#ifndef MAED_GEMM_ABLATE
+    constexpr int ablate = 0;
+#endif
     // operand tiles [NBUF][A|B][128*64] bf16; re-used by the epilogue as 4 per-wave fp32 staging areas of 32 rows x 68 floats
     constexpr int kTileElems = NBUF * 2 * GM_BM * GM_BK, kStageElems = 4 * 32 * GL_ST * 2;     // in 2-byte units
     __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kTileElems > kStageElems ? kTileElems : kStageElems];
     unsigned short (*lds)[2][GM_BM * GM_BK] = reinterpret_cast<unsigned short (*)[2][GM_BM * GM_BK]>(lds_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations (M0) stay on the SALU
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     const int nwg = gridDim.x;
@@ -350,22 +226,27 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
     if (kt_end > nkt_total) kt_end = nkt_total;
     if (kt_beg >= kt_end) return;
 
-    // staging: round i = 0..3, this wave fills rows (4i + wave)*8 .. +7; (row>>1)&7 = (4*wave + (lane>>4)) & 7 for every round
+    // staging: round i = 0..3, this wave fills rows (4i + wave)*8 .. +7; (row>>1)&7 = (4*wave + (lane>>4)) & 7 for every round.
+    // LDS-DMA in its cheapest form (MAED_LDS_DMA16): scalar base (operand + K offset) + 32-bit lane BYTE offset (host-checked < 4 GB),
+    // LDS destination from a scalar wave id -- no VALU and no v_readfirstlane per DMA (8 DMAs per 16 MFMAs in this kernel).
     const int srow = wave * 8 + (lane >> 3);                                        // + 32*i
     const int schunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
 #define GL_PTRS(i)                                                                              \
-    const bf16* gap##i; const bf16* gbp##i;                                                     \
+    uint32_t gao##i, gbo##i;                                                                    \
     {                                                                                           \
         const int row = srow + 32 * i;                                                          \
         const int64_t ar = (m0 + row < M) ? m0 + row : M - 1;                                   \
         const int64_t br = (n0 + row < N) ? n0 + row : N - 1;                                   \
-        gap##i = A + ar * lda + schunk * 8; gbp##i = B + br * ldb + schunk * 8;                 \
+        gao##i = (uint32_t)((ar * lda + schunk * 8) * 2); gbo##i = (uint32_t)((br * ldb + schunk * 8) * 2); \
     }
     GL_PTRS(0) GL_PTRS(1) GL_PTRS(2) GL_PTRS(3)
-#define GL_ISSUE1(i, buf_, k0__)                                                                                                         \
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(gap##i + k0__), (lds_void_t*)&lds[buf_][0][(4 * i + wave) * 8 * GM_BK], 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(gbp##i + k0__), (lds_void_t*)&lds[buf_][1][(4 * i + wave) * 8 * GM_BK], 16, 0, 0);
-#define GL_ISSUE_TILE(buf_, kt_) { const int64_t k0__ = (int64_t)(kt_) * GM_BK; GL_ISSUE1(0, buf_, k0__) GL_ISSUE1(1, buf_, k0__) GL_ISSUE1(2, buf_, k0__) GL_ISSUE1(3, buf_, k0__) }
+    const char* const Ab = reinterpret_cast<const char*>(A);
+    const char* const Bb = reinterpret_cast<const char*>(B);
+#define GL_ISSUE1(i, buf_, ak__, bk__)                                          \
+    MAED_LDS_DMA16(ak__, gao##i, &lds[buf_][0][(4 * i + wave) * 8 * GM_BK]);    \
+    MAED_LDS_DMA16(bk__, gbo##i, &lds[buf_][1][(4 * i + wave) * 8 * GM_BK]);
+#define GL_ISSUE_TILE(buf_, kt_) if (!(ablate & 2)) { const char* const ak__ = Ab + (int64_t)(kt_) * (GM_BK * 2); const char* const bk__ = Bb + (int64_t)(kt_) * (GM_BK * 2); \
+        GL_ISSUE1(0, buf_, ak__, bk__) GL_ISSUE1(1, buf_, ak__, bk__) GL_ISSUE1(2, buf_, ak__, bk__) GL_ISSUE1(3, buf_, ak__, bk__) }
 
     constexpr bool TR = (EPI != MAED_EPI_ATOMIC_F32);
     f32x16_t acc00, acc01, acc10, acc11;
@@ -373,7 +254,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
     const int fsw = (l31 >> 1) & 7;                                                 // swizzle term of this lane's fragment rows
 #define GL_COMPUTE_TILE(buf_)                                                                              \
-    {                                                                                                      \
+    if (!(ablate & 4)) {                                                                                   \
         const unsigned short* As = &lds[buf_][0][(wr * 64 + l31) * GM_BK];                                 \
         const unsigned short* Bs = &lds[buf_][1][(wc * 64 + l31) * GM_BK];                                 \
         _Pragma("unroll") for (int kk = 0; kk < GM_BK / 16; ++kk) {                                        \
@@ -444,7 +325,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
             const int64_t row = m0 + wr * 64 + (i_) * 32 + lr, c0 = n0 + wc * 64 + cc;                                 \
             float v8[8];                                                                                               \
             ld8(stg + lr * GL_ST + cc, v8);                                                                            \
-            if (row < M && c0 < N) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);                              \
+            if (row < M && c0 < N && !(ablate & 1)) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);             \
         }
         GL_SHUFFLE_HALF(acc00, acc01, 0)
         GL_SHUFFLE_HALF(acc10, acc11, 1)
@@ -459,8 +340,8 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
 // A-operand rows are GATHERED: every lane of the LDS-DMA computes its own source address, so "im2col" costs nothing -- for K tile
 // kt the tap is (kt*64)/Cin (Cin % 64 == 0: a K tile never straddles taps), and a lane whose shifted pixel falls outside the image
 // points at a 128-byte page of zeros instead (TF-SAME zero padding, any stride).  The input gradient of a stride-1 convolution is
-// the same kernel on dY with the flipped, transposed weight image.  Opt-in (MAED_CONV3X3=own in resnetv2.py): written after the
-// round-1 GPU budget was spent, verified on the host simulator only.
+// the same kernel on dY with the flipped, transposed weight image.  Default path of the backbone since it was timed against MIOpen
+// on MI355X (resnetv2.py; profiles/r02_call1_conv3x3_micro.txt).
 // ------------------------------------------------------------------------------------------------
 // B (weight) addressing: element (n, tap, c) of the GEMM's B operand lives at Wt[b_base + tap * b_tap + n * b_row + c]
 struct Conv3x3Dims { int F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left; int64_t b_row, b_tap, b_base; };
@@ -624,10 +505,20 @@ static int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, i
     int kps = (nkt + splitk - 1) / splitk;
     if (kps < 1) kps = 1;
     const int z = (nkt + kps - 1) / kps;
+#ifdef MAED_GEMM_ABLATE
+    const char* ev = getenv("MAED_GEMM_ABLATE");
+    hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
+                       (const bf16*)B, ldb, M, N, K, tn, kps, e, ev ? atoi(ev) : 0);
+#else
     hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
                        (const bf16*)B, ldb, M, N, K, tn, kps, e);
+#endif
     return MAED_OK;
 }
+
+// csrc/gemm256.hip: 256x256 tiles with the counted-vmcnt LDS-DMA pipeline
+bool maed_gemm_nt_256_launch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e,
+                             hipStream_t s);
 
 template <int EPI>
 static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype,
@@ -636,12 +527,20 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         MAED_CHECK_ARG(impl != MAED_IMPL_MFMA, MAED_ERR_UNSUPPORTED, "gemm_nt: f32 has no MFMA path (exact-f32 VALU kernel)");
         return launch_valu<EPI, float>(A, lda, B, ldb, M, N, K, e, splitk, s);
     }
+    // (the direct-to-LDS kernels address the operands with 32-bit lane byte offsets from a scalar base)
+    const bool fits32 = (uint64_t)M * (uint64_t)lda * 2 < (1ull << 32) && (uint64_t)N * (uint64_t)ldb * 2 < (1ull << 32);
     const bool mfma_ok = (K % GM_BK == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && is_aligned(A, 16) && is_aligned(B, 16);
     if (impl == MAED_IMPL_VALU) return launch_valu<EPI, bf16>(A, lda, B, ldb, M, N, K, e, splitk, s);
     if (impl == MAED_IMPL_MFMA_GLDS1 || impl == MAED_IMPL_MFMA_GLDS2) {
-        MAED_CHECK_ARG(mfma_ok, MAED_ERR_ALIGN, "gemm_nt(glds): need K%%64==0 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B", (long long)K);
+        MAED_CHECK_ARG(mfma_ok && fits32, MAED_ERR_ALIGN, "gemm_nt(glds): need K%%64==0 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B", (long long)K);
         return impl == MAED_IMPL_MFMA_GLDS1 ? launch_glds<EPI, 1>(A, lda, B, ldb, M, N, K, e, splitk, s)
                                             : launch_glds<EPI, 2>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    }
+    const bool ok256 = mfma_ok && fits32 && K >= 128 && splitk == 1 && EPI != MAED_EPI_ATOMIC_F32;
+    if (impl == MAED_IMPL_MFMA_256) {
+        MAED_CHECK_ARG(ok256, MAED_ERR_ALIGN, "gemm_nt(256): need K%%64==0, K>=128 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B, no split-K", (long long)K);
+        maed_gemm_nt_256_launch(EPI, A, lda, B, ldb, M, N, K, e, s);
+        return MAED_OK;
     }
     if (impl == MAED_IMPL_MFMA) {
         MAED_CHECK_ARG(mfma_ok, MAED_ERR_ALIGN, "gemm_nt(mfma): need K%%64==0 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B", (long long)K);
@@ -652,8 +551,19 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
     // epilogue the one-buffer kernel at 4 workgroups per CU wins or ties for every epilogue (fc1+GELU 110 vs 128 us, GELU'
     // 92 vs 112 us); the two-buffer kernel stays selectable (MAED_IMPL_MFMA_GLDS2); the split-K atomic epilogue keeps the
     // register-staged kernel
+    // 256x256 pipelined tiles (gemm256.hip) where they measure faster (profiles/r02_gemm_tile_variants.txt): long K (fc2 85 -> 64 us,
+    // d(qkv) 66 -> 47 us, 4096^3 964 -> 1250 TFLOP/s), or a grid that fits the chip in one round (proj 34 -> 32 us); with K = 512 and
+    // many tiles (qkv, fc1) the four 128x128 workgroups per CU overlap their prologues / epilogues better than one 256x256 workgroup.
+    // Never when the 256x256 grid would leave most CUs idle (stage-3 1x1 convolutions: 98 tiles).
+    if constexpr (EPI != MAED_EPI_ATOMIC_F32) {
+        const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+        if (ok256 && N >= 256 && tiles256 >= 180 && (K >= 1024 || tiles256 <= 256)) {
+            maed_gemm_nt_256_launch(EPI, A, lda, B, ldb, M, N, K, e, s);
+            return MAED_OK;
+        }
+    }
     if constexpr (EPI == MAED_EPI_ATOMIC_F32) return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
-    else return launch_glds<EPI, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    else return fits32 ? launch_glds<EPI, 1>(A, lda, B, ldb, M, N, K, e, splitk, s) : launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
 }
 
 extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // PARTIALS: instead of 2C atomics per workgroup onto the same 2C addresses (788 workgroups at cfg3: ~25k atomics per cache line, a
 // serial tail of ~20 us after ~31 us of streaming), every workgroup stores its column sums to row blockIdx.x of `dg` ([nwg][2C],
-// dgamma | dbeta) and ln_affine_finish_kernel adds the column totals to the gradients.  Opt-in (MAED_LN_DEFER_AFFINE=1, block.hip).
+// dgamma | dbeta) and ln_affine_finish_kernel adds the column totals to the gradients.  Default inside the fused block (block.hip; MAED_LN_DEFER_AFFINE=0 switches it off).
 template <typename T, int NV, bool PARTIALS = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ g, const float* __restrict__ mean_i,

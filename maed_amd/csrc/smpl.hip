@@ -54,9 +54,10 @@ __global__ __launch_bounds__(64) void ktd_chain_par_kernel(const float* __restri
         for (int i = o; i < NJ * 6; i += 8) pose[(int64_t)f * NJ * 6 + i] = ps[fs][i];
 }
 
-// MAED_TAIL_PARALLEL=1 selects the lane-parallel chain kernels (written after the round-1 GPU budget was spent; bit-identical to the
-// serial ones on the host simulator, not yet timed on hardware)
-static bool tail_parallel() { return maed_env_flag("MAED_TAIL_PARALLEL", false); }   // read per call: a getenv, three times per step
+// The lane-parallel chain kernels are the default since they were timed on MI355X (profiles/r02_call2_steady_*.csv: the four chain kernels
+// 0.44 ms -> 0.1 ms per step); MAED_TAIL_PARALLEL=0 selects the thread-per-frame ones (A/B knob; the two are bit-identical,
+// tests/test_hostsim_tail.py)
+static bool tail_parallel() { return maed_env_flag("MAED_TAIL_PARALLEL", true); }   // read per call: a getenv, three times per step
 
 extern "C" int maed_ktd_chain_fwd(const float* base, const float* w_anc, float* pose, int F, void* stream) {
     MAED_CHECK_ARG(base && w_anc && pose, MAED_ERR_ARG, "ktd_chain_fwd: null pointer");
@@ -169,7 +170,7 @@ __global__ void lbs_chain_kernel(maed_smpl_params sp, const float* __restrict__ 
     }
 }
 
-// lane-parallel variant (MAED_TAIL_PARALLEL=1): 16 lanes per frame, 4 frames per workgroup, J / Rw / tw in LDS.  The 72 rest-pose
+// lane-parallel variant (default; MAED_TAIL_PARALLEL=0 = thread per frame): 16 lanes per frame, 4 frames per workgroup, J / Rw / tw in LDS.  The 72 rest-pose
 // joint coordinates, the 12 outputs of each joint's transform and the 24 x 15 outputs are spread over the lanes; every scalar is
 // produced by the same expression as in lbs_chain_kernel (bit-identical), the tree is still walked joint by joint (any parent table).
 #define LC_FPB 4

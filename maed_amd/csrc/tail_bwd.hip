@@ -222,7 +222,7 @@ __global__ void smpl_chain_bwd_kernel(maed_smpl_params sp, const float* __restri
     }
 }
 
-// lane-parallel variant (MAED_TAIL_PARALLEL=1): 32 lanes per frame, 2 frames per workgroup, all chain state in LDS (2.9 KB per frame
+// lane-parallel variant (default; MAED_TAIL_PARALLEL=0 = thread per frame): 32 lanes per frame, 2 frames per workgroup, all chain state in LDS (2.9 KB per frame
 // that the kernel above keeps in scratch).  Every scalar is produced by the expression the serial kernel uses, joints are still
 // visited one after another where the recurrence requires it (children accumulate into their parent in the same order), so the
 // results are bit-identical; what runs in parallel are the independent outputs of each step.
@@ -320,7 +320,7 @@ extern "C" int maed_smpl_chain_bwd(const maed_smpl_params* sp, const float* beta
     MAED_CHECK_ARG(sp && betas && rotmat && dA && d_joints24 && dpf_dbeta && d_rotmat && d_betas, MAED_ERR_ARG, "smpl_chain_bwd: null pointer");
     MAED_CHECK_ARG(sp->J_template && sp->J_shapedirs && sp->parents, MAED_ERR_ARG, "smpl_chain_bwd: null SMPL parameter");
     if (F <= 0) return MAED_OK;
-    if (maed_env_flag("MAED_TAIL_PARALLEL", false))
+    if (maed_env_flag("MAED_TAIL_PARALLEL", true))
         hipLaunchKernelGGL(smpl_chain_bwd_par_kernel, dim3((F + SC_FPB - 1) / SC_FPB), dim3(64), 0, (hipStream_t)stream, *sp, betas, rotmat, dA,
                            d_joints24, dpf_dbeta, d_rotmat_in, d_betas_in, betas_in_stride, d_rotmat, d_betas, F);
     else
@@ -429,7 +429,7 @@ __global__ void ktd_chain_bwd_kernel(const float* __restrict__ w_anc, const floa
     for (int i = 0; i < 3; ++i) o[154 + i] = d_cam ? d_cam[(int64_t)f * 3 + i] : 0.f;
 }
 
-// lane-parallel variant (MAED_TAIL_PARALLEL=1): 16 lanes per frame, 4 frames per workgroup, g in LDS.  The 6*n_anc(j) gradient
+// lane-parallel variant (default; MAED_TAIL_PARALLEL=0 = thread per frame): 16 lanes per frame, 4 frames per workgroup, g in LDS.  The 6*n_anc(j) gradient
 // elements joint j feeds (distinct (ancestor, i) pairs) are updated by different lanes with the serial kernel's fmaf chain over o.
 #define KB_FPB 4
 __global__ __launch_bounds__(64) void ktd_chain_bwd_par_kernel(const float* __restrict__ w_anc, const float* __restrict__ d_pose,
@@ -487,7 +487,7 @@ extern "C" int maed_ktd_chain_bwd(const float* pose, const float* w_anc, const f
     MAED_CHECK_ARG(pose && w_anc && d_pose && d_out && d_w_anc && d_b_feat, MAED_ERR_ARG, "ktd_chain_bwd: null pointer");
     MAED_CHECK_ARG(ld_out >= KTD_OUT, MAED_ERR_SHAPE, "ktd_chain_bwd: ld_out=%lld < 157", (long long)ld_out);
     hipStream_t s = (hipStream_t)stream;
-    const bool parallel = maed_env_flag("MAED_TAIL_PARALLEL", false);
+    const bool parallel = maed_env_flag("MAED_TAIL_PARALLEL", true);
     if (F > 0 && parallel)
         hipLaunchKernelGGL(ktd_chain_bwd_par_kernel, dim3((F + KB_FPB - 1) / KB_FPB), dim3(64), 0, s, w_anc, d_pose, d_shape, d_cam, d_out, ld_out, F);
     else if (F > 0)

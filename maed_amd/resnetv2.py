@@ -23,17 +23,30 @@ import torch.nn.functional as F
 from . import ops
 
 
-# MAED_CONV3X3=own: the 3x3 convolutions on the library's implicit-GEMM kernel (ops.Conv3x3Fn).  Written after the round-1 GPU budget
-# was spent -- parity-green on the host simulator, not yet timed on hardware -- so the measured MIOpen path stays the default.
-_OWN_CONV3X3 = os.environ.get("MAED_CONV3X3", "miopen") == "own"
+# The 3x3 convolutions run on the library's implicit-GEMM kernel (ops.Conv3x3Fn): measured against MIOpen on MI355X at the cfg3 layer
+# shapes (profiles/r02_call1_conv3x3_micro.txt) forward 0.79 vs 1.71 ms, input gradient 0.66 vs 1.29 ms, weight gradient 1.09 vs
+# 1.44 ms per step; the train step 28.14 -> 26.38 ms.  MAED_CONV3X3=miopen switches back (A/B knob).
+_OWN_CONV3X3 = os.environ.get("MAED_CONV3X3", "own") == "own"
 
 
 # MAED_WS_PER_STAGE=1: weight standardisation launched per backbone stage, right before the stage runs, instead of once for all 53
 # convolutions.  Single-GPU cost: two more (tiny) launches per direction.  Purpose: data-parallel overlap -- a stage's convolution
 # weight gradients become final, and its gradient bucket starts its all-reduce, as soon as THAT stage's backward is done; with one
 # batched launch the whole backbone (47 MB at cfg3) is reported only by the very last kernel of the backward and reduced un-overlapped.
-# Written without GPU access: opt-in until it has run on hardware (logic covered on the simulator + gloo, tests/test_hostsim_resnet.py).
-_WS_PER_STAGE = os.environ.get("MAED_WS_PER_STAGE", "0") == "1"
+# Measured on one MI355X (profiles/r02_call2_steady_*.csv): +0.13 ms per step (ws_fwd 0.143 -> 0.160, ws_bwd 0.099 -> 0.145 ms, two more
+# fills).  Default "auto": per stage when the process is one rank of a data-parallel job (torch.distributed initialised with world > 1),
+# one batched launch otherwise; MAED_WS_PER_STAGE=0 / 1 forces either.
+_WS_PER_STAGE_ENV = os.environ.get("MAED_WS_PER_STAGE", "auto")
+
+
+def _ws_per_stage():
+    if _WS_PER_STAGE is not None:
+        return _WS_PER_STAGE
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+_WS_PER_STAGE = None if _WS_PER_STAGE_ENV == "auto" else _WS_PER_STAGE_ENV == "1"     # (tests monkeypatch this to True / False)
 
 
 class _WsGroup:
@@ -96,7 +109,7 @@ class StdConv2dSame(nn.Conv2d):
         assert not fork
         if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and x.dtype == torch.bfloat16
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and self.dilation == (1, 1) and self.groups == 1):
-            # opt-in (MAED_CONV3X3=own): implicit-GEMM forward / stride-1 input gradient on libmaed_hip instead of MIOpen
+            # implicit-GEMM forward / stride-1 input gradient on libmaed_hip instead of MIOpen
             # (_w_t / _dw: transposed image and fp32 dW slice from WeightStdFn for the stride-1 ones, see ResNetV2._own3x3)
             return ops.Conv3x3Fn.apply(x, w, self.stride[0], self._w_t, self._dw)
         if w is None:  # stand-alone use / CPU: per-conv ATen composition
@@ -266,7 +279,7 @@ class ResNetV2(nn.Module):
         if not ops.on_library_device(x):
             return self.stages(self.stem(x))
         x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
-        ws = None if _WS_PER_STAGE else ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
+        ws = None if _ws_per_stage() else ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
         # GroupNorm scratch for all layers of this pass: ONE zero-fill each instead of a memset per layer and direction
         N = x.shape[0]
         sums = torch.zeros(len(self._norms), N, 32, 2, dtype=torch.float64, device=x.device)

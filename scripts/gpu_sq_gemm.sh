@@ -1,22 +1,24 @@
 #!/bin/bash
+# SQ counters of one NT GEMM shape / implementation:   gpu_sq_gemm.sh [shape=qkv] [impl=0] [kernel-name substring]
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$(pwd); mkdir -p gpurun_out/pmc; export TMPDIR=/tmp
-python scripts/gemm_micro.py 30 | tee gpurun_out/pmc/gemm_micro.txt
+SHAPE=${1:-qkv}; IMPL=${2:-0}; KNAME=${3:-gemm_nt}
 run() { tag=$1; shift; rm -rf /tmp/pmc_$tag
-  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -o g -- python "$ROOT/scripts/gemm_micro.py" 5 qkv > "$ROOT/gpurun_out/pmc/$tag.log" 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -o g -- python "$ROOT/scripts/gemm_micro.py" 5 $SHAPE $IMPL > "$ROOT/gpurun_out/pmc/$tag.log" 2>&1)
   f=$(find /tmp/pmc_$tag -name "*counter_collection.csv" | head -1)
   [ -z "$f" ] && { echo "$tag: no output"; tail -3 "$ROOT/gpurun_out/pmc/$tag.log"; return; }
-  python - "$f" <<'PY'
+  python - "$f" "$KNAME" <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "gemm_nt_mfma" in r.get("Kernel_Name", ""):
+    if sys.argv[2] in r.get("Kernel_Name", ""):
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
     print(f"  {k:28s} mean {sum(v) / len(v):16.1f}  (n={len(v)})")
 PY
 }
+echo "== $SHAPE impl $IMPL"
 run g1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
 run g2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
-run g3 SQ_LDS_IDX_ACTIVE SQ_WAVES FETCH_SIZE
+run g3 SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM

@@ -222,6 +222,8 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t src0, uint32_t src1, uint3
     return r;
 }
 static inline void __builtin_amdgcn_s_barrier() { hostsim::t_block->bar.arrive_and_wait(); }
+static inline void __builtin_amdgcn_s_setprio(int) {}          // scheduling hints: nothing to simulate
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }

@@ -82,3 +82,29 @@ def test_gemm_tn_wgrad_and_bias(M, N, K):
         ops.gemm_tn_wgrad(Y, X, dW=dW, dbias=db)          # ACCUMULATES into dW / dbias
     assert torch.allclose(dW, dW0 + Y.float().t() @ X.float(), rtol=1e-4, atol=1e-3)
     assert torch.allclose(db, db0 + Y.float().sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (256, 256, 192), (70, 512, 320)])
+def test_gemm_nt_256_pipelined_tiles(M, N, K):
+    """csrc/gemm256.hip (256x256x64 tiles, half-tile LDS-DMA ring, staggered wave groups): slot / fragment / swizzle indexing, ragged M
+    and N edges, 2, 3 and 5 K tiles (even and odd tile counts: both drains) against torch on the bf16-rounded operands.  The
+    simulator lands an LDS-DMA when it is issued, i.e. EARLIER than hardware: a DMA that re-targets a slot too soon after its last
+    read shows up here as wrong numbers; landing too late is what the GPU tests are for."""
+    A, B, bias = rnd(M, K, seed=21).bfloat16(), rnd(N, K, seed=22, scale=K ** -0.5).bfloat16(), rnd(N, seed=23)
+    ref = A.float() @ B.float().t() + bias
+    with patched():
+        out = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias, impl=L.IMPL_MFMA_256)
+    assert (out.float() - ref).abs().max() <= 2 * 2 ** -8 * ref.abs().max() + 1e-2
+
+
+def test_gemm_nt_256_epilogues_and_transpose_detection():
+    M, N, K = 260, 256, 128
+    A, B, bias = rnd(M, K, seed=24).bfloat16(), rnd(N, K, seed=25, scale=K ** -0.5).bfloat16(), rnd(N, seed=26)
+    acc = A.float() @ B.float().t()
+    aux = rnd(M, N, seed=27)
+    with patched():
+        out = ops.gemm_nt(A, B, L.EPI_RESID_F32, bias=bias, aux=aux, impl=L.IMPL_MFMA_256)
+        act, pre = ops.gemm_nt(A, B, L.EPI_GELU, bias=bias, impl=L.IMPL_MFMA_256)
+    assert torch.allclose(out, aux + acc + bias, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(pre.float(), (acc + bias).bfloat16().float(), atol=2e-2) and torch.allclose(act.float(), gelu(pre.float()), rtol=2e-2, atol=2e-2)
+
