@@ -58,7 +58,8 @@ def test_layernorm_strided_rows():
 
 
 # ---------------------------------------------------------------------------------------------
-GEMM_CASES = [("f32-valu", torch.float32, 1), ("bf16-valu", torch.bfloat16, 1), ("bf16-mfma", torch.bfloat16, 2)]
+GEMM_CASES = [("f32-valu", torch.float32, 1), ("bf16-valu", torch.bfloat16, 1), ("bf16-mfma", torch.bfloat16, 2), ("bf16-auto", torch.bfloat16, 0),
+              ("bf16-glds1", torch.bfloat16, 3)]
 
 
 @pytest.mark.parametrize("name,dtype,impl", GEMM_CASES)
@@ -92,6 +93,50 @@ def test_gemm_epilogues(name, dtype, impl, M, N, K):
     splitk = 4 if K >= 256 else 1
     ops.gemm_nt(Ad, Bd, L.EPI_ATOMIC_F32, out=acc, splitk=splitk, impl=impl)
     report(f"gemm[{name},ATOMIC_F32,splitk={splitk}]", acc, acc0.cpu().double() + ref, rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (197 * 8, 512, 192), (1000, 1536, 512), (777, 256, 2048), (256, 512, 320)])
+def test_gemm_256_pipelined_tiles(M, N, K):
+    """csrc/gemm256.hip (256x256x64 tiles, half-tile LDS-DMA ring with counted vmcnt, staggered wave groups) against the fp64 oracle and
+    BITWISE against the 128x128 kernel (same k order, fp32 accumulation): ragged M / N edges, 2 ... 32 K tiles, even and odd tile counts
+    (both drains), every fused epilogue it carries."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    A, B = q(rnd(M, K, seed=11), dtype), q(rnd(N, K, seed=12, scale=K ** -0.5), dtype)
+    bias = rnd(N, seed=13)
+    Ad, Bd, bd = A.to(DEV).to(dtype), B.to(DEV).to(dtype), bias.to(DEV)
+    ref = A.double() @ B.double().t()
+    t = tol(dtype, 2)
+    out = ops.gemm_nt(Ad, Bd, L.EPI_STORE, bias=bd, impl=L.IMPL_MFMA_256)
+    report(f"gemm256[STORE,{M}x{N}x{K}]", out.float(), ref + bias.double(), **t)
+    assert torch.equal(out, ops.gemm_nt(Ad, Bd, L.EPI_STORE, bias=bd, impl=3))
+    res = rnd(M, N, seed=14)
+    out = ops.gemm_nt(Ad, Bd, L.EPI_RESID_F32, bias=bd, aux=res.to(DEV), impl=L.IMPL_MFMA_256)
+    report("gemm256[RESID_F32]", out, ref + bias.double() + res.double(), rtol=2e-5, atol=1e-4)
+    act, pre = ops.gemm_nt(Ad, Bd, L.EPI_GELU, bias=bd, impl=L.IMPL_MFMA_256)
+    report("gemm256[GELU.pre]", pre.float(), ref + bias.double(), **t)
+    report("gemm256[GELU.act]", act.float(), R.gelu(pre.float().cpu().double()), **t)
+    pre_in = q(rnd(M, N, seed=15), dtype)
+    out = ops.gemm_nt(Ad, Bd, L.EPI_MUL_DGELU, aux=pre_in.to(DEV).to(dtype), impl=L.IMPL_MFMA_256)
+    assert torch.equal(out, ops.gemm_nt(Ad, Bd, L.EPI_MUL_DGELU, aux=pre_in.to(DEV).to(dtype), impl=3))
+    out = ops.gemm_nt(Ad, Bd, L.EPI_STORE_F32, bias=bd, impl=L.IMPL_MFMA_256)
+    report("gemm256[STORE_F32]", out, ref + bias.double(), rtol=2e-5, atol=1e-4)
+
+
+def test_gemm_256_race_screen_at_cfg3_shapes():
+    """the benchmarked shapes (M = 128 frames x 197 tokens): 25 back-to-back launches each, every one bit-identical to the 128x128 kernel's
+    result.  A screen, not a proof -- the reads are placed by the vmcnt / barrier count (gemm256.hip header) -- but an LDS-DMA landing late
+    or a slot re-targeted early shows up here as a differing tile."""
+    ops, L = _ops()
+    M = 128 * 197
+    for N, K in [(512, 2048), (512, 1536), (512, 512), (1536, 512)]:
+        A = (torch.randn(M, K, device=DEV, generator=torch.Generator(device=DEV).manual_seed(K + N))).bfloat16()
+        B = (torch.randn(N, K, device=DEV, generator=torch.Generator(device=DEV).manual_seed(N)) * K ** -0.5).bfloat16()
+        want = ops.gemm_nt(A, B, L.EPI_STORE, impl=3)
+        bad = 0
+        for _ in range(25):
+            bad += int(not torch.equal(ops.gemm_nt(A, B, L.EPI_STORE, impl=L.IMPL_MFMA_256), want))
+        assert bad == 0, f"{bad}/25 launches of the 256x256 kernel differ at N={N} K={K}"
 
 
 def test_gemm_mfma_rejects_bad_k():
