@@ -9,9 +9,10 @@ batch of synthetic clips resident in HBM: BASELINE.json cfg3/cfg4 -- per GPU 8 c
 STE depth 6 / heads 8 / dim 512, KTD hidden 1024, bf16 compute with fp32 master weights and fp32
 residual stream.  Weak scaling: per-GPU batch fixed, value = (N * 8 clips) / max-over-ranks step time.
 Rank 0 prints ONE JSON line.  It also carries
-  roofline     : the STE spatial-attention forward kernel (the kernel north_star names), timed in situ with
-                 hipEvents on the launch stream (maed_prof_*), against its HBM roofline; the MFMA view and the
-                 other instrumented kernels are under "kernels".
+  roofline     : the step's dominant kernel family by time -- the bf16 NT GEMMs -- timed in situ with hipEvents on the
+                 launch stream (maed_prof_*), summed over every instrumented launch, against the dense bf16 MFMA peak;
+                 roofline_attention = the STE spatial-attention forward kernel north_star names (HBM roofline + MFMA
+                 view), roofline_wgrad = the weight-gradient GEMMs; per-shape numbers under "kernels".
   cpu_baseline : the CPU oracle (restatement of the reference's PyTorch CPU path, pinned to the reference by
                  tests/golden) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -116,6 +117,29 @@ def cpu_baseline(budget_s=25.0):
                        f"oracle/maed_ref.py on torch CPU ops, {cores} threads (of {os.cpu_count()} logical CPUs)", s_per_step=dt)
 
 
+def parity_probe(dev):
+    """part of the cpu_baseline leg (the only place bench.py may touch oracle/): the product's forward in both compute modes against the
+    CPU oracle on one small seeded clip (2 clips x 4 frames x 64^2, depth 2, dim 128) -- the error the measured mode carries, next to the
+    throughput it buys.  rel = max |out - oracle| / max |oracle| per output."""
+    import maed_amd
+    from oracle import maed_ref as R
+    depth, H, img, hidden = 2, 2, 64, 64
+    C = 64 * H
+    params = R.make_params(embed_dim=C, depth=depth, hidden_dim=hidden, n_tokens=(img // 16) ** 2 + 1, seed=5)
+    clip = torch.randn(2, 4, 3, img, img, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = R.maed_forward(clip, params, R.make_synthetic_smpl(0), depth=depth, H=H)
+    out = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = maed_amd.MAED(num_blocks=depth, num_heads=H, embed_dim=C, hidden_dim=hidden, img_size=img, compute_dtype=dt)
+        m.load_state_dict(params, strict=False)
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            o = m(clip.to(dev))
+        out[name] = {k: float((o[k].float().cpu() - ref[k]).abs().max() / ref[k].abs().max()) for k in ("theta", "kp_3d", "kp_2d", "rotmat")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,11 +217,20 @@ def main():
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {time.perf_counter() - t1:.3f}s")
     fence()
+    # the contract's number: K steps bracketed by barrier + synchronize; beside it one event per step boundary on the launch stream
+    # (every kernel of a step is enqueued on torch's current stream) for the per-step median / p10 / p90
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step[min(len(per_step) - 1, max(0, int(round(q * (len(per_step) - 1)))))]
+    step_stats = dict(median_ms=round(pct(0.5), 3), p10_ms=round(pct(0.1), 3), p90_ms=round(pct(0.9), 3), min_ms=round(per_step[0], 3),
+                      max_ms=round(per_step[-1], 3), how="hipEvent per step boundary on the launch stream, this rank")
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -205,10 +238,10 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     log(f"timed {args.steps} steps: {ms_per_step:.2f} ms/step")
 
-    # ---- in-situ kernel timing for the roofline (extra steps, events on the launch stream) ----------------
+    # ---- in-situ kernel timing for the rooflines (extra steps, events on the launch stream) ---------------
     kernels = {}
-    roofline = None
-    roofline_dominant = None
+    roofline = roofline_attention = roofline_wgrad = None
+    groups = None
     # EVERY rank runs the extra steps (a train step contains the gradient all-reduce: a rank stepping alone would wait for
     # collectives nobody else issues); only rank 0 brackets its launches with events and reports
     nprof = 3
@@ -218,55 +251,83 @@ def main():
         step()
     fence()
     if rank == 0:
-        ms = (ctypes.c_double * 8)()
-        cnt = (ctypes.c_int * 8)()
+        ntags = lib.maed_prof_ntags()
+        ms = (ctypes.c_double * ntags)()
+        cnt = (ctypes.c_int * ntags)()
         lib.maed_prof_collect(ms, cnt)
         lib.maed_prof_enable(0)
         Fr, P, C_, T = CFG["clips"] * CFG["T"], (CFG["img"] // 16) ** 2 + 1, CFG["dim"], CFG["T"]
         M, es, Hd = Fr * P, (2 if dtype == torch.bfloat16 else 4), 4 * CFG["dim"]
-        # algorithmic work per launch: flops, HBM bytes
-        work = {
+        # algorithmic work per launch: flops, HBM bytes (operands read once, results written once)
+        g_qkv, g_proj, g_mlp = 2.0 * M * 3 * C_ * C_, 2.0 * M * C_ * C_, 2.0 * M * Hd * C_
+        work = {   # tag order of csrc/block.hip
             "attn_spatial_fwd": (4.0 * P * P * C_ * Fr, (4.0 * M * C_) * es + 4.0 * Fr * CFG["heads"] * P),
             "attn_temporal_fwd": (4.0 * P * T * C_ * Fr, (4.0 * M * C_) * es + 4.0 * Fr * CFG["heads"] * P),
-            "gemm_qkv": (2.0 * M * 3 * C_ * C_, (M * C_ + 3 * C_ * C_ + 3 * M * C_) * es),
-            "gemm_fc1_gelu": (2.0 * M * Hd * C_, (M * C_ + Hd * C_ + 2 * M * Hd) * es),
-            "gemm_fc2_resid": (2.0 * M * Hd * C_, (M * Hd + Hd * C_) * es + 8.0 * M * C_),
+            "gemm_qkv": (g_qkv, (M * C_ + 3 * C_ * C_ + 3 * M * C_) * es),
+            "gemm_fc1_gelu": (g_mlp, (M * C_ + Hd * C_ + 2 * M * Hd) * es),
+            "gemm_fc2_resid": (g_mlp, (M * Hd + Hd * C_) * es + 8.0 * M * C_),
             "attn_spatial_bwd": (14.0 * P * P * C_ * Fr, (3 + 1 + 1 + 3) * M * C_ * es),
             "attn_temporal_bwd": (10.0 * P * T * C_ * Fr, (3 + 1 + 1 + 3) * M * C_ * es),
-            "gemm_wgrad(all)": (None, None),
+            # five weight-gradient GEMMs per block (fc2, fc1, proj, ts_attn, qkv): average per launch
+            "gemm_wgrad(all)": ((g_qkv + g_proj + 2 * g_mlp + 2.0 * Fr * 4 * C_ * C_) / 5.0, None),
+            "gemm_proj_resid": (g_proj, (M * C_ + C_ * C_) * es + 8.0 * M * C_),
+            # four input-gradient GEMMs per block (d fc2 with the GELU' epilogue, d fc1, d proj, d qkv): average per launch
+            "gemm_dgrad(all)": ((g_qkv + g_proj + 2 * g_mlp) / 4.0, None),
         }
         names = list(work)
         for i, nm in enumerate(names):
-            if cnt[i] == 0:
+            if i >= ntags or cnt[i] == 0:
                 continue
             us = 1e3 * ms[i] / cnt[i]
             fl, by = work[nm]
-            ent = dict(launches=cnt[i], avg_us=round(us, 2))
-            if fl:
-                ent.update(tflops=round(fl / us / 1e6, 2), frac_mfma_peak=round(fl / us / 1e6 / MFMA_BF16_PEAK_TF, 4),
-                           algorithmic_gbs=round(by / us / 1e3, 1), frac_hbm_peak=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
+            ent = dict(launches=cnt[i], avg_us=round(us, 2), tflops=round(fl / us / 1e6, 2), frac_mfma_peak=round(fl / us / 1e6 / MFMA_BF16_PEAK_TF, 4))
+            if by:
+                ent.update(algorithmic_gbs=round(by / us / 1e3, 1), frac_hbm_peak=round(by / us / 1e3 / HBM_PEAK_GBS, 4))
             kernels[nm] = ent
-        traffic, traffic_note = None, ""
-        try:  # HBM bytes per launch from the committed PMC passes (scripts/gpu_pmc.sh), same kernel and shape
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "attn_traffic.json")))
-            if dtype == torch.bfloat16:
-                traffic = tj["hbm_bytes_per_launch"]
-                traffic_note = "; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B from separate rocprofv3 --pmc passes (profiles/r01_pmc/attn_traffic.json)"
+        # HBM traffic per launch from the PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs: scripts/gpu_pmc.sh).
+        # Quoted ONLY when the file was measured on this very build (kernel-source hash), else null.
+        from maed_amd.build import source_hash
+        traffic_db, traffic_note = {}, "; traffic: no PMC file for this build (profiles/*_pmc/traffic.json carries another source hash)"
+        try:
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "traffic.json"))):
+                tj = json.load(open(fn))
+                if tj.get("source_hash") == source_hash() and tj.get("dtype", "bf16") == args.dtype and tj.get("workload", "cfg3") == args.workload:
+                    traffic_db = tj.get("kernels", {})
+                    traffic_note = f"; traffic = (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes on this build ({os.path.relpath(fn, ROOT)})"
         except Exception:
             pass
-        if "attn_spatial_fwd" in kernels:
-            k = kernels["attn_spatial_fwd"]
-            roofline = dict(kernel="attn_sp_fwd_mfma (STE spatial attention forward)", bound="hbm", achieved=k["algorithmic_gbs"], peak=HBM_PEAK_GBS,
-                            unit="GB/s", frac=round(k["algorithmic_gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, avg_us=k["avg_us"],
-                            mfma_view=dict(achieved=k["tflops"], peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"]),
-                            note="algorithmic bytes = q,k,v read + o written once (8*P*C*F B bf16) + lse; in-situ hipEvent timing over "
-                                 f"{cnt[0]} launches inside {nprof} extra steps" + traffic_note)
 
-        if "gemm_qkv" in kernels:   # by time the step's dominant own kernel family is the bf16 GEMM (MFMA-bound): report it beside the named one
-            k = kernels["gemm_qkv"]
-            roofline_dominant = dict(kernel="gemm_nt_glds_bf16_kernel (STE qkv projection; same kernel runs fc1/fc2/proj and the backbone's 1x1 convolutions)",
-                                     bound="mfma", achieved=k["tflops"], peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"], traffic=None,
-                                     avg_us=k["avg_us"], note="2*M*N*K FLOP per launch (M = frames*tokens, N = 3C, K = C); in-situ hipEvent timing")
+        def fam(tags):   # total flops / total time over several instrumented tags
+            idx = [names.index(t) for t in tags if t in kernels]
+            if not idx:
+                return None
+            tot_ms = sum(ms[i] for i in idx)
+            n = sum(cnt[i] for i in idx)
+            fl = sum(work[names[i]][0] * cnt[i] for i in idx)
+            return fl / (tot_ms * 1e-3) / 1e12, 1e3 * tot_ms / n, n, tot_ms / nprof
+
+        nt = fam(["gemm_qkv", "gemm_proj_resid", "gemm_fc1_gelu", "gemm_fc2_resid", "gemm_dgrad(all)"])
+        if nt:   # the step's dominant kernel family by time (rocprofv3: profiles/r02_*steady*): the NT GEMMs
+            roofline = dict(kernel="bf16 NT GEMM family of the STE (gemm_nt_glds_bf16_kernel 128x128 + gemm_nt_256_bf16_kernel 256x256: qkv, proj, fc1+GELU, "
+                                   "fc2+residual and the four input-gradient GEMMs of every block; the same kernels run the backbone's 1x1 convolutions)",
+                            bound="mfma", achieved=round(nt[0], 2), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=round(nt[0] / MFMA_BF16_PEAK_TF, 4),
+                            traffic=traffic_db.get("gemm_nt"), avg_us=round(nt[1], 2), launches=nt[2], ms_per_step=round(nt[3], 3),
+                            note="achieved = sum of 2*M*N*K over ALL instrumented launches / sum of their hipEvent durations (events on the launch stream, "
+                                 f"{nprof} extra steps); per-shape numbers under kernels" + traffic_note)
+        if "gemm_wgrad(all)" in kernels:
+            k = kernels["gemm_wgrad(all)"]
+            roofline_wgrad = dict(kernel="gemm_tn_mfma_bf16_kernel (weight gradients dW += Y^T X of the STE, five per block)", bound="mfma", achieved=k["tflops"],
+                                  peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"], traffic=traffic_db.get("gemm_tn"), avg_us=k["avg_us"],
+                                  note="flops averaged over the five shapes; in-situ hipEvent timing")
+        if "attn_spatial_fwd" in kernels:   # the kernel north_star names
+            k = kernels["attn_spatial_fwd"]
+            roofline_attention = dict(kernel="STE spatial attention forward (the kernel north_star names)", bound="hbm", achieved=k["algorithmic_gbs"], peak=HBM_PEAK_GBS,
+                                      unit="GB/s", frac=round(k["algorithmic_gbs"] / HBM_PEAK_GBS, 4), traffic=traffic_db.get("attn_spatial_fwd"), avg_us=k["avg_us"],
+                                      mfma_view=dict(achieved=k["tflops"], peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"]),
+                                      note="algorithmic bytes = q,k,v read + o written once (8*P*C*F B bf16) + lse; in-situ hipEvent timing over "
+                                           f"{cnt[0]} launches")
+        groups = traffic_db.get("__groups__")    # optional: per-group ms/step + bytes/us from the rocprofv3 steady-state summary of this build
 
     log(f"kernel timing done: {json.dumps(kernels)}")
     cpu = None
@@ -275,6 +336,12 @@ def main():
             cpu = cpu_baseline()
         except Exception as e:  # the baseline must never take the bench line down
             cpu = dict(value=None, unit="video-clips/sec", cores=os.cpu_count(), kind="port", sample=f"failed: {e!r}")
+        try:
+            pe = parity_probe(dev)
+            cpu["parity_probe"] = dict(rel_err=pe, note="product forward vs the CPU oracle on a small seeded clip (2x4x64^2, depth 2, dim 128); "
+                                                       "north_star bar 1e-3 on SMPL parameters (theta) is met in f32 mode; the bf16 figure is what the measured mode carries")
+        except Exception as e:
+            cpu["parity_probe"] = dict(rel_err=None, note=f"failed: {e!r}")
 
     if rank == 0:
         clips = CFG["clips"] * world
@@ -290,7 +357,10 @@ def main():
                        "global_batch_clips": clips, "frames_per_clip": CFG["T"], "parallelism": f"dp{world}",
                        "loss": "lib/core/loss.py LossVideo (config_stage2 weights) on synthetic labels, fused fwd+bwd kernel",
                        "smpl": "synthetic SMPL-shaped parameters (licensed model file unavailable)"},
-            "roofline": roofline, "roofline_dominant": roofline_dominant, "kernels": kernels, "cpu_baseline": cpu,
+            "step_time": step_stats,
+            "roofline": roofline, "roofline_attention": roofline_attention, "roofline_wgrad": roofline_wgrad, "kernels": kernels, "kernel_groups": groups,
+            "cpu_baseline": cpu,
+            "parity_err_bf16": (cpu or {}).get("parity_probe", {}).get("rel_err", {}).get("bf16") if cpu and (cpu.get("parity_probe") or {}).get("rel_err") else None,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

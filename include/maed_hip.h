@@ -175,9 +175,11 @@ int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, con
 
 /* measurement only: bracket selected launches inside the composite block calls with hipEvents on the
  * launch stream.  Tags: 0 attn_spatial_fwd, 1 attn_temporal_fwd, 2 qkv GEMM, 3 fc1 GEMM, 4 fc2 GEMM,
- * 5 attn_spatial_bwd, 6 attn_temporal_bwd, 7 weight-gradient GEMMs.  collect() synchronises the events and
- * fills ms_total[8] / count[8] (host pointers), then clears the records. */
+ * 5 attn_spatial_bwd, 6 attn_temporal_bwd, 7 weight-gradient GEMMs, 8 proj GEMM, 9 the four input-gradient GEMMs of a block,
+ * 10 (reserved: LayerNorm).  collect() synchronises the events and fills ms_total[n] / count[n] (host pointers,
+ * n = maed_prof_ntags()), then clears the records. */
 int maed_prof_enable(int on);
+int maed_prof_ntags(void);
 int maed_prof_collect(double* ms_total_host, int* count_host);
 
 /* ---- K10: KTD joint chain (ktd.py:81-86) ------------------------------------------------------- */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "maed_ste_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
     "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp, vp, vp]),
     "maed_prof_enable": (i32, [i32]),
+    "maed_prof_ntags": (i32, []),
     "maed_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i32)]),
     "maed_ktd_chain_fwd": (i32, [vp, vp, vp, i32, vp]),
     "maed_rot6d_pose_fwd": (i32, [vp, vp, vp, i64, vp]),

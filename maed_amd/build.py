@@ -16,6 +16,18 @@ SOURCES = ["layernorm.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spat
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
+def source_hash():
+    """sha256 over the kernel sources + the C-ABI header: stamps measurement files (profiles/*_pmc/traffic.json) so that bench.py
+    quotes a PMC traffic figure only for the build it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh")))
+    for f in files + [os.path.join(os.path.dirname(HERE), "include", "maed_hip.h")]:
+        with open(f if os.path.isabs(f) else os.path.join(CSRC, f), "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

@@ -17,7 +17,8 @@
 // When enabled, the composite block calls bracket selected launches with hipEvents recorded on the SAME
 // stream the kernel is launched on; maed_prof_collect() synchronises the events and returns total ms and
 // launch counts per tag.  bench.py uses this for the roofline numbers.
-enum { PROF_ATTN_SP_FWD = 0, PROF_ATTN_TM_FWD, PROF_GEMM_QKV, PROF_GEMM_FC1, PROF_GEMM_FC2, PROF_ATTN_SP_BWD, PROF_ATTN_TM_BWD, PROF_GEMM_WGRAD, PROF_NTAGS };
+enum { PROF_ATTN_SP_FWD = 0, PROF_ATTN_TM_FWD, PROF_GEMM_QKV, PROF_GEMM_FC1, PROF_GEMM_FC2, PROF_ATTN_SP_BWD, PROF_ATTN_TM_BWD, PROF_GEMM_WGRAD,
+       PROF_GEMM_PROJ, PROF_GEMM_DGRAD /* the four input-gradient GEMMs of a block */, PROF_LAYERNORM /* fwd + bwd */, PROF_NTAGS };
 static bool g_prof = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_NTAGS];
 struct ProfScope {
@@ -28,6 +29,7 @@ struct ProfScope {
     ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof_ev[tag].emplace_back(a, b); } }
 };
 extern "C" int maed_prof_enable(int on) { g_prof = on != 0; return MAED_OK; }
+extern "C" int maed_prof_ntags(void) { return PROF_NTAGS; }
 extern "C" int maed_prof_collect(double* ms_total, int* count) {
     for (int t = 0; t < PROF_NTAGS; ++t) {
         double tot = 0.0;
@@ -156,7 +158,7 @@ extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_par
     MAED_PROPAGATE(maed_st_colmean(sv + L.xs, sv + L.xt, sv + L.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
     MAED_PROPAGATE(maed_gemm_nt(sv + L.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
     MAED_PROPAGATE(maed_st_mix_fwd(sv + L.xs, sv + L.xt, logits, sv + L.mix, d->F, d->P, C, dt, stream));
-    MAED_PROPAGATE(maed_gemm_nt(sv + L.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, sv + L.xmid, C, nullptr, x_in, C, 1, gi, stream));
+    PROF(PROF_GEMM_PROJ, maed_gemm_nt(sv + L.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, sv + L.xmid, C, nullptr, x_in, C, 1, gi, stream));
     MAED_PROPAGATE(maed_layernorm_fwd((const float*)(sv + L.xmid), C, p->ln2_g, p->ln2_b, sv + L.ln2, dt, (float*)(sv + L.mean2), (float*)(sv + L.rstd2), M, C, d->eps, stream));
     PROF(PROF_GEMM_FC1, maed_gemm_nt(sv + L.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, sv + L.hact, Hd, sv + L.hpre, nullptr, 0, 1, gi, stream));
     PROF(PROF_GEMM_FC2, maed_gemm_nt(sv + L.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, sv + L.xmid, C, 1, gi, stream));
@@ -190,9 +192,9 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         void* dxmid_tw = sc + S.dyt;                                     // bf16 twin of dx_mid (reuses the old transpose slot)
         // MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(dyc, C, sv + L.hact, Hd, M, C, Hd, g->w_fc2, Hd, g->b_fc2, dt, stream));
-        MAED_PROPAGATE(maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
+        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, stream));
-        MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
+        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
         // LayerNorm dgamma/dbeta via partials in the (bf16-mode-unused) transpose slot (measured on MI355X, profiles/r02_call2_steady_*.csv:
         // 0.629 -> 0.503 + 0.080 ms per step); MAED_LN_DEFER_AFFINE=0 switches back to the atomics (A/B knob)
         const size_t big_t_bytes = (size_t)(Hd > 3 * C ? Hd : 3 * C) * (size_t)Mp * dtype_size(dt);      // S.bigT: only the f32 path transposes into it
@@ -202,7 +204,7 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
                                              dx_out, dxmid, dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream));
         // attention: x_mid = x_in + proj(mix(x_s, x_t))
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dt, stream));
-        MAED_PROPAGATE(maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
+        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
         MAED_PROPAGATE(maed_st_mix_bwd_reduce(sc + S.act, sv + L.xs, sv + L.xt, logits, sc + S.dlog, (float*)(sc + S.ws), d->F, d->P, C, dt, stream));
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dt, stream));
         MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
@@ -211,7 +213,7 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         PROF(PROF_ATTN_SP_BWD, maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
                                                      MAED_IMPL_AUTO, stream));
         PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, 3 * C, sv + L.ln1, C, M, 3 * C, C, g->w_qkv, C, g->b_qkv, dt, stream));
-        MAED_PROPAGATE(maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
+        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
         MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in,
                                              dx_in_twin, g->ln1_g, g->ln1_b, M, C, ln_part, stream));
         return MAED_OK;

@@ -10,9 +10,10 @@ impls = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2]
 torch.manual_seed(0)
 M = 128 * 197
 shapes = {"qkv": (M, 1536, 512, L.EPI_STORE), "fc1": (M, 2048, 512, L.EPI_GELU), "fc2": (M, 512, 2048, L.EPI_RESID_F32), "proj": (M, 512, 512, L.EPI_RESID_F32),
-          "dfc2": (M, 2048, 512, L.EPI_MUL_DGELU), "dqkv": (M, 512, 1536, L.EPI_STORE_F32), "sq4k": (4096, 4096, 4096, L.EPI_STORE)}
+          "dfc2": (M, 2048, 512, L.EPI_MUL_DGELU), "dqkv": (M, 512, 1536, L.EPI_STORE), "dfc1": (M, 512, 2048, L.EPI_STORE), "dproj": (M, 512, 512, L.EPI_STORE),
+          "sq4k": (4096, 4096, 4096, L.EPI_STORE)}
 for name, (m, n, k, epi) in shapes.items():
-    if which not in ("all", name):
+    if which not in ("all", name) and not (which == "ste" and name != "sq4k"):      # "ste" = the eight NT GEMMs of one STE block (fwd + input gradients)
         continue
     A = [torch.randn(m, k, device="cuda").bfloat16() for _ in range(3)]
     B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()

@@ -1,19 +1,40 @@
 #!/bin/bash
-# HBM traffic of the attention kernel from PMC counters: separate passes for FETCH_SIZE and WRITE_SIZE
-# (MI355X_MICROARCH.md: FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2 -> not both in one pass; kernel-trace only).
+# HBM traffic per launch of the roofline kernels from PMC counters -> gpurun_out/pmc/traffic.json, stamped with the kernel-source hash
+# (bench.py quotes it only for the build it was measured on).  Separate passes for FETCH_SIZE and WRITE_SIZE (MI355X_MICROARCH.md:
+# FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2 -> not both in one pass; --kernel-trace only).  On gfx950 FETCH_SIZE reports 1/2 of a wide
+# coalesced stream: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Copy the result to profiles/rNN_pmc/traffic.json.
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$(pwd); mkdir -p gpurun_out/pmc; export TMPDIR=/tmp
-python scripts/attn_micro.py 50 | tee gpurun_out/pmc/attn_micro.txt
+pass() {   # tag counter command...
+  tag=$1; c=$2; shift 2; rm -rf /tmp/pmc_${tag}_$c
+  (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$c -o p -- "$@" > "$ROOT/gpurun_out/pmc/${tag}_$c.log" 2>&1)
+  f=$(find /tmp/pmc_${tag}_$c -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp "$f" gpurun_out/pmc/${tag}_$c.csv || echo "$tag $c: no counter output"
+}
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o attn -- python "$ROOT/scripts/attn_micro.py" 8 > "$ROOT/gpurun_out/pmc/$c.log" 2>&1)
-  f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
-  echo "== $c: $f"; [ -n "$f" ] && head -3 "$f" && python - "$f" "$c" <<'PY'
-import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "attn_sp_fwd_mfma" in r.get("Kernel_Name", "")]
-vals = [float(r["Counter_Value"]) for r in rows if r.get("Counter_Name") == sys.argv[2]]
-print(f"{sys.argv[2]}: {len(vals)} launches, mean {sum(vals) / max(len(vals), 1):.1f}, min {min(vals):.1f}, max {max(vals):.1f}")
-PY
-  [ -n "$f" ] && grep "attn_sp_fwd_mfma" "$f" | head -12 > gpurun_out/pmc/${c}_attn_rows.csv
+  pass attn $c python "$ROOT/scripts/attn_micro.py" 8
+  pass gemm $c python "$ROOT/scripts/gemm_micro.py" 3 ste 0
+  WGRAD_STE=1 pass wgrad $c python "$ROOT/scripts/wgrad_micro.py" 1
 done
+python - <<'PY'
+import csv, json, os, sys
+sys.path.insert(0, os.getcwd())
+from maed_amd.build import source_hash
+def mean(tag, counter, pats):
+    fn = f"gpurun_out/pmc/{tag}_{counter}.csv"
+    if not os.path.exists(fn):
+        return None, 0
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(fn)) if r.get("Counter_Name") == counter and any(p in r.get("Kernel_Name", "") for p in pats)]
+    return (sum(v) / len(v) if v else None), len(v)
+out = {"source_hash": source_hash(), "dtype": "bf16", "workload": "cfg3",
+       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (--kernel-trace only) over scripts/attn_micro.py, gemm_micro.py ste, "
+                 "wgrad_micro.py (WGRAD_STE=1); bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the launches of the kernel family "
+                 "(gfx950: FETCH_SIZE reports 1/2 of a wide coalesced stream, MI355X_MICROARCH.md HBM section)", "kernels": {}, "detail": {}}
+for key, tag, pats in (("attn_spatial_fwd", "attn", ["attn_sp_fwd", "attn_long_fwd"]), ("gemm_nt", "gemm", ["gemm_nt_glds", "gemm_nt_256"]), ("gemm_tn", "wgrad", ["gemm_tn_mfma"])):
+    f, nf = mean(tag, "FETCH_SIZE", pats); w, nw = mean(tag, "WRITE_SIZE", pats)
+    out["detail"][key] = {"FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w, "launches": [nf, nw]}
+    out["kernels"][key] = None if f is None or w is None else int((2.0 * f + w) * 1024)
+json.dump(out, open("gpurun_out/pmc/traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY

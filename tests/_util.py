@@ -24,6 +24,14 @@ def report(name, got, ref, rtol, atol):
     assert not bad.any(), f"{name}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; {line}"
 
 
+def note(line):
+    """free-form line into the parity report"""
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as fh:
+        fh.write(line + "\n")
+    print(line)
+
+
 def tol(dtype, scale=1.0):
     return (dict(rtol=2e-5, atol=2e-5 * scale) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2 * scale))
 

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from oracle import maed_ref as R
-from _util import DEV, q, report, rnd
+from _util import DEV, note, q, report, rnd
 
 pytestmark = pytest.mark.gpu
 
@@ -393,3 +393,116 @@ def test_backbone_gemm_convolutions_match_miopen_path():
     allc = lambda gg: cos(torch.cat([gg[n].flatten() for n in g0]), torch.cat([pd[n].grad.flatten() for n in g0]))
     report(f"1 - cosine(backbone gradient, fp64 oracle): GEMM path (worst tensor {worst_name}: {worst_gemm:.3f})", torch.tensor([1 - allc(g1)]), torch.zeros(1), rtol=0, atol=0.1)
     report(f"1 - cosine(backbone gradient, fp64 oracle): all-MIOpen path (worst tensor: {worst_mio:.3f})", torch.tensor([1 - allc(g0)]), torch.zeros(1), rtol=0, atol=0.1)
+
+
+# ---- the benchmarked configuration at FULL module size (BASELINE.json configs[1] / configs[2]: C = 512, H = 8, depth 6, 224^2, T = 16) ------
+CFG3 = dict(depth=6, H=8, img=224, hidden=1024, T=16)
+
+
+def _cfg3_maed(dtype, seed=7):
+    import maed_amd
+    C = 64 * CFG3["H"]
+    P = (CFG3["img"] // 16) ** 2 + 1
+    params = R.make_params(embed_dim=C, depth=CFG3["depth"], hidden_dim=CFG3["hidden"], n_tokens=P, seed=seed)
+    m = maed_amd.MAED(num_blocks=CFG3["depth"], num_heads=CFG3["H"], embed_dim=C, hidden_dim=CFG3["hidden"], img_size=CFG3["img"], compute_dtype=dtype)
+    missing, unexpected = m.load_state_dict(params, strict=False)
+    assert not unexpected and all(".smpl." in k for k in missing), (missing, unexpected)
+    return m.to(DEV).eval(), params
+
+
+def test_cfg2_full_size_forward_f32_vs_oracle():
+    """cfg2 at full module size, one 16-frame 224^2 clip, f32 parity mode against the CPU oracle: north_star's 1e-3 on SMPL parameters.
+    (The 8-clip batch of the bench repeats this per clip: clips never interact -- SURVEY 8(e).)"""
+    m, params = _cfg3_maed(torch.float32)
+    clip = rnd(1, CFG3["T"], 3, CFG3["img"], CFG3["img"], seed=21)
+    with torch.no_grad():
+        ref = R.maed_forward(clip, params, R.make_synthetic_smpl(0), depth=CFG3["depth"], H=CFG3["H"])
+        out = m(clip.to(DEV))
+    for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts"):
+        scale = ref[k].abs().max().item()
+        report(f"cfg2 full size f32 {k} vs oracle", out[k], ref[k], rtol=0, atol=1e-3 * scale)
+
+
+def _rms_rel(a, ref):
+    return (((a.float().cpu() - ref) ** 2).mean().sqrt() / ref.std()).item()
+
+
+def test_cfg3_full_size_bf16_bounded_by_torch_autocast():
+    """the MEASURED mode (bf16 compute, fp32 residual stream and master weights) at full module size.  Finding of round 2
+    (scripts/diag_backbone_bf16.py, diag_backbone_aten_bf16.py): on RANDOM-INITIALISED weights the 50-layer weight-standardised
+    R50 amplifies rounding noise block by block -- bf16 rms error / std of the backbone output 0.46 with our kernels, 0.45 with the same
+    network under torch.autocast(bfloat16) in pure ATen, 0.64 with every tensor in bf16 -- so a fixed small tolerance against the fp32 oracle
+    is not a property any bf16 implementation of this network has.  The bound asserted here is therefore the reference framework's own
+    mixed precision: on the same weights and clip our bf16 mode is at most 1.35x as far from the fp32 oracle as the ORACLE ITSELF run on
+    the GPU under torch.autocast(bfloat16) (ATen / MIOpen only, no libmaed_hip kernel), for the encoder feature and every output."""
+    m, params = _cfg3_maed(torch.bfloat16)
+    clip = rnd(1, CFG3["T"], 3, CFG3["img"], CFG3["img"], seed=21)
+    sp = R.make_synthetic_smpl(0)
+    feat_of = lambda c, p: R.ste_forward_features(c.reshape(-1, *c.shape[2:]), p, "encoder.", CFG3["depth"], CFG3["H"], CFG3["T"])   # maed.py:43-50
+    with torch.no_grad():
+        ref = R.maed_forward(clip, params, sp, depth=CFG3["depth"], H=CFG3["H"])
+        ref["feature"] = feat_of(clip, params)
+        pd = {k: v.to(DEV) for k, v in params.items()}
+        with torch.autocast("cuda", dtype=torch.bfloat16):      # encoder + KTD head in mixed precision on the GPU (pure ATen) ...
+            xf = feat_of(clip.to(DEV), pd)
+            pose, shape, cam = R.ktd_head(xf, pd, "decoder.")
+        o = R.ktd_get_output(pose.float().cpu(), shape.float().cpu(), cam.float().cpu(), sp)      # ... the SMPL tail in fp32, as in our bf16 mode
+        N, T = clip.shape[:2]
+        auto = dict(theta=o["theta"].reshape(N, T, -1), verts=o["verts"].reshape(N, T, -1, 3), kp_2d=o["kp_2d"].reshape(N, T, -1, 2),
+                    kp_3d=o["kp_3d"].reshape(N, T, -1, 3), rotmat=o["rotmat"].reshape(N, T, -1, 3, 3), feature=xf.float().cpu())
+        out = m(clip.to(DEV))
+        out["feature"] = m.encoder(clip.reshape(-1, *clip.shape[2:]).to(DEV), seqlen=CFG3["T"])      # (extract_feature runs with seqlen 1, as the reference's does)
+    for k in ("feature", "theta", "kp_3d", "kp_2d", "rotmat", "verts"):
+        e_mine, e_auto = _rms_rel(out[k], ref[k]), _rms_rel(auto[k], ref[k])
+        line = f"cfg3 full size bf16 {k:8s}: rms err / std vs fp32 oracle: ours {e_mine:.3e}  torch.autocast(bf16) oracle {e_auto:.3e}  ratio {e_mine / max(e_auto, 1e-12):.2f}"
+        note(line)
+        assert not torch.isnan(out[k]).any(), k
+        assert e_mine <= 1.35 * e_auto + 2e-3, line
+
+
+def test_bf16_backbone_error_tracks_torch_autocast():
+    """the hybrid R50 alone at the cfg3 input size (4 frames): rms error / std of the bf16 output against fp32 ATen -- ours vs the oracle's
+    functional backbone under torch.autocast(bfloat16).  Also the f32 parity mode of the same module: 1e-4."""
+    from maed_amd.resnetv2 import ResNetV2
+    img, pre = 224, "encoder.patch_embed.backbone."
+    params = R.make_params(embed_dim=512, depth=1, hidden_dim=64, n_tokens=(img // 16) ** 2 + 1, seed=7)
+    x = rnd(4, 3, img, img, seed=21).to(DEV)
+    sdb = {k[len(pre):]: v for k, v in params.items() if k.startswith(pre)}
+    with torch.no_grad():
+        p32 = {k: v.to(DEV) for k, v in params.items() if k.startswith(pre)}
+        ref = R.resnetv2_features(x, p32, pre).cpu()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            auto = R.resnetv2_features(x, p32, pre)
+        outs = {}
+        for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            bb = ResNetV2(layers=(3, 4, 9), compute_dtype=dt)
+            bb.load_state_dict(sdb)
+            outs[name] = bb.to(DEV).eval()(x)
+    e32, e16, ea = _rms_rel(outs["f32"], ref), _rms_rel(outs["bf16"], ref), _rms_rel(auto, ref)
+    note(f"backbone rms err / std vs fp32 ATen: ours f32 {e32:.3e}  ours bf16 {e16:.3e}  torch.autocast(bf16) {ea:.3e}")
+    assert e32 <= 1e-4 and e16 <= 1.25 * ea + 2e-3
+
+
+def test_cfg3_full_size_block_bf16_fwd_bwd_vs_fp64_oracle():
+    """one STE Block at the benchmarked size (F = 128 frames x P = 197 tokens, C = 512, H = 8, T = 16) in the measured bf16 mode: forward and
+    EVERY gradient against fp64 autograd through the oracle -- the shapes bench.py runs (256x256 and 128x128 GEMM tiles, MFMA attention at
+    H = 8, the one-tile temporal backward) and no others."""
+    C, H, T, P, Fr = 512, 8, 16, 197, 128
+    p = {k[len("encoder.blocks.0."):]: v for k, v in R.make_params(embed_dim=C, depth=1, hidden_dim=64, layers=(1, 1, 1), n_tokens=P, seed=3).items()
+         if k.startswith("encoder.blocks.0.")}
+    p = {k: v * (3.0 if k.endswith("weight") and v.dim() == 2 else 1.0) for k, v in p.items()}
+    blk = make_block(C, H, torch.bfloat16, p, 0)
+    x, dy = rnd(Fr, P, C, seed=1), rnd(Fr, P, C, seed=2)
+    pd = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    xr = x.double().requires_grad_(True)
+    yref = R.block(xr, pd, "", H, T)
+    yref.backward(dy.double())
+    xg = x.to(DEV).requires_grad_(True)
+    y = blk(xg, T)
+    y.backward(dy.to(DEV))
+    # bf16 tolerance: 3e-2 relative + 1e-2 of the tensor's largest magnitude (the block's weights are scaled x3: outputs reach ~14)
+    report("cfg3 Block.forward bf16 [F128 P197 C512]", y, yref, rtol=3e-2, atol=1e-2 * yref.abs().max().item())
+    report("cfg3 Block.backward.dx bf16", xg.grad, xr.grad, rtol=3e-2, atol=1e-2 * xr.grad.abs().max().item())
+    for name, prm in blk.named_parameters():
+        ref = pd[name].grad
+        report(f"cfg3 Block.backward.d[{name}] bf16", prm.grad, ref, rtol=5e-2, atol=3e-2 * max(ref.abs().max().item(), 1e-3))
