@@ -136,6 +136,13 @@ int maed_embed_add_fwd(const void* patch, int dtype, const float* cls, const flo
 int maed_embed_add_bwd(const float* dtokens, void* dpatch, int dtype, float* dpos, float* frame_colsum,
                        int F, int P, int C, void* stream);
 
+/* ---- element-wise pieces of the training tail -------------------------------------------------- */
+/* nn.Dropout(p) in training (ktd.py:54,56): y[f32] = keep ? x / (1 - p) : 0 with keep = hash(seed, index) >= p; the same call with the
+ * same seed applied to dy is the backward (nothing is stored).  x == y (in place) is allowed. */
+int maed_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* backward of the GEMM's TANH epilogue (pre_logits, vision_transformer.py:350-353): dx[T] = dy[f32] * (1 - y[T]^2) */
+int maed_tanh_bwd(const float* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+
 /* ---- whole STE Block (vision_transformer.py:244-261 with Attention 'parallel' :146-158,176 and
  *      Mlp :106-112) as ONE host call that enqueues every kernel of the block -------------------- */
 typedef struct {
@@ -263,6 +270,11 @@ int maed_loss_fwd_bwd(const float* pred_kp2d, const float* gt_kp2d, int M2, cons
                       const float* pred_theta, const float* gt_theta, const uint8_t* w_smpl, int M3,
                       const maed_loss_weights* w, float* losses, float* d_kp2d, float* d_kp3d, float* d_theta,
                       double* partials, void* stream);
+
+/* acceleration term of LossVideo (loss.py:94-117; e_smpl_accl_loss > 0): pred_kp3d (N,T,49,3), gt_kp3d (N,T,49,4) whole clips, T >= 3.
+ * loss[1] (device, fp64) = weight * mean over (N, T-2, 49, 3) of (conf^4 * (second difference of pred - of gt))^2;
+ * d_kp3d (N,T,49,3) = its gradient w.r.t. pred_kp3d (overwritten). */
+int maed_loss_accl_fwd_bwd(const float* pred_kp3d, const float* gt_kp3d, int N, int T, float weight, double* loss, float* d_kp3d, void* stream);
 
 /* ---- backbone helpers (the convolutions themselves ride on MIOpen) ---------------------------------- */
 /* StdConv2dSame weight standardisation (resnetv2.py:74-93) for ALL convolutions in one launch.

@@ -75,6 +75,9 @@ SIGNATURES = {
     "maed_ste_block_scratch_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
     "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "maed_loss_accl_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp]),
+    "maed_dropout": (i32, [vp, vp, i64, f32, C.c_uint64, vp]),
+    "maed_tanh_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
     "maed_prof_enable": (i32, [i32]),
     "maed_prof_ntags": (i32, []),
     "maed_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i32)]),

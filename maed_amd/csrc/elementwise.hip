@@ -298,6 +298,53 @@ extern "C" int maed_transpose_cast(const void* in, int in_dtype, int64_t ldi, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// nn.Dropout(p) in training (ktd.py:54,56: the KTD's two Dropout(0.5) layers are the only active dropouts on the path) and
+// tanh' (pre_logits, vision_transformer.py:350-353) -- the two element-wise pieces of the training tail that used to be ATen ops.
+// The keep mask is a counter-based hash of (seed, element index): nothing is stored, the backward recomputes it from the seed.
+// (The reference draws its mask from torch's Philox stream on whatever device it runs on; no two devices share that stream, so
+// the contract is the distribution: keep probability 1-p, survivors scaled by 1/(1-p).)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh24) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;                 // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40) >= thresh24;                                // top 24 bits uniform in [0, 2^24)
+}
+
+// y = keep ? x * scale : 0     (the same kernel is its own backward: dx = keep ? dy * scale : 0)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, uint64_t seed, uint32_t thresh24,
+                                                      float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = dropout_keep(seed, (uint64_t)i, thresh24) ? x[i] * scale : 0.f;
+}
+
+extern "C" int maed_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    MAED_CHECK_ARG(x && y, MAED_ERR_ARG, "dropout: null pointer");
+    MAED_CHECK_ARG(n >= 0 && p >= 0.f && p < 1.f, MAED_ERR_ARG, "dropout: need 0 <= p < 1 (p=%f)", (double)p);
+    if (n == 0) return MAED_OK;
+    const uint32_t thresh = (uint32_t)((double)p * 16777216.0);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, thresh, 1.0f / (1.0f - p));
+    MAED_CHECK_LAUNCH("dropout");
+    return MAED_OK;
+}
+
+// dx = dy * (1 - y^2)   (y = tanh(.) as the GEMM's TANH epilogue stored it; T = its storage type)
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float t = ldf(y + i); stf(dx + i, dy[i] * (1.0f - t * t)); }
+}
+
+extern "C" int maed_tanh_bwd(const float* dy, const void* y, void* dx, int64_t n, int dtype, void* stream) {
+    MAED_CHECK_ARG(dy && y && dx, MAED_ERR_ARG, "tanh_bwd: null pointer");
+    if (n <= 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((tanh_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, (const T*)y, (T*)dx, n));
+    MAED_CHECK_LAUNCH("tanh_bwd");
+    return MAED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // batched weight refresh: for every fp32 master weight W_i (rows_i x cols_i) of the table write the compute-dtype copy and the
 // transposed compute-dtype copy in ONE launch (after an optimizer step the STE needs both images of 32 matrices: that was 32
 // launches of the kernel above)

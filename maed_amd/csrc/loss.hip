@@ -172,3 +172,48 @@ extern "C" int maed_loss_fwd_bwd(const float* pred_kp2d, const float* gt_kp2d, i
     MAED_CHECK_LAUNCH("loss_fwd_bwd");
     return MAED_OK;
 }
+
+
+// ---- acceleration term (loss.py:94-117, weight e_smpl_accl_loss; off in the shipped configs) ------------------------------------------
+//   L = w * mean_{n, t < T-2, j, c} ( conf[n][t+2][j]^4 * ((p[t+2] - 2 p[t+1] + p[t]) - (g[t+2] - 2 g[t+1] + g[t])) )^2
+// (conf_velocity = conf[1:]^2, conf_accl = conf_velocity[1:]^2 -- the reference squares the confidence twice).  One thread per (clip,
+// frame s, joint): it owns the value terms of t = s and gathers the gradient of p[s] from the <= 3 second differences that contain it.
+__global__ __launch_bounds__(256) void loss_accl_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int N, int T, float w,
+                                                        float* __restrict__ d_pred, double* __restrict__ loss) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)N * T * 49;
+    float val = 0.f;
+    if (i < total) {
+        const int j = (int)(i % 49), s = (int)((i / 49) % T);
+        const int64_t n = i / (49 * (int64_t)T);
+        const float scale = 2.0f * w / ((float)N * (float)(T - 2) * 147.0f);
+        float g3[3] = {0.f, 0.f, 0.f};
+        for (int t = s - 2; t <= s; ++t) {
+            if (t < 0 || t > T - 3) continue;
+            const int64_t b0 = ((n * T + t) * 49 + j), b1 = b0 + 49, b2 = b1 + 49;
+            const float c = gt[b2 * 4 + 3], c2 = c * c, c4 = c2 * c2, c8 = c4 * c4;
+            const float coef = (t == s - 1) ? -2.0f : 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float e = (pred[b2 * 3 + k] - 2.0f * pred[b1 * 3 + k] + pred[b0 * 3 + k]) - (gt[b2 * 4 + k] - 2.0f * gt[b1 * 4 + k] + gt[b0 * 4 + k]);
+                g3[k] += coef * c8 * e;
+                if (t == s) val += c8 * e * e;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d_pred[i * 3 + k] = scale * g3[k];
+    }
+    val = wave_sum(val);
+    if ((threadIdx.x & 63) == 0 && val != 0.f) atomicAdd(loss, (double)val * (double)w / ((double)N * (double)(T - 2) * 147.0));
+}
+
+extern "C" int maed_loss_accl_fwd_bwd(const float* pred_kp3d, const float* gt_kp3d, int N, int T, float weight, double* loss, float* d_kp3d, void* stream) {
+    MAED_CHECK_ARG(pred_kp3d && gt_kp3d && loss && d_kp3d, MAED_ERR_ARG, "loss_accl_fwd_bwd: null pointer");
+    MAED_CHECK_ARG(N >= 0 && T >= 3, MAED_ERR_SHAPE, "loss_accl_fwd_bwd: needs clips of at least 3 frames (T=%d)", T);
+    hipMemsetAsync(loss, 0, sizeof(double), (hipStream_t)stream);
+    if (N == 0) return MAED_OK;
+    const int64_t total = (int64_t)N * T * 49;
+    hipLaunchKernelGGL(loss_accl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred_kp3d, gt_kp3d, N, T, weight, d_kp3d, loss);
+    MAED_CHECK_LAUNCH("loss_accl_fwd_bwd");
+    return MAED_OK;
+}

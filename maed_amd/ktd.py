@@ -49,6 +49,7 @@ class KTD(nn.Module):
         nn.init.xavier_uniform_(self.decshape.weight, gain=0.01)
         nn.init.xavier_uniform_(self.deccam.weight, gain=0.01)
         self._packed_key, self._packed = None, None
+        self._fc_cache, self._fc_cache2 = ops.WeightCache(), ops.WeightCache()      # fp32 [out,in] master + transposed image of fc1 / fc2
         self._pending_backwards = 0
         self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
 
@@ -72,8 +73,10 @@ class KTD(nn.Module):
 
     def _head_train(self, x):
         """ktd.py:71-86 with the 26 small regressors as ONE packed GEMM + the chain kernel (differentiable)"""
-        x = self.drop1(self.fc1(x))
-        x = self.drop2(self.fc2(x))
+        from . import ste_modes
+        x = x.float()
+        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc1.weight, self.fc1.bias, self._fc_cache, True), self.drop1.p, self.drop1.training)
+        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc2.weight, self.fc2.bias, self._fc_cache2, True), self.drop2.p, self.drop2.training)
         return tail.KtdChainFn.apply(x, self, *self.fused_parameters())
 
     # ---- ATen path (training) -------------------------------------------------------------------
@@ -118,6 +121,10 @@ class KTD(nn.Module):
     def forward(self, x, seqlen, J_regressor=None, return_shape_cam=False, **kwargs):
         hip = self._use_hip(x)
         hip_train = self._use_hip_train(x, J_regressor)
+        if ops.on_library_device(x) and not hip and not hip_train:
+            # differentiable graph + an evaluation joint regressor: the reference only ever passes J_regressor under no_grad
+            # (lib/core/evaluate.py:78); there is no kernel for the regressor's backward and no silent ATen detour on the device
+            raise NotImplementedError("KTD: J_regressor is an inference-time input (call under torch.no_grad(), as lib/core/evaluate.py:78 does)")
         if hip:
             pred_pose, pred_shape, pred_cam = self._head_hip(x)
         elif hip_train:

@@ -8,9 +8,9 @@ lib/core/trainer.py:253-262.  Same classes, constructor arguments, call signatur
 
 On HIP tensors LossVideo / LossImage run as ONE fused forward+backward (maed_loss_fwd_bwd: two launches that
 produce the five weighted terms, their sum and d total / d preds) instead of ~90 ATen launches; the entries of
-loss_dict are then detached views of one device vector (they are only logged: trainer.py:209-211).  The ATen
-composition below is the same arithmetic for CPU tensors and for the optional acceleration term
-(e_smpl_accl_loss > 0, off in every shipped config).
+loss_dict are then detached views of one device vector (they are only logged: trainer.py:209-211); the optional acceleration
+term (e_smpl_accl_loss > 0, off in every shipped config) is one more launch (maed_loss_accl_fwd_bwd).  The ATen composition
+below is the same arithmetic for HOST tensors only -- a device tensor never reaches it.
 """
 import torch
 import torch.nn as nn
@@ -149,10 +149,14 @@ class LossVideo(_LossBase):
             n2 = 0
             gt_j2d = data_3d['kp_2d']
         w_smpl = data_3d['w_smpl'].type(torch.bool)
-        if _on_dev(preds['kp_2d']) and not self.e_smpl_accl_loss > 0:
+        if _on_dev(preds['kp_2d']):
             T = preds['kp_3d'].shape[1]
-            return self._terms_fused(preds['kp_2d'], gt_j2d, preds['kp_3d'], data_3d['kp_3d'], preds['theta'], data_3d['theta'], w_smpl,
-                                     n2 * T, self.e_3d_loss_weight)
+            total, d = self._terms_fused(preds['kp_2d'], gt_j2d, preds['kp_3d'], data_3d['kp_3d'], preds['theta'], data_3d['theta'], w_smpl,
+                                         n2 * T, self.e_3d_loss_weight)
+            if self.e_smpl_accl_loss > 0:      # the acceleration term as its own launch (maed_loss_accl_fwd_bwd); needs clips of >= 3 frames
+                d['loss_accl'] = tail.AcclLossFn.apply(preds['kp_3d'][n2:], data_3d['kp_3d'], self.e_smpl_accl_loss)
+                total = total + d['loss_accl']
+            return total, d
         pred_j3d, pred_theta = preds['kp_3d'][n2:], preds['theta'][n2:]
         return self._terms_aten(preds['kp_2d'], gt_j2d, pred_j3d, data_3d['kp_3d'], pred_theta, data_3d['theta'], w_smpl,
                                 self.e_3d_loss_weight, self.e_smpl_accl_loss, (pred_j3d, data_3d['kp_3d']))

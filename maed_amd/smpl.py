@@ -128,12 +128,16 @@ class SMPL(nn.Module):
             if changed:
                 self.synthetic = False
 
-    def pose_shape_dirs_t(self):
-        """(20670, 207+10) = [posedirs ; shapedirs^T]^T: the one GEMM operand of the LBS backward (tail.SmplTailFn)"""
+    def pose_shape_dirs(self):
+        """(207+10, 20670) = [posedirs ; shapedirs^T]: the K-contiguous B operand of the LBS backward's GEMM (tail.SmplTailFn)"""
         self.refresh_derived()
         if self._ps_t is None or self._ps_t.device != self.posedirs.device:
-            self._ps_t = torch.cat([self.posedirs, self.shapedirs.reshape(-1, 10).t()], dim=0).t().contiguous()
+            self._ps_t = torch.cat([self.posedirs, self.shapedirs.reshape(-1, 10).t()], dim=0).contiguous()
         return self._ps_t
+
+    def pose_shape_dirs_t(self):
+        """(20670, 207+10) view of pose_shape_dirs()"""
+        return self.pose_shape_dirs().t()
 
     # ---- ATen path (training graph; differentiable) ------------------------------------------------
     # Written for the GPU: every contraction is ONE large GEMM (frames folded into the N dimension) or a
@@ -209,9 +213,12 @@ class SMPL(nn.Module):
             raise NotImplementedError('pose2rot=True is not used on the MAED path (ktd.py:104)')
         rot = torch.cat([global_orient, body_pose], dim=1)
         needs_grad = torch.is_grad_enabled() and (betas.requires_grad or rot.requires_grad)
-        if needs_grad or not ops.on_library_device(betas):  # ATen composition = the training graph (device-agnostic)
+        if not ops.on_library_device(betas):                # host tensors: the ATen composition (device-agnostic, differentiable)
             verts, j24 = self.lbs_torch(betas, rot)
             joints = self.joints49_torch(verts, j24)
+        elif needs_grad:                                    # differentiable on the library: the decoder tail's kernels behind one Function
+            from . import tail
+            verts, joints = tail.SmplLbsFn.apply(betas, rot, self)
         else:
             verts, j24 = self.lbs_hip(betas.float(), rot.float())
             extra = self.joint_regress_hip(self.J_regressor_extra, verts)

@@ -157,6 +157,90 @@ class TokenMeanFn(torch.autograd.Function):
         return (dm / ctx.P).expand(-1, ctx.P, -1)
 
 
+class StMixFn(torch.autograd.Function):
+    """attentive addition of the parallel mode (vision_transformer.py:152-158): token means of [x_s || x_t] -> ts_attn Linear ->
+    pairwise softmax -> blend.  x_s, x_t (F,P,C) compute dtype -> mix (F,P,C) compute dtype"""
+
+    @staticmethod
+    def forward(ctx, x_s, x_t, w_ts, b_ts, cache):
+        (wc, wt), = cache.get([w_ts], x_s.dtype)
+        x_s, x_t = _as(x_s, x_s.dtype), _as(x_t, x_s.dtype)
+        means = ops.st_colmean(x_s, x_t)
+        logits = ops.gemm_nt(means, wc, L.EPI_STORE_F32, bias=b_ts)
+        ctx.save_for_backward(x_s, x_t, means, logits)
+        ctx.wt = wt
+        return ops.st_mix_fwd(x_s, x_t, logits)
+
+    @staticmethod
+    def backward(ctx, dmix):
+        x_s, x_t, means, logits = ctx.saved_tensors
+        dx_s, dx_t, dlogits = ops.st_mix_bwd(_as(dmix, x_s.dtype), x_s, x_t, logits, lambda dl: ops.gemm_nt(dl, ctx.wt, L.EPI_STORE))
+        dW, db = _wgrad(dlogits, means, True)
+        return dx_s, dx_t, dW, db, None
+
+
+class TanhLinearFn(torch.autograd.Function):
+    """tanh(x W^T + b) (pre_logits, vision_transformer.py:350-353): the GEMM's TANH epilogue forward, maed_tanh_bwd + the two GEMMs backward"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        (wc, wt), = cache.get([weight], x.dtype)
+        x = _as(x, x.dtype)
+        y = ops.gemm_nt(x, wc, L.EPI_TANH, bias=bias)
+        ctx.save_for_backward(x, y)
+        ctx.wt = wt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        g = torch.empty_like(y)
+        dy32 = _as(dy, torch.float32)        # (a named temporary: its storage must outlive the call that reads it)
+        L.check(L.lib().maed_tanh_bwd(ops._p(dy32), ops._p(y), ops._p(g), y.numel(), ops.dt_code(y.dtype), ops._stream()), "tanh_bwd")
+        dW, db = _wgrad(g, x, True)
+        dx = ops.gemm_nt(g, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
+        return dx, dW, db, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) in training on fp32 rows (ktd.py:54,56); the mask is a hash of (seed, index) -- recomputed, not stored"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _as(x, torch.float32)
+        y = torch.empty_like(x)
+        L.check(L.lib().maed_dropout(ops._p(x), ops._p(y), x.numel(), p, seed, ops._stream()), "dropout")
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _as(dy, torch.float32)
+        dx = torch.empty_like(dy)
+        L.check(L.lib().maed_dropout(ops._p(dy), ops._p(dx), dy.numel(), ctx.p, ctx.seed, ops._stream()), "dropout(bwd)")
+        return dx, None, None
+
+
+def dropout(x, p, training):
+    """F.dropout on the library: identity in eval / p = 0; the seed comes from torch's CPU generator (torch.manual_seed reproduces a run)"""
+    if not training or p == 0.0:
+        return x
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    return DropoutFn.apply(x, float(p), seed)
+
+
+def attention_parallel(attn, h, seqlen, compute_dtype, impl):
+    """stand-alone DIFFERENTIABLE Attention.forward in 'parallel' mode (vision_transformer.py:146-158,176) from the staged Functions
+    (inside a Block the same arithmetic runs as one fused call per direction): h (F,P,C) -> fp32 (F,P,C)"""
+    Fr, P, C_ = h.shape
+    h = h.to(compute_dtype)
+    qkv = LinearTokFn.apply(h.reshape(-1, C_), attn.qkv.weight, attn.qkv.bias, attn._cache, False).view(Fr, P, 3 * C_)
+    x_s = SpatialAttnFn.apply(qkv, attn.num_heads, impl)
+    x_t = TemporalAttnFn.apply(qkv, attn.num_heads, seqlen)
+    mix = StMixFn.apply(x_s, x_t, attn.ts_attn.weight, attn.ts_attn.bias, attn._cache)
+    return LinearTokFn.apply(mix.reshape(-1, C_), attn.proj.weight, attn.proj.bias, attn._cache, True).view(Fr, P, C_)
+
+
 def attention(attn, h, seqlen, compute_dtype, impl):
     """Attention.forward for mode != 'parallel': h (F,P,C) compute dtype -> fp32 (F,P,C), or (F,1,C) in 'temporal' mode"""
     Fr, P, C_ = h.shape

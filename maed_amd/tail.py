@@ -10,7 +10,8 @@ needs for the 24-joint chains:
                `grads_ready` callback tells the data-parallel bucketer when they are final).
   SmplTailFn : pose6d, shape, cam -> theta, verts, kp_2d, kp_3d, rotmat      ktd.py:94-124
 
-The two (F,217)/(F,hidden) GEMMs of the backward are plain library GEMMs (torch.mm -> rocBLAS).
+Every GEMM of the two Functions -- the packed (157 x hidden) projection and its two backward products, and the (F,20670) x (20670,217)
+pose-/shape-direction product of the LBS backward -- runs on maed_gemm_nt (exact-fp32 kernel, split-K where the output is tiny).
 """
 import ctypes as C
 
@@ -43,7 +44,7 @@ class KtdChainFn(ops.ReportingFn):
         w_anc = torch.empty(L.KTD_W_ANC, dtype=torch.float32, device=dev)
         tbl = ktd._ptr_table(False)
         L.check(lib.maed_ktd_pack(C.byref(tbl), hidden, ops._p(w_feat), ops._p(b_feat), ops._p(w_anc), ops._stream()), "ktd_pack")
-        out = torch.addmm(b_feat, h2, w_feat.t())                                   # (F, 144 + 10 + 3)
+        out = ops.gemm_nt(h2, w_feat, L.EPI_STORE, bias=b_feat)                      # (F, 144 + 10 + 3)
         base = out[:, :144].contiguous()
         pose = torch.empty_like(base)
         L.check(lib.maed_ktd_chain_fwd(ops._p(base), ops._p(w_anc), ops._p(pose), Fr, ops._stream()), "ktd_chain_fwd")
@@ -69,8 +70,14 @@ class KtdChainFn(ops.ReportingFn):
         d_b = torch.empty(157, dtype=torch.float32, device=dev)
         L.check(lib.maed_ktd_chain_bwd(ops._p(pose), ops._p(w_anc), ops._p(d_pose), ops._p(d_shape), ops._p(d_cam), ops._p(d_out), 157,
                                        ops._p(d_w_anc), ops._p(d_b), Fr, ops._stream()), "ktd_chain_bwd")
-        d_h2 = d_out @ w_feat if ctx.needs_input_grad[0] else None
-        d_w_feat = d_out.t() @ h2
+        # d_h2 = d_out W (K = 157), d_W = d_out^T h2 (K = F): NT GEMMs on transposed copies of the three small operands
+        d_out_t, _ = ops.transpose_cast(d_out, torch.float32, pad_to=1)             # (157, F)
+        d_h2 = None
+        if ctx.needs_input_grad[0]:
+            w_feat_t, _ = ops.transpose_cast(w_feat, torch.float32, pad_to=1)       # (hidden, 157)
+            d_h2 = ops.gemm_nt(d_out, w_feat_t, L.EPI_STORE)
+        h2_t, _ = ops.transpose_cast(h2, torch.float32, pad_to=1)                   # (hidden, F)
+        d_w_feat = ops.gemm_nt(d_out_t, h2_t, L.EPI_STORE)                          # (157, hidden)
         tbl = ktd._ptr_table(True)
         L.check(lib.maed_ktd_unpack_add(C.byref(tbl), hidden, ops._p(d_w_feat), ops._p(d_b), ops._p(d_w_anc), ops._stream()), "ktd_unpack_add")
         ktd._pending_backwards -= 1
@@ -123,13 +130,66 @@ class SmplTailFn(torch.autograd.Function):
         d_vposed = new(Fr, N_VERTS * 3)
         L.check(lib.maed_smpl_skin_bwd(C.byref(sp), ops._p(A), ops._p(v_posed), ops._p(d_verts), ops._p(d_e21), ops._p(smpl.extra_vertex_ids),
                                        ops._p(d_e9), ops._p(smpl.J_regressor_extra), ops._p(d_vposed), ops._p(dA), Fr, st), "smpl_skin_bwd")
-        dpf = d_vposed @ smpl.pose_shape_dirs_t()                                   # (F, 207 + 10)
+        # (F, 20670) x (20670, 207 + 10): tiny output, K = 20670 -> split-K with the fp32 atomic epilogue (8 output tiles x 32 K slices)
+        dpf = ops.gemm_nt(d_vposed, smpl.pose_shape_dirs(), L.EPI_ATOMIC_F32, splitk=32)
         d_rot, d_betas = new(Fr, 24, 9), new(Fr, 10)
         L.check(lib.maed_smpl_chain_bwd(C.byref(sp), ops._p(shape), ops._p(rotmat), ops._p(dA), ops._p(d_j24), ops._p(dpf), ops._p(d_rotmat),
                                         _off(d_theta, 75), 85, ops._p(d_rot), ops._p(d_betas), Fr, st), "smpl_chain_bwd")
         d_pose6d = new(Fr, 144)
         L.check(lib.maed_rot6d_pose_bwd(ops._p(pose6d), ops._p(d_rot), _off(d_theta, 3), 85, ops._p(d_pose6d), Fr * 24, st), "rot6d_pose_bwd")
         return d_pose6d, d_betas, d_cam, None
+
+
+class SmplLbsFn(torch.autograd.Function):
+    """SMPL.forward (lib/models/smpl.py:94-106 on smplx's lbs) as a differentiable stand-alone op on the library: betas (F,10), rotation
+    matrices (F,24,3,3) -> vertices (F,6890,3), the 49 joints (joint_map gather, bit-exact).  Same kernels as SmplTailFn without its
+    rot6d / projection ends (the projection kernels run with a unit camera and no 2D gradient)."""
+
+    @staticmethod
+    def forward(ctx, betas, rotmat, smpl):
+        lib = L.lib()
+        betas, rotmat = _f32(betas), _f32(rotmat)
+        Fr, dev = betas.shape[0], betas.device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        verts, j24, A, v_posed = new(Fr, N_VERTS, 3), new(Fr, 24, 3), new(Fr, 24, 12), new(Fr, N_VERTS, 3)
+        sp = smpl._c_params()
+        L.check(lib.maed_smpl_lbs_fwd(C.byref(sp), ops._p(betas), ops._p(rotmat), ops._p(verts), ops._p(j24), ops._p(A), ops._p(v_posed), Fr,
+                                      ops._stream()), "smpl_lbs_fwd")
+        extra9 = new(Fr, 9, 3)
+        L.check(lib.maed_joint_regress_fwd(ops._p(smpl.J_regressor_extra), 9, ops._p(verts), ops._p(extra9), Fr, ops._stream()), "joint_regress_fwd")
+        cam = torch.zeros(Fr, 3, dtype=torch.float32, device=dev)
+        cam[:, 0] = 1.0
+        joints, kp2d = new(Fr, 49, 3), new(Fr, 49, 2)
+        L.check(lib.maed_smpl_joints_project_fwd(ops._p(j24), ops._p(verts), ops._p(smpl.extra_vertex_ids), ops._p(extra9), ops._p(smpl.joint_map),
+                                                 ops._p(cam), None, 0, ops._p(joints), ops._p(kp2d), Fr, ops._stream()), "smpl_joints_project_fwd")
+        ctx.save_for_backward(betas, rotmat, A, v_posed, joints, cam)
+        ctx.smpl = smpl
+        ctx.set_materialize_grads(False)
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, d_verts, d_joints):
+        lib = L.lib()
+        betas, rotmat, A, v_posed, joints, cam = ctx.saved_tensors
+        smpl = ctx.smpl
+        Fr, dev = betas.shape[0], betas.device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        d_verts = None if d_verts is None else _f32(d_verts)
+        d_joints = None if d_joints is None else _f32(d_joints)
+        st = ops._stream()
+        d_j24, d_e21, d_e9, d_cam = new(Fr, 24, 3), new(Fr, 21, 3), new(Fr, 9, 3), new(Fr, 3)
+        L.check(lib.maed_smpl_joints_project_bwd(ops._p(joints), ops._p(cam), ops._p(smpl.joint_map), ops._p(d_joints), None, None, 0, ops._p(d_j24),
+                                                 ops._p(d_e21), ops._p(d_e9), ops._p(d_cam), Fr, st), "smpl_joints_project_bwd")
+        sp = smpl._c_params()
+        dA = torch.zeros(Fr, 24, 12, dtype=torch.float32, device=dev)
+        d_vposed = new(Fr, N_VERTS * 3)
+        L.check(lib.maed_smpl_skin_bwd(C.byref(sp), ops._p(A), ops._p(v_posed), ops._p(d_verts), ops._p(d_e21), ops._p(smpl.extra_vertex_ids),
+                                       ops._p(d_e9), ops._p(smpl.J_regressor_extra), ops._p(d_vposed), ops._p(dA), Fr, st), "smpl_skin_bwd")
+        dpf = ops.gemm_nt(d_vposed, smpl.pose_shape_dirs(), L.EPI_ATOMIC_F32, splitk=32)
+        d_rot, d_betas = new(Fr, 24, 9), new(Fr, 10)
+        L.check(lib.maed_smpl_chain_bwd(C.byref(sp), ops._p(betas), ops._p(rotmat), ops._p(dA), ops._p(d_j24), ops._p(dpf), None, None, 0,
+                                        ops._p(d_rot), ops._p(d_betas), Fr, st), "smpl_chain_bwd")
+        return d_betas, d_rot.view(Fr, 24, 3, 3), None
 
 
 class FusedLossFn(torch.autograd.Function):
@@ -167,3 +227,22 @@ class FusedLossFn(torch.autograd.Function):
     def backward(ctx, g_total, _g_losses):
         d_kp2d, d_kp3d, d_theta = ctx.saved_tensors
         return d_kp2d * g_total, d_kp3d * g_total, d_theta * g_total, None, None, None, None, None, None
+
+
+class AcclLossFn(torch.autograd.Function):
+    """acceleration term of LossVideo (lib/core/loss.py:94-117) value and gradient in one launch (maed_loss_accl_fwd_bwd)"""
+
+    @staticmethod
+    def forward(ctx, pred_kp3d, gt_kp3d, weight):
+        pred_kp3d, gt_kp3d = _f32(pred_kp3d), _f32(gt_kp3d)
+        N, T = pred_kp3d.shape[:2]
+        loss = torch.empty(1, dtype=torch.float64, device=pred_kp3d.device)
+        d = torch.empty_like(pred_kp3d)
+        L.check(L.lib().maed_loss_accl_fwd_bwd(ops._p(pred_kp3d), ops._p(gt_kp3d), N, T, float(weight), ops._p(loss), ops._p(d), ops._stream()), "loss_accl_fwd_bwd")
+        ctx.save_for_backward(d)
+        return loss[0].float()
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        return d * g, None, None

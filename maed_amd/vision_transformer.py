@@ -52,9 +52,10 @@ class Mlp(nn.Module):
 
     def forward(self, x, compute_dtype=torch.float32):
         """Stand-alone (inference) use; inside a Block the MLP runs fused in maed_ste_block_fwd."""
-        if _needs_grad(x, self.fc1.weight):
-            raise NotImplementedError("Mlp: the differentiable path is Block.forward (fused)")
         shp = x.shape
+        if _needs_grad(x, self.fc1.weight):     # stand-alone differentiable use: the staged Function (inside a Block the MLP runs fused)
+            y = ste_modes.MlpFn.apply(x.reshape(-1, shp[-1]).to(compute_dtype), self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self._cache)
+            return y.reshape(*shp[:-1], -1)
         (w1, _), (w2, _) = self._cache.get([self.fc1.weight, self.fc2.weight], compute_dtype)
         a = x.reshape(-1, shp[-1]).to(compute_dtype)
         act, _ = ops.gemm_nt(a, w1, L.EPI_GELU, bias=self.fc1.bias)
@@ -90,8 +91,8 @@ class Attention(nn.Module):
         the other modes are differentiable here."""
         if self.mode != 'parallel':
             return ste_modes.attention(self, x.to(compute_dtype), seqlen, compute_dtype, impl)
-        if _needs_grad(x, self.qkv.weight):
-            raise NotImplementedError("Attention: the differentiable path is Block.forward (fused)")
+        if _needs_grad(x, self.qkv.weight) and not return_parts:   # stand-alone differentiable use (inside a Block: one fused call per direction)
+            return ste_modes.attention_parallel(self, x, seqlen, compute_dtype, impl)
         Fr, P, C_ = x.shape
         (wq, _), (wt, _), (wp, _) = self._cache.get([self.qkv.weight, self.ts_attn.weight, self.proj.weight], compute_dtype)
         a = x.reshape(-1, C_).to(compute_dtype)
@@ -273,9 +274,10 @@ class VisionTransformer(nn.Module):
         Fr, P, C_ = tok.shape
         fc = self.pre_logits.fc if isinstance(self.pre_logits, nn.Sequential) else None
         if _needs_grad(tok, self.norm.weight):
-            # tail of the training graph ((F,C) rows only): ATen ops so autograd carries it
-            y = F.layer_norm(tok[:, 0], (C_,), self.norm.weight, self.norm.bias, self.norm.eps)
-            return torch.tanh(F.linear(y, fc.weight, fc.bias)) if fc is not None else y
+            # tail of the training graph ((F,C) cls rows): the same library kernels behind autograd Functions (LayerNorm fwd/bwd, GEMM with
+            # the tanh epilogue, maed_tanh_bwd, weight-gradient GEMMs); autograd's slice backward puts the row gradients back into (F,P,C)
+            y = ste_modes.LayerNormFn.apply(tok[:, 0], self.norm.weight, self.norm.bias, self.norm.eps, self.compute_dtype if fc is not None else torch.float32)
+            return ste_modes.TanhLinearFn.apply(y, fc.weight, fc.bias, self._cache).float() if fc is not None else y
         # inference: LayerNorm only the cls rows (row stride P*C), pre_logits GEMM with fused tanh
         y, _, _ = ops.layernorm_fwd(tok, self.norm.weight, self.norm.bias, self.compute_dtype if fc is not None else torch.float32,
                                     eps=self.norm.eps, row_stride=P * C_, rows=Fr)

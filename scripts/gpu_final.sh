@@ -1,14 +1,23 @@
 #!/bin/bash
-# evidence run: full GPU test suite, smoke, bench (with CPU baseline), steady-state rocprofv3 summary
+# evidence run at HEAD: full GPU test suite, smoke, bench (with CPU baseline + parity probe), forward-only and f32-mode bench lines,
+# steady-state rocprofv3 summary, PMC traffic passes (stamped with the kernel-source hash), GEMM micro-benchmark, cfg5.
+# Everything lands under gpurun_out/final/ -- copy what should be judged to profiles/rNN_*.
 set -u
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out; export TMPDIR=/tmp
+O=gpurun_out/final; mkdir -p $O; export TMPDIR=/tmp
 rm -f gpurun_out/parity_report.txt
-timeout 1200 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit: $?" >> gpurun_out/pytest_gpu.log
-tail -n 3 gpurun_out/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?" >> gpurun_out/smoke.log; tail -n 2 gpurun_out/smoke.log
-timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench exit: $?" >> gpurun_out/bench.err; tail -n 4 gpurun_out/bench.err; cat gpurun_out/bench.log
-timeout 300 python bench.py --steps 20 --warmup 3 --forward-only --no-cpu-baseline > gpurun_out/bench_fwd.log 2>/dev/null; cat gpurun_out/bench_fwd.log | cut -c1-400
-timeout 300 python scripts/gemm_micro.py 30 all 0 > gpurun_out/gemm_micro.log 2>&1; grep -E "impl 0" gpurun_out/gemm_micro.log | cut -c1-100
-bash scripts/gpu_prof.sh > gpurun_out/prof_stdout.log 2>&1; head -5 gpurun_out/prof_stdout.log | cut -c1-200
-timeout 600 python bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_cfg5.log 2> gpurun_out/bench_cfg5.err; cut -c1-200 gpurun_out/bench_cfg5.log
+timeout 1200 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest exit: $?" >> $O/pytest_gpu.log
+grep -E "passed|failed" $O/pytest_gpu.log | tail -n 2
+cp gpurun_out/parity_report.txt $O/parity_report_gpu.txt 2>/dev/null
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit: $?" >> $O/smoke.log; tail -n 2 $O/smoke.log
+timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench_train.json 2> $O/bench_train.err; echo "bench exit: $?" >> $O/bench_train.err; cut -c1-260 $O/bench_train.json
+timeout 300 python bench.py --steps 20 --warmup 3 --forward-only --no-cpu-baseline > $O/bench_forward.json 2>/dev/null; cut -c1-200 $O/bench_forward.json
+timeout 600 python bench.py --steps 5 --warmup 2 --dtype f32 --no-cpu-baseline > $O/bench_train_f32.json 2>/dev/null; cut -c1-200 $O/bench_train_f32.json
+timeout 300 python scripts/gemm_micro.py 30 all 0 > $O/gemm_micro.txt 2>&1; grep "gemm " $O/gemm_micro.txt | cut -c1-110
+rm -rf /tmp/prof_out
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_out -o bench -- python "$OLDPWD/bench.py" --steps 6 --warmup 3 --no-cpu-baseline > "$OLDPWD/$O/prof.log" 2>&1)
+tr=$(find /tmp/prof_out -name "*kernel_trace.csv" | head -1)
+python scripts/summarize_trace.py "$tr" $O/rocprofv3_steady_state_kernels.csv 4 && head -40 $O/rocprofv3_steady_state_kernels.csv | cut -c1-150
+cp $(find /tmp/prof_out -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_incl_warmup.csv 2>/dev/null
+bash scripts/gpu_pmc.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc/traffic.json $O/traffic.json 2>/dev/null; tail -30 $O/pmc.log
+timeout 600 python bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null; cut -c1-200 $O/bench_cfg5.json

@@ -87,7 +87,7 @@ def test_front_end_and_merge():
     assert front(pv) == (0, {})
 
 
-@pytest.mark.parametrize("name", ["video_2d3d", "video_3d", "video_novalid", "image", "image_mixed"])
+@pytest.mark.parametrize("name", ["video_2d3d", "video_3d", "video_novalid", "video_accl", "image", "image_mixed"])
 def test_fused_kernels_on_host_simulator(name, monkeypatch):
     """maed_loss_fwd_bwd (maed_amd/csrc/loss.hip) compiled for x86 against tests/hostsim: values AND gradients vs the
     reference's.  The fused path is selected by .is_cuda in the module, so call its back end directly."""
@@ -98,11 +98,7 @@ def test_fused_kernels_on_host_simulator(name, monkeypatch):
     with patched():
         if name.startswith("image"):
             total, terms = mloss.Loss(device="cpu").loss_image(leaves, d3)       # on_library_device: the simulator counts as the device
-        else:
-            mod = mloss.LossVideo(device="cpu")
-            n2 = d2["kp_2d"].shape[0] if d2 else 0
-            gt2d = torch.cat([d2["kp_2d"], d3["kp_2d"]], 0) if d2 else d3["kp_2d"]
-            total, terms = mod._terms_fused(leaves["kp_2d"], gt2d, leaves["kp_3d"], d3["kp_3d"], leaves["theta"], d3["theta"],
-                                            d3["w_smpl"].bool(), n2 * leaves["kp_3d"].shape[1], mod.e_3d_loss_weight)
+        else:      # (video_accl: the acceleration term's own kernel, maed_loss_accl_fwd_bwd, on top of the fused five)
+            total, terms = mloss.LossVideo(device="cpu", **(ACCL_KW if name == "video_accl" else {}))(leaves, d3, d2)
         (total * 1.0).backward()
     check(fx, name, total, terms, {k: v.grad for k, v in leaves.items()}, rtol=3e-5, atol=3e-6)
