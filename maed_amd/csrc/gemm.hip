@@ -472,6 +472,12 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
 }
 
 // ------------------------------------------------------------------------------------------------
+// out[r][c] = bias[c] (or 0): the starting value of a split-K accumulation
+__global__ __launch_bounds__(256) void bias_fill_kernel(float* __restrict__ out, int64_t ldo, const float* __restrict__ bias, int64_t M, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < M * N) { const int64_t r = i / N, c = i % N; out[r * ldo + c] = bias ? bias[c] : 0.f; }
+}
+
 template <int EPI, typename T>
 static int launch_valu(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                        const EpiArgs& e, int splitk, hipStream_t s) {
@@ -525,6 +531,20 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
                     const EpiArgs& e, int splitk, int impl, hipStream_t s) {
     if (dtype == MAED_F32) {
         MAED_CHECK_ARG(impl != MAED_IMPL_MFMA, MAED_ERR_UNSUPPORTED, "gemm_nt: f32 has no MFMA path (exact-f32 VALU kernel)");
+        // few output tiles, long K (the decoder tail's GEMMs: 128 frames x 1024 x 1024 is 32 tiles of 64 x 64 -- 86 us on 32 CUs): spread
+        // K over the chip -- the fp32 output starts as the bias and the K slices accumulate with fp32 atomics (15 us)
+        if constexpr (EPI == MAED_EPI_STORE || EPI == MAED_EPI_STORE_F32) {
+            const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+            if (splitk == 1 && tiles < 96 && K >= 256) {
+                int sk = (int)(256 / tiles);
+                if (sk > K / 64) sk = (int)(K / 64);
+                if (sk > 1) {
+                    hipLaunchKernelGGL(bias_fill_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, (float*)e.out, e.ldo, e.bias, M, N);
+                    EpiArgs ea{nullptr, e.out, e.ldo, nullptr, nullptr, 0};
+                    return launch_valu<MAED_EPI_ATOMIC_F32, float>(A, lda, B, ldb, M, N, K, ea, sk, s);
+                }
+            }
+        }
         return launch_valu<EPI, float>(A, lda, B, ldb, M, N, K, e, splitk, s);
     }
     // (the direct-to-LDS kernels address the operands with 32-bit lane byte offsets from a scalar base)

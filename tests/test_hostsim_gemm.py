@@ -108,3 +108,14 @@ def test_gemm_nt_256_epilogues_and_transpose_detection():
     assert torch.allclose(out, aux + acc + bias, rtol=1e-4, atol=1e-4)
     assert torch.allclose(pre.float(), (acc + bias).bfloat16().float(), atol=2e-2) and torch.allclose(act.float(), gelu(pre.float()), rtol=2e-2, atol=2e-2)
 
+
+
+def test_gemm_nt_f32_few_tiles_long_k_takes_the_split_k_route():
+    """fp32, few output tiles, K >= 256 (the decoder tail's GEMMs): bias fill + split-K atomics must equal the plain kernel's answer"""
+    M, N, K = 70, 128, 512
+    A, B, bias = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43)
+    ref = A.double() @ B.double().t() + bias.double()
+    with patched():
+        out = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias)
+        out_nb = ops.gemm_nt(A, B, L.EPI_STORE_F32)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-5) and torch.allclose(out_nb.double(), ref - bias.double(), rtol=1e-5, atol=1e-5)
