@@ -78,7 +78,10 @@ def usable_cores(cap=32):
 
 
 def cpu_baseline(budget_s=25.0):
-    """oracle train step (fwd + autograd bwd + torch Adam) on host cores; bounded sample: 1 clip x 16 frames."""
+    """oracle train step (fwd + autograd bwd + torch Adam) on host cores; bounded sample: 2 clips x 16 frames.  kind "port": the reference
+    itself cannot travel to the GPU box; in the build container the port's train step takes 1.19x the reference's own
+    (lib/models MAED + lib/core/loss.py + torch Adam; forward 1.00x) on the same inputs and threads, interleaved timing, outputs bit-identical
+    (oracle/time_reference_cpu.py -> profiles/r02_reference_vs_port_cpu.json)."""
     from oracle import loss_ref
     from oracle import maed_ref as R
     cores = usable_cores()
@@ -89,7 +92,7 @@ def cpu_baseline(budget_s=25.0):
     sp = R.make_synthetic_smpl(0)
     opt = torch.optim.Adam(list(params.values()), lr=1e-4, weight_decay=1e-5)
     gen = torch.Generator().manual_seed(1)
-    n_clips = 1
+    n_clips = 2
     clip = torch.randn(n_clips, CFG["T"], 3, CFG["img"], CFG["img"], generator=gen)
     tgt = make_targets(n_clips, CFG["T"], "cpu", gen)
 
@@ -114,7 +117,9 @@ def cpu_baseline(budget_s=25.0):
         dt = (time.perf_counter() - t0) / n
     return dict(value=n_clips / dt, unit="video-clips/sec", cores=cores, kind="port",
                 sample=f"{n} timed train steps (fwd+bwd+Adam, fp32) of {n_clips} clip x {CFG['T']} frames x {CFG['img']}^2 after 1 warm-up; "
-                       f"oracle/maed_ref.py on torch CPU ops, {cores} threads (of {os.cpu_count()} logical CPUs)", s_per_step=dt)
+                       f"oracle/maed_ref.py on torch CPU ops, {cores} threads (of {os.cpu_count()} logical CPUs); the reference's own CPU path "
+                       f"is 1.19x faster per train step than this port (build container, profiles/r02_reference_vs_port_cpu.json)", s_per_step=dt,
+                reference_over_port=1.19)
 
 
 def parity_probe(dev):

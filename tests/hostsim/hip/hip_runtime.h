@@ -221,6 +221,26 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t src0, uint32_t src1, uint3
     for (int b = 0; b < 4; ++b) r |= (uint32_t)((pool >> (8 * ((sel >> (8 * b)) & 7))) & 0xff) << (8 * b);
     return r;
 }
+// ds_read_b64_tr_b16: every lane reads 4 x 16 bit at ITS OWN address; inside each 16-lane group the 16 x 4 elements are transposed:
+// lane i, element j <- the element (i & 3) that lane 4j + (i >> 2) of the group loaded (column i of a 4 x 16 block whose row j is
+// covered by lanes 4j .. 4j+3)
+typedef short hostsim_v4i16 __attribute__((ext_vector_type(4)));
+static inline hostsim_v4i16 __builtin_amdgcn_ds_read_tr16_b64_v4i16(hostsim_v4i16* p) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    const unsigned q = hostsim::t_wop++ & 1u;
+    uint64_t mine;
+    memcpy(&mine, p, 8);
+    w.u64[q][lane] = mine;
+    w.bar.arrive_and_wait();
+    hostsim_v4i16 r;
+    const int i = lane & 15, g = lane & ~15;
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t src = w.u64[q][g + 4 * j + (i >> 2)];
+        r[j] = (short)(uint16_t)(src >> (16 * (i & 3)));
+    }
+    return r;
+}
 static inline void __builtin_amdgcn_s_barrier() { hostsim::t_block->bar.arrive_and_wait(); }
 static inline void __builtin_amdgcn_s_setprio(int) {}          // scheduling hints: nothing to simulate
 static inline void __builtin_amdgcn_sched_barrier(int) {}

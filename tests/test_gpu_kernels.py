@@ -437,7 +437,8 @@ def test_weight_std_batched(dtype):
                atol=(1e-4 if dtype == torch.float32 else 2e-2) * wd.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (197 * 8, 512, 256), (64, 128, 128), (1000, 1536, 512), (37, 8, 8)])
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (197 * 8, 512, 256), (64, 128, 128), (1000, 1536, 512), (37, 8, 8),
+                                   (197 * 128, 1536, 512), (197 * 128, 512, 2048)])                                        # the last two: cfg3 STE shapes
 def test_gemm_tn_wgrad(M, N, K):
     """dW += Y^T X and db += colsum(Y) straight from row-major bf16 operands (register 8x8 transposes, split-M atomics)"""
     ops, _ = _ops()

@@ -119,3 +119,4 @@ def test_gemm_nt_f32_few_tiles_long_k_takes_the_split_k_route():
         out = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias)
         out_nb = ops.gemm_nt(A, B, L.EPI_STORE_F32)
     assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-5) and torch.allclose(out_nb.double(), ref - bias.double(), rtol=1e-5, atol=1e-5)
+
