@@ -567,8 +567,11 @@ extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F
     const bool use_mfma = (dtype == MAED_BF16) && (impl != MAED_IMPL_VALU);
     MAED_CHECK_ARG(!((impl == MAED_IMPL_MFMA || impl == MAED_IMPL_MFMA_LONG) && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED,
                    "attn_spatial_fwd: MFMA path is bf16 only");
-    // sequences that do not fit one workgroup's LDS (st_mode='coupling': T*P tokens), or on request: the K/V-tiled kernels
-    if (use_mfma && (impl == MAED_IMPL_MFMA_LONG || P > 512)) return maed_attn_long_fwd_launch(qkv, o, lse, F, P, H, scale, s);
+    // the K/V-tiled kernels (128 query rows per workgroup, 64-key LDS tiles, lazy rescale): for sequences that do not fit one workgroup's
+    // LDS (st_mode='coupling': T*P tokens) -- and by default, since they measured faster than the whole-head kernel at the frame sizes of
+    // the path too (MI355X, profiles/r02_call1_attn_long_micro.txt: P = 197 33.9 vs 37.0 us, P = 257 71.7 vs 89.0 us).
+    // MAED_IMPL_MFMA selects the whole-head kernel (A/B, tests).
+    if (use_mfma && (impl == MAED_IMPL_MFMA_LONG || impl == MAED_IMPL_AUTO || P > 512)) return maed_attn_long_fwd_launch(qkv, o, lse, F, P, H, scale, s);
     if (use_mfma) {
         const int Pk = (P + 31) & ~31;
         MAED_CHECK_ARG(Pk / 32 <= 16, MAED_ERR_SHAPE, "attn_spatial_fwd(mfma): P=%d > 512 tokens per frame", P);
@@ -613,8 +616,12 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
     if (F == 0) return MAED_OK;
     const bool mfma_fits = ((P + 31) / 32) <= 10;  // 640-thread workgroups (register budget 168/lane)
     // sequences beyond the whole-head kernels (MFMA: 320 tokens, VALU: LDS), or on request: the tiled two-pass backward
+    // (default for frame sizes whose last 128-row tile is at least half full: P = 197 138.8 vs 147.0 us; at P = 257 the third tile holds ONE
+    //  row and the whole-head kernels win, 311.8 vs 342.2 us -- profiles/r02_call1_attn_long_micro.txt)
+    const bool tail_ok = (P % 128 == 0) || (P % 128 >= 64);
     if (dtype == MAED_BF16 && impl != MAED_IMPL_VALU &&
-        (impl == MAED_IMPL_MFMA_LONG || (!mfma_fits && (impl == MAED_IMPL_MFMA || valu_lds_bytes(P, true) > 160 * 1024))))
+        (impl == MAED_IMPL_MFMA_LONG || (impl == MAED_IMPL_AUTO && tail_ok) ||
+         (!mfma_fits && (impl == MAED_IMPL_MFMA || valu_lds_bytes(P, true) > 160 * 1024))))
         return maed_attn_long_bwd_launch(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     if (dtype == MAED_BF16 && impl != MAED_IMPL_VALU && mfma_fits) {
         const int Pk = (P + 31) & ~31;

@@ -29,7 +29,14 @@ template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* __restrict__ Y, int64_t ldy, const bf16* __restrict__ X,
                                                                    int64_t ldx, int64_t M, int N, int K, float* __restrict__ dW,
                                                                    int64_t ldw, float* __restrict__ dbias, int tiles_k, int mtiles_per_split,
-                                                                   TnConv cv) {
+                                                                   TnConv cv
+#ifdef MAED_GEMM_ABLATE
+                                                                   , int ablate    // diagnostic build only: 1 no atomics, 2 no global loads, 4 no MFMA / fragment reads, 8 no transposing LDS stores
+#endif
+                                                                   ) {
+#ifndef MAED_GEMM_ABLATE
+    constexpr int ablate = 0;
+#endif
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][128 * TN_LD];  // [buf][Y^T | X^T][row n|k][m]
     __shared__ float lcs[8][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
 #define TN_LD1(S, i, tb_) r##S##_##i = *reinterpret_cast<const uint4*>((tb_) + vo##i);
     // CONV, X side: row i of the 8-row group is taken from the image only if bit `tap` of its pixel's mask is set, else from the zero page
 #define TN_LD1M(S, i, tb_, mw_) r##S##_##i = *reinterpret_cast<const uint4*>(((((mw_) >> (((i) & 1) * 16 + tap)) & 1u) ? (tb_) + vo##i : cv.zero_page));
-#define TN_LOAD(S, mt_) { int mtc__ = (mt_); if (mtc__ > mt_endf - 1) mtc__ = mt_endf - 1; \
+#define TN_LOAD(S, mt_) if (!(ablate & 2)) { int mtc__ = (mt_); if (mtc__ > mt_endf - 1) mtc__ = mt_endf - 1; \
         const bf16* tb__ = src + (int64_t)mtc__ * TN_BM * lds_src; \
         bool masked__ = false; \
         if constexpr (CONV) masked__ = side != 0; \
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
                                          PERM(r##S##_4.COMP, r##S##_5.COMP), PERM(r##S##_6.COMP, r##S##_7.COMP))
 #define TN_CS(S, COMP, j0) { const uint32_t w__[8] = {r##S##_0.COMP, r##S##_1.COMP, r##S##_2.COMP, r##S##_3.COMP, r##S##_4.COMP, r##S##_5.COMP, r##S##_6.COMP, r##S##_7.COMP}; \
         _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) { cs[j0] += __uint_as_float(w__[i__] << 16); cs[j0 + 1] += __uint_as_float(w__[i__] & 0xffff0000u); } }
-#define TN_STORE(S, buf_) if (col_ok) { unsigned short* d__ = my_lds_base + (size_t)(buf_) * (2 * 128 * TN_LD) + wr_off; \
+#define TN_STORE(S, buf_) if (col_ok && !(ablate & 8)) { unsigned short* d__ = my_lds_base + (size_t)(buf_) * (2 * 128 * TN_LD) + wr_off; \
         *reinterpret_cast<uint4*>(d__ + 0 * TN_LD) = TN_ROW(S, x, perm_lo); *reinterpret_cast<uint4*>(d__ + 1 * TN_LD) = TN_ROW(S, x, perm_hi); \
         *reinterpret_cast<uint4*>(d__ + 2 * TN_LD) = TN_ROW(S, y, perm_lo); *reinterpret_cast<uint4*>(d__ + 3 * TN_LD) = TN_ROW(S, y, perm_hi); \
         *reinterpret_cast<uint4*>(d__ + 4 * TN_LD) = TN_ROW(S, z, perm_lo); *reinterpret_cast<uint4*>(d__ + 5 * TN_LD) = TN_ROW(S, z, perm_hi); \
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     // fragment reads: row = sub-tile base + l31, logical 16-B slot 2*kk + hi, physical slot ^ ((row >> 3) & 7)
     const int arow0 = wr * 64 + l31, arow1 = arow0 + 32, brow0 = wc * 64 + l31, brow1 = brow0 + 32;
     const int asw0 = (arow0 >> 3) & 7, asw1 = (arow1 >> 3) & 7, bsw0 = (brow0 >> 3) & 7, bsw1 = (brow1 >> 3) & 7;
-#define TN_COMPUTE(buf_) { const unsigned short* A__ = &lds[buf_][0][0]; const unsigned short* B__ = &lds[buf_][1][0]; \
+#define TN_COMPUTE(buf_) if (!(ablate & 4)) { const unsigned short* A__ = &lds[buf_][0][0]; const unsigned short* B__ = &lds[buf_][1][0]; \
         _Pragma("unroll") for (int kk = 0; kk < TN_BM / 16; ++kk) { const int sl = 2 * kk + hi; \
             const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(A__ + arow0 * TN_LD + ((sl ^ asw0) << 3)); \
             const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(A__ + arow1 * TN_LD + ((sl ^ asw1) << 3)); \
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     // D[row n][col k]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*hi -> atomics of a half-wave hit 32 consecutive k
 #define TN_EPI(acc_, i_, j_) { const int kcol = k0 + wc * 64 + (j_) * 32 + l31; \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int nrow = n0 + wr * 64 + (i_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; \
-            if (nrow < N && kcol < K) atomicAdd(dW + (int64_t)nrow * ldw + kcol, acc_[r]); } }
+            if (nrow < N && kcol < K && !(ablate & 1)) atomicAdd(dW + (int64_t)nrow * ldw + kcol, acc_[r]); } }
     TN_EPI(acc00, 0, 0) TN_EPI(acc01, 0, 1) TN_EPI(acc10, 1, 0) TN_EPI(acc11, 1, 1)
 
     if (bias_blk) {   // block-uniform branch
@@ -199,8 +206,14 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     if (splits < 1) splits = 1;
     const int per = (nmt + splits - 1) / splits;
     const int z = (nmt + per - 1) / per;
+#ifdef MAED_GEMM_ABLATE
+    const char* ev = getenv("MAED_GEMM_ABLATE");
+    hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
+                       N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, ev ? atoi(ev) : 0);
+#else
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
                        N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0});
+#endif
     MAED_CHECK_LAUNCH("gemm_tn_wgrad");
     return MAED_OK;
 }
@@ -248,7 +261,11 @@ extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tap
     const int z = (nmt + per - 1) / per;
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<true>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (int64_t)Cout,
                        (const bf16*)x, (int64_t)Cin, M, N, K, dW, (int64_t)K, (float*)nullptr, tk, per,
-                       TnConv{(const uint16_t*)tapmask, (const bf16*)zero_page, Cin, W});
+                       TnConv{(const uint16_t*)tapmask, (const bf16*)zero_page, Cin, W}
+#ifdef MAED_GEMM_ABLATE
+                       , 0
+#endif
+                       );
     MAED_CHECK_LAUNCH("conv3x3_wgrad");
     return MAED_OK;
 }

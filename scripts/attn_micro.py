@@ -10,12 +10,12 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 torch.manual_seed(0)
 bufs = [torch.randn(F_, P, 3 * C, device="cuda").bfloat16() for _ in range(4)]   # rotate buffers: 4 x 77 MB > L2, < MALL
 for q in bufs:
-    ops.attn_spatial_fwd(q, H, 2)
+    ops.attn_spatial_fwd(q, H)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for i in range(iters):
-    ops.attn_spatial_fwd(bufs[i % 4], H, 2)
+    ops.attn_spatial_fwd(bufs[i % 4], H)
 e1.record(); torch.cuda.synchronize()
 us = 1e3 * e0.elapsed_time(e1) / iters
 flops = 4.0 * P * P * C * F_

@@ -165,7 +165,7 @@ def _qkv(Fr, P, H, dtype, seed=0):
     return q(rnd(Fr, P, 3 * 64 * H, seed=seed), dtype)
 
 
-ATTN_CASES = [("f32-valu", torch.float32, 1), ("bf16-valu", torch.bfloat16, 1), ("bf16-mfma", torch.bfloat16, 2)]
+ATTN_CASES = [("f32-valu", torch.float32, 1), ("bf16-valu", torch.bfloat16, 1), ("bf16-mfma", torch.bfloat16, 2), ("bf16-auto", torch.bfloat16, 0)]   # auto = the K/V-tiled kernels where they measured faster
 
 
 @pytest.mark.parametrize("name,dtype,impl", ATTN_CASES)
