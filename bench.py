@@ -161,7 +161,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # launched by torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment): one process per GPU over RCCL.  A 1-process
+    # launch under torchrun initialises the group too, and MAED_FORCE_COLLECTIVES=1 then issues every bucket's all-reduce anyway -- the
+    # whole multi-GPU code path (init, broadcast, bucketed RCCL all-reduce overlapped with backward, barrier) on a single GPU box.
+    force_coll = os.environ.get("MAED_FORCE_COLLECTIVES", "0") == "1"
+    if world > 1 or (force_coll and "RANK" in os.environ and "MASTER_PORT" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
@@ -193,7 +197,7 @@ def main():
         if os.environ.get("MAED_COMM", "torch") == "direct":   # the library's own RCCL communicator + side stream (maed_comm_*)
             from maed_amd.ddp import RcclComm
             comm = RcclComm()
-        bucketer = GradBucketer(arena, model, comm=comm)
+        bucketer = GradBucketer(arena, model, comm=comm, force_collectives=force_coll)
         bucketer.broadcast_parameters(0)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=bucketer)  # configs/config_stage2.yaml:63-66
         criterion = LossVideo(**LOSS_W)                                        # lib/core/loss.py via maed_loss_fwd_bwd
@@ -206,7 +210,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -368,7 +372,7 @@ def main():
             "parity_err_bf16": (cpu or {}).get("parity_probe", {}).get("rel_err", {}).get("bf16") if cpu and (cpu.get("parity_probe") or {}).get("rel_err") else None,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
