@@ -297,7 +297,8 @@ int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int 
 /* GroupNorm(32 groups)(+ residual)(+ ReLU) on channels_last activations x (N, HW, C) (resnetv2.py:35-49,189-204):
  * y = act(GN(x) * gamma + beta [+ residual]).  sums: (N,32,2) doubles written by forward, read by backward.
  * sums_zeroed / ab_zeroed != 0: the caller hands in scratch that is already zero (one memset for all 52 layers of a
- * backbone pass instead of one per layer). */
+ * backbone pass instead of one per layer).  sums_zeroed == 2: sums already HOLD the statistics of x -- accumulated by the producing
+ * convolution's epilogue (maed_conv1x1_fwd / maed_conv3x3_fwd gn_sums) -- and the statistics pass over x is skipped. */
 int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
                        uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream);
 /* relu_mask (N*HW*C/8 bytes, bit j of byte (n,hw,c/8) = output channel 8*(c/8)+j > 0): written by forward when a residual is
@@ -349,9 +350,19 @@ int maed_comm_destroy(void);
  * The input gradient of a stride-1 convolution is this entry point on dY (Cin := forward Cout, Cout := forward Cin) with either the
  * flipped, transposed weight w'[ci][2-ky][2-kx][co] (w_layout 0) or, copy-free, the transposed image (3,3,Cin_f,Cout_f) that
  * maed_weight_std_fwd writes next to the forward image (w_layout 1: the tap flip becomes a negative tap stride).
- * Needs Cin % 64 == 0, Cout % 8 == 0.  Opt-in path (maed_amd/resnetv2.py MAED_CONV3X3=own). */
+ * Needs Cin % 64 == 0, Cout % 8 == 0.  The backbone's default 3x3 path (maed_amd/resnetv2.py; MAED_CONV3X3=miopen switches back).
+ * gn_sums (optional, fp64 (F,32,2), PRE-ZEROED): the GroupNorm(32) statistics of the stored output -- sums[f][g] += (sum y, sum y^2)
+ * over the pixels of frame f and the channels of group g -- for the GroupNorm that follows every convolution (resnetv2.py:35-49):
+ * maed_groupnorm_fwd then skips its statistics pass (stats = 2).  Needs Cout = 32 * 2^k >= 64, Ho*Wo >= 128, add == NULL. */
 int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* zero_page, void* y, int F, int H, int W, int Cin, int Cout,
-                     int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int w_layout, int dtype, void* stream);
+                     int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int w_layout, int dtype, double* gn_sums,
+                     void* stream);
+
+/* 1x1 stride-1 convolution on a channels_last activation viewed as (M = F*H*W, Cin) rows: y (M, Cout) = x w^T, w (Cout, Cin) the
+ * standardised weight (no bias: StdConv2dSame) -- maed_gemm_nt's STORE epilogue -- plus, optionally, the GroupNorm statistics of the
+ * output exactly as maed_conv3x3_fwd's gn_sums (hw = H*W pixels per frame).  bf16, Cin % 64 == 0. */
+int maed_conv1x1_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int Cout, int Cin, void* y, int64_t ldy, int hw,
+                     double* gn_sums, int dtype, void* stream);
 
 /* weight gradient of the stride-1 3x3 SAME convolution: dW (Cout, 9*Cin) fp32 += sum over pixels of dy (F,H,W,Cout) x shifted x (F,H,W,Cin)
  * (a TN GEMM over gathered rows on maed_gemm_tn_wgrad's kernel).  tapmask: F*H*W uint16 rounded up to a multiple of 64, filled once per

@@ -105,7 +105,8 @@ SIGNATURES = {
     "maed_comm_wait": (i32, [vp]),
     "maed_comm_world": (i32, []),
     "maed_comm_destroy": (i32, []),
-    "maed_conv3x3_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "maed_conv3x3_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
+    "maed_conv1x1_fwd": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, i32, vp, i32, vp]),
     "maed_conv3x3_tapmask": (i32, [vp, i32, i32, i32, vp]),
     "maed_conv3x3_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "maed_eval_pose_errors": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),

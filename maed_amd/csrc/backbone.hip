@@ -358,7 +358,8 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
     dim3 grid((HW + rows - 1) / rows, N);
     if (!sums_zeroed) hipMemsetAsync(sums, 0, (size_t)N * GN_G * 2 * sizeof(double), s);
     MAED_DISPATCH_DTYPE(dtype, T, {
-        hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)x, sums, HW, C, rows);
+        if (sums_zeroed != 2)       // 2: the producing convolution's epilogue accumulated the statistics already (maed_conv1x1_fwd / maed_conv3x3_fwd)
+            hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)x, sums, HW, C, rows);
         if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
         else if (residual) hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
         else if (relu) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);

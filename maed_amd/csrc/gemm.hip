@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16_kernel(const bf16* _
 //   NBUF == 2: 64 KB LDS, tile t+1 lands while tile t is multiplied, one barrier per K tile
 // ------------------------------------------------------------------------------------------------
 
-template <int EPI, int NBUF>
+template <int EPI, int NBUF, bool GN = false>        // GN: + GroupNorm statistics of the stored output (maed_conv1x1_fwd)
 __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                                      const bf16* __restrict__ B, int64_t ldb, int64_t M,
                                                                                      int64_t N, int64_t K, int tiles_n,
@@ -210,9 +210,13 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
     constexpr int ablate = 0;
 #endif
     // operand tiles [NBUF][A|B][128*64] bf16; re-used by the epilogue as 4 per-wave fp32 staging areas of 32 rows x 68 floats
+    // (+ the 1-KB GroupNorm-statistics table of the convolution epilogue behind both)
     constexpr int kTileElems = NBUF * 2 * GM_BM * GM_BK, kStageElems = 4 * 32 * GL_ST * 2;     // in 2-byte units
-    __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kTileElems > kStageElems ? kTileElems : kStageElems];
+    constexpr int kMainElems = kTileElems > kStageElems ? kTileElems : kStageElems;
+    __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kMainElems + (GN ? GN_TAB_FLOATS * 2 : 0)];
     unsigned short (*lds)[2][GM_BM * GM_BK] = reinterpret_cast<unsigned short (*)[2][GM_BM * GM_BK]>(lds_raw);
+    float* const gn_tab = reinterpret_cast<float*>(lds_raw + kMainElems);
+    if (GN && threadIdx.x < GN_TAB_FLOATS) gn_tab[threadIdx.x] = 0.f;                           // (published by the main loop's barriers)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations (M0) stay on the SALU
     const int wr = wave >> 1, wc = wave & 1;
@@ -313,6 +317,9 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
         const bool vec_ok = (e.ldo % 8 == 0) && (e.ldaux % 8 == 0);
         float* stg = reinterpret_cast<float*>(lds_raw) + wave * 32 * GL_ST;
         const int rr = lane >> 3, cc = (lane & 7) * 8;
+        const GnTile gnt = GN ? gn_tile(gn_tab, m0, n0, N, e.gn_hw) : GnTile{nullptr, 0, 0, 0};
+        GnRegs gnr;
+        if constexpr (GN) gn_zero(gnr);
 #define GL_SHUFFLE_HALF(accA_, accB_, i_)                                                                              \
         __syncthreads();                                                                                               \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
@@ -326,10 +333,16 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
             float v8[8];                                                                                               \
             ld8(stg + lr * GL_ST + cc, v8);                                                                            \
             if (row < M && c0 < N && !(ablate & 1)) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);             \
+            if constexpr (GN) { if (row < M && c0 < N) gn_acc8(gnr, gnt, v8, row); }                                   \
         }
         GL_SHUFFLE_HALF(acc00, acc01, 0)
         GL_SHUFFLE_HALF(acc10, acc11, 1)
 #undef GL_SHUFFLE_HALF
+        if constexpr (GN) {
+            gn_commit(gnr, gnt, lane, n0 + wc * 64 + cc, N);
+            __syncthreads();
+            gn_flush(gnt, e.gn_sums, m0, M, e.gn_hw, GM_BN, tid, 256);
+        }
     }
 }
 
@@ -348,12 +361,15 @@ struct Conv3x3Dims { int F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left; int64_
 
 // NARROW: 128 x 64 output tile for Cout <= 64 (stage 1 of the R50: a 128-wide tile would spend half its MFMAs on duplicated weight rows):
 // the four waves take 32 pixel rows each and both 32-column halves; only 64 weight rows are staged.
-template <int EPI, bool NARROW>
+template <int EPI, bool NARROW, bool GN>
 __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt, const bf16* __restrict__ zero_page,
                                                                    Conv3x3Dims d, int64_t M, int64_t N, int tiles_n, EpiArgs e) {
     constexpr int kTileElems = 2 * GM_BM * GM_BK, kStageElems = 4 * 32 * GL_ST * 2;
-    __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kTileElems > kStageElems ? kTileElems : kStageElems];
+    constexpr int kMainElems = kTileElems > kStageElems ? kTileElems : kStageElems;
+    __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kMainElems + (GN ? GN_TAB_FLOATS * 2 : 0)];   // (+ GroupNorm-statistics table)
     unsigned short (*lds)[GM_BM * GM_BK] = reinterpret_cast<unsigned short (*)[GM_BM * GM_BK]>(lds_raw);     // [A|B][128*64]
+    float* const gn_tab = reinterpret_cast<float*>(lds_raw + kMainElems);
+    if (GN && threadIdx.x < GN_TAB_FLOATS) gn_tab[threadIdx.x] = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = NARROW ? wave : wave >> 1, wc = NARROW ? 0 : wave & 1, l31 = lane & 31, hi = lane >> 5;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -422,6 +438,9 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
     const bool vec_ok = (e.ldo % 8 == 0) && (e.ldaux % 8 == 0);
     float* stg = reinterpret_cast<float*>(lds_raw) + wave * 32 * GL_ST;
     const int rr = lane >> 3, cc = (lane & 7) * 8;
+    const GnTile gnt = GN ? gn_tile(gn_tab, m0, n0, N, e.gn_hw) : GnTile{nullptr, 0, 0, 0};
+    GnRegs gnr;
+    if constexpr (GN) gn_zero(gnr);
 #define CV_SHUFFLE_HALF(accA_, accB_, i_)                                                                              \
     __syncthreads();                                                                                                   \
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                    \
@@ -435,14 +454,28 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
         float v8[8];                                                                                                   \
         ld8(stg + lr * GL_ST + cc, v8);                                                                                \
         if (row < M && c0 < N) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);                                  \
+        if constexpr (GN) { if (row < M && c0 < N) gn_acc8(gnr, gnt, v8, row); }                                       \
     }
     CV_SHUFFLE_HALF(acc00, acc01, 0)
     if constexpr (!NARROW) { CV_SHUFFLE_HALF(acc10, acc11, 1) }
 #undef CV_SHUFFLE_HALF
+    if constexpr (GN) {
+        gn_commit(gnr, gnt, lane, n0 + wc * 64 + cc, N);
+        __syncthreads();
+        gn_flush(gnt, e.gn_sums, m0, M, e.gn_hw, NARROW ? 64 : GM_BN, tid, 256);
+    }
+}
+
+static bool gn_stats_shape_ok(int64_t channels, int64_t hw) {          // 32 groups of 2^k channels; a 128-row tile spans at most two frames
+    const int64_t cpg = channels / 32;
+    return channels % 32 == 0 && cpg >= 2 && (cpg & (cpg - 1)) == 0 && hw >= 128;
 }
 
 extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* zero_page, void* y, int F, int H, int W, int Cin, int Cout,
-                                int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int w_layout, int dtype, void* stream) {
+                                int stride, int pad_top, int pad_left, int Ho, int Wo, const void* add, int w_layout, int dtype, double* gn_sums,
+                                void* stream) {
+    MAED_CHECK_ARG(!gn_sums || (gn_stats_shape_ok(Cout, (int64_t)Ho * Wo) && !add), MAED_ERR_SHAPE,
+                   "conv3x3_fwd: GroupNorm statistics need Cout = 32 * 2^k >= 64, Ho*Wo >= 128 and no `add` (Cout=%d Ho*Wo=%d)", Cout, Ho * Wo);
     MAED_CHECK_ARG(w_layout == 0 || w_layout == 1, MAED_ERR_ARG, "conv3x3_fwd: w_layout must be 0 (Cout,3,3,Cin) or 1 (transposed image of the forward weight)");
     MAED_CHECK_ARG(x && w_taps && zero_page && y, MAED_ERR_ARG, "conv3x3_fwd: null pointer");
     MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_fwd: bf16 only (the f32 parity mode keeps the library convolution)");
@@ -460,12 +493,13 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
     const Conv3x3Dims d = w_layout == 0
         ? Conv3x3Dims{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left, 9 * (int64_t)Cin, (int64_t)Cin, 0}
         : Conv3x3Dims{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left, (int64_t)Cin, -(int64_t)Cout * Cin, 8 * (int64_t)Cout * Cin};
-    EpiArgs e{nullptr, y, (int64_t)Cout, nullptr, add, (int64_t)Cout};
+    EpiArgs e{nullptr, y, (int64_t)Cout, nullptr, add, (int64_t)Cout, gn_sums, Ho * Wo};
     const dim3 grid((unsigned)(tm * tn));
-#define CV_LAUNCH(EPI_, NARROW_) hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<EPI_, NARROW_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, \
+#define CV_LAUNCH(EPI_, NARROW_, GN_) hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<EPI_, NARROW_, GN_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, \
                                                    (const bf16*)w_taps, (const bf16*)zero_page, d, M, N, tn, e)
-    if (add) { if (narrow) CV_LAUNCH(MAED_EPI_ADD, true); else CV_LAUNCH(MAED_EPI_ADD, false); }
-    else { if (narrow) CV_LAUNCH(MAED_EPI_STORE, true); else CV_LAUNCH(MAED_EPI_STORE, false); }
+    if (add) { if (narrow) CV_LAUNCH(MAED_EPI_ADD, true, false); else CV_LAUNCH(MAED_EPI_ADD, false, false); }
+    else if (gn_sums) { if (narrow) CV_LAUNCH(MAED_EPI_STORE, true, true); else CV_LAUNCH(MAED_EPI_STORE, false, true); }
+    else { if (narrow) CV_LAUNCH(MAED_EPI_STORE, true, false); else CV_LAUNCH(MAED_EPI_STORE, false, false); }
 #undef CV_LAUNCH
     MAED_CHECK_LAUNCH("conv3x3_fwd");
     return MAED_OK;
@@ -503,7 +537,7 @@ static int launch_mfma(const void* A, int64_t lda, const void* B, int64_t ldb, i
     return MAED_OK;
 }
 
-template <int EPI, int NBUF>
+template <int EPI, int NBUF, bool GN = false>
 static int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                        const EpiArgs& e, int splitk, hipStream_t s) {
     const int tm = (int)((M + GM_BM - 1) / GM_BM), tn = (int)((N + GM_BN - 1) / GM_BN);
@@ -513,10 +547,10 @@ static int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, i
     const int z = (nkt + kps - 1) / kps;
 #ifdef MAED_GEMM_ABLATE
     const char* ev = getenv("MAED_GEMM_ABLATE");
-    hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
+    hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF, GN>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
                        (const bf16*)B, ldb, M, N, K, tn, kps, e, ev ? atoi(ev) : 0);
 #else
-    hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
+    hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF, GN>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
                        (const bf16*)B, ldb, M, N, K, tn, kps, e);
 #endif
     return MAED_OK;
@@ -584,6 +618,25 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
     }
     if constexpr (EPI == MAED_EPI_ATOMIC_F32) return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
     else return fits32 ? launch_glds<EPI, 1>(A, lda, B, ldb, M, N, K, e, splitk, s) : launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
+}
+
+// 1x1 stride-1 convolution of the backbone on a channels_last activation viewed as (F*H*W, Cin) rows: y = x w^T (no bias: StdConv2dSame,
+// resnetv2.py:74-93) = maed_gemm_nt's STORE epilogue, plus the GroupNorm statistics of the output for the GroupNorm that follows
+extern "C" int maed_conv1x1_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int Cout, int Cin, void* y, int64_t ldy, int hw,
+                                double* gn_sums, int dtype, void* stream) {
+    MAED_CHECK_ARG(x && w && y, MAED_ERR_ARG, "conv1x1_fwd: null pointer");
+    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv1x1_fwd: bf16 only (the f32 parity mode keeps the library convolution)");
+    MAED_CHECK_ARG(M >= 0 && Cout > 0 && Cin > 0 && Cin % GM_BK == 0 && ldx >= Cin && ldw >= Cin && ldy >= Cout && ldx % 8 == 0 && ldw % 8 == 0, MAED_ERR_SHAPE,
+                   "conv1x1_fwd: need Cin %% 64 == 0 and 8-element aligned strides (Cin=%d Cout=%d)", Cin, Cout);
+    MAED_CHECK_ARG(is_aligned(x, 16) && is_aligned(w, 16) && is_aligned(y, 16), MAED_ERR_ALIGN, "conv1x1_fwd: 16-B alignment");
+    MAED_CHECK_ARG((uint64_t)M * (uint64_t)ldx * 2 < (1ull << 32), MAED_ERR_SHAPE, "conv1x1_fwd: activation larger than 4 GB");
+    MAED_CHECK_ARG(!gn_sums || gn_stats_shape_ok(Cout, hw), MAED_ERR_SHAPE, "conv1x1_fwd: GroupNorm statistics need Cout = 32 * 2^k >= 64 and hw >= 128 (Cout=%d hw=%d)", Cout, hw);
+    if (M == 0) return MAED_OK;
+    EpiArgs e{nullptr, y, ldy, nullptr, nullptr, 0, gn_sums, hw};
+    if (gn_sums) launch_glds<MAED_EPI_STORE, 1, true>(x, ldx, w, ldw, M, Cout, Cin, e, 1, (hipStream_t)stream);
+    else launch_glds<MAED_EPI_STORE, 1>(x, ldx, w, ldw, M, Cout, Cin, e, 1, (hipStream_t)stream);
+    MAED_CHECK_LAUNCH("conv1x1_fwd");
+    return MAED_OK;
 }
 
 extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,

@@ -8,6 +8,10 @@ struct EpiArgs {
     void* out; int64_t ldo;
     void* out2;
     const void* aux; int64_t ldaux;
+    // optional second output of a convolution GEMM (resnetv2.py:35-49: every convolution of the backbone feeds a GroupNorm(32)): the
+    // statistics of the STORED (bf16-rounded) output, sums[n][32][2] (fp64, pre-zeroed by the caller) += (sum x, sum x^2) with n = row / gn_hw,
+    // group = column / (N / 32) -- the separate statistics pass over the activation tensor disappears
+    double* gn_sums = nullptr; int gn_hw = 0;
 };
 
 template <int EPI, typename T>
@@ -125,6 +129,80 @@ __device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int
         st8((T*)e.out + r * e.ldo + c0, x);
     }
 }
+
+// ---- GroupNorm statistics in the LDS-shuffled epilogue of a 128-row tile ------------------------------------------------------------
+// A lane of the shuffled epilogue owns 8 consecutive output columns (c0 fixed) of 8 rows: it keeps (sum, sum of squares) per column
+// PAIR (the finest group the backbone has is 2 channels) and per frame (a tile of 128 rows touches at most two frames when
+// gn_hw >= 128) in registers, the 8 lanes of a wave that share c0 are folded with three shuffles, and only then 8 lanes per wave
+// add into the workgroup's LDS table [2 frames][64 groups][2] floats (zeroed at kernel start); gn_flush adds the table to the global
+// fp64 sums -- (2 frames x groups x 2) fp64 atomics per workgroup.
+#define GN_TAB_FLOATS (2 * 64 * 2)
+struct GnTile { float* tab; int64_t split_row; int sh, g0; };            // split_row: first row of the tile's second frame; sh = log2(channels per group)
+struct GnRegs { float s[2][4], q[2][4]; };
+__device__ __forceinline__ GnTile gn_tile(float* tab, int64_t m0, int64_t n0, int64_t N, int hw) {
+    const int cpg = (int)(N >> 5);                                        // N % 32 == 0 and a power of two per group (host-checked)
+    const int sh = 31 - __builtin_clz((unsigned)cpg);
+    return GnTile{tab, (m0 / hw + 1) * (int64_t)hw, sh, (int)(n0 >> sh)};
+}
+__device__ __forceinline__ void gn_zero(GnRegs& a) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { a.s[f][h] = 0.f; a.q[f][h] = 0.f; }
+}
+__device__ __forceinline__ void gn_acc8(GnRegs& a, const GnTile& g, const float (&v)[8], int64_t row) {
+    const bool second = row >= g.split_row;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float r0 = round_to<bf16>(v[2 * h]), r1 = round_to<bf16>(v[2 * h + 1]);      // what the GroupNorm will read back
+        const float ps = r0 + r1, pq = fmaf(r0, r0, r1 * r1);
+        a.s[0][h] += second ? 0.f : ps; a.q[0][h] += second ? 0.f : pq;
+        a.s[1][h] += second ? ps : 0.f; a.q[1][h] += second ? pq : 0.f;
+    }
+}
+// after the last gn_acc8: fold the lanes that share c0 (lane bits 3..5) and add to the LDS table
+__device__ __forceinline__ void gn_commit(GnRegs& a, const GnTile& g, int lane, int64_t c0, int64_t N) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1) { a.s[f][h] += __shfl_xor(a.s[f][h], m); a.q[f][h] += __shfl_xor(a.q[f][h], m); }
+        }
+    if ((lane >> 3) != 0 || c0 >= N) return;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        float* const tf = g.tab + f * 128;
+        if (g.sh >= 3) {                                                  // >= 8 channels per group: the lane's 8 columns are one group
+            float* t = tf + ((((int)(c0 >> g.sh)) - g.g0) << 1);
+            atomicAdd(t, (a.s[f][0] + a.s[f][1]) + (a.s[f][2] + a.s[f][3])); atomicAdd(t + 1, (a.q[f][0] + a.q[f][1]) + (a.q[f][2] + a.q[f][3]));
+        } else if (g.sh == 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float* t = tf + ((((int)(c0 >> 2)) + h - g.g0) << 1);
+                atomicAdd(t, a.s[f][2 * h] + a.s[f][2 * h + 1]); atomicAdd(t + 1, a.q[f][2 * h] + a.q[f][2 * h + 1]);
+            }
+        } else {                                                          // 2 channels per group
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float* t = tf + ((((int)(c0 >> 1)) + h - g.g0) << 1);
+                atomicAdd(t, a.s[f][h]); atomicAdd(t + 1, a.q[f][h]);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void gn_flush(const GnTile& g, double* sums, int64_t m0, int64_t M, int hw, int tile_cols, int tid, int nthr) {
+    const int ngl = ((tile_cols - 1) >> g.sh) + 1;                        // groups this tile's columns touch (<= 64)
+    const int64_t n_first = m0 / hw;
+    for (int i = tid; i < 2 * ngl * 2; i += nthr) {
+        const int k = i & 1, gl = (i >> 1) % ngl, f = (i >> 1) / ngl;
+        const int64_t n = n_first + f;
+        const int grp = g.g0 + gl;
+        const float v = g.tab[f * 128 + (gl << 1) + k];
+        if (n * hw < M && grp < 32 && v != 0.f) atomicAdd(sums + (n * 32 + grp) * 2 + k, (double)v);
+    }
+}
+
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // bijective remap: blocks that the dispatcher places on XCD x (bid % 8 == x) get a contiguous id range

@@ -478,6 +478,7 @@ class WeightStdFn(ReportingFn):
         check(L.lib().maed_weight_std_fwd(_p(tab_dev), len(weights), nf, _p(out), dt_code(dtype), _p(stats), eps, _stream()), "weight_std_fwd")
         ctx.owner, ctx.dtype, ctx.eps, ctx.stats, ctx.nf = owner, dtype, eps, stats, nf
         ctx.weights = weights
+        ctx.set_materialize_grads(False)     # the library convolutions hand their dW over in fp32 slices: no zero tensors in their place
         if ReportingFn.will_run_backward(ctx):
             owner._pending_backwards += 1
         views, off = [], 0
@@ -533,9 +534,10 @@ class GroupNormFn(torch.autograd.Function):
     owner module reports them through its grads_ready callback) instead of travelling through autograd."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, relu, direct, sums=None, ab=None):
+    def forward(ctx, x, residual, gamma, beta, eps, relu, direct, sums=None, ab=None, stats_ready=False):
         """sums (N,32,2) f64 / ab (N,C,2) f32: optional PRE-ZEROED scratch slices (ResNetV2 zeroes one arena per pass for all
-        its 52 layers instead of one memset per layer and direction)"""
+        its 52 layers instead of one memset per layer and direction).  stats_ready: `sums` already holds the statistics of x (the
+        producing convolution's epilogue accumulated them: Conv1x1Fn / Conv3x3Fn gn_sums) -- no statistics pass."""
         N, C_, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)
         if residual is not None:
@@ -549,7 +551,7 @@ class GroupNormFn(torch.autograd.Function):
         need_mask = relu and ctx.has_res and (x.requires_grad or residual.requires_grad or gamma.requires_grad)
         mask = torch.empty(N * H * W * (C_ // 8), dtype=torch.uint8, device=x.device) if need_mask else None
         check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), _p(mask), N, H * W, C_, eps, int(relu),
-                                         dt_code(x.dtype), int(zeroed), _stream()), "groupnorm_fwd")
+                                         dt_code(x.dtype), 2 if (stats_ready and zeroed) else int(zeroed), _stream()), "groupnorm_fwd")
         ctx.ab = ab
         ctx.save_for_backward(x, mask, sums)
         ctx.eps, ctx.relu, ctx.direct = eps, relu, direct
@@ -580,8 +582,8 @@ class GroupNormFn(torch.autograd.Function):
         check(L.lib().maed_groupnorm_bwd(_p(x), _p(mask), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
                                          N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), _stream()), "groupnorm_bwd")
         if ctx.direct:
-            return dx, dres, None, None, None, None, None, None, None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None
+            return dx, dres, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
 class MaxPool3s2SameFn(torch.autograd.Function):
@@ -619,8 +621,9 @@ class Conv1x1Fn(torch.autograd.Function):
     forward 1.01 vs 2.33 ms, input gradient 1.02 vs 1.88 ms, weight gradient 1.47 vs 2.63 ms per step."""
 
     @staticmethod
-    def forward(ctx, x, w, wt, dw, fork=False):
-        """x (N,I,H,W) channels_last; w (O,I,1,1) standardised weight (an output of WeightStdFn: the autograd edge orders
+    def forward(ctx, x, w, wt, dw, fork=False, gn_sums=None):
+        """gn_sums (optional, pre-zeroed (N,32,2) f64): GroupNorm statistics of the output, accumulated by the GEMM's epilogue.
+        x (N,I,H,W) channels_last; w (O,I,1,1) standardised weight (an output of WeightStdFn: the autograd edge orders
         its backward after ours); wt (I,O) transposed image; dw (O,I) fp32 accumulator (None when no gradient is wanted).
         fork=True additionally returns an alias of x for the block's identity shortcut: its gradient then arrives HERE and is
         added inside the input-gradient GEMM's epilogue (MAED_EPI_ADD) instead of by a separate autograd accumulation kernel."""
@@ -630,7 +633,12 @@ class Conv1x1Fn(torch.autograd.Function):
         w2 = w.reshape(O, I)
         w2 = w2 if w2.is_contiguous() else w2.contiguous()
         A = x.permute(0, 2, 3, 1).reshape(N * H * W, I)
-        y = gemm_nt(A, w2, L.EPI_STORE)
+        if gn_sums is not None:
+            y = torch.empty(N * H * W, O, dtype=x.dtype, device=x.device)
+            check(L.lib().maed_conv1x1_fwd(_p(A), A.stride(0), _p(w2), w2.stride(0), N * H * W, O, I, _p(y), O, H * W, _p(gn_sums), dt_code(x.dtype),
+                                           _stream()), "conv1x1_fwd")
+        else:
+            y = gemm_nt(A, w2, L.EPI_STORE)
         ctx.save_for_backward(A, wt)
         ctx.dw, ctx.geom = dw, (N, I, H, W, O)
         ctx.set_materialize_grads(False)
@@ -643,7 +651,7 @@ class Conv1x1Fn(torch.autograd.Function):
         N, I, H, W, O = ctx.geom
         dx = None
         if dy is None:              # only the shortcut carried a gradient
-            return g_short, None, None, None, None
+            return g_short, None, None, None, None, None
         Y = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(N * H * W, O)
         if ctx.needs_input_grad[0]:
             if g_short is not None:
@@ -654,7 +662,7 @@ class Conv1x1Fn(torch.autograd.Function):
             dx = dx.view(N, H, W, I).permute(0, 3, 1, 2)
         if ctx.dw is not None:
             gemm_tn_wgrad(Y, A, dW=ctx.dw)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 
@@ -670,7 +678,7 @@ def _zero_page(device):
     return _ZERO_PAGE[key]
 
 
-def conv3x3(x, w_taps, stride=1, add=None, w_layout=0):
+def conv3x3(x, w_taps, stride=1, add=None, w_layout=0, gn_sums=None):
     """y = conv3x3_SAME(x, w) on channels_last bf16 tensors through maed_conv3x3_fwd.  x (N,Cin,H,W) channels_last,
     w_taps: storage (Cout, 3, 3, Cin) contiguous (w_layout 0), or the transposed image (3, 3, Cout, Cin) of the FORWARD convolution whose
     input gradient this call computes (w_layout 1).  TF-SAME padding from the input size (resnetv2.py:51-59)."""
@@ -683,7 +691,7 @@ def conv3x3(x, w_taps, stride=1, add=None, w_layout=0):
     if add is not None:
         add = add.contiguous(memory_format=torch.channels_last)
     check(L.lib().maed_conv3x3_fwd(_p(x), _p(w_taps), _p(_zero_page(x.device)), _p(y), N, H, W, I, O, stride, ph // 2, pw // 2, Ho, Wo, _p(add),
-                                   w_layout, dt_code(x.dtype), _stream()), "conv3x3_fwd")
+                                   w_layout, dt_code(x.dtype), _p(gn_sums), _stream()), "conv3x3_fwd")
     return y
 
 
@@ -721,13 +729,13 @@ class Conv3x3Fn(torch.autograd.Function):
     place (no flipped copy) -- and the fp32 (O, 9*I) slice the weight gradient accumulates into (autograd then carries no dW)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, wt=None, dw=None):
+    def forward(ctx, x, w, stride, wt=None, dw=None, gn_sums=None):
         x = x.contiguous(memory_format=torch.channels_last)
         w_taps = w.permute(0, 2, 3, 1)
         w_taps = w_taps if w_taps.is_contiguous() else w_taps.contiguous()
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.wt, ctx.dw = stride, wt, dw
-        return conv3x3(x, w_taps, stride)
+        return conv3x3(x, w_taps, stride, gn_sums=gn_sums)
 
     @staticmethod
     def backward(ctx, dy):
@@ -767,4 +775,4 @@ class Conv3x3Fn(torch.autograd.Function):
                     dw = gw
             if need_x and not own_dx:
                 dx = gx if sym else gx[:, :, ph // 2:ph // 2 + H, pw // 2:pw // 2 + W]
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None

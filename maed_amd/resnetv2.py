@@ -38,6 +38,10 @@ _OWN_CONV3X3 = os.environ.get("MAED_CONV3X3", "own") == "own"
 # one batched launch otherwise; MAED_WS_PER_STAGE=0 / 1 forces either.
 _WS_PER_STAGE_ENV = os.environ.get("MAED_WS_PER_STAGE", "auto")
 
+# GroupNorm statistics accumulated in the epilogue of the convolution in front (maed_conv1x1_fwd / maed_conv3x3_fwd gn_sums) instead of
+# a separate pass over the activation (52 launches, 0.64 ms per step at cfg3).  MAED_GN_FUSE_STATS=0 switches back (A/B knob).
+_FUSE_GN_STATS = os.environ.get("MAED_GN_FUSE_STATS", "1") == "1"
+
 
 def _ws_per_stage():
     if _WS_PER_STAGE is not None:
@@ -99,19 +103,34 @@ class StdConv2dSame(nn.Conv2d):
     _w_t = None    # 1x1 stride-1 convolutions in bf16 mode: transposed standardised weight (I, O) -> the GEMM path
     _dw = None     # ... and the fp32 slice their weight gradient accumulates into
 
-    def forward(self, x, fork=False):
-        """fork=True (GEMM convolutions only): returns (conv(x), alias of x) -- see ops.Conv1x1Fn"""
+    @staticmethod
+    def _gn_sums_for(gn, x_shape, out_channels, stride):
+        """the pre-zeroed statistics slice of the GroupNorm that follows this convolution, if the convolution's epilogue may fill it
+        (library kernels only: 32 groups of 2^k >= 2 channels, >= 128 output pixels per frame); marks the norm so that it skips its own
+        statistics pass"""
+        if gn is None or not _FUSE_GN_STATS or gn._sums_buf is None or gn.num_groups != 32:
+            return None
+        cpg = out_channels // 32
+        hw = (-(-x_shape[-2] // stride)) * (-(-x_shape[-1] // stride))
+        if out_channels % 32 or cpg < 2 or cpg & (cpg - 1) or hw < 128 or x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3] * 2 >= 1 << 32:
+            return None
+        gn._stats_ready = True
+        return gn._sums_buf
+
+    def forward(self, x, fork=False, gn=None):
+        """fork=True (GEMM convolutions only): returns (conv(x), alias of x) -- see ops.Conv1x1Fn.
+        gn: the GroupNormAct this convolution feeds -- its statistics are then accumulated by the convolution's epilogue"""
         w = self._w_std
         if w is not None and self._w_t is not None and self.kernel_size == (1, 1):
             # 1x1, stride 1, bf16: three GEMMs on libmaed_hip instead of MIOpen's implicit-GEMM solvers (which zero-fill the
             # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
-            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork)
+            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork, self._gn_sums_for(gn, x.shape, self.out_channels, 1))
         assert not fork
         if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and x.dtype == torch.bfloat16
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and self.dilation == (1, 1) and self.groups == 1):
             # implicit-GEMM forward / stride-1 input gradient on libmaed_hip instead of MIOpen
             # (_w_t / _dw: transposed image and fp32 dW slice from WeightStdFn for the stride-1 ones, see ResNetV2._own3x3)
-            return ops.Conv3x3Fn.apply(x, w, self.stride[0], self._w_t, self._dw)
+            return ops.Conv3x3Fn.apply(x, w, self.stride[0], self._w_t, self._dw, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]))
         if w is None:  # stand-alone use / CPU: per-conv ATen composition
             w = self.get_weight().to(x.dtype)
             if ops.on_library_device(x):
@@ -132,6 +151,7 @@ class GroupNormAct(nn.GroupNorm):
     _direct_grad = False  # set by ResNetV2: the kernels accumulate dgamma/dbeta straight into .grad
     _sums_buf = None      # set by ResNetV2 per pass: pre-zeroed (N,32,2) f64 / (N,C,2) f32 scratch slices
     _ab_buf = None
+    _stats_ready = False  # set by the convolution in front when its epilogue filled _sums_buf (consumed by the next forward)
 
     def __init__(self, num_channels, num_groups=32, eps=1e-5, affine=True, apply_act=True):
         super().__init__(num_groups, num_channels, eps=eps, affine=affine)
@@ -141,7 +161,8 @@ class GroupNormAct(nn.GroupNorm):
         """y = act(GN(x) [+ residual]); relu defaults to the layer's own activation flag"""
         relu = self.apply_act if relu is None else relu
         if ops.on_library_device(x) and self.num_groups == 32:
-            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad, self._sums_buf, self._ab_buf)
+            ready, self._stats_ready = self._stats_ready and self._sums_buf is not None, False
+            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad, self._sums_buf, self._ab_buf, ready)
         x = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
         if residual is not None:
             x = x + residual
@@ -170,7 +191,7 @@ class DownsampleConv(nn.Module):
         self.norm = GroupNormAct(out_chs, apply_act=False)
 
     def forward(self, x):
-        return self.norm(self.conv(x))
+        return self.norm(self.conv(x, gn=self.norm))
 
 
 class Bottleneck(nn.Module):
@@ -193,14 +214,14 @@ class Bottleneck(nn.Module):
             # x feeds conv1 AND the shortcut (identity or downsample): conv1 (a GEMM convolution) hands out an alias of x for
             # the shortcut, so the shortcut branch's gradient is added inside conv1's input-gradient GEMM epilogue instead of
             # by a separate autograd accumulation kernel
-            y, xa = self.conv1(x, fork=True)
+            y, xa = self.conv1(x, fork=True, gn=self.norm1)
             shortcut = xa if self.downsample is None else self.downsample(xa)
             x = self.norm1(y)
         else:
             shortcut = x if self.downsample is None else self.downsample(x)
-            x = self.norm1(self.conv1(x))
-        x = self.norm2(self.conv2(x))
-        return self.norm3(self.conv3(x), residual=shortcut, relu=True)   # GN + shortcut add + ReLU in one pass
+            x = self.norm1(self.conv1(x, gn=self.norm1))
+        x = self.norm2(self.conv2(x, gn=self.norm2))      # (gn=: the convolution's epilogue accumulates the GroupNorm statistics)
+        return self.norm3(self.conv3(x, gn=self.norm3), residual=shortcut, relu=True)   # GN + shortcut add + ReLU in one pass
 
 
 class ResNetStage(nn.Module):

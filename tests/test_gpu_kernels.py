@@ -516,3 +516,25 @@ def test_conv1x1_fork_adds_shortcut_gradient_in_epilogue():
     y2, xa2 = ops.Conv1x1Fn.apply(xg2, wg, wg.detach().reshape(O, I).t().contiguous(), None, True)
     (xa2 * gs.to(DEV)).sum().backward()
     assert torch.equal(xg2.grad, gs.to(DEV).to(xg2.grad.dtype))
+
+
+@pytest.mark.parametrize("kind,F,H,W,Cin,Cout,stride", [("1x1", 16, 56, 56, 64, 256, 1), ("1x1", 8, 56, 56, 256, 64, 1), ("1x1", 6, 14, 14, 256, 1024, 1),
+                                                        ("1x1", 3, 12, 12, 512, 128, 1), ("3x3", 8, 56, 56, 64, 64, 1), ("3x3", 4, 28, 28, 128, 128, 1),
+                                                        ("3x3", 4, 56, 56, 128, 128, 2), ("3x3", 5, 14, 14, 256, 256, 1)])
+def test_convolution_epilogue_groupnorm_statistics(kind, F, H, W, Cin, Cout, stride):
+    """maed_conv1x1_fwd / maed_conv3x3_fwd gn_sums: the (sum, sum of squares) per (frame, group) the following GroupNorm needs, accumulated by
+    the convolution's epilogue from the bf16-rounded values it stores (2 ... 32 channels per group, frames of 144 ... 3136 pixels that
+    straddle the 128-row tiles) == the same sums computed from the stored tensor; the output itself is bit-identical to the plain call"""
+    ops, _ = _ops()
+    x = q(rnd(F, Cin, H, W, seed=1), torch.bfloat16).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    sums = torch.zeros(F, 32, 2, dtype=torch.float64, device=DEV)
+    if kind == "1x1":
+        w = q(rnd(Cout, Cin, 1, 1, seed=2, scale=Cin ** -0.5), torch.bfloat16).to(DEV).bfloat16()
+        y, y0 = ops.Conv1x1Fn.apply(x, w, None, None, False, sums), ops.Conv1x1Fn.apply(x, w, None, None, False, None)
+    else:
+        w = q(rnd(Cout, 3, 3, Cin, seed=2, scale=(9 * Cin) ** -0.5), torch.bfloat16).to(DEV).bfloat16()
+        y, y0 = ops.conv3x3(x, w, stride, gn_sums=sums), ops.conv3x3(x, w, stride)
+    assert torch.equal(y, y0)
+    yg = y.permute(0, 2, 3, 1).reshape(F, -1, 32, Cout // 32).double()
+    want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
+    report(f"conv{kind} gn statistics[{F}x{Cin}->{Cout},{H}x{W}/{stride}]", sums, want, rtol=2e-5, atol=2e-5 * want.abs().max().item())

@@ -192,3 +192,43 @@ def test_conv3x3_with_transposed_image_and_direct_dw_slice(N, I, O, H, W):
     assert torch.allclose(xs.grad.float(), xr.grad, rtol=2e-2, atol=2e-2), (xs.grad.float() - xr.grad).abs().max()
     got = (dw - prior).view(O, 3, 3, I).permute(0, 3, 1, 2)
     assert torch.allclose(got, wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max())), (got - wr.grad).abs().max()
+
+
+@pytest.mark.parametrize("F,HW,Cin,Cout", [(3, 144, 64, 64), (2, 200, 128, 256), (1, 130, 64, 128)])
+def test_conv1x1_epilogue_accumulates_groupnorm_statistics(F, HW, Cin, Cout):
+    """maed_conv1x1_fwd gn_sums: (sum, sum of squares) per (frame, group) of the STORED bf16 output, for 2 / 8 / 4 channels per group, frames
+    that straddle 128-row tiles (144, 200, 130 rows per frame) and a ragged last tile"""
+    torch.manual_seed(0)
+    x = torch.randn(F, Cin, HW, 1).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 1, 1) * Cin ** -0.5).bfloat16()
+    sums = torch.zeros(F, 32, 2, dtype=torch.float64)
+    with patched():
+        y = ops.Conv1x1Fn.apply(x, w, None, None, False, sums)
+        y0 = ops.Conv1x1Fn.apply(x, w, None, None, False, None)
+    assert torch.equal(y, y0)
+    yg = y.float().permute(0, 2, 3, 1).reshape(F, HW, 32, Cout // 32).double()
+    want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
+    assert torch.allclose(sums, want, rtol=1e-5, atol=1e-3), (sums - want).abs().max()
+
+
+@pytest.mark.parametrize("F,H,W,Cin,Cout,stride", [(2, 12, 12, 64, 64, 1), (1, 23, 12, 64, 128, 1), (2, 24, 24, 128, 128, 2)])
+def test_conv3x3_epilogue_accumulates_groupnorm_statistics(F, H, W, Cin, Cout, stride):
+    torch.manual_seed(1)
+    x = torch.randn(F, Cin, H, W).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(Cout, 3, 3, Cin) * (9 * Cin) ** -0.5).bfloat16()
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    sums = torch.zeros(F, 32, 2, dtype=torch.float64)
+    with patched():
+        y = ops.conv3x3(x, wt, stride, gn_sums=sums)
+        y0 = ops.conv3x3(x, wt, stride)
+    assert torch.equal(y, y0)
+    yg = y.float().permute(0, 2, 3, 1).reshape(F, Ho * Wo, 32, Cout // 32).double()
+    want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
+    assert torch.allclose(sums, want, rtol=1e-5, atol=1e-3), (sums - want).abs().max()
+
+
+def test_groupnorm_statistics_shape_guard_is_loud():
+    x = torch.randn(1, 64, 8, 8).bfloat16().contiguous(memory_format=torch.channels_last)      # 64 pixels per frame < 128
+    w = torch.randn(64, 64, 1, 1).bfloat16()
+    with patched(), pytest.raises(RuntimeError, match="GroupNorm statistics"):
+        ops.Conv1x1Fn.apply(x, w, None, None, False, torch.zeros(1, 32, 2, dtype=torch.float64))

@@ -159,3 +159,34 @@ def test_switching_gemm_convs_off_at_run_time_also_drops_their_direct_hand_over(
     net._gemm_convs = []
     assert net._direct_convs == net._own3x3
     assert all(g._direct_convs == [] for g in net._ws_groups) or bool(net._own3x3)
+
+
+def test_convolution_epilogues_feed_the_groupnorm_statistics(monkeypatch):
+    """>= 128 pixels per frame: every library convolution (1x1 GEMM, own 3x3) hands its GroupNorm the statistics; forward and gradients equal
+    the separate-statistics-pass variant (MAED_GN_FUSE_STATS=0) up to fp32 summation order"""
+    from maed_amd import ops
+    torch.manual_seed(0)
+    net = ResNetV2(layers=(2,), channels=(256,), in_chans=3, compute_dtype=torch.bfloat16)
+    for m in net._norms:
+        torch.nn.init.normal_(m.weight, 1.0, 0.2); torch.nn.init.normal_(m.bias, 0.0, 0.2)
+    x = torch.randn(2, 3, 48, 48)                     # stem /4 -> 12 x 12 = 144 pixels per frame
+    gout = torch.randn(2, 256, 12, 12)
+    seen = []
+    real = ops.GroupNormFn.forward
+    monkeypatch.setattr(ops.GroupNormFn, "forward", staticmethod(lambda ctx, *a: (seen.append(bool(a[9]) if len(a) > 9 else False), real(ctx, *a))[1]))
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(resnetv2, "_FUSE_GN_STATS", fuse)
+        seen.clear()
+        net.zero_grad()
+        for p in net.parameters():
+            p.grad = None
+        with patched():
+            y = net(x)
+            (y.float() * gout).sum().backward()
+        res[fuse] = (y.float().clone(), [p.grad.clone() for p in net.parameters()], list(seen))
+    # stem norm follows the 7x7 library (MIOpen/ATen) convolution: separate pass; all 7 block convolutions + the downsample one are fused
+    assert res[True][2].count(True) == len(net._norms) - 1 and not any(res[False][2]), res[True][2]
+    assert torch.allclose(res[True][0], res[False][0], rtol=2e-2, atol=2e-2) and cos(res[True][0], res[False][0]) > 0.9999
+    for a, b in zip(res[True][1], res[False][1]):
+        assert cos(a, b) > 0.999
