@@ -314,6 +314,12 @@ int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, 
 int maed_maxpool3s2_same_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype, void* stream);
 int maed_maxpool3s2_same_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int dtype, void* stream);
 
+/* Pixel subsampling of the 1x1 stride-2 downsample convolutions (resnetv2.py:207-216; TF-SAME padding of a 1x1 kernel is always zero):
+ * fwd: y (F,ceil(H/2),ceil(W/2),C) = x[:, ::2, ::2, :] on channels_last x (F,H,W,C), C % 8 == 0 -- the convolution is then
+ * maed_conv1x1_fwd on the packed rows; bwd: dx (F,H,W,C) = the packed gradient g spread back, zeros elsewhere (one write pass). */
+int maed_subsample2_fwd(const void* x, void* y, int F, int H, int W, int C, int dtype, void* stream);
+int maed_subsample2_bwd(const void* g, void* dx, int F, int H, int W, int C, int dtype, void* stream);
+
 /* compute-dtype images of the nn.Linear master weights after an optimizer step (ops.WeightCache), all in one launch:
  * for every entry dst_c (rows, cols) = cast(src) (NULL = skip) and dst_t (cols, rows) = cast(src)^T.
  * table: device array of n_entries maed_wt_entry; tile0 = index of the entry's first 64x64 tile, tiles_n = ceil(cols/64);

@@ -509,3 +509,59 @@ extern "C" int maed_maxpool3s2_same_bwd(const void* dy, const uint8_t* idx, void
     MAED_CHECK_LAUNCH("maxpool3s2_same_bwd");
     return MAED_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Pixel subsampling of a 1x1 stride-2 convolution (the downsample shortcut of stages 2 and 3, resnetv2.py:207-216: TF-SAME padding of a
+// 1x1 kernel is zero for every input size, so output pixel (oy, ox) reads input pixel (2 oy, 2 ox)).  Forward packs those pixels into a
+// dense (F, Ho, Wo, C) activation -- the convolution is then a plain GEMM on 1/4 of the rows, and the packed copy is also the weight
+// gradient's operand; backward spreads the packed input gradient back (every other pixel is zero: one write pass, no memset).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void subsample2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int H, int W, int C, int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread: 8 channels of one output pixel
+    if (i >= n) return;
+    const int cb = C / 8, c8 = (int)(i % cb) * 8;
+    const int64_t pix = i / cb;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+    const int64_t f = pix / ((int64_t)Wo * Ho);
+    float v[8];
+    ld8(x + ((f * H + 2 * oy) * W + 2 * ox) * C + c8, v);
+    st8(y + i * 8, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const T* __restrict__ g, T* __restrict__ dx, int64_t n, int H, int W, int C, int Ho, int Wo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread: 8 channels of one INPUT pixel
+    if (i >= n) return;
+    const int cb = C / 8, c8 = (int)(i % cb) * 8;
+    const int64_t pix = i / cb;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H);
+    const int64_t f = pix / ((int64_t)W * H);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!((ix | iy) & 1)) ld8(g + ((f * Ho + (iy >> 1)) * Wo + (ix >> 1)) * C + c8, v);
+    st8(dx + i * 8, v);
+}
+
+extern "C" int maed_subsample2_fwd(const void* x, void* y, int F, int H, int W, int C, int dtype, void* stream) {
+    MAED_CHECK_ARG(x && y, MAED_ERR_ARG, "subsample2_fwd: null pointer");
+    MAED_CHECK_ARG(F >= 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, MAED_ERR_SHAPE, "subsample2_fwd: C=%d must be a multiple of 8", C);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int64_t n = (int64_t)F * Ho * Wo * (C / 8);
+    if (n == 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((subsample2_fwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                                      (const T*)x, (T*)y, n, H, W, C, Ho, Wo));
+    MAED_CHECK_LAUNCH("subsample2_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_subsample2_bwd(const void* g, void* dx, int F, int H, int W, int C, int dtype, void* stream) {
+    MAED_CHECK_ARG(g && dx, MAED_ERR_ARG, "subsample2_bwd: null pointer");
+    MAED_CHECK_ARG(F >= 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, MAED_ERR_SHAPE, "subsample2_bwd: C=%d must be a multiple of 8", C);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int64_t n = (int64_t)F * H * W * (C / 8);
+    if (n == 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((subsample2_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                                      (const T*)g, (T*)dx, n, H, W, C, Ho, Wo));
+    MAED_CHECK_LAUNCH("subsample2_bwd");
+    return MAED_OK;
+}

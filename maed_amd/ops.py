@@ -621,48 +621,61 @@ class Conv1x1Fn(torch.autograd.Function):
     forward 1.01 vs 2.33 ms, input gradient 1.02 vs 1.88 ms, weight gradient 1.47 vs 2.63 ms per step."""
 
     @staticmethod
-    def forward(ctx, x, w, wt, dw, fork=False, gn_sums=None):
+    def forward(ctx, x, w, wt, dw, fork=False, gn_sums=None, stride=1):
         """gn_sums (optional, pre-zeroed (N,32,2) f64): GroupNorm statistics of the output, accumulated by the GEMM's epilogue.
         x (N,I,H,W) channels_last; w (O,I,1,1) standardised weight (an output of WeightStdFn: the autograd edge orders
         its backward after ours); wt (I,O) transposed image; dw (O,I) fp32 accumulator (None when no gradient is wanted).
         fork=True additionally returns an alias of x for the block's identity shortcut: its gradient then arrives HERE and is
-        added inside the input-gradient GEMM's epilogue (MAED_EPI_ADD) instead of by a separate autograd accumulation kernel."""
+        added inside the input-gradient GEMM's epilogue (MAED_EPI_ADD) instead of by a separate autograd accumulation kernel.
+        stride=2 (the downsample shortcuts of stages 2 and 3): the pixels the convolution reads are packed first (maed_subsample2_fwd),
+        all three GEMMs then run on a quarter of the rows and the input gradient is spread back in one write pass."""
         N, I, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)
         O = w.shape[0]
         w2 = w.reshape(O, I)
         w2 = w2 if w2.is_contiguous() else w2.contiguous()
-        A = x.permute(0, 2, 3, 1).reshape(N * H * W, I)
+        Ho, Wo = H, W
+        if stride == 2:
+            assert not fork
+            Ho, Wo = (H + 1) // 2, (W + 1) // 2
+            A = torch.empty(N * Ho * Wo, I, dtype=x.dtype, device=x.device)
+            check(L.lib().maed_subsample2_fwd(_p(x), _p(A), N, H, W, I, dt_code(x.dtype), _stream()), "subsample2_fwd")
+        else:
+            assert stride == 1
+            A = x.permute(0, 2, 3, 1).reshape(N * H * W, I)
         if gn_sums is not None:
-            y = torch.empty(N * H * W, O, dtype=x.dtype, device=x.device)
-            check(L.lib().maed_conv1x1_fwd(_p(A), A.stride(0), _p(w2), w2.stride(0), N * H * W, O, I, _p(y), O, H * W, _p(gn_sums), dt_code(x.dtype),
+            y = torch.empty(N * Ho * Wo, O, dtype=x.dtype, device=x.device)
+            check(L.lib().maed_conv1x1_fwd(_p(A), A.stride(0), _p(w2), w2.stride(0), N * Ho * Wo, O, I, _p(y), O, Ho * Wo, _p(gn_sums), dt_code(x.dtype),
                                            _stream()), "conv1x1_fwd")
         else:
             y = gemm_nt(A, w2, L.EPI_STORE)
         ctx.save_for_backward(A, wt)
-        ctx.dw, ctx.geom = dw, (N, I, H, W, O)
+        ctx.dw, ctx.geom, ctx.stride = dw, (N, I, H, W, O, Ho, Wo), stride
         ctx.set_materialize_grads(False)
-        y = y.view(N, H, W, O).permute(0, 3, 1, 2)
+        y = y.view(N, Ho, Wo, O).permute(0, 3, 1, 2)
         return (y, x.view_as(x)) if fork else y
 
     @staticmethod
     def backward(ctx, dy, g_short=None):
         A, wt = ctx.saved_tensors
-        N, I, H, W, O = ctx.geom
+        N, I, H, W, O, Ho, Wo = ctx.geom
         dx = None
         if dy is None:              # only the shortcut carried a gradient
-            return g_short, None, None, None, None, None
-        Y = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(N * H * W, O)
+            return g_short, None, None, None, None, None, None
+        Y = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(N * Ho * Wo, O)
         if ctx.needs_input_grad[0]:
             if g_short is not None:
                 G = g_short.contiguous(memory_format=torch.channels_last).to(Y.dtype).permute(0, 2, 3, 1).reshape(N * H * W, I)
                 dx = gemm_nt(Y, wt, L.EPI_ADD, aux=G)
             else:
                 dx = gemm_nt(Y, wt, L.EPI_STORE)
+            if ctx.stride == 2:
+                g, dx = dx, torch.empty(N * H * W, I, dtype=dx.dtype, device=dx.device)
+                check(L.lib().maed_subsample2_bwd(_p(g), _p(dx), N, H, W, I, dt_code(dx.dtype), _stream()), "subsample2_bwd")
             dx = dx.view(N, H, W, I).permute(0, 3, 1, 2)
         if ctx.dw is not None:
             gemm_tn_wgrad(Y, A, dW=ctx.dw)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 

@@ -124,7 +124,7 @@ class StdConv2dSame(nn.Conv2d):
         if w is not None and self._w_t is not None and self.kernel_size == (1, 1):
             # 1x1, stride 1, bf16: three GEMMs on libmaed_hip instead of MIOpen's implicit-GEMM solvers (which zero-fill the
             # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
-            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork, self._gn_sums_for(gn, x.shape, self.out_channels, 1))
+            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]), self.stride[0])
         assert not fork
         if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and x.dtype == torch.bfloat16
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and self.dilation == (1, 1) and self.groups == 1):
@@ -265,8 +265,10 @@ class ResNetV2(nn.Module):
         self._norms = [m for m in self.modules() if isinstance(m, GroupNormAct)]
         for m in self._norms:
             m._direct_grad = True
-        # 1x1 stride-1 convolutions with GEMM-friendly channel counts run on libmaed_hip in bf16 mode (ops.Conv1x1Fn)
-        self._gemm_convs = [i for i, c in enumerate(self._convs) if c.kernel_size == (1, 1) and c.stride == (1, 1)
+        # 1x1 convolutions (stride 1, and the stride-2 downsample shortcuts on packed pixels) with GEMM-friendly channel counts run on
+        # libmaed_hip in bf16 mode (ops.Conv1x1Fn)
+        strides = ((1, 1), (2, 2)) if os.environ.get("MAED_CONV1X1_S2", "1") == "1" else ((1, 1),)     # (A/B knob: stride-2 ones on MIOpen)
+        self._gemm_convs = [i for i, c in enumerate(self._convs) if c.kernel_size == (1, 1) and c.stride in strides
                             and c.in_channels % 64 == 0 and c.out_channels % 64 == 0]
         if os.environ.get("MAED_GEMM_CONVS", "1") == "0":      # measurement knob: every convolution on MIOpen
             self._gemm_convs = []

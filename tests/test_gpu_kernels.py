@@ -538,3 +538,26 @@ def test_convolution_epilogue_groupnorm_statistics(kind, F, H, W, Cin, Cout, str
     yg = y.permute(0, 2, 3, 1).reshape(F, -1, 32, Cout // 32).double()
     want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
     report(f"conv{kind} gn statistics[{F}x{Cin}->{Cout},{H}x{W}/{stride}]", sums, want, rtol=2e-5, atol=2e-5 * want.abs().max().item())
+
+
+@pytest.mark.parametrize("N,I,O,H,W", [(4, 256, 512, 56, 56), (3, 512, 1024, 28, 28), (2, 64, 128, 7, 9)])
+def test_conv1x1_stride2_on_packed_pixels(N, I, O, H, W):
+    """ops.Conv1x1Fn(stride=2): the downsample shortcuts of stages 2 / 3 (cfg3 extents in the first two cases) = maed_subsample2_fwd + GEMMs on a
+    quarter of the rows + maed_subsample2_bwd, vs fp64 conv2d(stride=2)"""
+    ops, _ = _ops()
+    x = q(rnd(N, I, H, W, seed=1), torch.bfloat16)
+    w = q(rnd(O, I, 1, 1, seed=2, scale=I ** -0.5), torch.bfloat16)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, stride=2)
+    dy = q(rnd(*ref.shape, seed=3), torch.bfloat16)
+    ref.backward(dy.double())
+    xg = x.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = w.to(DEV).bfloat16()
+    wt = wg.reshape(O, I).t().contiguous()
+    dw = torch.ones(O, I, dtype=torch.float32, device=DEV)
+    y = ops.Conv1x1Fn.apply(xg, wg, wt, dw, False, None, 2)
+    y.backward(dy.to(DEV).bfloat16())
+    tag = f"[{N}x{I}->{O},{H}x{W}/2]"
+    report(f"conv1x1s2 fwd{tag}", y.float(), ref, **tol(torch.bfloat16, 2))
+    report(f"conv1x1s2 dx{tag}", xg.grad.float(), xd.grad, **tol(torch.bfloat16, 2))
+    report(f"conv1x1s2 dw{tag}", dw - 1.0, wd.grad.reshape(O, I), rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())

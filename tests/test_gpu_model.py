@@ -359,7 +359,7 @@ def test_backbone_gemm_convolutions_match_miopen_path():
     from maed_amd.resnetv2 import ResNetV2
     torch.manual_seed(3)
     net = ResNetV2(layers=(1, 2, 1), channels=(256, 512, 1024), compute_dtype=torch.bfloat16).to(DEV)
-    assert len(net._gemm_convs) == 9
+    assert len(net._gemm_convs) == 11            # 9 stride-1 + the 2 stride-2 downsample shortcuts (on packed pixels)
     xa, xb = rnd(3, 3, 64, 64, seed=31), rnd(2, 3, 64, 64, seed=32)
     pd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
     ra, rb = R.resnetv2_features(xa.double(), pd, "", layers=(1, 2, 1)), R.resnetv2_features(xb.double(), pd, "", layers=(1, 2, 1))

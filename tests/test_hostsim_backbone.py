@@ -232,3 +232,26 @@ def test_groupnorm_statistics_shape_guard_is_loud():
     w = torch.randn(64, 64, 1, 1).bfloat16()
     with patched(), pytest.raises(RuntimeError, match="GroupNorm statistics"):
         ops.Conv1x1Fn.apply(x, w, None, None, False, torch.zeros(1, 32, 2, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("N,I,O,H,W", [(2, 64, 128, 6, 8), (1, 128, 64, 7, 5)])
+def test_conv1x1_stride2_on_packed_pixels_matches_aten(N, I, O, H, W):
+    """the downsample shortcut of stages 2 / 3 (resnetv2.py:207-216): Conv1x1Fn(stride=2) = maed_subsample2_fwd + GEMMs on a quarter of the rows +
+    maed_subsample2_bwd, against F.conv2d(stride=2) -- even and odd extents"""
+    torch.manual_seed(3)
+    x = torch.randn(N, I, H, W).bfloat16()
+    w = (torch.randn(O, I, 1, 1) * I ** -0.5).bfloat16()
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=2)
+    dy = torch.randn(*ref.shape).bfloat16()
+    ref.backward(dy.double())
+    xs = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = w.reshape(O, I).t().contiguous()
+    dw = torch.zeros(O, I)
+    with patched():
+        y = ops.Conv1x1Fn.apply(xs, w, wt, dw, False, None, 2)
+        y.backward(dy)
+    assert y.shape == ref.shape and torch.allclose(y.double(), ref, rtol=2e-2, atol=2e-2)
+    assert torch.allclose(xs.grad.double(), xr.grad, rtol=2e-2, atol=2e-2)
+    assert (xs.grad[:, :, 1::2] == 0).all() and (xs.grad[:, :, :, 1::2] == 0).all()
+    assert torch.allclose(dw.double(), wr.grad.reshape(O, I), rtol=1e-3, atol=1e-3 * wr.grad.abs().max().item())

@@ -155,7 +155,7 @@ def test_switching_gemm_convs_off_at_run_time_also_drops_their_direct_hand_over(
     """tests/test_gpu_model.py's all-MIOpen variant sets `net._gemm_convs = []` on a live model: WeightStdFn must then stop producing
     transposed images / fp32 slices for them (it reads `_direct_convs`, which therefore has to follow `_gemm_convs`)"""
     net = ResNetV2(layers=(1, 2, 1), channels=(256, 512, 1024), compute_dtype=torch.bfloat16)
-    assert len(net._gemm_convs) == 9 and net._direct_convs == net._gemm_convs + net._own3x3
+    assert len(net._gemm_convs) == 11 and net._direct_convs == net._gemm_convs + net._own3x3      # 9 stride-1 + the 2 stride-2 downsample shortcuts
     net._gemm_convs = []
     assert net._direct_convs == net._own3x3
     assert all(g._direct_convs == [] for g in net._ws_groups) or bool(net._own3x3)
@@ -190,3 +190,34 @@ def test_convolution_epilogues_feed_the_groupnorm_statistics(monkeypatch):
     assert torch.allclose(res[True][0], res[False][0], rtol=2e-2, atol=2e-2) and cos(res[True][0], res[False][0]) > 0.9999
     for a, b in zip(res[True][1], res[False][1]):
         assert cos(a, b) > 0.999
+
+
+def test_two_stage_backbone_downsample_shortcut_runs_on_packed_pixels():
+    """stage 2's 1x1 stride-2 downsample convolution is a library GEMM convolution (ops.Conv1x1Fn stride=2): forward and every parameter
+    gradient of a two-stage backbone against the fp32 ATen composition"""
+    from maed_amd import ops
+    torch.manual_seed(0)
+    ref = ResNetV2(layers=(1, 1), channels=(256, 512), in_chans=3, compute_dtype=torch.float32)
+    for m in ref._norms:
+        torch.nn.init.normal_(m.weight, 1.0, 0.2); torch.nn.init.normal_(m.bias, 0.0, 0.2)
+    sim = copy.deepcopy(ref)
+    sim.compute_dtype = torch.bfloat16
+    strided = [i for i in sim._gemm_convs if sim._convs[i].stride == (2, 2)]
+    assert len(strided) == 1 and strided[0] in sim._direct_convs
+    x = torch.randn(2, 3, 32, 32)
+    yr = ref(x)
+    gout = torch.randn_like(yr)
+    (yr * gout).sum().backward()
+    seen = []
+    real = ops.Conv1x1Fn.forward
+    with patched():
+        ops.Conv1x1Fn.forward = staticmethod(lambda ctx, *a: (seen.append(a[6] if len(a) > 6 else 1), real(ctx, *a))[1])
+        try:
+            ys = sim(x)
+            (ys.float() * gout).sum().backward()
+        finally:
+            ops.Conv1x1Fn.forward = real
+    assert seen.count(2) == 1, seen
+    assert cos(ys.float(), yr.detach()) > 0.999
+    for (n, p), q in zip(sim.named_parameters(), ref.parameters()):
+        assert p.grad is not None and cos(p.grad, q.grad) > 0.93, (n, cos(p.grad, q.grad))
