@@ -10,7 +10,13 @@
 // M-tiles; split-M workgroups accumulate with coalesced fp32 atomics straight into the gradient arena.  The
 // workgroups of K-tile 0 also produce the bias gradient (column sums of Y).
 #include "common.cuh"
+#include "gemm_epilogue.cuh"      // xcd_remap
 #include <stdlib.h>
+
+static int tn_remap() {                 // MAED_TN_XCD_REMAP=0: dispatch order as launched (A/B knob)
+    static const int v = maed_env_flag("MAED_TN_XCD_REMAP", true) ? 1 : 0;
+    return v;
+}
 
 #define TN_BM 64      // reduction rows per LDS tile
 #define TN_LD 72      // LDS row stride (elements): 144 B
@@ -29,7 +35,7 @@ template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* __restrict__ Y, int64_t ldy, const bf16* __restrict__ X,
                                                                    int64_t ldx, int64_t M, int N, int K, float* __restrict__ dW,
                                                                    int64_t ldw, float* __restrict__ dbias, int tiles_k, int mtiles_per_split,
-                                                                   TnConv cv
+                                                                   TnConv cv, int remap
 #ifdef MAED_GEMM_ABLATE
                                                                    , int ablate    // diagnostic build only: 1 no atomics, 2 no global loads, 4 no MFMA / fragment reads, 8 no transposing LDS stores
 #endif
@@ -41,10 +47,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     __shared__ float lcs[8][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
-    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x % tiles_k;
+    // XCD-aware order: the tn*tk workgroups of one M-split read the same rows of Y and X (each Y column tile tk times, each X column
+    // tile tn times).  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs (each with its own L2), which scattered a
+    // split over all of them: L2-miss traffic 2.7x the algorithmic bytes (profiles/r02_pmc, gemm_tn).  Remapped so that a split's
+    // workgroups share an XCD, they march down the same rows together and the re-reads hit its L2.
+    const int lin = remap ? xcd_remap((int)(blockIdx.z * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.z)) : (int)(blockIdx.z * gridDim.x + blockIdx.x);
+    const int bx = lin % (int)gridDim.x, bz = lin / (int)gridDim.x;
+    const int tile_n = bx / tiles_k, tile_k = bx % tiles_k;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
     const int nmt = (int)((M + TN_BM - 1) / TN_BM);
-    const int mt_beg = blockIdx.z * mtiles_per_split;
+    const int mt_beg = bz * mtiles_per_split;
     int mt_end = mt_beg + mtiles_per_split;
     if (mt_end > nmt) mt_end = nmt;
     if (mt_beg >= mt_end) return;
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     const int wr_off = (nc * 8) * TN_LD + ((mg ^ (nc & 7)) << 3);   // row (nc*8 + j), swizzled 16-B slot mg ^ ((row>>3)&7)
     // the column sums of a Y tile are needed once per (N-tile, M-split): the K-tile that takes them rotates with the split
     // index so the extra VALU work is spread over all workgroups instead of making the K-tile-0 ones stragglers
-    const bool bias_blk = (dbias != nullptr) && (tile_k == (int)(blockIdx.z % tiles_k));   // block-uniform
+    const bool bias_blk = (dbias != nullptr) && (tile_k == (int)(bz % tiles_k));   // block-uniform
     const bool do_bias = bias_blk && (side == 0);   // wave-uniform
     float cs[8];
 #pragma unroll
@@ -140,6 +152,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
             acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0); } }
 
     __syncthreads();                            // (zeroed LDS rows of out-of-range columns are in place)
+    // (a four-set variant -- loads issued three tile times ahead instead of one -- measured the same or slower: the loop is not waiting on
+    // vmcnt; profiles/r02_gemm_tn_ablation.txt: MFMA + LDS transposes alone take 3/4 of the kernel's time)
     if (mt_beg < mt_endf) {
         TN_LOAD(0, mt_beg);
         TN_LOAD(1, mt_beg + 1);
@@ -209,10 +223,10 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
 #ifdef MAED_GEMM_ABLATE
     const char* ev = getenv("MAED_GEMM_ABLATE");
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
-                       N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, ev ? atoi(ev) : 0);
+                       N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap(), ev ? atoi(ev) : 0);
 #else
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
-                       N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0});
+                       N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap());
 #endif
     MAED_CHECK_LAUNCH("gemm_tn_wgrad");
     return MAED_OK;
@@ -261,7 +275,7 @@ extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tap
     const int z = (nmt + per - 1) / per;
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<true>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (int64_t)Cout,
                        (const bf16*)x, (int64_t)Cin, M, N, K, dW, (int64_t)K, (float*)nullptr, tk, per,
-                       TnConv{(const uint16_t*)tapmask, (const bf16*)zero_page, Cin, W}
+                       TnConv{(const uint16_t*)tapmask, (const bf16*)zero_page, Cin, W}, tn_remap()
 #ifdef MAED_GEMM_ABLATE
                        , 0
 #endif
