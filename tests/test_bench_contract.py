@@ -21,9 +21,10 @@ def test_cli_flags_of_the_contract():
         assert flag in out.stdout
 
 
-@pytest.mark.parametrize("path", [os.path.join(ROOT, "profiles", "r01_bench_v10_train_27.6ms.json"), os.path.join(ROOT, "profiles", "r01_bench_v9_train_28.1ms.json")])
+@pytest.mark.parametrize("path", [os.path.join(ROOT, "profiles", "r02_bench_train.json"), os.path.join(ROOT, "profiles", "r02_bench_torchrun_world1_forced_collectives.json"),
+                                  os.path.join(ROOT, "profiles", "r01_bench_v10_train_27.6ms.json")])
 def test_committed_bench_lines_carry_the_contract_fields(path):
-    d = json.load(open(path))
+    d = json.loads(open(path).read().strip().split("\n")[-1])
     assert TOP <= set(d), TOP - set(d)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["unit"] == "video-clips/sec" and base["metric"].startswith(d["unit"]) and d["metric"].startswith(d["unit"])
@@ -37,3 +38,16 @@ def test_committed_bench_lines_carry_the_contract_fields(path):
     if d["cpu_baseline"] is not None:                                                         # (absent in --no-cpu-baseline A/B runs)
         c = d["cpu_baseline"]
         assert CPU <= set(c) and c["kind"] in ("port", "reference") and c["cores"] >= 1
+    if "step_time" in d:                                                                      # round 2 on: per-step hipEvent statistics
+        st = d["step_time"]
+        assert st["p10_ms"] <= st["median_ms"] <= st["p90_ms"] and abs(st["median_ms"] - d["ms_per_step"]) < 0.1 * d["ms_per_step"]
+
+
+def test_committed_pmc_traffic_is_stamped_with_a_source_hash():
+    """bench.py quotes roofline.traffic only from a PMC file measured on the running build: the committed file names the hash of the kernel sources it
+    was collected on and the per-launch bytes of the three roofline kernels"""
+    t = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc", "traffic.json")))
+    assert len(t["source_hash"]) == 16 and set(t["kernels"]) == {"attn_spatial_fwd", "gemm_nt", "gemm_tn"}
+    assert all(isinstance(v, int) and v > 0 for v in t["kernels"].values())
+    # the attention forward moves its algorithmic bytes and nothing more (4*M*C*2 + lse at cfg3 = 103.6 MB)
+    assert abs(t["kernels"]["attn_spatial_fwd"] - 103.6e6) < 0.02 * 103.6e6
