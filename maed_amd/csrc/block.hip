@@ -48,6 +48,38 @@ extern "C" int maed_prof_collect(double* ms_total, int* count) {
 }
 #define PROF(tag, expr) do { ProfScope ps__(tag, stream); MAED_PROPAGATE(expr); } while (0)
 
+// ---- side stream for the weight-gradient GEMMs of the backward ---------------------------------------------------------------------
+// dW += Y^T X depends only on operands the input-gradient chain has already produced and nothing downstream in the block reads dW, so the
+// five TN GEMMs of a block run on a second stream beside the chain (input-gradient GEMMs, LayerNorm / mix / attention backward): both kinds
+// of kernel leave most of the MFMA pipe idle on their own (0.2 / 0.3 of peak) and each kernel's ramp-up and tail fill with the other's
+// workgroups.  Fences: an event per operand hand-over (main -> side), one before the dqkv buffer is re-used and one at the end of the block
+// (side -> main), so everything after maed_ste_block_bwd on the caller's stream -- gradient all-reduce, Adam -- is ordered after the weight
+// gradients.  The only objects the library ever creates besides the opt-in communicator: one non-blocking stream and a ring of
+// timing-less events, made on first use, never destroyed.  MAED_WGRAD_SIDE_STREAM=0, the in-situ profiler (maed_prof_enable) and the f32 parity mode
+// keep everything on the caller's stream.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[64];
+    int next = 0;
+    bool ok = false;
+    SideStream() {
+        if (!maed_env_flag("MAED_WGRAD_SIDE_STREAM", true)) return;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+        for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return;
+        ok = true;
+    }
+    // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
+    void fence(hipStream_t from, hipStream_t to) {
+        hipEvent_t e = ev[next]; next = (next + 1) % 62;               // slots 62 / 63 are named fences, outside the ring
+        hipEventRecord(e, from);
+        hipStreamWaitEvent(to, e, 0);
+    }
+};
+static SideStream* side_stream() {
+    static SideStream ss;
+    return (ss.ok && !g_prof) ? &ss : nullptr;
+}
+
 namespace {
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -190,10 +222,19 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
             dyc = sc + S.dyc;
         }
         void* dxmid_tw = sc + S.dyt;                                     // bf16 twin of dx_mid (reuses the old transpose slot)
+        SideStream* ss = side_stream();
+        hipStream_t main_s = (hipStream_t)stream;
+        void* wst = ss ? (void*)ss->s : stream;                          // where the weight-gradient GEMMs go
+#define TO_SIDE() do { if (ss) ss->fence(main_s, ss->s); } while (0)   /* operands produced so far on the chain are visible to the side stream */
+#define FROM_SIDE() do { if (ss) ss->fence(ss->s, main_s); } while (0) /* the chain waits for the weight gradients issued so far */
+#define WGRAD(expr) do { ProfScope ps__(PROF_GEMM_WGRAD, wst); MAED_PROPAGATE(expr); } while (0)
         // MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
-        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(dyc, C, sv + L.hact, Hd, M, C, Hd, g->w_fc2, Hd, g->b_fc2, dt, stream));
+        TO_SIDE();
+        WGRAD(maed_gemm_tn_wgrad(dyc, C, sv + L.hact, Hd, M, C, Hd, g->w_fc2, Hd, g->b_fc2, dt, wst));
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
-        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, stream));
+        TO_SIDE();
+        WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, wst));
+        if (ss) hipEventRecord(ss->ev[63], ss->s);                       // "fc1 weight gradient done" (named slot, outside the ring)
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
         // LayerNorm dgamma/dbeta via partials in the (bf16-mode-unused) transpose slot (measured on MI355X, profiles/r02_call2_steady_*.csv:
         // 0.629 -> 0.503 + 0.080 ms per step); MAED_LN_DEFER_AFFINE=0 switches back to the atomics (A/B knob)
@@ -203,19 +244,27 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
                                              dx_out, dxmid, dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream));
         // attention: x_mid = x_in + proj(mix(x_s, x_t))
-        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dt, stream));
+        TO_SIDE();
+        WGRAD(maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dt, wst));
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
         MAED_PROPAGATE(maed_st_mix_bwd_reduce(sc + S.act, sv + L.xs, sv + L.xt, logits, sc + S.dlog, (float*)(sc + S.ws), d->F, d->P, C, dt, stream));
-        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dt, stream));
+        TO_SIDE();
+        WGRAD(maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dt, wst));
         MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
         MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
+        if (ss) hipStreamWaitEvent(main_s, ss->ev[63], 0);               // the attention backward overwrites bigA, which the fc1 weight gradient reads
         PROF(PROF_ATTN_TM_BWD, maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
         PROF(PROF_ATTN_SP_BWD, maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
                                                      MAED_IMPL_AUTO, stream));
-        PROF(PROF_GEMM_WGRAD, maed_gemm_tn_wgrad(sc + S.bigA, 3 * C, sv + L.ln1, C, M, 3 * C, C, g->w_qkv, C, g->b_qkv, dt, stream));
+        TO_SIDE();
+        WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, 3 * C, sv + L.ln1, C, M, 3 * C, C, g->w_qkv, C, g->b_qkv, dt, wst));
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
         MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in,
                                              dx_in_twin, g->ln1_g, g->ln1_b, M, C, ln_part, stream));
+        FROM_SIDE();                                                     // scratch and gradients: everything after this call sees the weight gradients
+#undef TO_SIDE
+#undef FROM_SIDE
+#undef WGRAD
         return MAED_OK;
     }
     // ---- f32 parity mode (and impl = VALU): NT GEMMs on transposed copies ---------------------------------------

@@ -6,6 +6,7 @@ is no PyTorch/CPU fallback (a CPU tensor or a missing library is an error).
 """
 import ctypes as C
 import math
+import os
 import weakref
 
 import numpy as _np
@@ -45,6 +46,41 @@ def dt_code(dtype):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- side stream for the backbone's weight-gradient GEMMs -----------------------------------------------------------------------------
+# dW += Y^T X of a convolution depends only on tensors that exist when its backward runs, and nothing reads dW before the batched
+# weight-standardisation backward.  On the caller's stream the TN kernel (bound by its LDS-side pipeline) sits between
+# the input-gradient GEMM and the GroupNorm backward of the layer in front (HBM-bound): on a second stream it runs beside them.
+# record_stream keeps the caching allocator from handing the operands' memory out while the side stream still reads them;
+# side_stream_join() orders the caller's stream after everything issued so far (WeightStdFn.backward calls it before it reads the dW slices).
+# MAED_WGRAD_SIDE_STREAM=0: everything on the caller's stream (A/B knob; the STE blocks' C++ driver reads the same variable).
+_SIDE_ON = os.environ.get("MAED_WGRAD_SIDE_STREAM", "1") == "1"
+_SIDE = {}
+
+
+def side_stream_run(fn, *tensors):
+    t0 = tensors[0]
+    if not (_SIDE_ON and t0.is_cuda):
+        return fn()
+    st = _SIDE.get(t0.device)
+    if st is None:
+        st = _SIDE[t0.device] = [torch.cuda.Stream(device=t0.device), False]
+    side = st[0]
+    side.wait_stream(torch.cuda.current_stream(t0.device))
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in tensors:
+        t.record_stream(side)
+    st[1] = True
+    return out
+
+
+def side_stream_join(device):
+    st = _SIDE.get(device)
+    if st is not None and st[1]:
+        torch.cuda.current_stream(device).wait_stream(st[0])
+        st[1] = False
 
 
 def _p(t):
@@ -503,6 +539,7 @@ class WeightStdFn(ReportingFn):
     @staticmethod
     def backward(ctx, *gouts):
         weights, owner = ctx.weights, ctx.owner
+        side_stream_join(weights[0].device)         # the fp32 dW slices are written on the side stream
         params = owner.conv_weights()
         keep, gptr, optr, f32 = [], [], [], []
         for i, (w, p, g) in enumerate(zip(weights, params, gouts)):
@@ -674,7 +711,8 @@ class Conv1x1Fn(torch.autograd.Function):
                 check(L.lib().maed_subsample2_bwd(_p(g), _p(dx), N, H, W, I, dt_code(dx.dtype), _stream()), "subsample2_bwd")
             dx = dx.view(N, H, W, I).permute(0, 3, 1, 2)
         if ctx.dw is not None:
-            gemm_tn_wgrad(Y, A, dW=ctx.dw)
+            dw = ctx.dw
+            side_stream_run(lambda: gemm_tn_wgrad(Y, A, dW=dw), Y, A, dw)
         return dx, None, None, None, None, None, None
 
 
@@ -771,7 +809,7 @@ class Conv3x3Fn(torch.autograd.Function):
         own_dw = need_w and s == 1 and (N * H * W) % 64 == 0 and I % 8 == 0 and O % 8 == 0
         if own_dw:                                               # TN GEMM over gathered rows; fp32, (O,3,3,I) like w's storage
             if dw_slice is not None:
-                conv3x3_wgrad(dy, x, out=dw_slice)
+                side_stream_run(lambda: conv3x3_wgrad(dy, x, out=dw_slice), dy, x, dw_slice)
             else:
                 dw = conv3x3_wgrad(dy, x).permute(0, 3, 1, 2)
             need_w = False

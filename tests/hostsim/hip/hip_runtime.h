@@ -250,6 +250,12 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuc
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+// side streams / fences: everything runs synchronously on the host, so a second stream is the same stream and a fence is nothing
+#define hipStreamNonBlocking 1u
+#define hipEventDisableTiming 2u
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 0
 template <typename K> static inline hipError_t hipFuncSetAttribute(K, int, int) { return hipSuccess; }
 
