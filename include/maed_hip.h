@@ -307,7 +307,9 @@ int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, 
  * dx (and dres = masked dy when dres != NULL); dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats */
 int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
-                       int relu, int dtype, int ab_zeroed, void* stream);
+                       int relu, int dtype, int ab_zeroed, void* aux_stream, void* stream);
+/* aux_stream (optional): a second stream of the caller's on which the closing dgamma/dbeta column sum is enqueued (fenced after the reduction
+ * pass on `stream`); the caller joins it before anybody reads dgamma/dbeta.  NULL: everything on `stream`. */
 
 /* MaxPool2dSame(kernel 3, stride 2) of the stem (resnetv2.py:61-72) on channels_last x (N,H,W,C), C % 8 == 0: y (N,ceil(H/2),
  * ceil(W/2),C) and the winning tap per output element (idx, uint8, same shape as y; ATen tie/NaN rule); backward gathers dx. */

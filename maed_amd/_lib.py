@@ -97,7 +97,7 @@ SIGNATURES = {
     "maed_weight_std_fwd": (i32, [vp, i32, i32, vp, i32, vp, f32, vp]),
     "maed_weight_std_bwd": (i32, [vp, i32, i32, i32, vp, f32, vp]),
     "maed_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp]),
-    "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp]),
+    "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp, vp]),
     "maed_comm_load": (i32, [C.c_char_p]),
     "maed_comm_unique_id": (i32, [vp]),
     "maed_comm_init": (i32, [i32, i32, vp]),

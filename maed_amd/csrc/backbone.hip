@@ -371,7 +371,7 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
 
 extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                                   void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
-                                  int relu, int dtype, int ab_zeroed, void* stream) {
+                                  int relu, int dtype, int ab_zeroed, void* aux_stream, void* stream) {
     MAED_CHECK_ARG(x && dy && sums && gamma && beta && dx && dgamma && dbeta && ab_scratch, MAED_ERR_ARG, "groupnorm_bwd: null pointer");
     MAED_CHECK_ARG(!(relu && dres) || relu_mask, MAED_ERR_ARG, "groupnorm_bwd: the forward's relu_mask is needed when a residual was added before the ReLU");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_bwd"));
@@ -394,7 +394,20 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
         sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
     MAED_DISPATCH_DTYPE(dtype, T, {
         if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);
-        if (defer) hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 63) / 64, (N + 63) / 64), dim3(256), 0, s, ab_scratch, dgamma, dbeta, N, C);
+        if (defer) {
+            // dgamma / dbeta are read by nobody before the caller joins aux_stream (ops.side_stream_join): the small column-sum kernel leaves the
+            // dy -> dx chain and runs beside the apply pass
+            hipStream_t sa = s;
+            if (aux_stream) {
+                static hipEvent_t ring[32]; static int next = -1;
+                if (next < 0) { for (int i = 0; i < 32; ++i) hipEventCreateWithFlags(&ring[i], hipEventDisableTiming); next = 0; }
+                hipEvent_t e = ring[next]; next = (next + 1) & 31;
+                hipEventRecord(e, s);
+                sa = (hipStream_t)aux_stream;
+                hipStreamWaitEvent(sa, e, 0);
+            }
+            hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 63) / 64, (N + 63) / 64), dim3(256), 0, sa, ab_scratch, dgamma, dbeta, N, C);
+        }
         if (dres && relu) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);
     });
 #undef GN_RED

@@ -185,8 +185,14 @@ extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_par
 
     MAED_PROPAGATE(maed_layernorm_fwd(x_in, C, p->ln1_g, p->ln1_b, sv + L.ln1, dt, (float*)(sv + L.mean1), (float*)(sv + L.rstd1), M, C, d->eps, stream));
     PROF(PROF_GEMM_QKV, maed_gemm_nt(sv + L.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, sv + L.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
-    PROF(PROF_ATTN_TM_FWD, maed_attn_temporal_fwd(sv + L.qkv, sv + L.xt, (float*)(sv + L.lse_t), d->F, d->P, d->H, d->T, scale, dt, stream));
-    PROF(PROF_ATTN_SP_FWD, maed_attn_spatial_fwd(sv + L.qkv, sv + L.xs, (float*)(sv + L.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
+    {   // the two attention branches read the same qkv and write disjoint outputs: temporal on the side stream beside spatial
+        SideStream* ss = (dt == MAED_BF16 && d->impl != MAED_IMPL_VALU) ? side_stream() : nullptr;
+        void* tst = ss ? (void*)ss->s : stream;
+        if (ss) ss->fence((hipStream_t)stream, ss->s);
+        { ProfScope ps__(PROF_ATTN_TM_FWD, tst); MAED_PROPAGATE(maed_attn_temporal_fwd(sv + L.qkv, sv + L.xt, (float*)(sv + L.lse_t), d->F, d->P, d->H, d->T, scale, dt, tst)); }
+        PROF(PROF_ATTN_SP_FWD, maed_attn_spatial_fwd(sv + L.qkv, sv + L.xs, (float*)(sv + L.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
+        if (ss) ss->fence(ss->s, (hipStream_t)stream);
+    }
     MAED_PROPAGATE(maed_st_colmean(sv + L.xs, sv + L.xt, sv + L.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
     MAED_PROPAGATE(maed_gemm_nt(sv + L.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
     MAED_PROPAGATE(maed_st_mix_fwd(sv + L.xs, sv + L.xt, logits, sv + L.mix, d->F, d->P, C, dt, stream));

@@ -76,6 +76,20 @@ def side_stream_run(fn, *tensors):
     return out
 
 
+def side_stream_handle(device, *tensors):
+    """raw handle of the side stream for entry points that fence a trailing kernel onto it themselves (maed_groupnorm_bwd aux_stream);
+    None when the side stream is off.  `tensors`: what that kernel reads / writes (kept alive for it)."""
+    if not (_SIDE_ON and device.type == "cuda"):
+        return None
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = [torch.cuda.Stream(device=device), False]
+    for t in tensors:
+        t.record_stream(st[0])
+    st[1] = True
+    return st[0].cuda_stream
+
+
 def side_stream_join(device):
     st = _SIDE.get(device)
     if st is not None and st[1]:
@@ -616,8 +630,10 @@ class GroupNormFn(torch.autograd.Function):
         ctx.ab = None                                   # single use: a second backward through this node gets fresh scratch
         if ab is None:
             ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
+        # kernel-written dgamma / dbeta are read only after WeightStdFn.backward's side_stream_join: their closing column sum goes to the side stream
+        aux = side_stream_handle(x.device, ab) if ctx.direct else None
         check(L.lib().maed_groupnorm_bwd(_p(x), _p(mask), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
-                                         N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), _stream()), "groupnorm_bwd")
+                                         N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), aux, _stream()), "groupnorm_bwd")
         if ctx.direct:
             return dx, dres, None, None, None, None, None, None, None, None
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None

@@ -61,7 +61,7 @@ for _ in range(10):
 t_enq = time.perf_counter() - t0; torch.cuda.synchronize(); t_all = time.perf_counter() - t0
 P(f"10 back-to-back steps: host enqueue {1e3 * t_enq / 10:.2f} ms/step (per step: {' '.join(f'{e:.1f}' for e in enq)}), wall incl. drain {1e3 * t_all / 10:.2f} ms/step")
 lib = L.lib(); lib.maed_prof_enable(1); step(); torch.cuda.synchronize()
-ms = (ctypes.c_double * 8)(); cnt = (ctypes.c_int * 8)(); lib.maed_prof_collect(ms, cnt); lib.maed_prof_enable(0)
+nt = lib.maed_prof_ntags(); ms = (ctypes.c_double * nt)(); cnt = (ctypes.c_int * nt)(); lib.maed_prof_collect(ms, cnt); lib.maed_prof_enable(0)
 names = ["attn_sp_fwd", "attn_tm_fwd", "gemm_qkv", "gemm_fc1", "gemm_fc2", "attn_sp_bwd", "attn_tm_bwd", "gemm_wgrad"]
 P("in-situ per-launch us: " + json.dumps({n: round(1e3 * ms[i] / max(cnt[i], 1), 1) for i, n in enumerate(names)}))
 P("in-situ total ms/step: " + json.dumps({n: round(ms[i], 2) for i, n in enumerate(names)}))
