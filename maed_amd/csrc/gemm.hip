@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
     constexpr int kMainElems = kTileElems > kStageElems ? kTileElems : kStageElems;
     __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kMainElems + (GN ? GN_TAB_FLOATS * 2 : 0)];
     unsigned short (*lds)[2][GM_BM * GM_BK] = reinterpret_cast<unsigned short (*)[2][GM_BM * GM_BK]>(lds_raw);
-    float* const gn_tab = reinterpret_cast<float*>(lds_raw + kMainElems);
-    if (GN && threadIdx.x < GN_TAB_FLOATS) gn_tab[threadIdx.x] = 0.f;                           // (published by the main loop's barriers)
+    double* const gn_tab = reinterpret_cast<double*>(lds_raw + kMainElems);
+    if (GN && threadIdx.x < GN_TAB_FLOATS / 2) gn_tab[threadIdx.x] = 0.0;                       // (published by the main loop's barriers)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations (M0) stay on the SALU
     const int wr = wave >> 1, wc = wave & 1;
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
     constexpr int kMainElems = kTileElems > kStageElems ? kTileElems : kStageElems;
     __shared__ __attribute__((aligned(1024))) unsigned short lds_raw[kMainElems + (GN ? GN_TAB_FLOATS * 2 : 0)];   // (+ GroupNorm-statistics table)
     unsigned short (*lds)[GM_BM * GM_BK] = reinterpret_cast<unsigned short (*)[GM_BM * GM_BK]>(lds_raw);     // [A|B][128*64]
-    float* const gn_tab = reinterpret_cast<float*>(lds_raw + kMainElems);
-    if (GN && threadIdx.x < GN_TAB_FLOATS) gn_tab[threadIdx.x] = 0.f;
+    double* const gn_tab = reinterpret_cast<double*>(lds_raw + kMainElems);
+    if (GN && threadIdx.x < GN_TAB_FLOATS / 2) gn_tab[threadIdx.x] = 0.0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = NARROW ? wave : wave >> 1, wc = NARROW ? 0 : wave & 1, l31 = lane & 31, hi = lane >> 5;
     const int id = xcd_remap(blockIdx.x, gridDim.x);

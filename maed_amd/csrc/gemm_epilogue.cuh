@@ -136,10 +136,12 @@ __device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int
 // gn_hw >= 128) in registers, the 8 lanes of a wave that share c0 are folded with three shuffles, and only then 8 lanes per wave
 // add into the workgroup's LDS table [2 frames][64 groups][2] floats (zeroed at kernel start); gn_flush adds the table to the global
 // fp64 sums -- (2 frames x groups x 2) fp64 atomics per workgroup.
-#define GN_TAB_FLOATS (2 * 64 * 2)
-struct GnTile { float* tab; int64_t split_row; int sh, g0; };            // split_row: first row of the tile's second frame; sh = log2(channels per group)
+// (fp64 table: the order in which waves arrive then changes the sums by ~1e-16 relative, never a bf16 rounding of the normalised output -- with fp32
+// LDS atomics the statistics moved in the 7th digit from run to run, and 50 layers of bf16 rounding amplify a flipped ulp chaotically)
+#define GN_TAB_FLOATS (2 * 64 * 2 * 2)                                      /* table size in 4-byte units: [2 frames][64 groups][2] doubles */
+struct GnTile { double* tab; int64_t split_row; int sh, g0; };            // split_row: first row of the tile's second frame; sh = log2(channels per group)
 struct GnRegs { float s[2][4], q[2][4]; };
-__device__ __forceinline__ GnTile gn_tile(float* tab, int64_t m0, int64_t n0, int64_t N, int hw) {
+__device__ __forceinline__ GnTile gn_tile(double* tab, int64_t m0, int64_t n0, int64_t N, int hw) {
     const int cpg = (int)(N >> 5);                                        // N % 32 == 0 and a power of two per group (host-checked)
     const int sh = 31 - __builtin_clz((unsigned)cpg);
     return GnTile{tab, (m0 / hw + 1) * (int64_t)hw, sh, (int)(n0 >> sh)};
@@ -172,21 +174,21 @@ __device__ __forceinline__ void gn_commit(GnRegs& a, const GnTile& g, int lane, 
     if ((lane >> 3) != 0 || c0 >= N) return;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        float* const tf = g.tab + f * 128;
+        double* const tf = g.tab + f * 128;
         if (g.sh >= 3) {                                                  // >= 8 channels per group: the lane's 8 columns are one group
-            float* t = tf + ((((int)(c0 >> g.sh)) - g.g0) << 1);
-            atomicAdd(t, (a.s[f][0] + a.s[f][1]) + (a.s[f][2] + a.s[f][3])); atomicAdd(t + 1, (a.q[f][0] + a.q[f][1]) + (a.q[f][2] + a.q[f][3]));
+            double* t = tf + ((((int)(c0 >> g.sh)) - g.g0) << 1);
+            atomicAdd(t, (double)((a.s[f][0] + a.s[f][1]) + (a.s[f][2] + a.s[f][3]))); atomicAdd(t + 1, (double)((a.q[f][0] + a.q[f][1]) + (a.q[f][2] + a.q[f][3])));
         } else if (g.sh == 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float* t = tf + ((((int)(c0 >> 2)) + h - g.g0) << 1);
-                atomicAdd(t, a.s[f][2 * h] + a.s[f][2 * h + 1]); atomicAdd(t + 1, a.q[f][2 * h] + a.q[f][2 * h + 1]);
+                double* t = tf + ((((int)(c0 >> 2)) + h - g.g0) << 1);
+                atomicAdd(t, (double)(a.s[f][2 * h] + a.s[f][2 * h + 1])); atomicAdd(t + 1, (double)(a.q[f][2 * h] + a.q[f][2 * h + 1]));
             }
         } else {                                                          // 2 channels per group
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                float* t = tf + ((((int)(c0 >> 1)) + h - g.g0) << 1);
-                atomicAdd(t, a.s[f][h]); atomicAdd(t + 1, a.q[f][h]);
+                double* t = tf + ((((int)(c0 >> 1)) + h - g.g0) << 1);
+                atomicAdd(t, (double)a.s[f][h]); atomicAdd(t + 1, (double)a.q[f][h]);
             }
         }
     }
@@ -198,8 +200,8 @@ __device__ __forceinline__ void gn_flush(const GnTile& g, double* sums, int64_t 
         const int k = i & 1, gl = (i >> 1) % ngl, f = (i >> 1) / ngl;
         const int64_t n = n_first + f;
         const int grp = g.g0 + gl;
-        const float v = g.tab[f * 128 + (gl << 1) + k];
-        if (n * hw < M && grp < 32 && v != 0.f) atomicAdd(sums + (n * 32 + grp) * 2 + k, (double)v);
+        const double v = g.tab[f * 128 + (gl << 1) + k];
+        if (n * hw < M && grp < 32 && v != 0.0) atomicAdd(sums + (n * 32 + grp) * 2 + k, v);
     }
 }
 

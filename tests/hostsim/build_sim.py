@@ -15,7 +15,12 @@ CSRC = os.path.join(ROOT, "maed_amd", "csrc")
 #   LD_PRELOAD=$(dirname $(which clang))/../lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so MAED_SIM_TSAN=1 python -m pytest ...
 # (tests/hostsim/race_check.py does all of that).
 TSAN = os.environ.get("MAED_SIM_TSAN", "0") not in ("", "0")
-OUT_DIR = os.path.join(HERE, "_build_tsan" if TSAN else "_build")
+# MAED_SIM_ASAN=1: AddressSanitizer build.  Global memory is ordinary heap memory in the simulator (tensors of the framework's CPU allocator), so a kernel
+# that loads or stores past the end of a tensor -- invisible on the GPU, where it lands in a neighbouring allocation -- is a heap-buffer-overflow
+# report with the kernel's source line (tests/hostsim/oob_check.py).
+ASAN = os.environ.get("MAED_SIM_ASAN", "0") not in ("", "0")
+SAN = ["-fsanitize=thread"] if TSAN else ["-fsanitize=address"] if ASAN else []
+OUT_DIR = os.path.join(HERE, "_build_tsan" if TSAN else "_build_asan" if ASAN else "_build")
 OUT = os.path.join(OUT_DIR, "libmaed_hostsim.so")
 SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip", "attn_long.hip"]
 CLANG = os.environ.get("MAED_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
@@ -29,8 +34,8 @@ def build(force=False):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     flags = [CLANG, "-std=c++20", "-O1", "-fPIC", "-pthread", "-I", HERE, "-Wno-unused-value"]
-    if TSAN:
-        flags += ["-fsanitize=thread", "-g", "-fno-omit-frame-pointer"]
+    if SAN:
+        flags += SAN + ["-g", "-fno-omit-frame-pointer"]
 
     def compile_one(src):     # one object per source, in parallel (the whole library is ~14 translation units)
         obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
@@ -42,7 +47,7 @@ def build(force=False):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    subprocess.run([CLANG, "-shared", "-pthread"] + (["-fsanitize=thread", "-shared-libsan"] if TSAN else []) + ["-o", OUT] + objs, check=True)
+    subprocess.run([CLANG, "-shared", "-pthread"] + (SAN + ["-shared-libsan"] if SAN else []) + ["-o", OUT] + objs, check=True)
     return OUT
 
 

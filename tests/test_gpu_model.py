@@ -395,6 +395,37 @@ def test_backbone_gemm_convolutions_match_miopen_path():
     report(f"1 - cosine(backbone gradient, fp64 oracle): all-MIOpen path (worst tensor: {worst_mio:.3f})", torch.tensor([1 - allc(g0)]), torch.zeros(1), rtol=0, atol=0.1)
 
 
+def test_backbone_weight_gradients_on_the_side_stream_equal_the_single_stream_ones(monkeypatch):
+    """ops.side_stream_run / maed_groupnorm_bwd aux_stream: the convolution weight gradients (TN GEMMs) and the GroupNorm dgamma/dbeta column sums run on
+    a second stream beside the input-gradient chain and are joined before the batched weight-standardisation backward reads them.  Same backbone,
+    same inputs, two backward passes in a row per variant (buffers recycled by the caching allocator in between): every parameter gradient must equal
+    the single-stream one up to the summation order of fp32 atomics -- a missing fence or a recycled operand shows up as a wrong tensor."""
+    from maed_amd import ops
+    from maed_amd.resnetv2 import ResNetV2
+    torch.manual_seed(5)
+    net = ResNetV2(layers=(2, 2, 2), channels=(256, 512, 1024), compute_dtype=torch.bfloat16).to(DEV)
+    x = rnd(16, 3, 96, 96, seed=51).to(DEV)
+    cot = rnd(16, 1024, 6, 6, seed=52).to(DEV)
+    grads = {}
+    for side in (False, False, True, True):
+        monkeypatch.setattr(ops, "_SIDE_ON", side)
+        for rep in range(2):
+            for p in net.parameters():
+                p.grad = None
+            (net(x).float() * cot).sum().backward()
+            junk = [torch.randn(1 << 22, device=DEV) for _ in range(4)]        # churn the allocator: freed operands get overwritten
+            del junk
+        torch.cuda.synchronize()
+        grads.setdefault(side, []).append({n: p.grad.detach().float().cpu() for n, p in net.named_parameters()})
+    ref = grads[False][0]
+    dist = lambda g: max((g[n] - ref[n]).abs().max().item() / (ref[n].abs().max().item() + 1e-12) for n in ref)
+    # two single-stream runs already differ (fp32 / fp64 atomics in different orders, then 50 layers of bf16 rounding): that is the yardstick
+    noise = dist(grads[False][1])
+    worst = max(dist(g) for g in grads[True])
+    report(f"backbone parameter gradients, side stream vs single stream: max rel-to-max error {worst:.2e} (two single-stream runs differ by {noise:.2e})",
+           torch.tensor([worst]), torch.zeros(1), rtol=0, atol=4 * noise + 1e-3)
+
+
 # ---- the benchmarked configuration at FULL module size (BASELINE.json configs[1] / configs[2]: C = 512, H = 8, depth 6, 224^2, T = 16) ------
 CFG3 = dict(depth=6, H=8, img=224, hidden=1024, T=16)
 
