@@ -14,8 +14,9 @@ timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench_train.json 2> $O/be
 timeout 300 python bench.py --steps 20 --warmup 3 --forward-only --no-cpu-baseline > $O/bench_forward.json 2>/dev/null; cut -c1-200 $O/bench_forward.json
 timeout 600 python bench.py --steps 5 --warmup 2 --dtype f32 --no-cpu-baseline > $O/bench_train_f32.json 2>/dev/null; cut -c1-200 $O/bench_train_f32.json
 # the multi-GPU launch line of the contract with ONE rank and every bucket's all-reduce forced: process group, broadcast, bucketed RCCL
-# all-reduce overlapped with backward, barrier -- the code path the driver's N = 2/4/8 runs take, on this single-GPU box
-MAED_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_torchrun_world1_forced_collectives.json 2> $O/bench_torchrun.err; echo "torchrun bench exit: $?"; cut -c1-200 $O/bench_torchrun_world1_forced_collectives.json
+# all-reduce overlapped with backward, barrier, per-stage weight standardisation (the world > 1 default) -- the code path the driver's N = 2/4/8 runs take, on this
+# single-GPU box
+MAED_FORCE_COLLECTIVES=1 MAED_WS_PER_STAGE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_torchrun_world1_forced_collectives.json 2> $O/bench_torchrun.err; echo "torchrun bench exit: $?"; cut -c1-200 $O/bench_torchrun_world1_forced_collectives.json
 timeout 300 python scripts/gemm_micro.py 30 all 0 > $O/gemm_micro.txt 2>&1; grep "gemm " $O/gemm_micro.txt | cut -c1-110
 bash scripts/gpu_gemm_variants.sh > /dev/null 2>&1
 rm -rf /tmp/prof_out

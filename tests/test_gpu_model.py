@@ -426,6 +426,37 @@ def test_backbone_weight_gradients_on_the_side_stream_equal_the_single_stream_on
            torch.tensor([worst]), torch.zeros(1), rtol=0, atol=4 * noise + 1e-3)
 
 
+def test_backbone_per_stage_weight_standardisation_equals_the_batched_mode(monkeypatch):
+    """what runs by default when the process group has more than one rank (MAED_WS_PER_STAGE=auto): weights standardised stage by stage so that a stage's
+    gradients are final -- and its bucket's all-reduce can start -- when that stage's backward ends.  Same features, same gradients as the one-launch mode
+    (within the run-to-run noise of the fp32 atomics), and the readiness reports arrive last stage first."""
+    from maed_amd import resnetv2
+    from maed_amd.resnetv2 import ResNetV2
+    torch.manual_seed(6)
+    net = ResNetV2(layers=(1, 2, 1), channels=(256, 512, 1024), compute_dtype=torch.bfloat16).to(DEV)
+    x = rnd(8, 3, 96, 96, seed=61).to(DEV)
+    cot = rnd(8, 1024, 6, 6, seed=62).to(DEV)
+    res, order = {}, []
+    net.grads_ready = lambda owner: order.append(owner)
+    for mode in (False, False, True):
+        monkeypatch.setattr(resnetv2, "_WS_PER_STAGE", mode)
+        order.clear()
+        for p in net.parameters():
+            p.grad = None
+        y = net(x)
+        (y.float() * cot).sum().backward()
+        torch.cuda.synchronize()
+        res.setdefault(mode, []).append((y.detach().float().cpu(), {n: p.grad.detach().float().cpu() for n, p in net.named_parameters()}, list(order)))
+    (y0, g0, o0), (y0b, g0b, _) = res[False]
+    y1, g1, o1 = res[True][0]
+    assert torch.equal(y1, y0), "standardising per stage must not change the forward"
+    dist = lambda g: max((g[n] - g0[n]).abs().max().item() / (g0[n].abs().max().item() + 1e-12) for n in g0)
+    report(f"backbone gradients, per-stage vs batched weight standardisation (two batched runs differ by {dist(g0b):.2e})", torch.tensor([dist(g1)]), torch.zeros(1),
+           rtol=0, atol=4 * dist(g0b) + 1e-3)
+    assert len(o0) == 1 and o0[0] is net
+    assert len(o1) == 3 and [o.conv_idx[0] for o in o1] == sorted((o.conv_idx[0] for o in o1), reverse=True), "last stage reports first"
+
+
 # ---- the benchmarked configuration at FULL module size (BASELINE.json configs[1] / configs[2]: C = 512, H = 8, depth 6, 224^2, T = 16) ------
 CFG3 = dict(depth=6, H=8, img=224, hidden=1024, T=16)
 
