@@ -34,14 +34,30 @@ __global__ __launch_bounds__(256) void gemm_nt_valu_kernel(const T* __restrict__
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
     const int64_t ar = (m0 + lr < M) ? m0 + lr : M - 1;
     const int64_t br = (n0 + lr < N) ? n0 + lr : N - 1;
+    // a thread stages 4 consecutive k of one row per operand: one 16-byte load when the rows allow it, and the NEXT K step's loads are issued
+    // before this step's FMAs (a step used to be one exposed global-load latency: 3 us x 16 steps for the decoder head's GEMMs)
+    const bool vec = sizeof(T) == 4 && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (kbeg % 4 == 0);   // block-uniform
+    float va[4], vb[4];
+    auto fetch = [&](int64_t k0) {
+        const int64_t k = k0 + lk;
+        if (vec && k + 4 <= kend) {
+            const float4 a4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(A) + ar * lda + k);
+            const float4 b4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(B) + br * ldb + k);
+            va[0] = a4.x; va[1] = a4.y; va[2] = a4.z; va[3] = a4.w; vb[0] = b4.x; vb[1] = b4.y; vb[2] = b4.z; vb[3] = b4.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[i] = (k + i < kend) ? ldf(A + ar * lda + k + i) : 0.f;
+                vb[i] = (k + i < kend) ? ldf(B + br * ldb + k + i) : 0.f;
+            }
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
     for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t k = k0 + lk + i;
-            As[lk + i][lr] = (k < kend) ? ldf(A + ar * lda + k) : 0.f;
-            Bs[lk + i][lr] = (k < kend) ? ldf(B + br * ldb + k) : 0.f;
-        }
+        for (int i = 0; i < 4; ++i) { As[lk + i][lr] = va[i]; Bs[lk + i][lr] = vb[i]; }
         __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             float a[4], b[4];
@@ -570,7 +586,11 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         if constexpr (EPI == MAED_EPI_STORE || EPI == MAED_EPI_STORE_F32) {
             const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
             if (splitk == 1 && tiles < 96 && K >= 256) {
-                int sk = (int)(256 / tiles);
+                // more K slices would hide more load latency, but every slice adds an output tile of fp32 atomics: ~256 workgroups measured best (128 x 1024 x 2136: 50.7 / 55.4 / 69.3 us
+                // at 256 / 512 / 1024; MAED_F32_SPLIT_WGS: sweep knob)
+                static int target = 0;
+                if (!target) { const char* ev = getenv("MAED_F32_SPLIT_WGS"); target = ev ? atoi(ev) : 256; if (target < 32) target = 256; }
+                int sk = (int)(target / tiles);
                 if (sk > K / 64) sk = (int)(K / 64);
                 if (sk > 1) {
                     hipLaunchKernelGGL(bias_fill_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, (float*)e.out, e.ldo, e.bias, M, N);
