@@ -216,7 +216,10 @@ __global__ __launch_bounds__(64) void lbs_chain_par_kernel(maed_smpl_params sp, 
 }
 
 // kernel B: thread per vertex, LBS_FB frames per workgroup so posedirs (17 MB) is streamed once per LBS_FB frames
+// (measured at 128 frames, scripts/lbs_micro.py: 1 / 2 / 4 / 8 frames per workgroup = 319 / 279 / 164 / 194 us)
+#ifndef LBS_FB
 #define LBS_FB 4
+#endif
 __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
                                                        const float* __restrict__ A, float* __restrict__ verts,
                                                        float* __restrict__ v_posed, int F) {

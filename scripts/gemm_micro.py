@@ -11,9 +11,17 @@ torch.manual_seed(0)
 M = 128 * 197
 shapes = {"qkv": (M, 1536, 512, L.EPI_STORE), "fc1": (M, 2048, 512, L.EPI_GELU), "fc2": (M, 512, 2048, L.EPI_RESID_F32), "proj": (M, 512, 512, L.EPI_RESID_F32),
           "dfc2": (M, 2048, 512, L.EPI_MUL_DGELU), "dqkv": (M, 512, 1536, L.EPI_STORE), "dfc1": (M, 512, 2048, L.EPI_STORE), "dproj": (M, 512, 512, L.EPI_STORE),
-          "sq4k": (4096, 4096, 4096, L.EPI_STORE)}
+          "sq4k": (4096, 4096, 4096, L.EPI_STORE),
+          # the backbone's 1x1 convolutions at cfg3 (128 frames): stage 3 / 2 / 1, conv1- and conv3-shaped ("conv" selector)
+          "c3a": (25088, 256, 1024, L.EPI_STORE), "c3b": (25088, 1024, 256, L.EPI_STORE), "c2a": (100352, 128, 512, L.EPI_STORE), "c2b": (100352, 512, 128, L.EPI_STORE),
+          "c1a": (401408, 64, 256, L.EPI_STORE), "c1b": (401408, 256, 64, L.EPI_STORE)}
+CONV = ("c3a", "c3b", "c2a", "c2b", "c1a", "c1b")
 for name, (m, n, k, epi) in shapes.items():
-    if which not in ("all", name) and not (which == "ste" and name != "sq4k"):      # "ste" = the eight NT GEMMs of one STE block (fwd + input gradients)
+    if name in CONV and which not in ("conv", name):
+        continue
+    if which == "conv" and name not in CONV:
+        continue
+    if which not in ("all", "conv", name) and not (which == "ste" and name != "sq4k"):      # "ste" = the eight NT GEMMs of one STE block (fwd + input gradients)
         continue
     A = [torch.randn(m, k, device="cuda").bfloat16() for _ in range(3)]
     B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
