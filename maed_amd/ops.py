@@ -552,8 +552,26 @@ class WeightStdFn(ReportingFn):
 
     @staticmethod
     def backward(ctx, *gouts):
+        """Runs on the caller's stream after joining the side stream (the fp32 dW slices and the GroupNorm dgamma/dbeta sums are written there) --
+        except for a group the owner marked `_ws_on_side` (per-stage mode: every stage but the one whose backward runs last): those enqueue
+        their kernel AND their readiness report on the side stream itself, behind that stage's weight gradients, so the caller's stream -- the
+        dy -> dx chain of the next stage -- never waits for them; the last group's join covers them."""
+        dev = ctx.weights[0].device
+        st = _SIDE.get(dev) if (_SIDE_ON and getattr(ctx.owner, "_ws_on_side", False)) else None
+        if st is None or not st[1]:
+            side_stream_join(dev)
+            return WeightStdFn._backward_body(ctx, gouts)
+        side = st[0]
+        side.wait_stream(torch.cuda.current_stream(dev))     # gradients autograd carried here (MIOpen convolutions), p.grad zero-fills
+        with torch.cuda.stream(side):
+            for g in gouts:
+                if g is not None:
+                    g.record_stream(side)
+            return WeightStdFn._backward_body(ctx, gouts)
+
+    @staticmethod
+    def _backward_body(ctx, gouts):
         weights, owner = ctx.weights, ctx.owner
-        side_stream_join(weights[0].device)         # the fp32 dW slices are written on the side stream
         params = owner.conv_weights()
         keep, gptr, optr, f32 = [], [], [], []
         for i, (w, p, g) in enumerate(zip(weights, params, gouts)):

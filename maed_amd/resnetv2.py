@@ -59,6 +59,7 @@ class _WsGroup:
     def __init__(self, parent, conv_idx, norms):
         self.parent, self.conv_idx, self.norms = parent, list(conv_idx), list(norms)
         self._pending_backwards = 0
+        self._ws_on_side = False
         self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
 
     def conv_weights(self):
@@ -328,6 +329,10 @@ class ResNetV2(nn.Module):
                     c = self._convs[ci]
                     c._w_std, c._w_t, c._dw = w, g._w_std_t.get(k), g._dw_slices.get(k)
                 x = self.stages[0](self.stem(x)) if gi == 0 else self.stages[gi](x)
+            # backward order is last stage first: every group but the one that runs last may finish on the side stream (ops.WeightStdFn.backward)
+            runs = [g for g in self._ws_groups if g._pending_backwards > 0]
+            for k, g in enumerate(self._ws_groups):
+                g._ws_on_side = bool(runs) and g is not runs[0] and g in runs
             return x
         finally:
             for c in self._convs:
