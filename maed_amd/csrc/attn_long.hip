@@ -218,9 +218,11 @@ __global__ __launch_bounds__(256, 3) void attn_long_bwd_dq_mfma(const bf16* __re
         for (int sub = 0; sub < 2; ++sub) {
             const int k0 = kt * LT + sub * 32;
             if (k0 >= L) break;
+            // per score: one fma, one exp2, one multiply.  delta rides in the dP accumulator's initial value (a lane owns one query), the
+            // 1/sqrt(d) factor is applied once to the dQ accumulators at the end, and only the sequence's last sub-tile masks padding keys
             f32x16_t s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -Dq; }
             const int off = (sub * 32 + l31) * KLD + hi * 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -228,10 +230,10 @@ __global__ __launch_bounds__(256, 3) void attn_long_bwd_dq_mfma(const bf16* __re
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Vs + off + t * 16), dof[t], dp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float p = (k < L) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, -L2)) : 0.f;
-                s[r] = p * (dp[r] - Dq) * scale;    // dS^T
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, -L2)) * dp[r];    // dS^T / scale
+            if (k0 + 32 > L) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (k0 + (r & 3) + 8 * (r >> 2) + 4 * hi < L) ? s[r] : 0.f;
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {        // dQ^T += K^T dS^T
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(256, 3) void attn_long_bwd_dq_mfma(const bf16* __re
             }
         }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
     if (active && q < L) store_rowT(dqkv + ((int64_t)f * L + q) * ld + h * D, dq, hi, accumulate);
 }
 
@@ -276,40 +280,55 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
     const int nqt = (L + LT - 1) / LT;
-    TileRegs qreg, doreg;
+    // delta = rowsum(dO * O) of the tile's queries comes from the dO chunks a thread stages anyway and the matching O chunks, prefetched with them
+    // (8 threads share a row: three shuffles) -- the first version had 64 threads re-read dO and O between the two barriers of every tile, an
+    // exposed global-load latency per tile
+    TileRegs qreg, doreg, oreg;
+    float lreg = 0.f;
+    auto load_stats = [&](int qt_) {
+        tile_load(oreg, obase, C, qt_ * LT, L, tid);
+        if (tid < LT) { int qi = qt_ * LT + tid; if (qi > L - 1) qi = L - 1; lreg = lse[((int64_t)f * H + h) * L + qi] * l2e; }
+    };
+    auto chunk_dot = [](const uint4& a, const uint4& b) {
+        const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d = fmaf(__uint_as_float(x[j] << 16), __uint_as_float(y[j] << 16), d);
+            d = fmaf(__uint_as_float(x[j] & 0xffff0000u), __uint_as_float(y[j] & 0xffff0000u), d);
+        }
+        return d;
+    };
     tile_load(qreg, base, ld, 0, L, tid);
     tile_load(doreg, dobase, C, 0, L, tid);
+    load_stats(0);
     for (int qt = 0; qt < nqt; ++qt) {
         __syncthreads();
         tile_store(qreg, Qs, Qt, tid);
         tile_store(doreg, dOs, dOt, tid);
-        if (tid < LT) {                             // lse (in log2 units) and delta of the tile's 64 queries
-            int qi = qt * LT + tid;
-            if (qi > L - 1) qi = L - 1;
-            float dsum = 0.f;
+        {   // chunk idx = tid (row tid >> 3) and tid + 256 (row 32 + (tid >> 3)); the 8 threads of a row are consecutive lanes
+            float d0 = chunk_dot(doreg.a, oreg.a), d1 = chunk_dot(doreg.b, oreg.b);
 #pragma unroll
-            for (int c = 0; c < D; c += 8) {
-                float a[8], b[8];
-                ld8(dobase + (int64_t)qi * C + c, a); ld8(obase + (int64_t)qi * C + c, b);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dsum = fmaf(a[j], b[j], dsum);
-            }
-            Ds[tid] = dsum;
-            Ls[tid] = lse[((int64_t)f * H + h) * L + qi] * l2e;
+            for (int m = 1; m < 8; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
+            if ((tid & 7) == 0) { Ds[tid >> 3] = d0; Ds[32 + (tid >> 3)] = d1; }
+            if (tid < LT) Ls[tid] = lreg;
         }
         __syncthreads();
         if (qt + 1 < nqt) {
             tile_load(qreg, base, ld, (qt + 1) * LT, L, tid);
             tile_load(doreg, dobase, C, (qt + 1) * LT, L, tid);
+            load_stats(qt + 1);
         }
         if (!active) continue;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int q0 = qt * LT + sub * 32;
             if (q0 >= L) break;
+            // as in the dQ pass: -delta is the dP accumulator's initial value (here a register owns a query: read from LDS), the 1/sqrt(d) factor is
+            // applied once to the dK accumulators at the end, padding queries are masked in the sequence's last sub-tile only
             f32x16_t s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = -Ds[sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]; }
             const int off = (sub * 32 + l31) * KLD + hi * 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -319,9 +338,15 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;         // row within the tile
-                const float p = (qt * LT + ql < L) ? __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, -Ls[ql])) : 0.f;
-                dp[r] = p * (dp[r] - Ds[ql]) * scale;   // dS
-                s[r] = p;                               // P
+                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl2e, -Ls[ql]));         // P
+                dp[r] *= s[r];                                                     // dS / scale
+            }
+            if (q0 + 32 > L) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi < L;
+                    s[r] = ok ? s[r] : 0.f; dp[r] = ok ? dp[r] : 0.f;
+                }
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -335,6 +360,8 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __r
             }
         }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] *= scale; dk[1][r] *= scale; }
     if (active && k < L) {
         bf16* drow = dqkv + ((int64_t)f * L + k) * ld + h * D;
         store_rowT(drow + C, dk, hi, accumulate);
