@@ -72,7 +72,7 @@ __device__ __forceinline__ void tile_store(const TileRegs& t, unsigned short* ro
 __global__ __launch_bounds__(256, 4) void attn_long_fwd_mfma(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
                                                           int L, int H, int ntile, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[LT * KLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Vt[D * LVLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[LT * KLD];      // row-major: V^T fragments come from transposing reads
     const int bid = long_xcd_remap(blockIdx.x, gridDim.x);
     const int item = bid / ntile, tile = bid - item * ntile;
     const int f = item / H, h = item - f * H, C = H * D;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 4) void attn_long_fwd_mfma(const bf16* __restr
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                            // every wave is done with the previous tile
         tile_store(kreg, Ks, nullptr, tid);
-        tile_store(vreg, nullptr, Vt, tid);
+        tile_store(vreg, Vs, nullptr, tid);
         __syncthreads();
         if (kt + 1 < nkt) {                         // next tile's loads fly while this one is consumed
             tile_load(kreg, base + C, ld, (kt + 1) * LT, L, tid);
@@ -145,8 +145,7 @@ __global__ __launch_bounds__(256, 4) void attn_long_fwd_mfma(const bf16* __restr
                 const bf16x8_t pf = pack_frag(s, st);
 #pragma unroll
                 for (int et = 0; et < 2; ++et)
-                    oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Vt + (et * 32 + l31) * LVLD + sub * 32 + 16 * st + 4 * hi), pf,
-                                                                       oacc[et], 0, 0, 0);
+                    oacc[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr_rm(Vs, sub * 32 + 16 * st, et * 32, lane), pf, oacc[et], 0, 0, 0);
             }
         }
     }
@@ -171,7 +170,6 @@ __global__ __launch_bounds__(256, 3) void attn_long_bwd_dq_mfma(const bf16* __re
                                                              int ntile, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[LT * KLD];
     __shared__ __attribute__((aligned(16))) unsigned short Vs[LT * KLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Kt[D * LVLD];
     const int bid = long_xcd_remap(blockIdx.x, gridDim.x);
     const int item = bid / ntile, tile = bid - item * ntile;
     const int f = item / H, h = item - f * H, C = H * D;
@@ -206,7 +204,7 @@ __global__ __launch_bounds__(256, 3) void attn_long_bwd_dq_mfma(const bf16* __re
     tile_load(vreg, base + 2 * C, ld, 0, L, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        tile_store(kreg, Ks, Kt, tid);
+        tile_store(kreg, Ks, nullptr, tid);
         tile_store(vreg, Vs, nullptr, tid);
         __syncthreads();
         if (kt + 1 < nkt) {
@@ -240,8 +238,7 @@ __global__ __launch_bounds__(256, 3) void attn_long_bwd_dq_mfma(const bf16* __re
                 const bf16x8_t dsf = pack_frag(s, st);
 #pragma unroll
                 for (int et = 0; et < 2; ++et)
-                    dq[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Kt + (et * 32 + l31) * LVLD + sub * 32 + 16 * st + 4 * hi), dsf,
-                                                                     dq[et], 0, 0, 0);
+                    dq[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr_rm(Ks, sub * 32 + 16 * st, et * 32, lane), dsf, dq[et], 0, 0, 0);
             }
         }
     }
@@ -255,8 +252,6 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __r
                                                               int ntile, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[LT * KLD];
     __shared__ __attribute__((aligned(16))) unsigned short dOs[LT * KLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Qt[D * LVLD];
-    __shared__ __attribute__((aligned(16))) unsigned short dOt[D * LVLD];
     __shared__ float Ls[LT], Ds[LT];
     const int bid = long_xcd_remap(blockIdx.x, gridDim.x);
     const int item = bid / ntile, tile = bid - item * ntile;
@@ -304,8 +299,8 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __r
     load_stats(0);
     for (int qt = 0; qt < nqt; ++qt) {
         __syncthreads();
-        tile_store(qreg, Qs, Qt, tid);
-        tile_store(doreg, dOs, dOt, tid);
+        tile_store(qreg, Qs, nullptr, tid);
+        tile_store(doreg, dOs, nullptr, tid);
         {   // chunk idx = tid (row tid >> 3) and tid + 256 (row 32 + (tid >> 3)); the 8 threads of a row are consecutive lanes
             float d0 = chunk_dot(doreg.a, oreg.a), d1 = chunk_dot(doreg.b, oreg.b);
 #pragma unroll
@@ -353,9 +348,8 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __r
                 const bf16x8_t pf = pack_frag(s, st), dsf = pack_frag(dp, st);
 #pragma unroll
                 for (int et = 0; et < 2; ++et) {
-                    const int toff = (et * 32 + l31) * LVLD + sub * 32 + 16 * st + 4 * hi;
-                    dv[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(dOt + toff), pf, dv[et], 0, 0, 0);    // dV^T += dO^T P
-                    dk[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Qt + toff), dsf, dk[et], 0, 0, 0);    // dK^T += Q^T dS
+                    dv[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr_rm(dOs, sub * 32 + 16 * st, et * 32, lane), pf, dv[et], 0, 0, 0);    // dV^T += dO^T P
+                    dk[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr_rm(Qs, sub * 32 + 16 * st, et * 32, lane), dsf, dk[et], 0, 0, 0);     // dK^T += Q^T dS
                 }
             }
         }

@@ -10,6 +10,19 @@ __device__ __forceinline__ bf16x8_t lds_frag_tr(const unsigned short* base) {  /
     f.u[1] = *reinterpret_cast<const uint2*>(base + 8);
     return f.v;
 }
+// The same fragment -- row e_base + (lane & 31) of the TRANSPOSE, k slots key_base + {4 hi .. 4 hi + 3} and + 8 -- straight from a ROW-MAJOR image
+// X[key][e] (row stride KLD) with two transposing reads: inside a 16-lane group, lane 4j + t reads X[key0 + j][e0 + 4t .. + 3] and receives column
+// (lane & 15) of that 4 x 16 block.  No transposed copy of the tile has to be staged (2-byte LDS writes, 16 per 16-byte chunk).
+__device__ __forceinline__ bf16x8_t lds_frag_tr_rm(const unsigned short* X, int key_base, int e_base, int lane) {
+    const int i = lane & 15;
+    const unsigned short* p = X + (key_base + 4 * (lane >> 5) + (i >> 2)) * KLD + e_base + (lane & 16) + 4 * (i & 3);
+    union { bf16x8_t v; uint2 u[2]; } f;
+    auto lo = MAED_DS_READ_TR16(p);
+    auto hi = MAED_DS_READ_TR16(p + 8 * KLD);
+    __builtin_memcpy(&f.u[0], &lo, 8);
+    __builtin_memcpy(&f.u[1], &hi, 8);
+    return f.v;
+}
 __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& x, int st) {
     union { bf16x8_t v; uint32_t u[4]; } f;
 #pragma unroll

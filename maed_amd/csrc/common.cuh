@@ -17,6 +17,7 @@
 #define MAED_LDS_DMA16(base_, voff_, lds_ptr_) __builtin_amdgcn_global_load_lds((const char*)(base_) + (voff_), (void*)(lds_ptr_), 16, 0, 0)
 typedef void maed_lds_void_t;
 typedef const void maed_glb_void_t;
+#define MAED_DS_READ_TR16(p_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((hostsim_v4i16*)(p_))
 #else
 #define MAED_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define MAED_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")      // counted: the n most recent VMEM operations stay in flight
@@ -30,6 +31,9 @@ typedef const void maed_glb_void_t;
                  :: "v"((uint32_t)(voff_)), "s"((uint32_t)(uintptr_t)(lds_ptr_)), "s"((const char*)(base_)) : "memory")
 typedef __attribute__((address_space(3))) void maed_lds_void_t;
 typedef const __attribute__((address_space(1))) void maed_glb_void_t;
+// ds_read_b64_tr_b16: every lane reads 8 bytes at its own LDS address; inside each 16-lane group the 16 x 4 elements come back transposed
+typedef short maed_v4i16_t __attribute__((ext_vector_type(4)));
+#define MAED_DS_READ_TR16(p_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) maed_v4i16_t*)(p_))
 #endif
 
 // dynamic LDS of a kernel (the host simulator of tests/hostsim substitutes its own definition)
