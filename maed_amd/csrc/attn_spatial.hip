@@ -615,12 +615,11 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
                    "attn_spatial_bwd: MFMA path is bf16 only");
     if (F == 0) return MAED_OK;
     const bool mfma_fits = ((P + 31) / 32) <= 10;  // 640-thread workgroups (register budget 168/lane)
-    // sequences beyond the whole-head kernels (MFMA: 320 tokens, VALU: LDS), or on request: the tiled two-pass backward
-    // (default for frame sizes whose last 128-row tile is at least half full: P = 197 138.8 vs 147.0 us; at P = 257 the third tile holds ONE
-    //  row and the whole-head kernels win, 311.8 vs 342.2 us -- profiles/r02_call1_attn_long_micro.txt)
-    const bool tail_ok = (P % 128 == 0) || (P % 128 >= 64);
+    // the tiled two-pass backward is the default for every length since its round-2 rework (delta from staged chunks, transposing LDS reads, trimmed
+    // score arithmetic): P = 197 108.5 vs 147.7 us for the whole-head kernels, P = 257 (third row tile holds ONE row) 252.6 vs 314.1 us
+    // (profiles/r02_attn_long_micro_v2.txt); the whole-head kernels stay reachable with impl = MAED_IMPL_MFMA
     if (dtype == MAED_BF16 && impl != MAED_IMPL_VALU &&
-        (impl == MAED_IMPL_MFMA_LONG || (impl == MAED_IMPL_AUTO && tail_ok) ||
+        (impl == MAED_IMPL_MFMA_LONG || impl == MAED_IMPL_AUTO ||
          (!mfma_fits && (impl == MAED_IMPL_MFMA || valu_lds_bytes(P, true) > 160 * 1024))))
         return maed_attn_long_bwd_launch(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
     if (dtype == MAED_BF16 && impl != MAED_IMPL_VALU && mfma_fits) {

@@ -663,17 +663,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_BLOCKS) void attn_tm_bwd_mfma(cons
 // ==================================================================================================
 // The same backward specialised for virtual sequences of ONE 32-row tile (T <= 32: cfg3's T = 16 packs two tokens per workgroup) --
 // a one-wave workgroup.  With a single tile the "other side's" rows of both passes ARE the wave's own rows, so every row-major MFMA
-// operand (Q, K, V, dO fragments) is loaded straight from global memory in fragment layout and only the three TRANSPOSED images
-// (Q^T, K^T, dO^T: the A operands of the dQ / dK / dV products) go through LDS: 13.8 KB per workgroup instead of 32.5 KB, i.e. 11
-// resident one-wave workgroups per CU instead of 4 (the general kernel runs at one wave per SIMD at T = 16), and no row-major LDS
-// stores.  Default for one-tile problems since it was timed on MI355X (profiles/r02_call1_attn_tm_wide_regs.txt: cfg3 backward 123.0 -> 73.8 us);
+// operand (Q, K, V, dO fragments) is loaded straight from global memory in fragment layout and only the A operands of the dQ / dK / dV
+// products (Q^T, K^T, dO^T) go through LDS -- as row-major copies of the fragments the lane holds anyway, read back transposed by
+// ds_read_b64_tr_b16: 13.8 KB per workgroup instead of 32.5 KB, i.e. 11 resident one-wave workgroups per CU instead of 4 (the general
+// kernel runs at one wave per SIMD at T = 16).  Default for one-tile problems since it was timed on MI355X (profiles/r02_call1_attn_tm_wide_regs.txt: cfg3 backward 123.0 -> 73.8 us);
 // MAED_TM_BWD_L32=0 switches back to the general kernel (A/B knob).
 // ==================================================================================================
 __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse, bf16* __restrict__ dqkv, int accumulate, int P, int H,
                                                                int Tn, int G, int ngroups, float scale) {
-    constexpr int VLD = 36;                          // 32 rows + 4 pad: conflict-free ds_read_b64 of the transposed images
-    __shared__ __attribute__((aligned(16))) unsigned short Qt[D * VLD], Kt[D * VLD], dOt[D * VLD];
+    // row-major images of the wave's own Q / K / dO rows: the transposed A operands of the dQ / dK / dV products are read from them with
+    // ds_read_b64_tr_b16 (lds_frag_tr_rm) -- four 16-byte LDS writes per lane and operand instead of 32 two-byte writes of a transposed copy
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[32 * KLD], Ks[32 * KLD], dOs[32 * KLD];
     __shared__ float Ls[32], Ds[32];
     const int L = G * Tn, C = H * D;
     const int64_t ld = 3 * (int64_t)C;
@@ -709,19 +710,9 @@ __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __rest
 #pragma unroll
             for (int j = 0; j < 8; ++j) dsum = fmaf(a[j], b[j], dsum);
         }
-        const uint32_t wq[4] = {qf[t].u.x, qf[t].u.y, qf[t].u.z, qf[t].u.w}, wk[4] = {kf[t].u.x, kf[t].u.y, kf[t].u.z, kf[t].u.w},
-                       wg[4] = {dof[t].u.x, dof[t].u.y, dof[t].u.z, dof[t].u.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                // transposed images: element (e, row)
-            const int a0 = (e0 + 2 * j) * VLD + row, a1 = a0 + VLD;
-            Qt[a0] = (unsigned short)(wq[j] & 0xffffu); Qt[a1] = (unsigned short)(wq[j] >> 16);
-            Kt[a0] = (unsigned short)(wk[j] & 0xffffu); Kt[a1] = (unsigned short)(wk[j] >> 16);
-            dOt[a0] = (unsigned short)(wg[j] & 0xffffu); dOt[a1] = (unsigned short)(wg[j] >> 16);
-        }
-    }
-    for (int i = lane; i < D * 4; i += 64) {         // the 4 pad columns
-        const int e = (i >> 2) * VLD + 32 + (i & 3);
-        Qt[e] = 0; Kt[e] = 0; dOt[e] = 0;
+        *reinterpret_cast<uint4*>(Qs + row * KLD + e0) = qf[t].u;       // (rows beyond the sequence were zero-filled above)
+        *reinterpret_cast<uint4*>(Ks + row * KLD + e0) = kf[t].u;
+        *reinterpret_cast<uint4*>(dOs + row * KLD + e0) = dof[t].u;
     }
     dsum += __shfl_xor(dsum, 32, 64);
     const float Dq = dsum;
@@ -735,7 +726,7 @@ __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __rest
     {   // ---- pass A: lane = query;  S^T = K Q^T, dP^T = V dO^T (rows = keys = the wave's own rows) ----
         f32x16_t sa, dp, dq[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; dq[0][r] = 0.f; dq[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = -Dq; dq[0][r] = 0.f; dq[1][r] = 0.f; }      // (dP - delta straight out of the accumulator)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t].v, qf[t].v, sa, 0, 0, 0);
@@ -746,21 +737,23 @@ __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __rest
             const int k = (r & 3) + 8 * (r >> 2) + 4 * hi;
             const bool ok = row_ok && TM_ROW_OK(k) && (k / Tn == rg);
             const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], sl2e, -L2)) : 0.f;
-            sa[r] = pr * (dp[r] - Dq) * scale;       // dS
+            sa[r] = pr * dp[r];                      // dS / scale
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const bf16x8_t dsf = pack_frag(sa, st);
 #pragma unroll
             for (int et = 0; et < 2; ++et)
-                dq[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Kt + (et * 32 + l31) * VLD + 16 * st + 4 * hi), dsf, dq[et], 0, 0, 0);
+                dq[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr_rm(Ks, 16 * st, et * 32, lane), dsf, dq[et], 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
         if (row_ok) store_rowT(drow, dq, hi, accumulate);
     }
     {   // ---- pass B: lane = key;  S = Q K^T, dP = dO V^T (rows = queries = the wave's own rows) ----
         f32x16_t sb, dp, dk[2], dv[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dp[r] = 0.f; dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dp[r] = -Ds[(r & 3) + 8 * (r >> 2) + 4 * hi]; dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[t].v, kf[t].v, sb, 0, 0, 0);
@@ -771,7 +764,7 @@ __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __rest
             const int qq = (r & 3) + 8 * (r >> 2) + 4 * hi;
             const bool ok = row_ok && TM_ROW_OK(qq) && (qq / Tn == rg);
             const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sb[r], sl2e, -Ls[qq])) : 0.f;
-            dp[r] = pr * (dp[r] - Ds[qq]) * scale;   // dS
+            dp[r] *= pr;                             // dS / scale
             sb[r] = pr;                              // P
         }
 #pragma unroll
@@ -779,11 +772,12 @@ __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __rest
             const bf16x8_t pf = pack_frag(sb, st), dsf = pack_frag(dp, st);
 #pragma unroll
             for (int et = 0; et < 2; ++et) {
-                const int off = (et * 32 + l31) * VLD + 16 * st + 4 * hi;
-                dv[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(dOt + off), pf, dv[et], 0, 0, 0);
-                dk[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr(Qt + off), dsf, dk[et], 0, 0, 0);
+                dv[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr_rm(dOs, 16 * st, et * 32, lane), pf, dv[et], 0, 0, 0);
+                dk[et] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_tr_rm(Qs, 16 * st, et * 32, lane), dsf, dk[et], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[0][r] *= scale; dk[1][r] *= scale; }
         if (row_ok) {
             store_rowT(drow + C, dk, hi, accumulate);
             store_rowT(drow + 2 * C, dv, hi, accumulate);
