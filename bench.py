@@ -302,7 +302,8 @@ def main():
             for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "traffic.json"))):
                 tj = json.load(open(fn))
                 if tj.get("source_hash") == source_hash() and tj.get("dtype", "bf16") == args.dtype and tj.get("workload", "cfg3") == args.workload:
-                    traffic_db = tj.get("kernels", {})
+                    traffic_db = dict(tj.get("kernels", {}))
+                    traffic_db["__groups__"] = tj.get("__groups__")     # per-group time (+ GroupNorm bytes/s) from the single-stream rocprofv3 summary of this build
                     traffic_note = f"; traffic = (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes on this build ({os.path.relpath(fn, ROOT)})"
         except Exception:
             pass

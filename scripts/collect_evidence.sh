@@ -7,6 +7,7 @@ for f in bench_train bench_forward bench_train_f32 bench_cfg5 bench_torchrun_wor
 cp $F/gemm_micro.txt profiles/${R}_gemm_micro.txt; cp $F/gemm_tile_variants.txt profiles/${R}_gemm_tile_variants.txt
 cp $F/parity_report_gpu.txt profiles/${R}_parity_report_gpu.txt; cp $F/pytest_gpu.log profiles/${R}_pytest_gpu.log; cp $F/smoke.log profiles/${R}_smoke.log
 cp $F/rocprofv3_steady_state_kernels.csv profiles/${R}_rocprofv3_steady_state_kernels.csv
+cp $F/rocprofv3_steady_state_kernels_single_stream.csv profiles/${R}_rocprofv3_steady_state_kernels_single_stream.csv 2>/dev/null || true
 cp $F/rocprofv3_kernel_stats_incl_warmup.csv profiles/${R}_rocprofv3_kernel_stats_incl_warmup.csv
 cp $F/rocprofv3_steady_state_kernels_last_step_sequence.txt profiles/${R}_rocprofv3_last_step_kernel_sequence.txt
 mkdir -p profiles/${R}_pmc; cp $F/traffic.json profiles/${R}_pmc/traffic.json; cp gpurun_out/pmc/*.csv profiles/${R}_pmc/
