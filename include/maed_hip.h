@@ -52,7 +52,9 @@ typedef enum {
     MAED_EPI_ATOMIC_F32 = 4, /* out[f32] += acc  (atomic; weight gradients, split-K allowed)        */
     MAED_EPI_STORE_F32 = 5,  /* out[f32] = acc + bias                                               */
     MAED_EPI_TANH = 6,       /* out[T]   = tanh(acc + bias)                                         */
-    MAED_EPI_ADD = 7         /* out[T]   = aux[T] + acc + bias  (gradient accumulation at a residual fork) */
+    MAED_EPI_ADD = 7         /* out[T]   = aux[T] + acc + bias  (gradient accumulation at a residual fork); out2 != NULL: aux is first
+                              * masked by 1 bit per element (bit c & 7 of byte (r * ldaux + c) / 8 = maed_groupnorm_fwd's relu_mask: the
+                              * masked residual gradient of a GroupNorm + residual + ReLU is then never materialised) */
 } maed_epilogue;
 
 /* kernel implementation selector for ops that have both */
@@ -304,7 +306,8 @@ int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, 
 /* relu_mask (N*HW*C/8 bytes, bit j of byte (n,hw,c/8) = output channel 8*(c/8)+j > 0): written by forward when a residual is
  * added before the ReLU (optional: inference passes NULL), required by backward in that case -- without a residual the mask is
  * recomputed from x.  16x less traffic than re-reading the saved output in both backward passes.
- * dx (and dres = masked dy when dres != NULL); dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats */
+ * dx (and dres = masked dy when dres != NULL; with a relu_mask dres may be NULL: the consumer masks dy itself, MAED_EPI_ADD with out2 = relu_mask);
+ * dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats */
 int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
                        int relu, int dtype, int ab_zeroed, void* aux_stream, void* stream);

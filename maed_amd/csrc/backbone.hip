@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                 for (int j = 0; j < 8; ++j) d[j] = fmaf((v[j] - mu[j]) * rs[j], gg[j], be[j]) > 0.f ? d[j] : 0.f;
             }
         }
-        if (RES) st8(dres + base + (int64_t)r * C, d);
+        if (RES && dres) st8(dres + base + (int64_t)r * C, d);          // (dres == nullptr: the consumer applies the bit mask to dy itself, MAED_EPI_ADD)
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rs[j] * (gg[j] * d[j] - m1[j] - (v[j] - mu[j]) * rs[j] * m2[j]);
         st8(dx + base + (int64_t)r * C, o);
@@ -384,7 +384,7 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
     dim3 rgrid((HW + rrows - 1) / rrows, N);
     if (!ab_zeroed) hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
-    const bool ymask = relu && dres;
+    const bool ymask = relu && relu_mask;      // residual added before the ReLU: the forward's bit mask (dres may be NULL: not materialised)
     // default since it was timed on MI355X (profiles/r02_call2_steady_*.csv: reduction passes 2.15 -> 1.42 ms per step + 0.31 ms closing kernels);
     // MAED_GN_DEFER_AFFINE=0 switches back to the atomics (A/B knob)
     const int defer = maed_env_flag("MAED_GN_DEFER_AFFINE", true) ? 1 : 0;
@@ -408,7 +408,7 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
             }
             hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 63) / 64, (N + 63) / 64), dim3(256), 0, sa, ab_scratch, dgamma, dbeta, N, C);
         }
-        if (dres && relu) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);
+        if (ymask) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);
     });
 #undef GN_RED
 #undef GN_APP

@@ -33,7 +33,9 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int6
     } else if constexpr (EPI == MAED_EPI_TANH) {
         stf((T*)e.out + r * e.ldo + c, tanhf(acc + (e.bias ? e.bias[c] : 0.f)));
     } else if constexpr (EPI == MAED_EPI_ADD) {
-        stf((T*)e.out + r * e.ldo + c, ldf((const T*)e.aux + r * e.ldaux + c) + acc + (e.bias ? e.bias[c] : 0.f));
+        float x = ldf((const T*)e.aux + r * e.ldaux + c);
+        if (e.out2) x = ((((const uint8_t*)e.out2)[(r * e.ldaux + c) >> 3] >> (c & 7)) & 1) ? x : 0.f;     // aux masked by 1 bit per element (see maed_gemm_nt)
+        stf((T*)e.out + r * e.ldo + c, x + acc + (e.bias ? e.bias[c] : 0.f));
     }
 }
 
@@ -76,6 +78,11 @@ __device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int
         st4((T*)e.out + r * e.ldo + c0, o);
     } else if constexpr (EPI == MAED_EPI_ADD) {
         float x[4]; ld4((const T*)e.aux + r * e.ldaux + c0, x);
+        if (e.out2) {
+            const uint32_t m = ((const uint8_t*)e.out2)[(r * e.ldaux + c0) >> 3] >> (c0 & 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = ((m >> j) & 1u) ? x[j] : 0.f;
+        }
         float o[4] = {x[0] + v[0], x[1] + v[1], x[2] + v[2], x[3] + v[3]};
         st4((T*)e.out + r * e.ldo + c0, o);
     }
@@ -124,6 +131,11 @@ __device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int
         st8((T*)e.out + r * e.ldo + c0, v);
     } else if constexpr (EPI == MAED_EPI_ADD) {
         float x[8]; ld8((const T*)e.aux + r * e.ldaux + c0, x);
+        if (e.out2) {
+            const uint32_t m = ((const uint8_t*)e.out2)[(r * e.ldaux + c0) >> 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = ((m >> j) & 1u) ? x[j] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] += v[j];
         st8((T*)e.out + r * e.ldo + c0, x);

@@ -160,7 +160,8 @@ def gemm_tn_wgrad(Y, X, dW=None, dbias=None):
 
 
 def gemm_nt(A, B, epilogue=L.EPI_STORE, bias=None, out=None, out2=None, aux=None, splitk=1, impl=L.IMPL_AUTO, M=None, K=None):
-    """out = epilogue(A[M,K] @ B[N,K]^T).  A/B in the compute dtype (f32 or bf16); bias fp32."""
+    """out = epilogue(A[M,K] @ B[N,K]^T).  A/B in the compute dtype (f32 or bf16); bias fp32.
+    EPI_ADD: out2 (optional, uint8) = 1 bit per element of aux: aux is masked by it before the add (GroupNormFn's lazily masked residual gradient)."""
     assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
     M = A.shape[0] if M is None else M
     K = A.shape[1] if K is None else K
@@ -597,13 +598,18 @@ class WeightStdFn(ReportingFn):
         return (None, None, None) + (None,) * len(weights)
 
 
+# residual gradients handed on unmasked: data_ptr of the tensor -> (weakref to it, the ReLU bit mask that still has to be applied); consumed (popped) by
+# Conv1x1Fn.backward.  Keyed by address AND identity (the weakref must still point at the tensor that arrives).
+LAZY_RES = {}
+
+
 class GroupNormFn(torch.autograd.Function):
     """y = act(GroupNorm32(x) * gamma + beta [+ residual]) on channels_last tensors (maed_groupnorm_fwd/bwd).
     direct=True: gamma/beta gradients are accumulated by the kernel straight into gamma.grad / beta.grad (the
     owner module reports them through its grads_ready callback) instead of travelling through autograd."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, relu, direct, sums=None, ab=None, stats_ready=False):
+    def forward(ctx, x, residual, gamma, beta, eps, relu, direct, sums=None, ab=None, stats_ready=False, lazy_res=False):
         """sums (N,32,2) f64 / ab (N,C,2) f32: optional PRE-ZEROED scratch slices (ResNetV2 zeroes one arena per pass for all
         its 52 layers instead of one memset per layer and direction).  stats_ready: `sums` already holds the statistics of x (the
         producing convolution's epilogue accumulated them: Conv1x1Fn / Conv3x3Fn gn_sums) -- no statistics pass."""
@@ -624,6 +630,9 @@ class GroupNormFn(torch.autograd.Function):
         ctx.ab = ab
         ctx.save_for_backward(x, mask, sums)
         ctx.eps, ctx.relu, ctx.direct = eps, relu, direct
+        # lazy_res: the residual's gradient (dy masked by the ReLU bits) is not materialised -- backward hands dy itself on and registers the bit mask
+        # for it; the consumer (Conv1x1Fn.backward of the block's conv1, which adds the shortcut gradient inside its input-gradient GEMM) applies it
+        ctx.lazy_res = bool(lazy_res) and need_mask
         ctx.gamma, ctx.beta = gamma, beta   # parameters (leaf tensors): kept by reference for .grad access
         return y
 
@@ -634,7 +643,7 @@ class GroupNormFn(torch.autograd.Function):
         N, C_, H, W = x.shape
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
-        dres = torch.empty_like(x, memory_format=torch.channels_last) if ctx.has_res else None
+        dres = torch.empty_like(x, memory_format=torch.channels_last) if (ctx.has_res and not ctx.lazy_res) else None
         if ctx.direct:
             if gamma.grad is None:
                 gamma.grad = torch.zeros_like(gamma)
@@ -652,9 +661,12 @@ class GroupNormFn(torch.autograd.Function):
         aux = side_stream_handle(x.device, ab) if ctx.direct else None
         check(L.lib().maed_groupnorm_bwd(_p(x), _p(mask), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
                                          N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), aux, _stream()), "groupnorm_bwd")
+        if ctx.lazy_res:
+            LAZY_RES[dy.data_ptr()] = (weakref.ref(dy), mask)
+            dres = dy
         if ctx.direct:
-            return dx, dres, None, None, None, None, None, None, None, None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+            return dx, dres, None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class MaxPool3s2SameFn(torch.autograd.Function):
@@ -692,7 +704,7 @@ class Conv1x1Fn(torch.autograd.Function):
     forward 1.01 vs 2.33 ms, input gradient 1.02 vs 1.88 ms, weight gradient 1.47 vs 2.63 ms per step."""
 
     @staticmethod
-    def forward(ctx, x, w, wt, dw, fork=False, gn_sums=None, stride=1):
+    def forward(ctx, x, w, wt, dw, fork=False, gn_sums=None, stride=1, lazy_short=False):
         """gn_sums (optional, pre-zeroed (N,32,2) f64): GroupNorm statistics of the output, accumulated by the GEMM's epilogue.
         x (N,I,H,W) channels_last; w (O,I,1,1) standardised weight (an output of WeightStdFn: the autograd edge orders
         its backward after ours); wt (I,O) transposed image; dw (O,I) fp32 accumulator (None when no gradient is wanted).
@@ -722,6 +734,7 @@ class Conv1x1Fn(torch.autograd.Function):
             y = gemm_nt(A, w2, L.EPI_STORE)
         ctx.save_for_backward(A, wt)
         ctx.dw, ctx.geom, ctx.stride = dw, (N, I, H, W, O, Ho, Wo), stride
+        ctx.lazy_short = bool(lazy_short) and fork      # the shortcut's gradient will arrive unmasked, its ReLU bits registered in LAZY_RES
         ctx.set_materialize_grads(False)
         y = y.view(N, Ho, Wo, O).permute(0, 3, 1, 2)
         return (y, x.view_as(x)) if fork else y
@@ -731,13 +744,22 @@ class Conv1x1Fn(torch.autograd.Function):
         A, wt = ctx.saved_tensors
         N, I, H, W, O, Ho, Wo = ctx.geom
         dx = None
+        mask = None
+        if ctx.lazy_short and g_short is not None:
+            ent = LAZY_RES.pop(g_short.data_ptr(), None)
+            if ent is None or ent[0]() is not g_short:
+                raise RuntimeError("Conv1x1Fn: the shortcut gradient was announced as lazily masked (GroupNormFn lazy_res) but arrived as another tensor -- "
+                                   "the residual must feed exactly one GroupNorm")
+            mask = ent[1]
         if dy is None:              # only the shortcut carried a gradient
-            return g_short, None, None, None, None, None, None
+            if mask is not None:
+                raise RuntimeError("Conv1x1Fn: lazily masked shortcut gradient without a gradient for the convolution itself")
+            return g_short, None, None, None, None, None, None, None
         Y = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(N * Ho * Wo, O)
         if ctx.needs_input_grad[0]:
             if g_short is not None:
                 G = g_short.contiguous(memory_format=torch.channels_last).to(Y.dtype).permute(0, 2, 3, 1).reshape(N * H * W, I)
-                dx = gemm_nt(Y, wt, L.EPI_ADD, aux=G)
+                dx = gemm_nt(Y, wt, L.EPI_ADD, aux=G, out2=mask)
             else:
                 dx = gemm_nt(Y, wt, L.EPI_STORE)
             if ctx.stride == 2:
@@ -747,7 +769,9 @@ class Conv1x1Fn(torch.autograd.Function):
         if ctx.dw is not None:
             dw = ctx.dw
             side_stream_run(lambda: gemm_tn_wgrad(Y, A, dW=dw), Y, A, dw)
-        return dx, None, None, None, None, None, None
+        if mask is not None and dx is None:
+            raise RuntimeError("Conv1x1Fn: lazily masked shortcut gradient but no input gradient requested")
+        return dx, None, None, None, None, None, None, None
 
 
 

@@ -38,6 +38,9 @@ _OWN_CONV3X3 = os.environ.get("MAED_CONV3X3", "own") == "own"
 # one batched launch otherwise; MAED_WS_PER_STAGE=0 / 1 forces either.
 _WS_PER_STAGE_ENV = os.environ.get("MAED_WS_PER_STAGE", "auto")
 
+# identity blocks: masked residual gradient applied by the consumer instead of written by the GroupNorm backward (MAED_GN_LAZY_DRES=0: materialise it; A/B knob)
+_LAZY_RES_GRAD = os.environ.get("MAED_GN_LAZY_DRES", "1") == "1"
+
 # GroupNorm statistics accumulated in the epilogue of the convolution in front (maed_conv1x1_fwd / maed_conv3x3_fwd gn_sums) instead of
 # a separate pass over the activation (52 launches, 0.64 ms per step at cfg3).  MAED_GN_FUSE_STATS=0 switches back (A/B knob).
 _FUSE_GN_STATS = os.environ.get("MAED_GN_FUSE_STATS", "1") == "1"
@@ -118,14 +121,14 @@ class StdConv2dSame(nn.Conv2d):
         gn._stats_ready = True
         return gn._sums_buf
 
-    def forward(self, x, fork=False, gn=None):
+    def forward(self, x, fork=False, gn=None, lazy_short=False):
         """fork=True (GEMM convolutions only): returns (conv(x), alias of x) -- see ops.Conv1x1Fn.
         gn: the GroupNormAct this convolution feeds -- its statistics are then accumulated by the convolution's epilogue"""
         w = self._w_std
         if w is not None and self._w_t is not None and self.kernel_size == (1, 1):
             # 1x1, stride 1, bf16: three GEMMs on libmaed_hip instead of MIOpen's implicit-GEMM solvers (which zero-fill the
             # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
-            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]), self.stride[0])
+            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]), self.stride[0], lazy_short)
         assert not fork
         if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and x.dtype == torch.bfloat16
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and self.dilation == (1, 1) and self.groups == 1):
@@ -158,12 +161,12 @@ class GroupNormAct(nn.GroupNorm):
         super().__init__(num_groups, num_channels, eps=eps, affine=affine)
         self.apply_act = apply_act
 
-    def forward(self, x, residual=None, relu=None):
+    def forward(self, x, residual=None, relu=None, lazy_res=False):
         """y = act(GN(x) [+ residual]); relu defaults to the layer's own activation flag"""
         relu = self.apply_act if relu is None else relu
         if ops.on_library_device(x) and self.num_groups == 32:
             ready, self._stats_ready = self._stats_ready and self._sums_buf is not None, False
-            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad, self._sums_buf, self._ab_buf, ready)
+            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad, self._sums_buf, self._ab_buf, ready, lazy_res)
         x = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
         if residual is not None:
             x = x + residual
@@ -215,9 +218,14 @@ class Bottleneck(nn.Module):
             # x feeds conv1 AND the shortcut (identity or downsample): conv1 (a GEMM convolution) hands out an alias of x for
             # the shortcut, so the shortcut branch's gradient is added inside conv1's input-gradient GEMM epilogue instead of
             # by a separate autograd accumulation kernel
-            y, xa = self.conv1(x, fork=True, gn=self.norm1)
+            # identity blocks: the shortcut's gradient is dy of norm3 masked by its ReLU bits -- never materialised: norm3's backward hands dy on,
+            # conv1's input-gradient GEMM applies the bits while it adds (ops.GroupNormFn lazy_res / Conv1x1Fn lazy_short)
+            lazy = self.downsample is None and _LAZY_RES_GRAD
+            y, xa = self.conv1(x, fork=True, gn=self.norm1, lazy_short=lazy)
             shortcut = xa if self.downsample is None else self.downsample(xa)
             x = self.norm1(y)
+            x = self.norm2(self.conv2(x, gn=self.norm2))
+            return self.norm3(self.conv3(x, gn=self.norm3), residual=shortcut, relu=True, lazy_res=lazy)
         else:
             shortcut = x if self.downsample is None else self.downsample(x)
             x = self.norm1(self.conv1(x, gn=self.norm1))

@@ -120,3 +120,20 @@ def test_gemm_nt_f32_few_tiles_long_k_takes_the_split_k_route():
         out_nb = ops.gemm_nt(A, B, L.EPI_STORE_F32)
     assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-5) and torch.allclose(out_nb.double(), ref - bias.double(), rtol=1e-5, atol=1e-5)
 
+
+
+@pytest.mark.parametrize("impl", [L.IMPL_AUTO, L.IMPL_MFMA, L.IMPL_MFMA_256])
+def test_gemm_nt_add_epilogue_masks_aux_by_bits(impl):
+    """MAED_EPI_ADD with out2 = 1 bit per element of aux (bit c & 7 of byte (r * ldaux + c) / 8: the GroupNorm forward's ReLU mask): the masked residual
+    gradient is applied while it is added -- all three epilogue widths (8 / 4 columns, scalar tail)"""
+    M, N, K = (260, 256, 128) if impl == L.IMPL_MFMA_256 else (130, 136, 64)
+    A, B = rnd(M, K, seed=31).bfloat16(), rnd(N, K, seed=32, scale=K ** -0.5).bfloat16()
+    aux = rnd(M, N, seed=33).bfloat16()
+    keep = torch.rand(M, N, generator=torch.Generator().manual_seed(34)) > 0.4
+    bits = (keep.view(M, N // 8, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(-1).to(torch.uint8).contiguous()
+    ref = A.float() @ B.float().t() + aux.float() * keep
+    with patched():
+        out = ops.gemm_nt(A, B, L.EPI_ADD, aux=aux, out2=bits, impl=impl)
+        out_plain = ops.gemm_nt(A, B, L.EPI_ADD, aux=aux, impl=impl)
+    assert torch.allclose(out.float(), ref, rtol=2e-2, atol=2e-2)
+    assert torch.allclose(out_plain.float(), A.float() @ B.float().t() + aux.float(), rtol=2e-2, atol=2e-2)
