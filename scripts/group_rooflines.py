@@ -4,7 +4,7 @@
 With a traffic.json the result is stored under "__groups__" (bench.py then reports it as kernel_groups for the same source hash).
 GroupNorm bytes per step at cfg3 (128 frames, bf16), from the layer list of the hybrid R50: forward apply reads x (+ residual) and writes y (+ 1 bit per element
 when a residual precedes the ReLU); the three layers behind MIOpen convolutions also read x once for the statistics; backward reduce reads x, dy (+ bits);
-backward apply reads x, dy (+ bits) and writes dx (+ the masked residual gradient)."""
+backward apply reads x, dy (+ bits) and writes dx (+ the masked residual gradient in the four downsample blocks)."""
 import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -21,14 +21,14 @@ def groupnorm_bytes(frames=128, E=2):
                 layers.append((chans[s], H[s], False, False))            # downsample.norm
             layers.append((mid, h_in, False, False))                     # norm1
             layers.append((mid, H[s], False, b == 0 and s > 0))          # norm2 (behind the strided 3x3: own kernel forward -> fused stats; kept False)
-            layers.append((chans[s], H[s], True, False))                 # norm3 (+ residual, ReLU)
+            layers.append((chans[s], H[s], True if b == 0 else "lazy", False))   # norm3 (+ residual, ReLU); identity blocks do not write the masked residual gradient
     fwd = bwd = 0
     for C, h, res, stats_pass in layers:
         t = frames * h * h * C * E
         bits = t // (8 * E) if res else 0
         fwd += t * (2 + (1 if res else 0)) + bits + (t if stats_pass else 0)
         bwd += t * 2 + bits                                              # reduce
-        bwd += t * (3 + (1 if res else 0)) + bits                        # apply
+        bwd += t * (3 + (1 if res is True else 0)) + bits                # apply
     return len(layers), fwd, bwd
 
 
