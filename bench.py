@@ -236,7 +236,9 @@ def main():
         marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    log("per-step ms (hipEvents, in order): " + " ".join(f"{t:.1f}" for t in in_order))
+    per_step = sorted(in_order)
     pct = lambda q: per_step[min(len(per_step) - 1, max(0, int(round(q * (len(per_step) - 1)))))]
     step_stats = dict(median_ms=round(pct(0.5), 3), p10_ms=round(pct(0.1), 3), p90_ms=round(pct(0.9), 3), min_ms=round(per_step[0], 3),
                       max_ms=round(per_step[-1], 3), how="hipEvent per step boundary on the launch stream, this rank")
