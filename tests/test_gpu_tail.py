@@ -56,6 +56,43 @@ def test_tail_training_path_vs_aten(F, feat, hidden, keys):
     report(f"tail bwd: worst rel-to-max gradient error vs ATen autograd (F={F}, worst {worst_name})", torch.tensor([worst]), torch.zeros(1), rtol=0, atol=5e-4)
 
 
+@pytest.mark.parametrize("F,feat,hidden", [(16, 512, 1024), (3, 64, 32)])
+def test_tail_training_path_vs_fp64_oracle(F, feat, hidden):
+    """the same forward + backward against the ORACLE itself (oracle/maed_ref.py ktd_head + ktd_get_output: rot6d -> SMPL LBS -> 49 joints -> projection,
+    evaluated in fp64 with autograd on the host) instead of the package's own ATen composition: outputs and the gradients w.r.t. the input features and every KTD
+    parameter, cotangents on theta / kp_2d / kp_3d / verts / rotmat"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import maed_ref as R
+    ktd = make_ktd(feat, hidden)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(F, feat, generator=g)
+    pd = {"d." + k: v.detach().cpu().double().requires_grad_(True) for k, v in ktd.state_dict().items() if not k.startswith("smpl.")}
+    xd = x.double().requires_grad_(True)
+    ref = R.ktd_get_output(*R.ktd_head(xd, pd, "d."), R.make_synthetic_smpl(0, dtype=torch.float64))
+    keys = ("theta", "kp_2d", "kp_3d", "verts", "rotmat")
+    cot = {k: torch.randn(ref[k].shape, generator=g) for k in keys}
+    sum((ref[k] * cot[k].double()).sum() for k in keys).backward()
+    xg = x.to(DEV).requires_grad_(True)
+    for p_ in ktd.parameters():
+        p_.grad = None
+    assert ktd._use_hip_train(xg, None)
+    out = ktd(xg, seqlen=1)
+    sum((out[k] * cot[k].to(DEV)).sum() for k in keys).backward()
+    for k in keys:
+        report(f"tail vs oracle fwd {k} (F={F}, feat {feat})", out[k].detach().reshape(ref[k].shape), ref[k].detach(), rtol=1e-4, atol=1e-4 * ref[k].abs().max().item())
+    worst, worst_name = 0.0, ""
+    for n, p_ in [("x", xg)] + list(ktd.named_parameters()):
+        b = xd.grad if n == "x" else pd["d." + n].grad
+        if b is None:
+            continue
+        assert p_.grad is not None, n
+        e = (p_.grad.detach().cpu().double() - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+        if e > worst:
+            worst, worst_name = e, n
+    report(f"tail vs oracle bwd: worst rel-to-max gradient error over x and all KTD parameters (F={F}, worst {worst_name})", torch.tensor([worst]), torch.zeros(1), rtol=0, atol=1e-3)
+
+
 def test_tail_joint_gather_backward_is_scatter_add():
     """joint_map maps several of the 49 outputs onto the same source joint (smpl.py:16-53): the backward must SUM them."""
     from maed_amd import _lib as L, ops
