@@ -368,3 +368,33 @@ def test_smpl_derived_tables_follow_a_loaded_state_dict():
     finally:
         if old is not None:
             os.environ["MAED_SYNTHETIC_SMPL_OK"] = old
+
+
+def test_weight_initialisation_distributions_follow_the_reference():
+    """trunc_normal(std 0.02) for Linear weights and the embeddings with zero biases and unit LayerNorm (vision_transformer.py:357-375), kaiming
+    normal fan_out for the backbone's convolutions (resnetv2.py:330-335), xavier uniform with gain 0.01 for the KTD regressors (ktd.py:56-61) -- checked on the
+    empirical moments / ranges of a freshly built model"""
+    import math
+    import maed_amd
+    os.environ.setdefault("MAED_SYNTHETIC_SMPL_OK", "1")
+    torch.manual_seed(0)
+    m = maed_amd.MAED(num_blocks=2, num_heads=8, embed_dim=512, hidden_dim=1024)
+    enc, dec = m.encoder, m.decoder
+    for name, mod in enc.blocks.named_modules():
+        if isinstance(mod, torch.nn.Linear):
+            w = mod.weight.detach()
+            assert abs(w.std().item() - 0.02) < 0.002 and abs(w.mean().item()) < 1e-3 and w.abs().max().item() <= 2.0, name      # truncation at +-2 (absolute), as the reference
+            assert mod.bias is None or bool((mod.bias == 0).all())
+        if isinstance(mod, torch.nn.LayerNorm):
+            assert bool((mod.weight == 1).all()) and bool((mod.bias == 0).all())
+    for t in (enc.pos_embed, enc.temp_embed):
+        assert abs(t.std().item() - 0.02) < 0.003
+    convs = [c for c in enc.patch_embed.backbone.modules() if isinstance(c, torch.nn.Conv2d) and c.weight.numel() > 50000]
+    for c in convs[:8]:
+        fan_out = c.out_channels * c.kernel_size[0] * c.kernel_size[1]
+        assert abs(c.weight.std().item() / math.sqrt(2.0 / fan_out) - 1.0) < 0.05                  # kaiming_normal_(mode='fan_out', nonlinearity='relu')
+    for lin in (dec.decshape, dec.deccam, dec.joint_regs[0], dec.joint_regs[10]):
+        fan_in, fan_out = lin.weight.shape[1], lin.weight.shape[0]
+        bound = 0.01 * math.sqrt(6.0 / (fan_in + fan_out))                                          # xavier_uniform_(gain=0.01)
+        w = lin.weight.detach()
+        assert w.abs().max().item() <= bound * (1 + 1e-6) and abs(w.std().item() / (bound / math.sqrt(3.0)) - 1.0) < 0.1
