@@ -662,6 +662,8 @@ class GroupNormFn(torch.autograd.Function):
         check(L.lib().maed_groupnorm_bwd(_p(x), _p(mask), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
                                          N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), aux, _stream()), "groupnorm_bwd")
         if ctx.lazy_res:
+            for k in [k for k, (r, _) in LAZY_RES.items() if r() is None]:      # announcements whose consumer never ran (an interrupted backward)
+                del LAZY_RES[k]
             LAZY_RES[dy.data_ptr()] = (weakref.ref(dy), mask)
             dres = dy
         if ctx.direct:
