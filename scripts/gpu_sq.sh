@@ -13,7 +13,7 @@ run() { tag=$1; shift; rm -rf /tmp/pmc_$tag
 import csv, sys, collections
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "attn_sp_fwd_mfma" in r.get("Kernel_Name", ""):
+    if "attn_sp_fwd_mfma" in r.get("Kernel_Name", "") or "attn_long_fwd_mfma" in r.get("Kernel_Name", ""):
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
     print(f"  {k:28s} mean {sum(v) / len(v):16.1f}  (n={len(v)})")
