@@ -59,6 +59,17 @@ _SIDE_ON = os.environ.get("MAED_WGRAD_SIDE_STREAM", "1") == "1"
 _SIDE = {}
 
 
+def _join_at_end_of_backward(device, st):
+    """whoever reads the side stream's results without going through WeightStdFn.backward (GroupNorm parameters of a backbone whose convolutions are
+    frozen, a caller's own optimizer reading .grad right after backward()) is covered by one join queued for the end of the running backward pass"""
+    if st[1]:
+        return                          # already pending: the callback of this pass is queued
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: side_stream_join(device))
+    except RuntimeError:
+        pass                            # not inside a backward pass (direct calls from tests / micro-benchmarks): the caller joins
+
+
 def side_stream_run(fn, *tensors):
     t0 = tensors[0]
     if not (_SIDE_ON and t0.is_cuda):
@@ -72,6 +83,7 @@ def side_stream_run(fn, *tensors):
         out = fn()
     for t in tensors:
         t.record_stream(side)
+    _join_at_end_of_backward(t0.device, st)
     st[1] = True
     return out
 
@@ -86,6 +98,7 @@ def side_stream_handle(device, *tensors):
         st = _SIDE[device] = [torch.cuda.Stream(device=device), False]
     for t in tensors:
         t.record_stream(st[0])
+    _join_at_end_of_backward(device, st)
     st[1] = True
     return st[0].cuda_stream
 
