@@ -46,6 +46,7 @@ class ParamArena:
 
     def __init__(self, model, device=None):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        definition_order = [id(p) for _, p in named]            # model.named_parameters() order: the reference optimizer's group order
         named.sort(key=lambda np_: _forward_order_key(np_[0]))  # stable: keeps definition order inside a group
         device = device or named[0][1].device
         self.names, self.params, self.offsets = [], [], []
@@ -65,6 +66,7 @@ class ParamArena:
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
         self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.definition_order = [self.index[i] for i in definition_order]
 
     def zero_grad(self):
         self.grad.zero_()
@@ -136,6 +138,8 @@ class GradBucketer:
             self.buckets.append([cur_start, end, cur_n])
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._seen = [False] * len(arena.params)      # parameters that reported a gradient since the last finish()
+        self.unmarked = []                             # ... and the ones that did not, as of the last finish() (FusedAdam skips them like torch.optim.Adam)
         self._works = []
         self._fused = set()
         self._fused_modules = []
@@ -153,6 +157,7 @@ class GradBucketer:
         i = self.arena.index.get(id(p))
         if i is None:
             return
+        self._seen[i] = True
         b = self.bucket_of[i]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -188,6 +193,8 @@ class GradBucketer:
             self.comm.wait()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self.unmarked = [i for i, seen in enumerate(self._seen) if not seen]
+        self._seen = [False] * len(self._seen)
         for m in self._fused_modules:       # a backward that never ran (an exception, a detached output) must not poison the next step
             m._pending_backwards = 0
 
@@ -209,7 +216,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def __init__(self, arena, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucketer=None, model=None):
         self.arena, self.bucketer = arena, bucketer
-        order = list(range(len(arena.params)))
+        order = list(getattr(arena, "definition_order", range(len(arena.params))))     # named_parameters() order even without model=
         if model is not None:   # the reference's group order = named_parameters() order (the arena is in forward order)
             order = [arena.index[id(p)] for _, p in model.named_parameters() if id(p) in arena.index]
             assert len(order) == len(arena.params)
@@ -242,12 +249,30 @@ class FusedAdam(torch.optim.Optimizer):
             world = self.bucketer.world
         self.step_count += 1
         a = self.arena
-        if self._uniform():     # the reference's case: every group shares the schedule -> one launch over the whole arena
+        # torch.optim.Adam skips parameters whose .grad is None (ts_attn in the non-parallel st_modes, any unused parameter): no moment decay, no weight
+        # decay.  The arena's gradients are never None, so "received no gradient this step" comes from the bucketer's readiness reports.
+        skip = set(self.bucketer.unmarked) if self.bucketer is not None else set()
+        if self._uniform():     # the reference's case: every group shares the schedule -> one launch over the whole arena (or per run of active tensors)
             g = self.param_groups[0]
-            ops.adam_step(a.flat, a.grad, self.exp_avg, self.exp_avg_sq, None, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                          g["weight_decay"], self.step_count, gscale=1.0 / world)
+            runs = [(0, a.numel)]
+            if skip:
+                runs, start = [], None
+                for i in range(len(a.params)):
+                    end_i = a.offsets[i + 1] if i + 1 < len(a.params) else a.numel
+                    if i in skip:
+                        if start is not None:
+                            runs.append((start, a.offsets[i])); start = None
+                    elif start is None:
+                        start = a.offsets[i]
+                    if i + 1 == len(a.params) and start is not None:
+                        runs.append((start, end_i))
+            for lo, hi in runs:
+                ops.adam_step(a.flat[lo:hi], a.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], None, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                              g["weight_decay"], self.step_count, gscale=1.0 / world)
         else:                   # per-group hyper-parameters: one launch per tensor
             for g, i in zip(self.param_groups, self._order):
+                if i in skip:
+                    continue
                 o, n = a.offsets[i], a.params[i].numel()
                 ops.adam_step(a.flat[o:o + n], a.grad[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], None, g["lr"],
                               g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count, gscale=1.0 / world)

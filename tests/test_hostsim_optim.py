@@ -138,3 +138,37 @@ def test_weight_cache_batched_refresh_on_simulator():
             assert f1.data_ptr() == w2.data_ptr() and torch.equal(f1t, w2.t().contiguous())
         finally:
             lib.maed_weight_refresh = real
+
+
+class TinyWithUnused(Tiny):
+    def __init__(self):
+        super().__init__()
+        self.encoder["spare"] = nn.Linear(7, 7)               # a parameter pair that never takes part in the forward (attn.ts_attn in the non-parallel st_modes)
+
+
+def test_fused_adam_skips_parameters_without_a_gradient_like_torch_adam_and_orders_groups_by_definition():
+    """torch.optim.Adam leaves a parameter whose .grad is None alone -- no weight decay, no moment update.  The arena's gradients are never None, so
+    FusedAdam takes "received no gradient this step" from the bucketer's readiness reports and steps the runs of active tensors only.  Also: without model=
+    the parameter groups follow model.named_parameters() order (the reference optimizer's), not the arena's forward order."""
+    from maed_amd.ddp import GradBucketer
+    torch.manual_seed(1)
+    ref_model = TinyWithUnused()
+    model = copy.deepcopy(ref_model)
+    x, y = torch.randn(8, 6), torch.randn(8, 5)
+    ref_opt = reference_optimizer(ref_model, 1e-2, 0.1)
+    with patched():
+        arena = ParamArena(model)
+        opt = FusedAdam(arena, lr=1e-2, weight_decay=0.1, bucketer=GradBucketer(arena, model))
+        assert [g["name"] for g in opt.param_groups] == [n for n, _ in model.named_parameters()]
+        for _ in range(3):
+            for m, o in ((ref_model, ref_opt), (model, opt)):
+                o.zero_grad(set_to_none=True) if o is ref_opt else o.zero_grad()
+                ((m(x) - y) ** 2).mean().backward()
+                o.step()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref_model.named_parameters()):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-7), n
+    torch.manual_seed(1)
+    fresh = TinyWithUnused()
+    for (n, p), (_, q) in zip(model.named_parameters(), fresh.named_parameters()):
+        if "spare" in n:
+            assert torch.equal(p, q), f"{n} must not have been touched (weight decay 0.1 would have shrunk it)"
