@@ -61,10 +61,33 @@ typedef enum {
 typedef enum { MAED_IMPL_AUTO = 0, MAED_IMPL_VALU = 1, MAED_IMPL_MFMA = 2,
                MAED_IMPL_MFMA_GLDS1 = 3, MAED_IMPL_MFMA_GLDS2 = 4, /* gemm_nt only: direct global->LDS staging, 1 or 2 LDS buffers */
                MAED_IMPL_MFMA_LONG = 5, /* attn_spatial only: K/V-tiled long-sequence kernels (chosen automatically past 512 / 320 tokens) */
-               MAED_IMPL_MFMA_256 = 6 /* gemm_nt only: 256x256 tiles, counted-vmcnt LDS-DMA pipeline (csrc/gemm256.hip) */ } maed_impl;
+               MAED_IMPL_MFMA_256 = 6, /* gemm_nt only: 256x256 tiles, counted-vmcnt LDS-DMA pipeline (csrc/gemm256.hip) */
+               MAED_IMPL_X3 = 7, MAED_IMPL_X6 = 8 /* MAED_F32 matrix products on the bf16 matrix cores: every fp32 operand split into 2 / 3 bf16
+                                                   * terms, 3 / 6 MFMAs per product, fp32 accumulation (csrc/gemm_x3.hip): |error| ~2^-16 / ~2^-23
+                                                   * of |a||b| instead of bf16's 2^-8.  MAED_IMPL_AUTO takes them when MAED_OPT_F32_MATMUL says so. */
+} maed_impl;
 
 const char* maed_last_error(void);
 int maed_version(void);
+
+/* ---- process-wide options -------------------------------------------------------------------------
+ * The library reads no environment variables: the host sets what it wants after loading it.  Options are plain integers, may be changed
+ * between calls (a call reads them once when it enqueues its kernels) and are safe to set from any host thread. */
+typedef enum {
+    MAED_OPT_F32_MATMUL = 0,    /* arithmetic of the matrix products (GEMMs, convolutions, attention contractions) of MAED_F32 calls with MAED_IMPL_AUTO:
+                                 * 0 (default) exact fp32 FMA chains on the VALU -- the bit-for-bit parity mode;
+                                 * 1 "bf16x3": operands split into two bf16 terms, three MFMAs per product, fp32 accumulation (error ~2^-16);
+                                 * 2 "bf16x6": three terms, six MFMAs (error ~2^-23, fp32 level).
+                                 * The analogue of torch.set_float32_matmul_precision: storage stays fp32, only the contraction engine changes.
+                                 * Entry points that have no exact fp32 kernel (maed_conv1x1_fwd, maed_conv3x3_fwd, maed_gemm_tn_wgrad,
+                                 * maed_conv3x3_wgrad) accept MAED_F32 only with 1 or 2. */
+    MAED_OPT_SIDE_STREAM = 1,   /* 1 (default): weight-gradient GEMMs / temporal attention of the fused STE block on the library's side stream */
+    MAED_OPT_TN_TARGET_WGS = 2, /* workgroups a weight-gradient GEMM is split into along M (default 384; tuning knob of scripts/gpu_tn_sweep.sh) */
+    MAED_OPT_ABLATE = 3,        /* diagnostic builds (-DMAED_GEMM_ABLATE) only: bit mask of pipeline stages to drop */
+    MAED_OPT_COUNT
+} maed_option;
+int maed_set_option(int key, int value);   /* MAED_OK or MAED_ERR_ARG */
+int maed_get_option(int key);              /* the value, or MAED_ERR_ARG (negative) for an unknown key */
 
 /* ---- K1: nn.LayerNorm(eps=1e-6)  (vision_transformer.py:249,254,344,569) ---------------------- */
 /* y[T](rows,C) = LN(x[f32]) ; saves mean/rstd (fp32, rows) for backward.  x rows may be strided. */

@@ -16,6 +16,8 @@ EPI_STORE, EPI_GELU, EPI_RESID_F32, EPI_MUL_DGELU, EPI_ATOMIC_F32, EPI_STORE_F32
 IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
+IMPL_X3, IMPL_X6 = 7, 8  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
+OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE = range(4)   # maed_option (include/maed_hip.h)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -56,6 +58,8 @@ KTD_W_ANC = 3420
 SIGNATURES = {
     "maed_last_error": (C.c_char_p, []),
     "maed_version": (i32, []),
+    "maed_set_option": (i32, [i32, i32]),
+    "maed_get_option": (i32, [i32]),
     "maed_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i32, vp, vp, i64, i32, f32, vp]),
     "maed_layernorm_bwd": (i32, [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
     "maed_gemm_tn_wgrad": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp, i32, vp]),
@@ -140,7 +144,35 @@ def lib():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
         _lib = handle
+        apply_options(handle)
     return _lib
+
+
+# what the host wants from the library's process-wide options (the library itself reads no environment variables).  The measurement
+# knobs of README.md that live inside the library are translated here, once, when a library handle is bound.
+_OPTIONS = {
+    OPT_F32_MATMUL: {"exact": 0, "0": 0, "bf16x3": 1, "1": 1, "bf16x6": 2, "2": 2}[os.environ.get("MAED_F32_MATMUL", "exact")],
+    OPT_SIDE_STREAM: int(os.environ.get("MAED_WGRAD_SIDE_STREAM", "1") == "1"),
+    OPT_TN_TARGET_WGS: max(64, int(os.environ.get("MAED_TN_TARGET_WGS", "384"))),
+    OPT_ABLATE: int(os.environ.get("MAED_GEMM_ABLATE", "0")),
+}
+
+
+def apply_options(handle):
+    """push the host's option values into a freshly bound library (the product library, or the simulator the tests swap in)"""
+    for k, v in _OPTIONS.items():
+        if handle.maed_set_option(k, v) != 0:
+            raise MaedHipError(f"maed_set_option({k}, {v}) failed")
+
+
+def set_option(key, value):
+    _OPTIONS[key] = int(value)
+    if _lib is not None:
+        check(_lib.maed_set_option(key, int(value)), "set_option")
+
+
+def get_option(key):
+    return _OPTIONS[key]
 
 
 def check(rc, what=""):

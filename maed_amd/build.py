@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmaed_hip.so")
-SOURCES = ["layernorm.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "elementwise.hip", "block.hip", "smpl.hip", "backbone.hip", "tail_bwd.hip", "loss.hip", "comm.hip", "eval_metrics.hip", "attn_long.hip"]
+SOURCES = ["layernorm.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "elementwise.hip", "block.hip", "smpl.hip", "backbone.hip", "tail_bwd.hip", "loss.hip", "comm.hip", "eval_metrics.hip", "attn_long.hip", "gemm_x3.hip", "options.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -21,7 +21,7 @@ def source_hash():
     quotes a PMC traffic figure only for the build it was measured on"""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh")))
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh", ".h")))
     for f in files + [os.path.join(os.path.dirname(HERE), "include", "maed_hip.h")]:
         with open(f if os.path.isabs(f) else os.path.join(CSRC, f), "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
@@ -45,7 +45,8 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "gemm_epilogue.cuh"), os.path.join(os.path.dirname(HERE), "include", "maed_hip.h")]
+    # every header of csrc/ is a dependency of every object (a header-only edit must never leave stale objects in the library)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))) + [os.path.join(os.path.dirname(HERE), "include", "maed_hip.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

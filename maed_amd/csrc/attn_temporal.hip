@@ -787,18 +787,12 @@ __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __rest
 #undef TM_TOK
 }
 
-// bf16 default; MAED_TEMPORAL_MFMA=0 falls back to the LDS-staged thread-per-row kernels (measurement knob).
-// Measured on MI355X (profiles/r01_attn_temporal_mfma_ab.txt): cfg3 (T=16) forward 61.8 -> 27.7 us, backward 133.8 -> 123.3 us;
-// cfg5 (T=64) forward 251 -> 62 us, backward 578 -> 304 us.
-static bool tm_mfma_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* ev = getenv("MAED_TEMPORAL_MFMA"); on = (ev && atoi(ev) == 0) ? 0 : 1; }
-    return on != 0;
-}
+// bf16: always the MFMA kernels.  Measured on MI355X against the LDS-staged thread-per-row kernels, which remain the f32 parity path
+// (profiles/r01_attn_temporal_mfma_ab.txt): cfg3 (T=16) forward 61.8 -> 27.7 us, backward 133.8 -> 123.3 us; cfg5 (T=64) forward 251 -> 62 us,
+// backward 578 -> 304 us.
 
 static bool launch_tm_bwd_mfma(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int P, int H,
                                int Tn, float scale, hipStream_t s) {
-    if (!tm_mfma_enabled()) return false;
     const int G = Tn >= 32 ? 1 : 32 / Tn;
     const int L = G * Tn, Lk = (L + 31) & ~31;
     if (Lk / 32 > 16) return false;
@@ -812,16 +806,14 @@ static bool launch_tm_bwd_mfma(const void* qkv, const void* o, const void* d_o, 
     }
     const int ngroups = (P + G - 1) / G;
     const dim3 grid((unsigned)((F / Tn) * H * ngroups)), block(64 * (Lk / 32));
-    if (Lk == 32 && maed_env_flag("MAED_TM_BWD_L32", true)) {       // one-tile specialisation (see above)
+    if (Lk == 32) {                                                   // one-tile specialisation (see above)
         hipLaunchKernelGGL(attn_tm_bwd_mfma_l32, grid, dim3(64), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, accumulate,
                            P, H, Tn, G, ngroups, scale);
         return true;
     }
     // up to four waves per workgroup: the spill-free instantiation (166 VGPRs; measured on MI355X, profiles/r02_call1_attn_tm_wide_regs.txt:
-    // cfg5 T = 64 backward 305.8 -> 215.9 us, cfg3 123.0 -> 90.6 us); MAED_TM_BWD_WIDE_REGS=0 switches back (A/B knob)
-    static int wide = -1;
-    if (wide < 0) { const char* ev = getenv("MAED_TM_BWD_WIDE_REGS"); wide = (ev && atoi(ev) == 0) ? 0 : 1; }
-    if (wide && Lk / 32 <= 4)
+    // cfg5 T = 64 backward 305.8 -> 215.9 us, cfg3 123.0 -> 90.6 us)
+    if (Lk / 32 <= 4)
         hipLaunchKernelGGL((attn_tm_bwd_mfma<256, 2>), grid, block, lds, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv,
                            accumulate, P, H, Tn, G, ngroups, scale);
     else
@@ -831,7 +823,6 @@ static bool launch_tm_bwd_mfma(const void* qkv, const void* o, const void* d_o, 
 }
 
 static bool launch_tm_fwd_mfma(const void* qkv, void* o, float* lse, int F, int P, int H, int Tn, float scale, hipStream_t s) {
-    if (!tm_mfma_enabled()) return false;
     const int G = Tn >= 32 ? 1 : 32 / Tn;
     const int L = G * Tn, Lk = (L + 31) & ~31;
     if (Lk / 32 > 16) return false;                                   // at most 16 waves per workgroup

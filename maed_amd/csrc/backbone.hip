@@ -385,9 +385,9 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
     if (!ab_zeroed) hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
     const bool ymask = relu && relu_mask;      // residual added before the ReLU: the forward's bit mask (dres may be NULL: not materialised)
-    // default since it was timed on MI355X (profiles/r02_call2_steady_*.csv: reduction passes 2.15 -> 1.42 ms per step + 0.31 ms closing kernels);
-    // MAED_GN_DEFER_AFFINE=0 switches back to the atomics (A/B knob)
-    const int defer = maed_env_flag("MAED_GN_DEFER_AFFINE", true) ? 1 : 0;
+    // dgamma / dbeta from per-workgroup partials + a closing column sum instead of contended atomics in the reduction pass
+    // (timed on MI355X, profiles/r02_call2_steady_*.csv: reduction passes 2.15 -> 1.42 ms per step + 0.31 ms closing kernels)
+    constexpr int defer = 1;
 #define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows, defer)
 #define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, relu_mask, (const T*)dy, \

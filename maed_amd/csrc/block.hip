@@ -9,6 +9,7 @@
 // backward: the mirror image; weight gradients are NT GEMMs on transposed copies (split-K, fp32 atomics
 //           into the caller's gradient arena), bias gradients fall out of the transposes.
 #include "common.cuh"
+#include "gemm_x3.h"
 #include <hip/hip_runtime.h>
 #include <utility>
 #include <vector>
@@ -63,7 +64,6 @@ struct SideStream {
     int next = 0;
     bool ok = false;
     SideStream() {
-        if (!maed_env_flag("MAED_WGRAD_SIDE_STREAM", true)) return;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
         for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return;
         ok = true;
@@ -76,8 +76,9 @@ struct SideStream {
     }
 };
 static SideStream* side_stream() {
+    if (!maed_opt(MAED_OPT_SIDE_STREAM) || g_prof) return nullptr;      // (before the static: with the option off the stream is never created)
     static SideStream ss;
-    return (ss.ok && !g_prof) ? &ss : nullptr;
+    return ss.ok ? &ss : nullptr;
 }
 
 namespace {
@@ -186,7 +187,7 @@ extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_par
     MAED_PROPAGATE(maed_layernorm_fwd(x_in, C, p->ln1_g, p->ln1_b, sv + L.ln1, dt, (float*)(sv + L.mean1), (float*)(sv + L.rstd1), M, C, d->eps, stream));
     PROF(PROF_GEMM_QKV, maed_gemm_nt(sv + L.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, sv + L.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
     {   // the two attention branches read the same qkv and write disjoint outputs: temporal on the side stream beside spatial
-        SideStream* ss = (dt == MAED_BF16 && d->impl != MAED_IMPL_VALU) ? side_stream() : nullptr;
+        SideStream* ss = (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || maed_x3_planes())) ? side_stream() : nullptr;
         void* tst = ss ? (void*)ss->s : stream;
         if (ss) ss->fence((hipStream_t)stream, ss->s);
         { ProfScope ps__(PROF_ATTN_TM_FWD, tst); MAED_PROPAGATE(maed_attn_temporal_fwd(sv + L.qkv, sv + L.xt, (float*)(sv + L.lse_t), d->F, d->P, d->H, d->T, scale, dt, tst)); }
@@ -220,14 +221,14 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
     const float* logits = (const float*)(sv + L.logits);
     float* dxmid = (float*)(sc + S.dxmid);
 
-    if (dt == MAED_BF16 && d->impl != MAED_IMPL_VALU) {
-        // ---- bf16: weight gradients straight from the row-major operands (maed_gemm_tn_wgrad), no transposed copies ----
-        const void* dyc = dx_out_twin;                                   // dx_out in bf16
+    if (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || maed_x3_planes())) {
+        // ---- bf16, and f32 in the split-bf16 matmul mode: weight gradients straight from the row-major operands (maed_gemm_tn_wgrad), no transposed copies ----
+        const void* dyc = dt == MAED_F32 ? (const void*)dx_out : dx_out_twin;   // dx_out in the compute dtype
         if (!dyc) {                                                      // first block of the backward: cast once
             MAED_PROPAGATE(maed_transpose_cast(dx_out, MAED_F32, C, M, C, nullptr, 0, sc + S.dyc, C, nullptr, dt, stream));
             dyc = sc + S.dyc;
         }
-        void* dxmid_tw = sc + S.dyt;                                     // bf16 twin of dx_mid (reuses the old transpose slot)
+        void* dxmid_tw = dt == MAED_F32 ? (void*)dxmid : (void*)(sc + S.dyt);   // compute-dtype twin of dx_mid (f32: dx_mid itself; bf16: the old transpose slot)
         SideStream* ss = side_stream();
         hipStream_t main_s = (hipStream_t)stream;
         void* wst = ss ? (void*)ss->s : stream;                          // where the weight-gradient GEMMs go
@@ -242,13 +243,12 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, wst));
         if (ss) hipEventRecord(ss->ev[63], ss->s);                       // "fc1 weight gradient done" (named slot, outside the ring)
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
-        // LayerNorm dgamma/dbeta via partials in the (bf16-mode-unused) transpose slot (measured on MI355X, profiles/r02_call2_steady_*.csv:
-        // 0.629 -> 0.503 + 0.080 ms per step); MAED_LN_DEFER_AFFINE=0 switches back to the atomics (A/B knob)
-        const size_t big_t_bytes = (size_t)(Hd > 3 * C ? Hd : 3 * C) * (size_t)Mp * dtype_size(dt);      // S.bigT: only the f32 path transposes into it
-        float* ln_part = (maed_env_flag("MAED_LN_DEFER_AFFINE", true) && maed_layernorm_bwd_partials_bytes(M, C) <= big_t_bytes)
-                             ? (float*)(sc + S.bigT) : nullptr;
+        // LayerNorm dgamma/dbeta via partials in the (here unused) transpose slot instead of contended atomics (measured on MI355X,
+        // profiles/r02_call2_steady_*.csv: 0.629 -> 0.503 + 0.080 ms per step)
+        const size_t big_t_bytes = (size_t)(Hd > 3 * C ? Hd : 3 * C) * (size_t)Mp * dtype_size(dt);      // S.bigT: only the exact-f32 path transposes into it
+        float* ln_part = maed_layernorm_bwd_partials_bytes(M, C) <= big_t_bytes ? (float*)(sc + S.bigT) : nullptr;
         MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
-                                             dx_out, dxmid, dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream));
+                                             dx_out, dxmid, dt == MAED_F32 ? nullptr : dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream));
         // attention: x_mid = x_in + proj(mix(x_s, x_t))
         TO_SIDE();
         WGRAD(maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dt, wst));

@@ -54,11 +54,8 @@ void maed_set_error(const char* fmt, ...);
     maed_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return MAED_ERR_LAUNCH; } } while (0)
 #define MAED_PROPAGATE(expr) do { int rc__ = (expr); if (rc__ != MAED_OK) return rc__; } while (0)
 
-// opt-in/opt-out switches read once from the environment (measurement knobs, documented in README.md)
-static inline bool maed_env_flag(const char* name, bool dflt) {
-    const char* ev = getenv(name);
-    return ev ? atoi(ev) != 0 : dflt;
-}
+// process-wide options (csrc/options.hip; maed_set_option in include/maed_hip.h)
+int maed_opt(int key);
 
 static inline bool is_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 

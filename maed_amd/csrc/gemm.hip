@@ -11,6 +11,7 @@
 // Split-K (grid.z) is available for the atomic weight-gradient epilogue.
 #include "common.cuh"
 #include "gemm_epilogue.cuh"
+#include "gemm_x3.h"
 
 // ------------------------------------------------------------------------------------------------
 // VALU kernel (any T; used for f32 and as the cross-check for the MFMA kernel)
@@ -494,9 +495,11 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
                    "conv3x3_fwd: GroupNorm statistics need Cout = 32 * 2^k >= 64, Ho*Wo >= 128 and no `add` (Cout=%d Ho*Wo=%d)", Cout, Ho * Wo);
     MAED_CHECK_ARG(w_layout == 0 || w_layout == 1, MAED_ERR_ARG, "conv3x3_fwd: w_layout must be 0 (Cout,3,3,Cin) or 1 (transposed image of the forward weight)");
     MAED_CHECK_ARG(x && w_taps && zero_page && y, MAED_ERR_ARG, "conv3x3_fwd: null pointer");
-    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_fwd: bf16 only (the f32 parity mode keeps the library convolution)");
+    MAED_CHECK_ARG(dtype == MAED_BF16 || dtype == MAED_F32, MAED_ERR_ARG, "conv3x3_fwd: bad dtype %d", dtype);
+    const int x3np = dtype == MAED_F32 ? maed_x3_planes() : 0;
+    MAED_CHECK_ARG(dtype == MAED_BF16 || x3np, MAED_ERR_UNSUPPORTED, "conv3x3_fwd: f32 needs the split-bf16 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL, 1 or 2))");
     MAED_CHECK_ARG(F >= 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride >= 1 && pad_top >= 0 && pad_left >= 0, MAED_ERR_SHAPE, "conv3x3_fwd: bad extents");
-    MAED_CHECK_ARG(Cin % GM_BK == 0 && Cout % 8 == 0, MAED_ERR_SHAPE, "conv3x3_fwd: need Cin %% 64 == 0 and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    MAED_CHECK_ARG(Cin % (dtype == MAED_F32 ? 32 : GM_BK) == 0 && Cout % 8 == 0, MAED_ERR_SHAPE, "conv3x3_fwd: need Cin %% 64 == 0 (f32: 32) and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
     MAED_CHECK_ARG((Ho - 1) * stride - pad_top + 2 < H + 2 && (Wo - 1) * stride - pad_left + 2 < W + 2, MAED_ERR_SHAPE, "conv3x3_fwd: output extent exceeds the padded input");
     MAED_CHECK_ARG(is_aligned(x, 16) && is_aligned(w_taps, 16) && is_aligned(zero_page, 16) && is_aligned(y, 16), MAED_ERR_ALIGN, "conv3x3_fwd: 16-B alignment");
     if (F == 0) return MAED_OK;
@@ -510,6 +513,12 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
         ? Conv3x3Dims{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left, 9 * (int64_t)Cin, (int64_t)Cin, 0}
         : Conv3x3Dims{F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left, (int64_t)Cin, -(int64_t)Cout * Cin, 8 * (int64_t)Cout * Cin};
     EpiArgs e{nullptr, y, (int64_t)Cout, nullptr, add, (int64_t)Cout, gn_sums, Ho * Wo};
+    if (dtype == MAED_F32) {        // fp32 operands on the split-bf16 MFMA kernel (gemm_x3.hip): out-of-image taps are zeros in registers, zero_page unused
+        const X3ConvDims xd{d.F, d.H, d.W, d.Cin, d.Ho, d.Wo, d.stride, d.pad_top, d.pad_left, d.b_row, d.b_tap, d.b_base};
+        MAED_PROPAGATE(maed_conv3x3_x3_launch(x3np, x, w_taps, xd, M, Cout, e, add != nullptr, gn_sums != nullptr, (hipStream_t)stream));
+        MAED_CHECK_LAUNCH("conv3x3_fwd(x3)");
+        return MAED_OK;
+    }
     const dim3 grid((unsigned)(tm * tn));
 #define CV_LAUNCH(EPI_, NARROW_, GN_) hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<EPI_, NARROW_, GN_>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, \
                                                    (const bf16*)w_taps, (const bf16*)zero_page, d, M, N, tn, e)
@@ -562,9 +571,8 @@ static int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, i
     if (kps < 1) kps = 1;
     const int z = (nkt + kps - 1) / kps;
 #ifdef MAED_GEMM_ABLATE
-    const char* ev = getenv("MAED_GEMM_ABLATE");
     hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF, GN>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
-                       (const bf16*)B, ldb, M, N, K, tn, kps, e, ev ? atoi(ev) : 0);
+                       (const bf16*)B, ldb, M, N, K, tn, kps, e, maed_opt(MAED_OPT_ABLATE));
 #else
     hipLaunchKernelGGL((gemm_nt_glds_bf16_kernel<EPI, NBUF, GN>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, (const bf16*)A, lda,
                        (const bf16*)B, ldb, M, N, K, tn, kps, e);
@@ -580,16 +588,26 @@ template <int EPI>
 static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype,
                     const EpiArgs& e, int splitk, int impl, hipStream_t s) {
     if (dtype == MAED_F32) {
-        MAED_CHECK_ARG(impl != MAED_IMPL_MFMA, MAED_ERR_UNSUPPORTED, "gemm_nt: f32 has no MFMA path (exact-f32 VALU kernel)");
+        MAED_CHECK_ARG(impl == MAED_IMPL_AUTO || impl == MAED_IMPL_VALU || impl == MAED_IMPL_X3 || impl == MAED_IMPL_X6, MAED_ERR_UNSUPPORTED,
+                       "gemm_nt: f32 runs on the exact-f32 VALU kernel (MAED_IMPL_VALU) or the split-bf16 MFMA kernel (MAED_IMPL_X3 / _X6); impl=%d", impl);
+        // split-bf16 MFMA kernel (gemm_x3.hip): explicitly, or when the process-wide fp32 matmul mode asks for it.  GEMMs with few output tiles
+        // (ts_attn, the decoder head: M = frames) keep the exact split-K VALU route below -- a 128-row tile would leave most of the chip idle.
+        const int np = impl == MAED_IMPL_X3 ? 2 : impl == MAED_IMPL_X6 ? 3 : impl == MAED_IMPL_AUTO ? maed_x3_planes() : 0;
+        if (np) {
+            const bool ok = maed_x3_nt_shape_ok(A, lda, B, ldb, K);
+            MAED_CHECK_ARG(ok || impl == MAED_IMPL_AUTO, MAED_ERR_ALIGN, "gemm_nt(x3): need K%%32==0 (K=%lld), lda/ldb%%4==0, 16-B aligned A/B", (long long)K);
+            const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+            if (ok && (impl != MAED_IMPL_AUTO || tiles128 >= 48 || EPI == MAED_EPI_ATOMIC_F32))
+                return maed_gemm_nt_x3_launch(EPI, np, A, lda, B, ldb, M, N, K, e, splitk, s);
+        }
         // few output tiles, long K (the decoder tail's GEMMs: 128 frames x 1024 x 1024 is 32 tiles of 64 x 64 -- 86 us on 32 CUs): spread
         // K over the chip -- the fp32 output starts as the bias and the K slices accumulate with fp32 atomics (15 us)
         if constexpr (EPI == MAED_EPI_STORE || EPI == MAED_EPI_STORE_F32) {
             const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
             if (splitk == 1 && tiles < 96 && K >= 256) {
                 // more K slices would hide more load latency, but every slice adds an output tile of fp32 atomics: ~256 workgroups measured best (128 x 1024 x 2136: 50.7 / 55.4 / 69.3 us
-                // at 256 / 512 / 1024; MAED_F32_SPLIT_WGS: sweep knob)
-                static int target = 0;
-                if (!target) { const char* ev = getenv("MAED_F32_SPLIT_WGS"); target = ev ? atoi(ev) : 256; if (target < 32) target = 256; }
+                // at 256 / 512 / 1024)
+                constexpr int target = 256;
                 int sk = (int)(target / tiles);
                 if (sk > K / 64) sk = (int)(K / 64);
                 if (sk > 1) {
@@ -645,14 +663,24 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
 extern "C" int maed_conv1x1_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int Cout, int Cin, void* y, int64_t ldy, int hw,
                                 double* gn_sums, int dtype, void* stream) {
     MAED_CHECK_ARG(x && w && y, MAED_ERR_ARG, "conv1x1_fwd: null pointer");
-    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv1x1_fwd: bf16 only (the f32 parity mode keeps the library convolution)");
+    MAED_CHECK_ARG(dtype == MAED_BF16 || dtype == MAED_F32, MAED_ERR_ARG, "conv1x1_fwd: bad dtype %d", dtype);
+    MAED_CHECK_ARG(is_aligned(x, 16) && is_aligned(w, 16) && is_aligned(y, 16), MAED_ERR_ALIGN, "conv1x1_fwd: 16-B alignment");
+    MAED_CHECK_ARG(!gn_sums || gn_stats_shape_ok(Cout, hw), MAED_ERR_SHAPE, "conv1x1_fwd: GroupNorm statistics need Cout = 32 * 2^k >= 64 and hw >= 128 (Cout=%d hw=%d)", Cout, hw);
+    EpiArgs e{nullptr, y, ldy, nullptr, nullptr, 0, gn_sums, hw};
+    if (dtype == MAED_F32) {        // fp32 operands on the split-bf16 MFMA kernel (gemm_x3.hip)
+        const int x3np = maed_x3_planes();
+        MAED_CHECK_ARG(x3np, MAED_ERR_UNSUPPORTED, "conv1x1_fwd: f32 needs the split-bf16 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL, 1 or 2))");
+        MAED_CHECK_ARG(M >= 0 && Cout > 0 && Cin > 0 && ldx >= Cin && ldw >= Cin && ldy >= Cout && ldy % 4 == 0 && maed_x3_nt_shape_ok(x, ldx, w, ldw, Cin), MAED_ERR_SHAPE,
+                       "conv1x1_fwd(f32): need Cin %% 32 == 0 and 4-element aligned strides (Cin=%d Cout=%d)", Cin, Cout);
+        if (M == 0) return MAED_OK;
+        MAED_PROPAGATE(maed_conv1x1_x3_launch(x3np, x, ldx, w, ldw, M, Cout, Cin, e, gn_sums != nullptr, (hipStream_t)stream));
+        MAED_CHECK_LAUNCH("conv1x1_fwd(x3)");
+        return MAED_OK;
+    }
     MAED_CHECK_ARG(M >= 0 && Cout > 0 && Cin > 0 && Cin % GM_BK == 0 && ldx >= Cin && ldw >= Cin && ldy >= Cout && ldx % 8 == 0 && ldw % 8 == 0, MAED_ERR_SHAPE,
                    "conv1x1_fwd: need Cin %% 64 == 0 and 8-element aligned strides (Cin=%d Cout=%d)", Cin, Cout);
-    MAED_CHECK_ARG(is_aligned(x, 16) && is_aligned(w, 16) && is_aligned(y, 16), MAED_ERR_ALIGN, "conv1x1_fwd: 16-B alignment");
     MAED_CHECK_ARG((uint64_t)M * (uint64_t)ldx * 2 < (1ull << 32), MAED_ERR_SHAPE, "conv1x1_fwd: activation larger than 4 GB");
-    MAED_CHECK_ARG(!gn_sums || gn_stats_shape_ok(Cout, hw), MAED_ERR_SHAPE, "conv1x1_fwd: GroupNorm statistics need Cout = 32 * 2^k >= 64 and hw >= 128 (Cout=%d hw=%d)", Cout, hw);
     if (M == 0) return MAED_OK;
-    EpiArgs e{nullptr, y, ldy, nullptr, nullptr, 0, gn_sums, hw};
     if (gn_sums) launch_glds<MAED_EPI_STORE, 1, true>(x, ldx, w, ldw, M, Cout, Cin, e, 1, (hipStream_t)stream);
     else launch_glds<MAED_EPI_STORE, 1>(x, ldx, w, ldw, M, Cout, Cin, e, 1, (hipStream_t)stream);
     MAED_CHECK_LAUNCH("conv1x1_fwd");

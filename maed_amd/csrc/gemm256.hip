@@ -217,8 +217,7 @@ template <int EPI>
 static void launch_256(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e, hipStream_t s) {
     const int tm = (int)((M + G2_T - 1) / G2_T), tn = (int)((N + G2_T - 1) / G2_T);
 #ifdef MAED_GEMM_ABLATE
-    const char* ev = getenv("MAED_GEMM_ABLATE");
-    hipLaunchKernelGGL((gemm_nt_256_bf16_kernel<EPI>), dim3((unsigned)(tm * tn)), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)B, ldb, M, N, K, tn, e, ev ? atoi(ev) : 0);
+    hipLaunchKernelGGL((gemm_nt_256_bf16_kernel<EPI>), dim3((unsigned)(tm * tn)), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)B, ldb, M, N, K, tn, e, maed_opt(MAED_OPT_ABLATE));
 #else
     hipLaunchKernelGGL((gemm_nt_256_bf16_kernel<EPI>), dim3((unsigned)(tm * tn)), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)B, ldb, M, N, K, tn, e);
 #endif

@@ -164,11 +164,12 @@ __device__ __forceinline__ void gn_zero(GnRegs& a) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) { a.s[f][h] = 0.f; a.q[f][h] = 0.f; }
 }
+template <typename T = bf16>                                             // T: storage type of the convolution's output
 __device__ __forceinline__ void gn_acc8(GnRegs& a, const GnTile& g, const float (&v)[8], int64_t row) {
     const bool second = row >= g.split_row;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        const float r0 = round_to<bf16>(v[2 * h]), r1 = round_to<bf16>(v[2 * h + 1]);      // what the GroupNorm will read back
+        const float r0 = round_to<T>(v[2 * h]), r1 = round_to<T>(v[2 * h + 1]);            // what the GroupNorm will read back
         const float ps = r0 + r1, pq = fmaf(r0, r0, r1 * r1);
         a.s[0][h] += second ? 0.f : ps; a.q[0][h] += second ? 0.f : pq;
         a.s[1][h] += second ? ps : 0.f; a.q[1][h] += second ? pq : 0.f;

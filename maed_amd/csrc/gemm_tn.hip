@@ -11,12 +11,10 @@
 // workgroups of K-tile 0 also produce the bias gradient (column sums of Y).
 #include "common.cuh"
 #include "gemm_epilogue.cuh"      // xcd_remap
+#include "gemm_x3.h"
 #include <stdlib.h>
 
-static int tn_remap() {                 // MAED_TN_XCD_REMAP=0: dispatch order as launched (A/B knob)
-    static const int v = maed_env_flag("MAED_TN_XCD_REMAP", true) ? 1 : 0;
-    return v;
-}
+static int tn_remap() { return 1; }     // XCD-aware (split, tile) order: -6...8 % and 292 -> 189 MB of HBM traffic per launch (profiles/r02_pmc)
 
 #define TN_BM 64      // reduction rows per LDS tile
 #define TN_LD 72      // LDS row stride (elements): 144 B
@@ -204,15 +202,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
 extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw,
                                   float* dbias, int dtype, void* stream) {
     MAED_CHECK_ARG(Y && X && dW, MAED_ERR_ARG, "gemm_tn_wgrad: null pointer");
-    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "gemm_tn_wgrad: bf16 only (the f32 parity mode uses transposed copies + gemm_nt)");
+    if (dtype == MAED_F32) {        // fp32 operands on the split-bf16 MFMA kernel (gemm_x3.hip)
+        const int np = maed_x3_planes();
+        MAED_CHECK_ARG(np, MAED_ERR_UNSUPPORTED, "gemm_tn_wgrad: f32 needs the split-bf16 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL, 1 or 2)); the exact mode uses "
+                                                 "transposed copies + gemm_nt");
+        MAED_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldw >= K, MAED_ERR_SHAPE,
+                       "gemm_tn_wgrad(f32): need N, K, ldy, ldx multiples of 4 (N=%d K=%d)", N, K);
+        MAED_CHECK_ARG(is_aligned(Y, 16) && is_aligned(X, 16), MAED_ERR_ALIGN, "gemm_tn_wgrad: Y/X must be 16-B aligned");
+        MAED_PROPAGATE(maed_gemm_tn_x3_launch(np, Y, ldy, X, ldx, M, N, K, dW, ldw, dbias, nullptr, maed_opt(MAED_OPT_TN_TARGET_WGS), (hipStream_t)stream));
+        MAED_CHECK_LAUNCH("gemm_tn_wgrad(x3)");
+        return MAED_OK;
+    }
+    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_ARG, "gemm_tn_wgrad: bad dtype %d", dtype);
     MAED_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldw >= K, MAED_ERR_SHAPE,
                    "gemm_tn_wgrad: need N, K, ldy, ldx multiples of 8 (N=%d K=%d)", N, K);
     MAED_CHECK_ARG(is_aligned(Y, 16) && is_aligned(X, 16), MAED_ERR_ALIGN, "gemm_tn_wgrad: Y/X must be 16-B aligned");
     MAED_CHECK_ARG(ldy < (1 << 24) && ldx < (1 << 24), MAED_ERR_SHAPE, "gemm_tn_wgrad: row strides must be < 2^24 elements");
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     const int nmt = (int)((M + TN_BM - 1) / TN_BM);
-    static int target = 0;                                   // MAED_TN_TARGET_WGS: measurement knob for the split heuristic
-    if (!target) { const char* ev = getenv("MAED_TN_TARGET_WGS"); target = ev ? atoi(ev) : 384; if (target < 64) target = 384; }
+    const int target = maed_opt(MAED_OPT_TN_TARGET_WGS);     // measurement knob for the split heuristic (default 384)
     // ~384 workgroups (1.5 per CU): measured optimum at the STE and backbone shapes (profiles/r01_tn_split_sweep.txt) -- every
     // extra split adds a 128x128 tile of fp32 atomics, and the kernel runs at two workgroups per CU anyway
     int splits = (target + tn * tk - 1) / (tn * tk);
@@ -221,9 +229,8 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     const int per = (nmt + splits - 1) / splits;
     const int z = (nmt + per - 1) / per;
 #ifdef MAED_GEMM_ABLATE
-    const char* ev = getenv("MAED_GEMM_ABLATE");
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
-                       N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap(), ev ? atoi(ev) : 0);
+                       N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap(), maed_opt(MAED_OPT_ABLATE));
 #else
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
                        N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap());
@@ -260,9 +267,19 @@ extern "C" int maed_conv3x3_tapmask(void* mask, int F, int H, int W, void* strea
 extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tapmask, const void* zero_page, float* dW, int F, int H, int W, int Cin,
                                   int Cout, int dtype, void* stream) {
     MAED_CHECK_ARG(dy && x && tapmask && zero_page && dW, MAED_ERR_ARG, "conv3x3_wgrad: null pointer");
-    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_wgrad: bf16 only");
+    MAED_CHECK_ARG(dtype == MAED_BF16 || dtype == MAED_F32, MAED_ERR_ARG, "conv3x3_wgrad: bad dtype %d", dtype);
     const int64_t M = (int64_t)F * H * W;
     const int N = Cout, K = 9 * Cin;
+    if (dtype == MAED_F32) {        // fp32 operands on the split-bf16 MFMA kernel (gemm_x3.hip)
+        const int np = maed_x3_planes();
+        MAED_CHECK_ARG(np, MAED_ERR_UNSUPPORTED, "conv3x3_wgrad: f32 needs the split-bf16 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL, 1 or 2))");
+        MAED_CHECK_ARG(M > 0 && M % 32 == 0 && Cin % 4 == 0 && Cout % 4 == 0, MAED_ERR_SHAPE, "conv3x3_wgrad(f32): F*H*W = %lld must be a multiple of 32, Cin / Cout of 4", (long long)M);
+        MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16) && is_aligned(tapmask, 16), MAED_ERR_ALIGN, "conv3x3_wgrad: 16-B alignment");
+        const X3TnConv cv{(const uint16_t*)tapmask, Cin, W};
+        MAED_PROPAGATE(maed_gemm_tn_x3_launch(np, dy, (int64_t)Cout, x, (int64_t)Cin, M, N, K, dW, (int64_t)K, nullptr, &cv, 384, (hipStream_t)stream));
+        MAED_CHECK_LAUNCH("conv3x3_wgrad(x3)");
+        return MAED_OK;
+    }
     MAED_CHECK_ARG(M > 0 && M % TN_BM == 0, MAED_ERR_SHAPE, "conv3x3_wgrad: F*H*W = %lld must be a multiple of 64", (long long)M);
     MAED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && Cin < (1 << 20) && W + 1 < (1 << 10), MAED_ERR_SHAPE, "conv3x3_wgrad: need Cin, Cout multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
     MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16) && is_aligned(tapmask, 16) && is_aligned(zero_page, 16), MAED_ERR_ALIGN, "conv3x3_wgrad: 16-B alignment");

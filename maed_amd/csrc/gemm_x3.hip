@@ -1,0 +1,426 @@
+// fp32-accurate GEMMs on the bf16 matrix cores ("bf16x3" / "bf16x6" split arithmetic): the f32 parity mode at MFMA speed.
+//
+// Why: the reference's arithmetic is fp32 throughout (vision_transformer.py:98-111,124-128,146-228; resnetv2.py:74-93) and north_star's
+// bar is 1e-3 relative on SMPL parameters.  gfx950 has no TF32; its fp32-input MFMA runs at the VALU rate (157 TFLOP/s, 1/16 of bf16),
+// and the exact-f32 VALU kernels of gemm.hip made the parity mode 6x slower than the bf16 mode (139 vs 23 ms per cfg3 train step).
+// Every fp32 operand x is written as a sum of NP bf16 numbers, x = x0 + x1 (+ x2) with x0 = bf16(x), x1 = bf16(x - x0), ... (each
+// subtraction is exact in fp32), and the product of two operands is the sum of the partial products whose orders add up to less than NP:
+//     NP = 2 ("bf16x3"): a0 b0 + a0 b1 + a1 b0             3 MFMAs per product, |error| <= ~2^-16 |a b|  (dropped a1 b1 and the x2 tails)
+//     NP = 3 ("bf16x6"): + a0 b2 + a1 b1 + a2 b0           6 MFMAs per product, |error| <= ~2^-23 |a b|  (fp32 level)
+// all accumulated in the MFMA's fp32 accumulators.  Peak is 2.5 PFLOP/s / 3 = 833 TFLOP/s (x3) or 417 (x6) against 157 for the fp32 MFMA.
+//
+// Operands stay fp32 in HBM (the parity mode's activations and standardised weights: 4 B per element, read once): a thread loads 16-byte
+// pieces into registers, splits them on the VALU (v_cvt_pk_bf16_f32 + exact residual) and writes the NP planes of the LDS image, so the
+// split costs no extra memory pass and -- because staging goes through registers anyway -- gathered rows (implicit-GEMM 3x3 convolution)
+// and transposing staging (weight gradients, reduction over rows) come for free: the fragments a MFMA lane needs are picked element by
+// element while packing.  LDS image per operand and plane: 128 rows x 32 k (bf16), rows padded to 80 B (20 dwords = 4 x odd:
+// conflict-free ds_read_b128 fragments and ds_write_b128 rows).  One LDS buffer, the next K tile's global loads in flight under the
+// current tile's MFMAs, LDS-shuffled epilogue as in gemm.hip (all fused epilogues, GroupNorm statistics), XCD-aware tile order.
+//
+//   gemm_nt_x3_kernel   out = epi(A[M,K] B[N,K]^T)      nn.Linear forward / input gradients, 1x1 convolutions; CONV: 3x3 implicit GEMM
+//   gemm_tn_x3_kernel   dW[N,K] += Y[M,N]^T X[M,K]      weight gradients (reduction over rows), CONV: 3x3 weight gradient over gathered rows
+#include "common.cuh"
+#include "gemm_epilogue.cuh"
+#include "gemm_x3.h"
+
+#define X3_BK 32
+#define X3_LD 40
+
+namespace {
+
+// 4 consecutive fp32 -> NP planes of 4 bf16 (2 dwords per plane)
+template <int NP>
+__device__ __forceinline__ void split4(float r0, float r1, float r2, float r3, uint2 (&pl)[NP]) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t w0 = pack_bf2(r0, r1), w1 = pack_bf2(r2, r3);
+        pl[p] = make_uint2(w0, w1);
+        if (p + 1 < NP) {
+            r0 -= __uint_as_float(w0 << 16); r1 -= __uint_as_float(w0 & 0xffff0000u);
+            r2 -= __uint_as_float(w1 << 16); r3 -= __uint_as_float(w1 & 0xffff0000u);
+        }
+    }
+}
+
+// one K step (16) of a wave's 2x2 (or 1x2) block of 32x32 tiles from the split LDS planes; TR: accumulators hold the transposed tiles
+template <int NP, bool TR, bool HALF_ROWS>
+__device__ __forceinline__ void x3_kstep(const unsigned short* Ap, const unsigned short* Bp, int plane_elems, f32x16_t& acc00, f32x16_t& acc01,
+                                         f32x16_t& acc10, f32x16_t& acc11) {
+    bf16x8_t a0[NP], a1[NP], b0[NP], b1[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        a0[p] = *reinterpret_cast<const bf16x8_t*>(Ap + p * plane_elems);
+        b0[p] = *reinterpret_cast<const bf16x8_t*>(Bp + p * plane_elems);
+        b1[p] = *reinterpret_cast<const bf16x8_t*>(Bp + p * plane_elems + 32 * X3_LD);
+        if constexpr (!HALF_ROWS) a1[p] = *reinterpret_cast<const bf16x8_t*>(Ap + p * plane_elems + 32 * X3_LD);
+    }
+    // smallest partial products first, the leading a0 b0 last
+#pragma unroll
+    for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int pa = 0; pa <= ord; ++pa) {
+            const int pb = ord - pa;
+            if constexpr (TR) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[pb], a0[pa], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[pb], a0[pa], acc01, 0, 0, 0);
+                if constexpr (!HALF_ROWS) {
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[pb], a1[pa], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[pb], a1[pa], acc11, 0, 0, 0);
+                }
+            } else {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[pa], b0[pb], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[pa], b1[pb], acc01, 0, 0, 0);
+                if constexpr (!HALF_ROWS) {
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[pa], b0[pb], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[pa], b1[pb], acc11, 0, 0, 0);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// NT:  out = epi(A[M,K] B[N,K]^T), fp32 operands, K % 32 == 0, 16-byte aligned rows.
+// CONV: A rows are gathered pixels of a channels_last image (3x3 taps, TF-SAME zero padding, any stride) and B is addressed as
+//       element (n, tap, c) = B[b_base + tap * b_tap + n * b_row + c] -- exactly gemm.hip's conv3x3_glds_bf16_kernel, in fp32.
+// NARROW: 128 x 64 output tile (N <= 64: stage 1 of the R50), the four waves take 32 rows each.
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int EPI, int NP, bool NARROW, bool CONV, bool GN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                            int64_t M, int64_t N, int64_t K, int tiles_n, int ktiles_per_split, X3ConvDims d,
+                                                            EpiArgs e) {
+    constexpr int kPlane = 128 * X3_LD;
+    constexpr int kTileElems = 2 * NP * kPlane, kStageElems = 4 * 32 * GL_ST * 2;
+    constexpr int kMainElems = kTileElems > kStageElems ? kTileElems : kStageElems;
+    __shared__ __attribute__((aligned(16))) unsigned short lds_raw[kMainElems + (GN ? GN_TAB_FLOATS * 2 : 0)];
+    double* const gn_tab = reinterpret_cast<double*>(lds_raw + kMainElems);
+    if (GN && threadIdx.x < GN_TAB_FLOATS / 2) gn_tab[threadIdx.x] = 0.0;                       // (published by the main loop's barriers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = NARROW ? wave : wave >> 1, wc = NARROW ? 0 : wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(id / tiles_n) * 128, n0 = (int64_t)(id % tiles_n) * (NARROW ? 64 : 128);
+    const int nkt_total = CONV ? 9 * d.Cin / X3_BK : (int)(K / X3_BK);
+    const int kt_beg = blockIdx.z * ktiles_per_split;
+    int kt_end = kt_beg + ktiles_per_split;
+    if (kt_end > nkt_total) kt_end = nkt_total;
+    if (kt_beg >= kt_end) return;
+
+    // staging map: a 128 x 32 fp32 tile = 1024 16-byte pieces, 4 per thread: row (tid >> 3) + 32 i, k offset (tid & 7) * 4 -- 8 lanes cover one
+    // 128-byte row segment
+    const int srow = tid >> 3, skc = (tid & 7) * 4;
+    const float* ap[4]; const float* bp[4];
+    int iy[4], ix[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        const int64_t m = (m0 + row < M) ? m0 + row : M - 1;
+        const int64_t br = (n0 + row < N) ? n0 + row : N - 1;
+        if constexpr (CONV) {
+            const int ox = (int)(m % d.Wo), oy = (int)((m / d.Wo) % d.Ho);
+            const int64_t f = m / ((int64_t)d.Wo * d.Ho);
+            iy[i] = oy * d.stride - d.pad_top; ix[i] = ox * d.stride - d.pad_left;
+            ap[i] = A + ((f * d.H + iy[i]) * d.W + ix[i]) * (int64_t)d.Cin + skc;
+            bp[i] = B + d.b_base + br * d.b_row + skc;
+        } else {
+            iy[i] = 0; ix[i] = 0;
+            ap[i] = A + m * lda + skc;
+            bp[i] = B + br * ldb + skc;
+        }
+    }
+    float4 ra[4], rb[4];
+    int ty = 0, tx = 0, c0 = 0;                                     // CONV: K tile -> (tap, channel chunk), advanced with the loads
+    if constexpr (CONV) { const int k = kt_beg * X3_BK; const int tap = k / d.Cin; ty = tap / 3; tx = tap % 3; c0 = k - tap * d.Cin; }
+    auto load_tile = [&](int kt) {
+        if constexpr (CONV) {
+            const int64_t toff = ((int64_t)ty * d.W + tx) * d.Cin + c0, k0 = (int64_t)(ty * 3 + tx) * d.b_tap + c0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (unsigned)(iy[i] + ty) < (unsigned)d.H && (unsigned)(ix[i] + tx) < (unsigned)d.W;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(ap[i] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!NARROW || i < 2) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+            }
+            c0 += X3_BK;
+            if (c0 == d.Cin) { c0 = 0; if (++tx == 3) { tx = 0; ++ty; } }
+        } else {
+            const int64_t k0 = (int64_t)kt * X3_BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const float4*>(ap[i] + k0);
+                if (!NARROW || i < 2) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (srow + 32 * i) * X3_LD + skc;
+            uint2 pl[NP];
+            split4<NP>(ra[i].x, ra[i].y, ra[i].z, ra[i].w, pl);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(lds_raw + p * kPlane + off) = pl[p];
+            if (!NARROW || i < 2) {
+                split4<NP>(rb[i].x, rb[i].y, rb[i].z, rb[i].w, pl);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(lds_raw + (NP + p) * kPlane + off) = pl[p];
+            }
+        }
+    };
+
+    constexpr bool TR = (EPI != MAED_EPI_ATOMIC_F32);
+    f32x16_t acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    const unsigned short* const Afrag = lds_raw + (wr * (NARROW ? 32 : 64) + l31) * X3_LD + hi * 8;
+    const unsigned short* const Bfrag = lds_raw + NP * kPlane + (wc * 64 + l31) * X3_LD + hi * 8;
+
+    load_tile(kt_beg);
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        __syncthreads();                                    // every wave is done with the previous tile's fragments
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);             // in flight under this tile's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < X3_BK / 16; ++kk)
+            x3_kstep<NP, TR, NARROW>(Afrag + kk * 16, Bfrag + kk * 16, kPlane, acc00, acc01, acc10, acc11);
+    }
+
+    if constexpr (!TR) {
+        // natural orientation: D[row m][col n], col = lane & 31 -> the 32 lanes of a half-wave hit 32 consecutive columns (coalesced atomics)
+#define X3_ATOMIC_EPI(acc_, i_, j_) { const int64_t c = n0 + wc * 64 + (j_) * 32 + l31; \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int64_t row = m0 + wr * (NARROW ? 32 : 64) + (i_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; \
+            if (row < M && c < N) epilogue_store<EPI, float>(e, row, c, acc_[r]); } }
+        X3_ATOMIC_EPI(acc00, 0, 0) X3_ATOMIC_EPI(acc01, 0, 1)
+        if constexpr (!NARROW) { X3_ATOMIC_EPI(acc10, 1, 0) X3_ATOMIC_EPI(acc11, 1, 1) }
+#undef X3_ATOMIC_EPI
+    } else {
+        // LDS-shuffled epilogue (gemm.hip): a lane owns one output row in the accumulators; each wave parks its 32 x 64 half-tile in LDS and re-reads
+        // it with 8 lanes per row -> 32-byte stores / auxiliary reads, full lines per row
+        const bool vec_ok = (e.ldo % 8 == 0) && (e.ldaux % 8 == 0);
+        float* stg = reinterpret_cast<float*>(lds_raw) + wave * 32 * GL_ST;
+        const int rr = lane >> 3, cc = (lane & 7) * 8;
+        const GnTile gnt = GN ? gn_tile(gn_tab, m0, n0, N, e.gn_hw) : GnTile{nullptr, 0, 0, 0};
+        GnRegs gnr;
+        if constexpr (GN) gn_zero(gnr);
+#define X3_SHUFFLE_HALF(accA_, accB_, i_)                                                                              \
+        __syncthreads();                                                                                               \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+            *reinterpret_cast<float4*>(stg + l31 * GL_ST + 8 * g + 4 * hi) = make_float4(accA_[4 * g], accA_[4 * g + 1], accA_[4 * g + 2], accA_[4 * g + 3]);      \
+            *reinterpret_cast<float4*>(stg + l31 * GL_ST + 32 + 8 * g + 4 * hi) = make_float4(accB_[4 * g], accB_[4 * g + 1], accB_[4 * g + 2], accB_[4 * g + 3]); \
+        }                                                                                                              \
+        __syncthreads();                                                                                               \
+        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                             \
+            const int lr = ps * 8 + rr;                                                                                \
+            const int64_t row = m0 + wr * (NARROW ? 32 : 64) + (i_) * 32 + lr, col0 = n0 + wc * 64 + cc;               \
+            float v8[8];                                                                                               \
+            ld8(stg + lr * GL_ST + cc, v8);                                                                            \
+            if (row < M && col0 < N) epilogue_store8<EPI, float>(e, row, col0, N, v8, vec_ok);                         \
+            if constexpr (GN) { if (row < M && col0 < N) gn_acc8<float>(gnr, gnt, v8, row); }                          \
+        }
+        X3_SHUFFLE_HALF(acc00, acc01, 0)
+        if constexpr (!NARROW) { X3_SHUFFLE_HALF(acc10, acc11, 1) }
+#undef X3_SHUFFLE_HALF
+        if constexpr (GN) {
+            gn_commit(gnr, gnt, lane, n0 + wc * 64 + cc, N);
+            __syncthreads();
+            gn_flush(gnt, e.gn_sums, m0, M, e.gn_hw, NARROW ? 64 : 128, tid, 256);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// TN:  dW[N,K] += Y[M,N]^T X[M,K]   (fp32 operands, fp32 atomics, split over M; dbias[N] += colsum(Y), exact fp32)
+// The MFMA fragments want 8 consecutive REDUCTION elements per lane while memory is N/K-contiguous: a thread loads an 8 (m) x 4 (column)
+// block with eight 16-byte loads and, while splitting, packs each column's 8 m-values into one 16-byte row of the M-contiguous LDS image
+// [column][m] -- the transpose is free (v_cvt_pk_bf16_f32 takes any two registers).
+// CONV: the weight gradient of a stride-1 3x3 SAME convolution, dW[co][tap*Cin + ci] += sum_m dY[m][co] X[m + shift(tap)][ci] inside(m, tap),
+// with the per-pixel 9-bit tap mask of maed_conv3x3_tapmask (a thread's 4 K-columns lie in one tap: Cin % 4 == 0).
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int NP, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ X, int64_t ldx,
+                                                            int64_t M, int N, int K, float* __restrict__ dW, int64_t ldw,
+                                                            float* __restrict__ dbias, int tiles_k, int mtiles_per_split, X3TnConv cv) {
+    constexpr int kPlane = 128 * X3_LD;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * NP * kPlane];     // [Y^T | X^T][plane][column][m]
+    __shared__ float lcs[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    // XCD-aware order: the workgroups of one M-split read the same rows of Y and X -> one XCD, its L2 serves the re-reads (gemm_tn.hip)
+    const int lin = xcd_remap((int)(blockIdx.z * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.z));
+    const int bx = lin % (int)gridDim.x, bz = lin / (int)gridDim.x;
+    const int tile_n = bx / tiles_k, tile_k = bx % tiles_k;
+    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const int nmt = (int)((M + X3_BK - 1) / X3_BK);
+    const int mt_beg = bz * mtiles_per_split;
+    int mt_end = mt_beg + mtiles_per_split;
+    if (mt_end > nmt) mt_end = nmt;
+    if (mt_beg >= mt_end) return;
+
+    // staging role: threads 0..127 transpose the Y tile, 128..255 the X tile; a thread owns rows mg*8 .. +7 and 4 columns
+    const int side = __builtin_amdgcn_readfirstlane(tid >> 7), st = tid & 127;
+    const int mg = st & 3, nc = st >> 2;
+    const float* src = side ? X : Y;
+    const int64_t ld = side ? ldx : ldy;
+    const int c0 = (side ? k0 : n0) + nc * 4;
+    const bool col_ok = c0 < (side ? K : N);                  // N, K are multiples of 4 (launcher)
+    int tap = 0, col_in = col_ok ? c0 : 0, shift = 0;
+    if constexpr (CONV) {
+        if (side) { tap = col_in / cv.Cin; col_in -= tap * cv.Cin; shift = (tap / 3 - 1) * cv.Wimg + (tap % 3 - 1); }
+    }
+    const float* const lane_src = src + ((int64_t)(mg * 8 + shift)) * ld + col_in;
+    unsigned short* const my_lds = lds + side * NP * kPlane + (nc * 4) * X3_LD + mg * 8;
+    const bool bias_blk = (dbias != nullptr) && (tile_k == (int)(bz % tiles_k));   // block-uniform: the K tile that takes the column sums rotates
+    const bool do_bias = bias_blk && (side == 0);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    float4 r[8];
+    auto load_tile = [&](int mt) {
+        const int64_t row0 = (int64_t)mt * X3_BK + mg * 8;
+        const float* tb = lane_src + (int64_t)mt * X3_BK * ld;
+        uint32_t mw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        bool masked = false;
+        if constexpr (CONV) masked = side != 0;
+        if (masked) { const uint4 mk = *reinterpret_cast<const uint4*>(cv.tapmask + row0); mw[0] = mk.x; mw[1] = mk.y; mw[2] = mk.z; mw[3] = mk.w; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bool ok = col_ok && (row0 + j < M);
+            if (masked) ok = ok && ((mw[j >> 1] >> ((j & 1) * 16 + tap)) & 1u);
+            r[j] = ok ? *reinterpret_cast<const float4*>(tb + (int64_t)j * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+#define X3_TN_COL(COMP, jj_) { \
+            uint2 p0[NP], p1[NP]; \
+            split4<NP>(r[0].COMP, r[1].COMP, r[2].COMP, r[3].COMP, p0); split4<NP>(r[4].COMP, r[5].COMP, r[6].COMP, r[7].COMP, p1); \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) \
+                *reinterpret_cast<uint4*>(my_lds + p * kPlane + (jj_) * X3_LD) = make_uint4(p0[p].x, p0[p].y, p1[p].x, p1[p].y); \
+            if (do_bias) cs[jj_] += ((r[0].COMP + r[1].COMP) + (r[2].COMP + r[3].COMP)) + ((r[4].COMP + r[5].COMP) + (r[6].COMP + r[7].COMP)); }
+        X3_TN_COL(x, 0) X3_TN_COL(y, 1) X3_TN_COL(z, 2) X3_TN_COL(w, 3)
+#undef X3_TN_COL
+    };
+
+    f32x16_t acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc00[q] = 0.f; acc01[q] = 0.f; acc10[q] = 0.f; acc11[q] = 0.f; }
+    const unsigned short* const Afrag = lds + (wr * 64 + l31) * X3_LD + hi * 8;
+    const unsigned short* const Bfrag = lds + NP * kPlane + (wc * 64 + l31) * X3_LD + hi * 8;
+
+    load_tile(mt_beg);
+    for (int mt = mt_beg; mt < mt_end; ++mt) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (mt + 1 < mt_end) load_tile(mt + 1);
+#pragma unroll
+        for (int kk = 0; kk < X3_BK / 16; ++kk)
+            x3_kstep<NP, false, false>(Afrag + kk * 16, Bfrag + kk * 16, kPlane, acc00, acc01, acc10, acc11);
+    }
+
+    // D[row n][col k]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*hi -> atomics of a half-wave hit 32 consecutive k
+#define X3_TN_EPI(acc_, i_, j_) { const int kcol = k0 + wc * 64 + (j_) * 32 + l31; \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) { const int nrow = n0 + wr * 64 + (i_) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi; \
+            if (nrow < N && kcol < K) atomicAdd(dW + (int64_t)nrow * ldw + kcol, acc_[q]); } }
+    X3_TN_EPI(acc00, 0, 0) X3_TN_EPI(acc01, 0, 1) X3_TN_EPI(acc10, 1, 0) X3_TN_EPI(acc11, 1, 1)
+#undef X3_TN_EPI
+
+    if (bias_blk) {   // block-uniform branch
+        if (side == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lcs[mg][nc * 4 + j] = cs[j];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float s = (lcs[0][tid] + lcs[1][tid]) + (lcs[2][tid] + lcs[3][tid]);
+            if (n0 + tid < N) atomicAdd(dbias + n0 + tid, s);
+        }
+    }
+}
+
+}  // namespace
+
+// ---- launchers (C++ linkage; called by the extern "C" entry points of gemm.hip / gemm_tn.hip) -----------------------------------------------
+
+bool maed_x3_nt_shape_ok(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t K) {
+    return K % X3_BK == 0 && lda % 4 == 0 && ldb % 4 == 0 && is_aligned(A, 16) && is_aligned(B, 16);
+}
+
+template <int EPI, int NP, bool NARROW, bool CONV, bool GN>
+static void launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const X3ConvDims& d, const EpiArgs& e,
+                      int splitk, hipStream_t s) {
+    const int tm = (int)((M + 127) / 128), tn = NARROW ? 1 : (int)((N + 127) / 128);
+    const int nkt = CONV ? 9 * d.Cin / X3_BK : (int)(K / X3_BK);
+    int kps = (nkt + splitk - 1) / splitk;
+    if (kps < 1) kps = 1;
+    const int z = (nkt + kps - 1) / kps;
+    hipLaunchKernelGGL((gemm_nt_x3_kernel<EPI, NP, NARROW, CONV, GN>), dim3((unsigned)(tm * tn), 1, (unsigned)z), dim3(256), 0, s, A, lda, B, ldb, M, N, K, tn, kps,
+                       d, e);
+}
+
+template <int EPI>
+static void launch_nt_np(int np, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e, int splitk,
+                         hipStream_t s) {
+    const X3ConvDims d{};
+    if (np == 3) launch_nt<EPI, 3, false, false, false>(A, lda, B, ldb, M, N, K, d, e, splitk, s);
+    else launch_nt<EPI, 2, false, false, false>(A, lda, B, ldb, M, N, K, d, e, splitk, s);
+}
+
+int maed_gemm_nt_x3_launch(int epilogue, int np, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e,
+                           int splitk, hipStream_t s) {
+    const float* a = (const float*)A; const float* b = (const float*)B;
+    switch (epilogue) {
+        case MAED_EPI_STORE: launch_nt_np<MAED_EPI_STORE>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
+        case MAED_EPI_GELU: launch_nt_np<MAED_EPI_GELU>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
+        case MAED_EPI_RESID_F32: launch_nt_np<MAED_EPI_RESID_F32>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
+        case MAED_EPI_MUL_DGELU: launch_nt_np<MAED_EPI_MUL_DGELU>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
+        case MAED_EPI_ATOMIC_F32: launch_nt_np<MAED_EPI_ATOMIC_F32>(np, a, lda, b, ldb, M, N, K, e, splitk, s); break;
+        case MAED_EPI_STORE_F32: launch_nt_np<MAED_EPI_STORE_F32>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
+        case MAED_EPI_TANH: launch_nt_np<MAED_EPI_TANH>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
+        case MAED_EPI_ADD: launch_nt_np<MAED_EPI_ADD>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
+        default: maed_set_error("gemm_nt(x3): bad epilogue %d", epilogue); return MAED_ERR_ARG;
+    }
+    return MAED_OK;
+}
+
+// 1x1 convolution: STORE epilogue (+ GroupNorm statistics of the stored fp32 output)
+int maed_conv1x1_x3_launch(int np, const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int Cout, int Cin, const EpiArgs& e, bool gn, hipStream_t s) {
+    const X3ConvDims d{};
+    const float* a = (const float*)x; const float* b = (const float*)w;
+    const bool narrow = Cout <= 64;
+#define X3_C1(NP_, NARROW_, GN_) launch_nt<MAED_EPI_STORE, NP_, NARROW_, false, GN_>(a, ldx, b, ldw, M, Cout, Cin, d, e, 1, s)
+    if (np == 3) { if (gn) { if (narrow) X3_C1(3, true, true); else X3_C1(3, false, true); } else { if (narrow) X3_C1(3, true, false); else X3_C1(3, false, false); } }
+    else { if (gn) { if (narrow) X3_C1(2, true, true); else X3_C1(2, false, true); } else { if (narrow) X3_C1(2, true, false); else X3_C1(2, false, false); } }
+#undef X3_C1
+    return MAED_OK;
+}
+
+// 3x3 implicit GEMM: STORE (+ GN) or ADD epilogue
+int maed_conv3x3_x3_launch(int np, const void* x, const void* w, const X3ConvDims& d, int64_t M, int Cout, const EpiArgs& e, bool add, bool gn, hipStream_t s) {
+    const float* a = (const float*)x; const float* b = (const float*)w;
+    const bool narrow = Cout <= 64;
+#define X3_C3(EPI_, NP_, NARROW_, GN_) launch_nt<EPI_, NP_, NARROW_, true, GN_>(a, 0, b, 0, M, Cout, 9 * (int64_t)d.Cin, d, e, 1, s)
+#define X3_C3_NP(NP_) \
+    if (add) { if (narrow) X3_C3(MAED_EPI_ADD, NP_, true, false); else X3_C3(MAED_EPI_ADD, NP_, false, false); } \
+    else if (gn) { if (narrow) X3_C3(MAED_EPI_STORE, NP_, true, true); else X3_C3(MAED_EPI_STORE, NP_, false, true); } \
+    else { if (narrow) X3_C3(MAED_EPI_STORE, NP_, true, false); else X3_C3(MAED_EPI_STORE, NP_, false, false); }
+    if (np == 3) { X3_C3_NP(3) } else { X3_C3_NP(2) }
+#undef X3_C3_NP
+#undef X3_C3
+    return MAED_OK;
+}
+
+int maed_gemm_tn_x3_launch(int np, const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw, float* dbias,
+                           const X3TnConv* conv, int target_wgs, hipStream_t s) {
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    const int nmt = (int)((M + X3_BK - 1) / X3_BK);
+    int splits = (target_wgs + tn * tk - 1) / (tn * tk);
+    if (splits > (nmt + 7) / 8) splits = (nmt + 7) / 8;      // at least 8 M-tiles (256 rows) per workgroup
+    if (splits < 1) splits = 1;
+    const int per = (nmt + splits - 1) / splits;
+    const int z = (nmt + per - 1) / per;
+    const dim3 grid(tn * tk, 1, z);
+    const X3TnConv cv = conv ? *conv : X3TnConv{nullptr, 0, 0};
+#define X3_TN(NP_, CONV_) hipLaunchKernelGGL((gemm_tn_x3_kernel<NP_, CONV_>), grid, dim3(256), 0, s, (const float*)Y, ldy, (const float*)X, ldx, M, N, K, dW, ldw, \
+                                             dbias, tk, per, cv)
+    if (np == 3) { if (conv) X3_TN(3, true); else X3_TN(3, false); }
+    else { if (conv) X3_TN(2, true); else X3_TN(2, false); }
+#undef X3_TN
+    return MAED_OK;
+}

@@ -1,0 +1,33 @@
+// Process-wide options of libmaed_hip (maed_set_option / maed_get_option, include/maed_hip.h).  They replace the environment variables the
+// library used to read at call time: the host (maed_amd/_lib.py) translates its own configuration into option values once after loading the
+// library; the kernels' launchers read them through maed_opt().
+#include "common.cuh"
+#include "gemm_x3.h"
+#include <atomic>
+
+static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
+    {0},      // MAED_OPT_F32_MATMUL: exact
+    {1},      // MAED_OPT_SIDE_STREAM
+    {384},    // MAED_OPT_TN_TARGET_WGS
+    {0},      // MAED_OPT_ABLATE
+};
+
+extern "C" int maed_set_option(int key, int value) {
+    MAED_CHECK_ARG(key >= 0 && key < MAED_OPT_COUNT, MAED_ERR_ARG, "set_option: unknown option %d", key);
+    if (key == MAED_OPT_F32_MATMUL) MAED_CHECK_ARG(value >= 0 && value <= 2, MAED_ERR_ARG, "set_option: MAED_OPT_F32_MATMUL takes 0 (exact), 1 (bf16x3) or 2 (bf16x6)");
+    if (key == MAED_OPT_TN_TARGET_WGS) MAED_CHECK_ARG(value >= 64, MAED_ERR_ARG, "set_option: MAED_OPT_TN_TARGET_WGS must be >= 64");
+    g_opt[key].store(value, std::memory_order_relaxed);
+    return MAED_OK;
+}
+
+extern "C" int maed_get_option(int key) {
+    if (key < 0 || key >= MAED_OPT_COUNT) { maed_set_error("get_option: unknown option %d", key); return MAED_ERR_ARG; }
+    return g_opt[key].load(std::memory_order_relaxed);
+}
+
+int maed_opt(int key) { return g_opt[key].load(std::memory_order_relaxed); }
+
+int maed_x3_planes(void) {
+    const int v = maed_opt(MAED_OPT_F32_MATMUL);
+    return v == 1 ? 2 : v == 2 ? 3 : 0;
+}

@@ -5,31 +5,9 @@
 #include "ktd_tables.cuh"
 
 // ---- K10: pose[f][6j+o] = base[f][6j+o] + sum_{slot,i} W_j[o][6*slot+i] * pose[f][6*anc(j,slot)+i] ------------
-__global__ void ktd_chain_kernel(const float* __restrict__ base, const float* __restrict__ w_anc, float* __restrict__ pose, int F) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    float ps[NJ * 6];
-    for (int i = 0; i < NJ * 6; ++i) ps[i] = base[(int64_t)f * NJ * 6 + i];
-    for (int j = 1; j < NJ; ++j) {
-        const int na = c_anc_cnt[j];
-        const float* W = w_anc + 36 * c_anc_start[j];  // (6, 6*na) row-major
-        float out[6];
-        for (int o = 0; o < 6; ++o) {
-            float s = ps[j * 6 + o];
-            for (int sl = 0; sl < na; ++sl) {
-                const int a = c_anc[c_anc_start[j] + sl];
-                for (int i = 0; i < 6; ++i) s = fmaf(W[o * 6 * na + sl * 6 + i], ps[a * 6 + i], s);
-            }
-            out[o] = s;
-        }
-        for (int o = 0; o < 6; ++o) ps[j * 6 + o] = out[o];
-    }
-    for (int i = 0; i < NJ * 6; ++i) pose[(int64_t)f * NJ * 6 + i] = ps[i];
-}
-
-// The same recurrence with the 6 outputs of a joint on 6 lanes (8 lanes per frame, 8 frames per 64-thread workgroup) and the pose in
-// LDS instead of a 576-B private array in scratch: every output keeps the serial kernel's fmaf chain (bit-identical results), the
-// dependent chain per frame drops from 3420 to 570 FMAs.  The thread-per-frame kernel above puts 128 frames on two waves.
+// The 6 outputs of a joint on 6 lanes (8 lanes per frame, 8 frames per 64-thread workgroup), the pose in LDS: every output is one fmaf chain over its
+// ancestors' elements in slot order, the dependent chain per frame is 570 FMAs (a thread-per-frame kernel: 3420, with the pose in scratch; it
+// was 4x slower on MI355X -- profiles/r02_call2_steady_*.csv -- and is gone).
 #define KC_FPB 8
 __global__ __launch_bounds__(64) void ktd_chain_par_kernel(const float* __restrict__ base, const float* __restrict__ w_anc, float* __restrict__ pose, int F) {
     __shared__ float ps[KC_FPB][NJ * 6];
@@ -54,18 +32,11 @@ __global__ __launch_bounds__(64) void ktd_chain_par_kernel(const float* __restri
         for (int i = o; i < NJ * 6; i += 8) pose[(int64_t)f * NJ * 6 + i] = ps[fs][i];
 }
 
-// The lane-parallel chain kernels are the default since they were timed on MI355X (profiles/r02_call2_steady_*.csv: the four chain kernels
-// 0.44 ms -> 0.1 ms per step); MAED_TAIL_PARALLEL=0 selects the thread-per-frame ones (A/B knob; the two are bit-identical,
-// tests/test_hostsim_tail.py)
-static bool tail_parallel() { return maed_env_flag("MAED_TAIL_PARALLEL", true); }   // read per call: a getenv, three times per step
 
 extern "C" int maed_ktd_chain_fwd(const float* base, const float* w_anc, float* pose, int F, void* stream) {
     MAED_CHECK_ARG(base && w_anc && pose, MAED_ERR_ARG, "ktd_chain_fwd: null pointer");
     if (F <= 0) return MAED_OK;
-    if (tail_parallel())
-        hipLaunchKernelGGL(ktd_chain_par_kernel, dim3((F + KC_FPB - 1) / KC_FPB), dim3(64), 0, (hipStream_t)stream, base, w_anc, pose, F);
-    else
-        hipLaunchKernelGGL(ktd_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, base, w_anc, pose, F);
+    hipLaunchKernelGGL(ktd_chain_par_kernel, dim3((F + KC_FPB - 1) / KC_FPB), dim3(64), 0, (hipStream_t)stream, base, w_anc, pose, F);
     MAED_CHECK_LAUNCH("ktd_chain_fwd");
     return MAED_OK;
 }
@@ -131,48 +102,9 @@ extern "C" int maed_rot6d_pose_fwd(const float* pose6d, float* rotmat, float* an
 }
 
 // ---- K12: SMPL LBS (smplx.lbs.lbs, pose2rot=False) ---------------------------------------
-// kernel A: one thread per frame walks the kinematic chain -> A (24 x 3x4 skinning transforms) + posed joints
-__global__ void lbs_chain_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
-                                 float* __restrict__ joints24, float* __restrict__ A, int F) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    float J[NJ][3], Rw[NJ][9], tw[NJ][3];
-    const float* b = betas + (int64_t)f * 10;
-    for (int j = 0; j < NJ; ++j)
-        for (int c = 0; c < 3; ++c) {
-            float s = sp.J_template[j * 3 + c];
-            for (int l = 0; l < 10; ++l) s = fmaf(sp.J_shapedirs[(j * 3 + c) * 10 + l], b[l], s);
-            J[j][c] = s;
-        }
-    const float* R = rotmat + (int64_t)f * NJ * 9;
-    for (int j = 0; j < NJ; ++j) {
-        const int p = sp.parents[j];
-        const float* Rj = R + j * 9;
-        if (p < 0) {
-            for (int k = 0; k < 9; ++k) Rw[j][k] = Rj[k];
-            for (int c = 0; c < 3; ++c) tw[j][c] = J[j][c];
-        } else {
-            float rel[3] = {J[j][0] - J[p][0], J[j][1] - J[p][1], J[j][2] - J[p][2]};
-            for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c)
-                    Rw[j][r * 3 + c] = Rw[p][r * 3 + 0] * Rj[0 * 3 + c] + Rw[p][r * 3 + 1] * Rj[1 * 3 + c] + Rw[p][r * 3 + 2] * Rj[2 * 3 + c];
-                tw[j][r] = Rw[p][r * 3 + 0] * rel[0] + Rw[p][r * 3 + 1] * rel[1] + Rw[p][r * 3 + 2] * rel[2] + tw[p][r];
-            }
-        }
-    }
-    for (int j = 0; j < NJ; ++j) {
-        float* Aj = A + ((int64_t)f * NJ + j) * 12;
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) Aj[r * 4 + c] = Rw[j][r * 3 + c];
-            Aj[r * 4 + 3] = tw[j][r] - (Rw[j][r * 3 + 0] * J[j][0] + Rw[j][r * 3 + 1] * J[j][1] + Rw[j][r * 3 + 2] * J[j][2]);
-            joints24[((int64_t)f * NJ + j) * 3 + r] = tw[j][r];
-        }
-    }
-}
-
-// lane-parallel variant (default; MAED_TAIL_PARALLEL=0 = thread per frame): 16 lanes per frame, 4 frames per workgroup, J / Rw / tw in LDS.  The 72 rest-pose
-// joint coordinates, the 12 outputs of each joint's transform and the 24 x 15 outputs are spread over the lanes; every scalar is
-// produced by the same expression as in lbs_chain_kernel (bit-identical), the tree is still walked joint by joint (any parent table).
+// kernel A: the kinematic chain -> A (24 x 3x4 skinning transforms) + posed joints.  16 lanes per frame, 4 frames per workgroup, J / Rw / tw in LDS: the
+// 72 rest-pose joint coordinates, the 12 outputs of each joint's transform and the 24 x 15 outputs are spread over the lanes, the tree is walked
+// joint by joint (any parent table).
 #define LC_FPB 4
 __global__ __launch_bounds__(64) void lbs_chain_par_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
                                                            float* __restrict__ joints24, float* __restrict__ A, int F) {
@@ -293,10 +225,7 @@ extern "C" int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas,
                    MAED_ERR_ARG, "smpl_lbs_fwd: null SMPL parameter");
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (tail_parallel())
-        hipLaunchKernelGGL(lbs_chain_par_kernel, dim3((F + LC_FPB - 1) / LC_FPB), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
-    else
-        hipLaunchKernelGGL(lbs_chain_kernel, dim3((F + 63) / 64), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
+    hipLaunchKernelGGL(lbs_chain_par_kernel, dim3((F + LC_FPB - 1) / LC_FPB), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
     hipLaunchKernelGGL(lbs_skin_kernel, dim3((NV + 255) / 256, (F + LBS_FB - 1) / LBS_FB), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
     MAED_CHECK_LAUNCH("smpl_lbs_fwd");
     return MAED_OK;

@@ -143,89 +143,10 @@ extern "C" int maed_smpl_skin_bwd(const maed_smpl_params* sp, const float* A, co
 }
 
 // ---- K12 backward, kinematic chain -----------------------------------------------------------------------------------------
-// thread per frame (mirror of lbs_chain_kernel): recompute J, Rw, tw, then walk the tree from the leaves.
+// recompute J, Rw, tw, then walk the tree from the leaves.
 //   forward:  Rw_j = Rw_p R_j,  tw_j = Rw_p (J_j - J_p) + tw_p,  A_j = [Rw_j | tw_j - Rw_j J_j],  joints24_j = tw_j
-__global__ void smpl_chain_bwd_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
-                                      const float* __restrict__ dA, const float* __restrict__ d_j24, const float* __restrict__ dpf_dbeta,
-                                      const float* __restrict__ d_rot_in, const float* __restrict__ d_betas_in, int64_t betas_in_stride,
-                                      float* __restrict__ d_rotmat, float* __restrict__ d_betas, int F) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    float J[NJ][3], Rw[NJ][9], tw[NJ][3], gRw[NJ][9], gtw[NJ][3], gJ[NJ][3];
-    const float* b = betas + (int64_t)f * 10;
-    for (int j = 0; j < NJ; ++j)
-        for (int c = 0; c < 3; ++c) {
-            float s = sp.J_template[j * 3 + c];
-            for (int l = 0; l < 10; ++l) s = fmaf(sp.J_shapedirs[(j * 3 + c) * 10 + l], b[l], s);
-            J[j][c] = s;
-        }
-    const float* R = rotmat + (int64_t)f * NJ * 9;
-    for (int j = 0; j < NJ; ++j) {
-        const int p = sp.parents[j];
-        const float* Rj = R + j * 9;
-        if (p < 0) {
-            for (int k = 0; k < 9; ++k) Rw[j][k] = Rj[k];
-            for (int c = 0; c < 3; ++c) tw[j][c] = J[j][c];
-        } else {
-            const float rel[3] = {J[j][0] - J[p][0], J[j][1] - J[p][1], J[j][2] - J[p][2]};
-            for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c)
-                    Rw[j][r * 3 + c] = Rw[p][r * 3 + 0] * Rj[0 * 3 + c] + Rw[p][r * 3 + 1] * Rj[1 * 3 + c] + Rw[p][r * 3 + 2] * Rj[2 * 3 + c];
-                tw[j][r] = Rw[p][r * 3 + 0] * rel[0] + Rw[p][r * 3 + 1] * rel[1] + Rw[p][r * 3 + 2] * rel[2] + tw[p][r];
-            }
-        }
-    }
-    // outputs -> chain variables
-    for (int j = 0; j < NJ; ++j) {
-        const float* g = dA + ((int64_t)f * NJ + j) * 12;
-        const float* gj = d_j24 + ((int64_t)f * NJ + j) * 3;
-        for (int c = 0; c < 3; ++c) gJ[j][c] = 0.f;
-        for (int r = 0; r < 3; ++r) {
-            const float gt = g[r * 4 + 3];                       // d trel_j[r]
-            for (int c = 0; c < 3; ++c) {
-                gRw[j][r * 3 + c] = g[r * 4 + c] - gt * J[j][c];
-                gJ[j][c] -= Rw[j][r * 3 + c] * gt;
-            }
-            gtw[j][r] = gt + gj[r];
-        }
-    }
-    float* gR = d_rotmat + (int64_t)f * NJ * 9;
-    const float* gin = d_rot_in ? d_rot_in + (int64_t)f * NJ * 9 : nullptr;
-    const float* gpf = dpf_dbeta + (int64_t)f * 217;
-    for (int j = NJ - 1; j >= 1; --j) {
-        const int p = sp.parents[j];
-        const float* Rj = R + j * 9;
-        const float rel[3] = {J[j][0] - J[p][0], J[j][1] - J[p][1], J[j][2] - J[p][2]};
-        for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < 3; ++c) {
-                const float s = Rw[p][0 * 3 + a] * gRw[j][0 * 3 + c] + Rw[p][1 * 3 + a] * gRw[j][1 * 3 + c] + Rw[p][2 * 3 + a] * gRw[j][2 * 3 + c];
-                gR[j * 9 + a * 3 + c] = s + gpf[(j - 1) * 9 + a * 3 + c] + (gin ? gin[j * 9 + a * 3 + c] : 0.f);
-            }
-        for (int r = 0; r < 3; ++r)
-            for (int a = 0; a < 3; ++a)
-                gRw[p][r * 3 + a] += gRw[j][r * 3 + 0] * Rj[a * 3 + 0] + gRw[j][r * 3 + 1] * Rj[a * 3 + 1] + gRw[j][r * 3 + 2] * Rj[a * 3 + 2]
-                                     + gtw[j][r] * rel[a];
-        for (int a = 0; a < 3; ++a) {
-            const float grel = Rw[p][0 * 3 + a] * gtw[j][0] + Rw[p][1 * 3 + a] * gtw[j][1] + Rw[p][2 * 3 + a] * gtw[j][2];
-            gJ[j][a] += grel; gJ[p][a] -= grel;
-        }
-        for (int r = 0; r < 3; ++r) gtw[p][r] += gtw[j][r];
-    }
-    for (int k = 0; k < 9; ++k) gR[k] = gRw[0][k] + (gin ? gin[k] : 0.f);
-    for (int c = 0; c < 3; ++c) gJ[0][c] += gtw[0][c];
-    const float* bi = d_betas_in ? d_betas_in + (int64_t)f * betas_in_stride : nullptr;
-    for (int l = 0; l < 10; ++l) {
-        float s = gpf[207 + l] + (bi ? bi[l] : 0.f);
-        for (int j = 0; j < NJ; ++j)
-            for (int c = 0; c < 3; ++c) s = fmaf(sp.J_shapedirs[(j * 3 + c) * 10 + l], gJ[j][c], s);
-        d_betas[(int64_t)f * 10 + l] = s;
-    }
-}
-
-// lane-parallel variant (default; MAED_TAIL_PARALLEL=0 = thread per frame): 32 lanes per frame, 2 frames per workgroup, all chain state in LDS (2.9 KB per frame
-// that the kernel above keeps in scratch).  Every scalar is produced by the expression the serial kernel uses, joints are still
-// visited one after another where the recurrence requires it (children accumulate into their parent in the same order), so the
-// results are bit-identical; what runs in parallel are the independent outputs of each step.
+// 32 lanes per frame, 2 frames per workgroup, all chain state in LDS (2.9 KB per frame).  Joints are visited one after another where the
+// recurrence requires it (children accumulate into their parent in a fixed order); what runs in parallel are the independent outputs of each step.
 #define SC_FPB 2
 __global__ __launch_bounds__(64) void smpl_chain_bwd_par_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
                                                                 const float* __restrict__ dA, const float* __restrict__ d_j24,
@@ -320,12 +241,8 @@ extern "C" int maed_smpl_chain_bwd(const maed_smpl_params* sp, const float* beta
     MAED_CHECK_ARG(sp && betas && rotmat && dA && d_joints24 && dpf_dbeta && d_rotmat && d_betas, MAED_ERR_ARG, "smpl_chain_bwd: null pointer");
     MAED_CHECK_ARG(sp->J_template && sp->J_shapedirs && sp->parents, MAED_ERR_ARG, "smpl_chain_bwd: null SMPL parameter");
     if (F <= 0) return MAED_OK;
-    if (maed_env_flag("MAED_TAIL_PARALLEL", true))
-        hipLaunchKernelGGL(smpl_chain_bwd_par_kernel, dim3((F + SC_FPB - 1) / SC_FPB), dim3(64), 0, (hipStream_t)stream, *sp, betas, rotmat, dA,
-                           d_joints24, dpf_dbeta, d_rotmat_in, d_betas_in, betas_in_stride, d_rotmat, d_betas, F);
-    else
-        hipLaunchKernelGGL(smpl_chain_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, *sp, betas, rotmat, dA, d_joints24, dpf_dbeta,
-                           d_rotmat_in, d_betas_in, betas_in_stride, d_rotmat, d_betas, F);
+    hipLaunchKernelGGL(smpl_chain_bwd_par_kernel, dim3((F + SC_FPB - 1) / SC_FPB), dim3(64), 0, (hipStream_t)stream, *sp, betas, rotmat, dA,
+                       d_joints24, dpf_dbeta, d_rotmat_in, d_betas_in, betas_in_stride, d_rotmat, d_betas, F);
     MAED_CHECK_LAUNCH("smpl_chain_bwd");
     return MAED_OK;
 }
@@ -405,32 +322,8 @@ extern "C" int maed_rot6d_pose_bwd(const float* pose6d, const float* d_rotmat, c
 // ---- K10 backward ---------------------------------------------------------------------------------------------------------------
 // pose_j = base_j + sum_slot W_j[:, slot] pose_anc(j,slot):  walking j = 23..1, g_anc += W_j[:, slot]^T g_j (ancestors have
 // smaller indices, so g_j is final when j is visited).  d_base = g.
-__global__ void ktd_chain_bwd_kernel(const float* __restrict__ w_anc, const float* __restrict__ d_pose, const float* __restrict__ d_shape,
-                                     const float* __restrict__ d_cam, float* __restrict__ d_out, int64_t ld, int F) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    float g[NJ * 6];
-    for (int i = 0; i < NJ * 6; ++i) g[i] = d_pose[(int64_t)f * NJ * 6 + i];
-    for (int j = NJ - 1; j >= 1; --j) {
-        const int na = c_anc_cnt[j];
-        const float* W = w_anc + 36 * c_anc_start[j];
-        for (int sl = 0; sl < na; ++sl) {
-            const int a = c_anc[c_anc_start[j] + sl];
-            for (int i = 0; i < 6; ++i) {
-                float s = g[a * 6 + i];
-                for (int o = 0; o < 6; ++o) s = fmaf(W[o * 6 * na + sl * 6 + i], g[j * 6 + o], s);
-                g[a * 6 + i] = s;
-            }
-        }
-    }
-    float* o = d_out + (int64_t)f * ld;
-    for (int i = 0; i < NJ * 6; ++i) o[i] = g[i];
-    for (int i = 0; i < 10; ++i) o[144 + i] = d_shape ? d_shape[(int64_t)f * 10 + i] : 0.f;
-    for (int i = 0; i < 3; ++i) o[154 + i] = d_cam ? d_cam[(int64_t)f * 3 + i] : 0.f;
-}
-
-// lane-parallel variant (default; MAED_TAIL_PARALLEL=0 = thread per frame): 16 lanes per frame, 4 frames per workgroup, g in LDS.  The 6*n_anc(j) gradient
-// elements joint j feeds (distinct (ancestor, i) pairs) are updated by different lanes with the serial kernel's fmaf chain over o.
+// 16 lanes per frame, 4 frames per workgroup, g in LDS.  The 6*n_anc(j) gradient elements joint j feeds (distinct (ancestor, i) pairs) are
+// updated by different lanes, each with one fmaf chain over o.
 #define KB_FPB 4
 __global__ __launch_bounds__(64) void ktd_chain_bwd_par_kernel(const float* __restrict__ w_anc, const float* __restrict__ d_pose,
                                                                const float* __restrict__ d_shape, const float* __restrict__ d_cam,
@@ -487,11 +380,8 @@ extern "C" int maed_ktd_chain_bwd(const float* pose, const float* w_anc, const f
     MAED_CHECK_ARG(pose && w_anc && d_pose && d_out && d_w_anc && d_b_feat, MAED_ERR_ARG, "ktd_chain_bwd: null pointer");
     MAED_CHECK_ARG(ld_out >= KTD_OUT, MAED_ERR_SHAPE, "ktd_chain_bwd: ld_out=%lld < 157", (long long)ld_out);
     hipStream_t s = (hipStream_t)stream;
-    const bool parallel = maed_env_flag("MAED_TAIL_PARALLEL", true);
-    if (F > 0 && parallel)
+    if (F > 0)
         hipLaunchKernelGGL(ktd_chain_bwd_par_kernel, dim3((F + KB_FPB - 1) / KB_FPB), dim3(64), 0, s, w_anc, d_pose, d_shape, d_cam, d_out, ld_out, F);
-    else if (F > 0)
-        hipLaunchKernelGGL(ktd_chain_bwd_kernel, dim3((F + 63) / 64), dim3(64), 0, s, w_anc, d_pose, d_shape, d_cam, d_out, ld_out, F);
     hipLaunchKernelGGL(ktd_wanc_bwd_kernel, dim3((MAED_KTD_W_ANC + KTD_OUT + 127) / 128), dim3(128), 0, s, pose, d_out, ld_out, d_w_anc, d_b_feat, F);
     MAED_CHECK_LAUNCH("ktd_chain_bwd");
     return MAED_OK;

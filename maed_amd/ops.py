@@ -36,6 +36,34 @@ def on_library_device(t):
 SIM_MODULE_PATHS = True     # tests may switch the simulator's module-level paths off (tests/_hostsim.patched(module_paths=False))
 
 
+# ---- fp32 matmul precision (the analogue of torch.set_float32_matmul_precision) -------------------------------------------------
+# compute_dtype=torch.float32 keeps every activation and weight in fp32; what this chooses is the engine of the fp32 matrix products:
+#   "exact"   fp32 FMA chains on the VALU (bit-for-bit parity mode; convolutions on MIOpen) -- the default
+#   "bf16x3"  every operand split into two bf16 terms, three MFMAs per product, fp32 accumulation: error ~2^-16 per product (csrc/gemm_x3.hip)
+#   "bf16x6"  three terms, six MFMAs: fp32-level error
+# Process-wide (a library option: MAED_OPT_F32_MATMUL), like torch's flag; MAED_F32_MATMUL in the environment sets the initial value.
+_F32_MODES = {"exact": 0, "highest": 0, "bf16x3": 1, "high": 1, "bf16x6": 2}
+
+
+def set_float32_matmul_precision(mode):
+    L.set_option(L.OPT_F32_MATMUL, _F32_MODES[mode])
+
+
+def get_float32_matmul_precision():
+    return ("exact", "bf16x3", "bf16x6")[L.get_option(L.OPT_F32_MATMUL)]
+
+
+def f32_split():
+    """True when fp32 matrix products run on the split-bf16 MFMA kernels: the library's own GEMM / convolution / weight-gradient entry points then
+    take fp32 operands, and the f32 mode follows the bf16 mode's code paths (no transposed copies, no MIOpen)"""
+    return L.get_option(L.OPT_F32_MATMUL) != 0
+
+
+def lib_matmul_dtype(dtype):
+    """dtypes whose matrix products have library kernels for every role (forward, input gradient, weight gradient straight from row-major operands)"""
+    return dtype == torch.bfloat16 or (dtype == torch.float32 and f32_split())
+
+
 def dt_code(dtype):
     if dtype == torch.float32:
         return F32
@@ -55,7 +83,7 @@ def _stream():
 # record_stream keeps the caching allocator from handing the operands' memory out while the side stream still reads them;
 # side_stream_join() orders the caller's stream after everything issued so far (WeightStdFn.backward calls it before it reads the dW slices).
 # MAED_WGRAD_SIDE_STREAM=0: everything on the caller's stream (A/B knob; the STE blocks' C++ driver reads the same variable).
-_SIDE_ON = os.environ.get("MAED_WGRAD_SIDE_STREAM", "1") == "1"
+_SIDE_ON = L.get_option(L.OPT_SIDE_STREAM) == 1
 _SIDE = {}
 
 
@@ -383,6 +411,10 @@ class LinearFn(torch.autograd.Function):
         x, weight, bias = ctx.saved_tensors
         dy = _c(dy)
         db = torch.zeros_like(bias) if bias is not None else None
+        if lib_matmul_dtype(dy.dtype) and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0:
+            dW = gemm_tn_wgrad(dy, x, dbias=db)
+            dx = gemm_nt(dy, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
+            return dx, dW, db, None
         dyt, _ = transpose_cast(dy, dy.dtype, colsum=db)
         xt, _ = transpose_cast(x, x.dtype)
         tiles = max(1, (weight.shape[0] // 128) * (weight.shape[1] // 128))
@@ -533,7 +565,7 @@ class WeightStdFn(ReportingFn):
         weights = [_c(w) for w in weights]
         # convolutions that run on the library's own kernels: they also get the transposed image and an fp32 dW slice
         direct = getattr(owner, "_direct_convs", None)
-        gemm = set((direct if direct is not None else getattr(owner, "_gemm_convs", ())) or ()) if dtype != torch.float32 else set()
+        gemm = set((direct if direct is not None else getattr(owner, "_gemm_convs", ())) or ()) if lib_matmul_dtype(dtype) else set()
         tab, _, nf, total, t_offs = _ws_table(weights, transposed=gemm)
         dev = weights[0].device
         out = torch.empty(total, dtype=dtype, device=dev)

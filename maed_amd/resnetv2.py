@@ -116,7 +116,7 @@ class StdConv2dSame(nn.Conv2d):
             return None
         cpg = out_channels // 32
         hw = (-(-x_shape[-2] // stride)) * (-(-x_shape[-1] // stride))
-        if out_channels % 32 or cpg < 2 or cpg & (cpg - 1) or hw < 128 or x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3] * 2 >= 1 << 32:
+        if out_channels % 32 or cpg < 2 or cpg & (cpg - 1) or hw < 128 or x_shape[0] * x_shape[1] * x_shape[2] * x_shape[3] * 2 >= 1 << 32:     # (bf16 kernels: 32-bit byte offsets)
             return None
         gn._stats_ready = True
         return gn._sums_buf
@@ -130,7 +130,7 @@ class StdConv2dSame(nn.Conv2d):
             # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
             return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]), self.stride[0], lazy_short)
         assert not fork
-        if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and x.dtype == torch.bfloat16
+        if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and ops.lib_matmul_dtype(x.dtype)
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and self.dilation == (1, 1) and self.groups == 1):
             # implicit-GEMM forward / stride-1 input gradient on libmaed_hip instead of MIOpen
             # (_w_t / _dw: transposed image and fp32 dW slice from WeightStdFn for the stride-1 ones, see ResNetV2._own3x3)

@@ -27,7 +27,7 @@ def _wgrad(dy, x, need_bias):
     """(dW fp32 [N,K], db fp32 [N] or None) for y = x W^T + b; dy (M,N), x (M,K) in the same compute dtype"""
     N, K = dy.shape[1], x.shape[1]
     db = torch.zeros(N, dtype=torch.float32, device=dy.device) if need_bias else None
-    if dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0:
+    if ops.lib_matmul_dtype(dy.dtype) and N % 8 == 0 and K % 8 == 0:
         dW = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
         ops.gemm_tn_wgrad(dy, x, dW, db)
         return dW, db

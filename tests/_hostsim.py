@@ -19,6 +19,7 @@ def load():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
     assert h.maed_version() < 0, "this must be the simulator, not the product library"
+    L.apply_options(h)          # the host's option values (fp32 matmul mode, side stream ...) as the product library would get them
     return h
 
 

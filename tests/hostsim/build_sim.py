@@ -22,14 +22,14 @@ ASAN = os.environ.get("MAED_SIM_ASAN", "0") not in ("", "0")
 SAN = ["-fsanitize=thread"] if TSAN else ["-fsanitize=address"] if ASAN else []
 OUT_DIR = os.path.join(HERE, "_build_tsan" if TSAN else "_build_asan" if ASAN else "_build")
 OUT = os.path.join(OUT_DIR, "libmaed_hostsim.so")
-SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip", "attn_long.hip"]
+SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip", "attn_long.hip", "gemm_x3.hip", "options.hip"]
 CLANG = os.environ.get("MAED_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 def build(force=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + [os.path.join(HERE, "sim_support.cpp")]
-    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "gemm_epilogue.cuh"), os.path.join(CSRC, "dual.cuh"),
-                   os.path.join(CSRC, "ktd_tables.cuh"), os.path.join(ROOT, "include", "maed_hip.h")]
+    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))) + [
+        os.path.join(ROOT, "include", "maed_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)

@@ -1,0 +1,189 @@
+"""The split-bf16 ("bf16x3" / "bf16x6") fp32 GEMM family of csrc/gemm_x3.hip on the host simulator: fp32 operands split into 2 / 3 bf16 planes
+while staging, 3 / 6 MFMAs per product.  Checks the plane / fragment / staging index algebra of the NT kernel (all fused epilogues, ragged
+edges, split-K atomics, narrow tiles, GroupNorm statistics), the gathered 3x3 implicit GEMM (forward, transposed-image input gradient, any
+stride), the transposing TN weight-gradient kernel (+ bias gradient, ragged M, the 3x3 tap mask) -- and that the ERROR is what the scheme
+promises: ~2^-16 of |a||b| for x3, fp32 level for x6 (vs 2^-8 for plain bf16), measured against fp64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from maed_amd import _lib as L
+from maed_amd import ops
+
+from _hostsim import patched
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / 2 ** 0.5))
+
+
+def dgelu(x):
+    return 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+
+
+def bound(A, B, np_):
+    """elementwise error bound of the split product: eps * (|A| |B|^T) with eps = 2^-15 (x3: 3 * 2^-18 dropped terms + fp32 accumulation) / 2^-21 (x6)"""
+    return (A.abs().double() @ B.abs().double().t()) * (2.0 ** -15 if np_ == 2 else 2.0 ** -21)
+
+
+@pytest.fixture
+def x3_mode():
+    """process-wide fp32 matmul mode = bf16x3 for the duration of a test"""
+    old = ops.get_float32_matmul_precision()
+    ops.set_float32_matmul_precision("bf16x3")
+    yield
+    ops.set_float32_matmul_precision(old)
+
+
+@pytest.mark.parametrize("impl,np_", [(L.IMPL_X3, 2), (L.IMPL_X6, 3)])
+@pytest.mark.parametrize("M,N,K", [(130, 136, 96), (64, 256, 32), (257, 72, 160)])
+def test_gemm_nt_x3_store_and_error_level(impl, np_, M, N, K):
+    A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = A.double() @ B.double().t() + bias.double()
+    with patched():
+        out = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias, impl=impl)
+    err = (out.double() - ref).abs()
+    assert (err <= bound(A, B, np_) + 1e-6 * ref.abs()).all(), (err.max().item(), bound(A, B, np_).max().item())
+    # and it is NOT merely bf16: plain bf16 operands would be ~2^-9 relative
+    assert err.max() <= 1e-4 * ref.abs().max()
+
+
+@pytest.mark.parametrize("epi", ["gelu", "resid", "dgelu", "store_f32", "tanh", "add", "add_mask"])
+def test_gemm_nt_x3_fused_epilogues(epi):
+    M, N, K = 96, 200, 64
+    A, B, bias = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6)
+    acc = (A.double() @ B.double().t()).float()
+    tol = dict(rtol=1e-4, atol=1e-4)
+    with patched():
+        if epi == "gelu":
+            out, pre = ops.gemm_nt(A, B, L.EPI_GELU, bias=bias, impl=L.IMPL_X3)
+            assert torch.allclose(pre, acc + bias, **tol) and torch.allclose(out, gelu(pre), **tol)
+        elif epi == "resid":
+            aux = rnd(M, N, seed=7)
+            assert torch.allclose(ops.gemm_nt(A, B, L.EPI_RESID_F32, bias=bias, aux=aux, impl=L.IMPL_X3), aux + acc + bias, **tol)
+        elif epi == "dgelu":
+            aux = rnd(M, N, seed=8)
+            assert torch.allclose(ops.gemm_nt(A, B, L.EPI_MUL_DGELU, aux=aux, impl=L.IMPL_X3), acc * dgelu(aux), **tol)
+        elif epi == "store_f32":
+            assert torch.allclose(ops.gemm_nt(A, B, L.EPI_STORE_F32, bias=bias, impl=L.IMPL_X3), acc + bias, **tol)
+        elif epi == "tanh":
+            assert torch.allclose(ops.gemm_nt(A, B, L.EPI_TANH, bias=bias, impl=L.IMPL_X3), torch.tanh(acc + bias), **tol)
+        elif epi == "add":
+            aux = rnd(M, N, seed=9)
+            assert torch.allclose(ops.gemm_nt(A, B, L.EPI_ADD, aux=aux, impl=L.IMPL_X3), acc + aux, **tol)
+        else:
+            aux = rnd(M, N, seed=9)
+            keep = torch.rand(M, N, generator=torch.Generator().manual_seed(34)) > 0.4
+            bits = (keep.view(M, N // 8, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(-1).to(torch.uint8).contiguous()
+            assert torch.allclose(ops.gemm_nt(A, B, L.EPI_ADD, aux=aux, out2=bits, impl=L.IMPL_X3), acc + aux * keep, **tol)
+
+
+def test_gemm_nt_x3_splitk_atomic_and_auto_dispatch(x3_mode):
+    M, N, K = 70, 128, 256
+    A, B = rnd(M, K, seed=10), rnd(N, K, seed=11, scale=K ** -0.5)
+    ref = A.double() @ B.double().t()
+    with patched():
+        out = ops.gemm_nt(A, B, L.EPI_ATOMIC_F32, splitk=2)                  # AUTO + mode bf16x3 -> the split kernel, K range per z
+        exact = ops.gemm_nt(A, B, L.EPI_STORE, impl=L.IMPL_VALU)            # the exact kernel stays selectable
+        few = ops.gemm_nt(A, B, L.EPI_STORE)                                # few tiles: AUTO keeps the exact split-K route
+        Ab, Bb = rnd(1024, 64, seed=12), rnd(768, 64, seed=13)
+        many = ops.gemm_nt(Ab, Bb, L.EPI_STORE)                             # 48 tiles: AUTO takes the split kernel
+    assert (out.double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+    assert torch.allclose(exact.double(), ref, rtol=1e-5, atol=1e-5) and torch.allclose(few.double(), ref, rtol=1e-5, atol=1e-5)
+    refm = Ab.double() @ Bb.double().t()
+    errm = (many.double() - refm).abs().max()
+    assert 1e-7 * refm.abs().max() < errm <= 1e-4 * refm.abs().max()          # split arithmetic, not the exact kernel and not bf16
+
+
+@pytest.mark.parametrize("Cout,hw", [(64, 128), (256, 196)])
+def test_conv1x1_x3_with_groupnorm_statistics(x3_mode, Cout, hw):
+    Fr, Cin = 2, 64
+    M = Fr * hw
+    x, w = rnd(M, Cin, seed=20), rnd(Cout, Cin, seed=21, scale=Cin ** -0.5)
+    sums = torch.zeros(Fr, 32, 2, dtype=torch.float64)
+    y = torch.empty(M, Cout)
+    with patched() as lib:
+        L.check(lib.maed_conv1x1_fwd(x.data_ptr(), Cin, w.data_ptr(), Cin, M, Cout, Cin, y.data_ptr(), Cout, hw, sums.data_ptr(), L.F32, None), "conv1x1")
+    ref = x.double() @ w.double().t()
+    assert (y.double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+    g = y.double().view(Fr, hw, 32, Cout // 32)
+    want = torch.stack([g.sum((1, 3)), (g * g).sum((1, 3))], -1)
+    assert torch.allclose(sums, want, rtol=1e-5, atol=1e-3)          # per-lane fp32 partials, fp64 across lanes
+
+
+def _conv_ref(x, w, stride):
+    """TF-SAME 3x3 convolution in fp64 (resnetv2.py:51-59 padding)"""
+    H, W = x.shape[-2:]
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw = max((Ho - 1) * stride + 3 - H, 0), max((Wo - 1) * stride + 3 - W, 0)
+    xp = F.pad(x.double(), [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+    return F.conv2d(xp, w.double(), None, stride)
+
+
+@pytest.mark.parametrize("stride,H,W,Cin,Cout", [(1, 9, 7, 32, 64), (2, 10, 9, 64, 136), (1, 6, 6, 64, 72)])
+def test_conv3x3_x3_forward(x3_mode, stride, H, W, Cin, Cout):
+    N = 3
+    x = rnd(N, Cin, H, W, seed=30).contiguous(memory_format=torch.channels_last)
+    w = rnd(Cout, Cin, 3, 3, seed=31, scale=(9 * Cin) ** -0.5)
+    w_taps = w.permute(0, 2, 3, 1).contiguous()
+    ref = _conv_ref(x, w, stride)
+    with patched():
+        y = ops.conv3x3(x, w_taps, stride)
+        add = rnd(*ref.shape, seed=32).contiguous(memory_format=torch.channels_last)
+        y2 = ops.conv3x3(x, w_taps, stride, add=add)
+    assert y.shape == ref.shape and (y.double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+    assert (y2.double() - ref - add.double()).abs().max() <= 1e-4 * ref.abs().max()
+
+
+def test_conv3x3_x3_input_gradient_from_transposed_image_and_wgrad(x3_mode):
+    N, Cin, Cout, H, W = 2, 32, 64, 8, 8          # N*H*W = 128 (the weight-gradient kernel needs a multiple of 32)
+    x = rnd(N, Cin, H, W, seed=40).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=41, scale=(9 * Cin) ** -0.5).requires_grad_(True)
+    dy = rnd(N, Cout, H, W, seed=42).contiguous(memory_format=torch.channels_last)
+    y = F.conv2d(x.double(), w.double(), None, 1, 1)
+    gx, gw = torch.autograd.grad(y, (x, w), dy.double())
+    wt = w.detach().permute(2, 3, 1, 0).contiguous()          # transposed image (3,3,I,O) as maed_weight_std_fwd writes it
+    with patched():
+        dx = ops.conv3x3(dy, wt, 1, w_layout=1)
+        dW = ops.conv3x3_wgrad(dy, x.detach())
+    assert (dx.double() - gx).abs().max() <= 1e-4 * gx.abs().max()
+    assert (dW.permute(0, 3, 1, 2).double() - gw).abs().max() <= 1e-4 * gw.abs().max()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 72), (64, 128, 128), (37, 8, 8), (130, 64, 256)])
+def test_gemm_tn_x3_wgrad_and_bias(x3_mode, M, N, K):
+    Y, X = rnd(M, N, seed=12), rnd(M, K, seed=13)
+    dW0, db0 = rnd(N, K, seed=14), rnd(N, seed=15)
+    dW, db = dW0.clone(), db0.clone()
+    with patched():
+        ops.gemm_tn_wgrad(Y, X, dW=dW, dbias=db)          # ACCUMULATES into dW / dbias
+    ref = Y.double().t() @ X.double()
+    assert ((dW - dW0).double() - ref).abs().max() <= 1e-4 * ref.abs().max()
+    assert torch.allclose(db, db0 + Y.sum(0), rtol=1e-5, atol=1e-4)      # the bias gradient is exact fp32
+
+
+def test_gemm_tn_x6_is_fp32_level():
+    M, N, K = 256, 128, 128
+    Y, X = rnd(M, N, seed=16), rnd(M, K, seed=17)
+    ref = Y.double().t() @ X.double()
+    old = ops.get_float32_matmul_precision()
+    try:
+        ops.set_float32_matmul_precision("bf16x6")
+        with patched():
+            dW = ops.gemm_tn_wgrad(Y, X)
+    finally:
+        ops.set_float32_matmul_precision(old)
+    assert (dW.double() - ref).abs().max() <= 2e-6 * ref.abs().max()
+
+
+def test_f32_library_convolutions_need_the_split_mode():
+    """in the exact mode the entry points without an exact fp32 kernel refuse fp32 (loudly: no silent precision change)"""
+    assert ops.get_float32_matmul_precision() == "exact"
+    Y, X = rnd(64, 8, seed=1), rnd(64, 8, seed=2)
+    with patched():
+        with pytest.raises(L.MaedHipError, match="split-bf16"):
+            ops.gemm_tn_wgrad(Y, X)
