@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--f32-matmul", default=None, choices=["exact", "bf16x3", "bf16x6"],
+                    help="--dtype f32 only: engine of the fp32 matrix products (maed_amd.set_float32_matmul_precision); default: MAED_F32_MATMUL or exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="cfg2: inference forward instead of the train step")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"], help="cfg3 = BASELINE's metric workload (default); cfg5 = long-clip stress")
@@ -177,6 +179,9 @@ def main():
     from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
     from maed_amd.loss import LossVideo
     lib = L.lib()  # raises if libmaed_hip.so is missing: no fallback
+    if args.f32_matmul:
+        import maed_amd
+        maed_amd.set_float32_matmul_precision(args.f32_matmul)
 
     log(f"building model ({args.dtype}) on {dev}")
     model = build_model(dtype, dev)

@@ -41,13 +41,9 @@ def test_attn_spatial_fwd_bwd(name, dtype, impl, Fr, P, H):
     close(dqkv.float(), x.grad, **tol(dtype, 0.5))
 
 
-@pytest.mark.parametrize("l32", ["0", "1"])          # MAED_TM_BWD_L32: one-tile specialisation of the MFMA backward (T <= 32)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,T,P,H", [(2, 3, 5, 2), (1, 16, 9, 1), (1, 64, 3, 1)])
-def test_attn_temporal_fwd_bwd(dtype, N, T, P, H, l32, monkeypatch):
-    if l32 == "1" and (dtype != torch.bfloat16 or T > 32):
-        pytest.skip("the specialisation only exists for bf16 sequences of one 32-row tile")
-    monkeypatch.setenv("MAED_TM_BWD_L32", l32)
+@pytest.mark.parametrize("N,T,P,H", [(2, 3, 5, 2), (1, 16, 9, 1), (1, 64, 3, 1)])       # bf16: one-tile backward (T <= 32) and the general one (T = 64)
+def test_attn_temporal_fwd_bwd(dtype, N, T, P, H):
     Fr = N * T
     qkv = q(rnd(Fr, P, 3 * 64 * H, seed=5), dtype)
     do = q(rnd(Fr, P, 64 * H, seed=6), dtype)
@@ -62,15 +58,17 @@ def test_attn_temporal_fwd_bwd(dtype, N, T, P, H, l32, monkeypatch):
     close(dqkv.float(), x.grad, **tol(dtype, 0.5))
 
 
-@pytest.mark.parametrize("dtype,impl,ln_defer", [(torch.float32, 0, "0"), (torch.bfloat16, 0, "0"), (torch.bfloat16, 0, "1")])
-def test_ste_block_forward_backward_vs_oracle(dtype, impl, ln_defer, monkeypatch):
-    """one whole Block through maed_ste_block_fwd/bwd (vision_transformer.py:244-261) incl. every parameter gradient; f32 parity mode,
-    bf16 MFMA throughput mode, and the latter with LayerNorm dgamma/dbeta through per-workgroup partials (MAED_LN_DEFER_AFFINE=1)"""
-    monkeypatch.setenv("MAED_LN_DEFER_AFFINE", ln_defer)
+@pytest.mark.parametrize("dtype,f32_mode,rows", [(torch.float32, "exact", 9), (torch.float32, "bf16x3", 20), (torch.float32, "bf16x6", 9), (torch.bfloat16, "exact", 9),
+                                                 (torch.bfloat16, "exact", 20)])
+def test_ste_block_forward_backward_vs_oracle(dtype, f32_mode, rows):
+    """one whole Block through maed_ste_block_fwd/bwd (vision_transformer.py:244-261) incl. every parameter gradient: f32 parity mode (exact VALU
+    kernels + transposed copies), f32 on the split-bf16 MFMA kernels (bf16x3 / bf16x6: the bf16 mode's kernel sequence on fp32 operands) and the
+    bf16 MFMA throughput mode; 20 tokens x 2 frames = 40 rows = 2 LayerNorm workgroups for the dgamma / dbeta partials"""
+    impl = 0
     from functools import partial
     import torch.nn as nn
     from maed_amd.vision_transformer import Block
-    N, T, P, H = 1, 2, (20 if ln_defer == "1" else 9), 2          # 40 rows = 2 LayerNorm workgroups of 32 rows for the partials path
+    N, T, P, H = 1, 2, rows, 2
     C, Fr = 64 * H, N * T
     p = {k[len("encoder.blocks.0."):]: v for k, v in R.make_params(embed_dim=C, depth=1, hidden_dim=64, layers=(1, 1, 1), n_tokens=P, seed=3).items()
          if k.startswith("encoder.blocks.0.")}
@@ -83,11 +81,16 @@ def test_ste_block_forward_backward_vs_oracle(dtype, impl, ln_defer, monkeypatch
     blk = Block(C, H, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", compute_dtype=dtype, impl=impl)
     blk.load_state_dict(p)
     xg = x.clone().requires_grad_(True)
-    with patched():
-        y = blk(xg, T)
-        y.backward(dy)
+    old = ops.get_float32_matmul_precision()
+    try:
+        ops.set_float32_matmul_precision(f32_mode)
+        with patched():
+            y = blk(xg, T)
+            y.backward(dy)
+    finally:
+        ops.set_float32_matmul_precision(old)
     f32 = dtype == torch.float32
-    tl = dict(rtol=1e-4, atol=1e-4) if f32 else dict(rtol=3e-2, atol=3e-2)
+    tl = (dict(rtol=3e-4, atol=3e-4) if f32_mode == "bf16x3" else dict(rtol=1e-4, atol=1e-4)) if f32 else dict(rtol=3e-2, atol=3e-2)
     close(y.detach(), yref.detach(), **tl)
     close(xg.grad, xr.grad, **tl)
     for name, prm in blk.named_parameters():

@@ -33,10 +33,8 @@ def test_maxpool_same_matches_aten_with_ties(N, C, H, W):
     assert torch.allclose(xs.grad, xr.grad, atol=1e-6), (xs.grad - xr.grad).abs().max()
 
 
-@pytest.mark.parametrize("defer_affine", ["0", "1"])      # MAED_GN_DEFER_AFFINE: dgamma/dbeta from the per-frame partials instead of atomics
 @pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, False), (False, True)])
-def test_groupnorm_fused_matches_aten(relu, res, defer_affine, monkeypatch):
-    monkeypatch.setenv("MAED_GN_DEFER_AFFINE", defer_affine)
+def test_groupnorm_fused_matches_aten(relu, res):
     torch.manual_seed(1)
     N, C, H, W = 2, 64, 5, 6
     x = torch.randn(N, C, H, W); r = torch.randn(N, C, H, W) if res else None

@@ -142,38 +142,3 @@ def test_forward_without_backward_does_not_block_the_readiness_report():
         assert ktd._pending_backwards == 1
         (pose.sum() + shape.sum() + cam.sum()).backward()
     assert fired == [ktd] and ktd._pending_backwards == 0
-
-
-def test_lane_parallel_chain_kernels_are_bit_identical_to_the_serial_ones(monkeypatch):
-    """MAED_TAIL_PARALLEL=1 (ktd_chain_par / ktd_chain_bwd_par / lbs_chain_par): same fmaf chains, spread over lanes -> torch.equal.
-    (End-to-end gradients are not compared bitwise: the skinning backward reduces with LDS atomics in thread-arrival order.)"""
-    from maed_amd import _lib as L, ops
-    ktd = make_ktd(seed=5)
-    F_ = 11                                                      # ragged last workgroup for every frames-per-workgroup choice
-    g = torch.Generator().manual_seed(2)
-    x = torch.randn(F_, 48, generator=g)
-    w_anc = torch.randn(L.KTD_W_ANC, generator=g) * 0.2
-    pose_in, d_pose = torch.randn(F_, 144, generator=g), torch.randn(F_, 144, generator=g)
-    d_shape, d_cam = torch.randn(F_, 10, generator=g), torch.randn(F_, 3, generator=g)
-    from maed_amd.geometry import rot6d_to_rotmat
-    chain_in = dict(betas=torch.randn(F_, 10, generator=g), rotmat=rot6d_to_rotmat(torch.randn(F_ * 24, 6, generator=g)).reshape(F_, 24, 9).contiguous(),
-                    dA=torch.randn(F_, 24, 12, generator=g), d_j24=torch.randn(F_, 24, 3, generator=g), dpf=torch.randn(F_, 217, generator=g),
-                    d_rot_in=torch.randn(F_, 24, 9, generator=g), d_theta=torch.randn(F_, 85, generator=g))
-    outs = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("MAED_TAIL_PARALLEL", flag)
-        with patched() as lib, torch.no_grad():
-            inf = ktd.get_output(*ktd._head_hip(x), None, hip=True)          # ktd_chain_fwd + lbs_chain (+ everything downstream)
-            d_out, d_w, d_b = torch.empty(F_, 160), torch.empty(L.KTD_W_ANC), torch.empty(157)
-            L.check(lib.maed_ktd_chain_bwd(ops._p(pose_in), ops._p(w_anc), ops._p(d_pose), ops._p(d_shape), ops._p(d_cam), ops._p(d_out), 160,
-                                           ops._p(d_w), ops._p(d_b), F_, None), "ktd_chain_bwd")
-            # SMPL kinematic-chain backward on fixed inputs
-            import ctypes as C
-            sp = ktd.smpl._c_params()
-            d_rotmat, d_betas = torch.empty(F_, 24, 9), torch.empty(F_, 10)
-            L.check(lib.maed_smpl_chain_bwd(C.byref(sp), ops._p(chain_in["betas"]), ops._p(chain_in["rotmat"]), ops._p(chain_in["dA"]),
-                                            ops._p(chain_in["d_j24"]), ops._p(chain_in["dpf"]), ops._p(chain_in["d_rot_in"]),
-                                            ops._p(chain_in["d_theta"]) + 4 * 75, 85, ops._p(d_rotmat), ops._p(d_betas), F_, None), "smpl_chain_bwd")
-        outs[flag] = [inf[k] for k in ("theta", "verts", "kp_3d", "kp_2d", "rotmat")] + [d_out[:, :157].clone(), d_w, d_b, d_rotmat, d_betas]
-    for a, b in zip(outs["0"], outs["1"]):
-        assert torch.equal(a, b)
