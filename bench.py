@@ -42,11 +42,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s 
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 
-def build_model(dtype, device):
+def build_model(dtype, device, backbone_f32_matmul=None):
     import maed_amd
     torch.manual_seed(0)
     m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["heads"], embed_dim=CFG["dim"], hidden_dim=CFG["hidden"],
-                      img_size=CFG["img"], max_seqlen=max(16, CFG["T"]), compute_dtype=dtype)
+                      img_size=CFG["img"], max_seqlen=max(16, CFG["T"]), compute_dtype=dtype, backbone_f32_matmul=backbone_f32_matmul)
     return m.to(device)
 
 
@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="cfg2: inference forward instead of the train step")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"], help="cfg3 = BASELINE's metric workload (default); cfg5 = long-clip stress")
+    ap.add_argument("--backbone-f32-matmul", default=None, choices=["bf16x3", "bf16x6"],
+                    help="--dtype f32 only: the backbone's own engine (MAED(backbone_f32_matmul=...)); default: the process-wide mode")
     args = ap.parse_args()
 
     if args.workload == "cfg5":   # BASELINE.json configs[4]: long-clip stress (per-GPU clips stated in config.workload)
@@ -184,7 +186,7 @@ def main():
         maed_amd.set_float32_matmul_precision(args.f32_matmul)
 
     log(f"building model ({args.dtype}) on {dev}")
-    model = build_model(dtype, dev)
+    model = build_model(dtype, dev, args.backbone_f32_matmul)
     gen = torch.Generator().manual_seed(1000 + rank)
     clip = torch.randn(CFG["clips"], CFG["T"], 3, CFG["img"], CFG["img"], generator=gen).to(dev)
     tgt = make_targets(CFG["clips"], CFG["T"], dev, gen)

@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-typedef enum { MAED_F32 = 0, MAED_BF16 = 1 } maed_dtype;
+typedef enum { MAED_F32 = 0, MAED_BF16 = 1,
+               /* fp32 STORAGE with an explicit matrix-product engine (the per-call form of MAED_OPT_F32_MATMUL; accepted by the matrix-product entry
+                * points maed_gemm_nt, maed_gemm_tn_wgrad, maed_conv1x1_fwd, maed_conv3x3_fwd, maed_conv3x3_wgrad): split-bf16 with 3 / 6 MFMAs per product */
+               MAED_F32X3 = 2, MAED_F32X6 = 3 } maed_dtype;
 
 typedef enum {
     MAED_OK = 0,

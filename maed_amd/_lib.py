@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAED_HIP_LIB") or os.path.join(HERE, "libmaed_hip.so")   # override: A/B builds of the same C-ABI
 
 F32, BF16 = 0, 1
+F32X3, F32X6 = 2, 3     # fp32 storage with an explicit matrix-product engine (split-bf16, 3 / 6 MFMAs per product): matrix-product entry points only
 EPI_STORE, EPI_GELU, EPI_RESID_F32, EPI_MUL_DGELU, EPI_ATOMIC_F32, EPI_STORE_F32, EPI_TANH, EPI_ADD = range(8)
 IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles

@@ -13,6 +13,7 @@
 //  * generic-T VALU kernels (f32 parity mode, and the backward of both modes in this round):
 //    thread per row, the other side's matrices broadcast-read from LDS.
 #include "common.cuh"
+#include "gemm_x3.h"
 
 #define D HEAD_DIM
 
@@ -566,7 +567,12 @@ extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F
     hipStream_t s = (hipStream_t)stream;
     const bool use_mfma = (dtype == MAED_BF16) && (impl != MAED_IMPL_VALU);
     MAED_CHECK_ARG(!((impl == MAED_IMPL_MFMA || impl == MAED_IMPL_MFMA_LONG) && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED,
-                   "attn_spatial_fwd: MFMA path is bf16 only");
+                   "attn_spatial_fwd: the bf16 MFMA kernels need bf16 (f32: MAED_IMPL_X3 / _X6 or the process-wide fp32 matmul mode)");
+    // fp32 q/k/v with split-bf16 contractions on the matrix cores (attn_x3.hip): explicitly, or when the process-wide fp32 matmul mode asks for it
+    if (dtype == MAED_F32 && impl != MAED_IMPL_VALU) {
+        const int np = impl == MAED_IMPL_X3 ? 2 : impl == MAED_IMPL_X6 ? 3 : maed_x3_planes();
+        if (np) return maed_attn_x3_fwd_launch(np, qkv, o, lse, F, P, H, scale, s);
+    }
     // the K/V-tiled kernels (128 query rows per workgroup, 64-key LDS tiles, lazy rescale): for sequences that do not fit one workgroup's
     // LDS (st_mode='coupling': T*P tokens) -- and by default, since they measured faster than the whole-head kernel at the frame sizes of
     // the path too (MI355X, profiles/r02_call1_attn_long_micro.txt: P = 197 33.9 vs 37.0 us, P = 257 71.7 vs 89.0 us).
@@ -612,8 +618,12 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
     MAED_CHECK_ARG(qkv && o && d_o && lse && dqkv, MAED_ERR_ARG, "attn_spatial_bwd: null pointer");
     MAED_CHECK_ARG(F >= 0 && P > 0 && H > 0, MAED_ERR_SHAPE, "attn_spatial_bwd: bad extents");
     MAED_CHECK_ARG(!((impl == MAED_IMPL_MFMA || impl == MAED_IMPL_MFMA_LONG) && dtype != MAED_BF16), MAED_ERR_UNSUPPORTED,
-                   "attn_spatial_bwd: MFMA path is bf16 only");
+                   "attn_spatial_bwd: the bf16 MFMA kernels need bf16 (f32: MAED_IMPL_X3 / _X6 or the process-wide fp32 matmul mode)");
     if (F == 0) return MAED_OK;
+    if (dtype == MAED_F32 && impl != MAED_IMPL_VALU) {
+        const int np = impl == MAED_IMPL_X3 ? 2 : impl == MAED_IMPL_X6 ? 3 : maed_x3_planes();
+        if (np) return maed_attn_x3_bwd_launch(np, qkv, o, d_o, lse, dqkv, accumulate, F, P, H, scale, (hipStream_t)stream);
+    }
     const bool mfma_fits = ((P + 31) / 32) <= 10;  // 640-thread workgroups (register budget 168/lane)
     // the tiled two-pass backward is the default for every length since its round-2 rework (delta from staged chunks, transposing LDS reads, trimmed
     // score arithmetic): P = 197 108.5 vs 147.7 us for the whole-head kernels, P = 257 (third row tile holds ONE row) 252.6 vs 314.1 us

@@ -495,8 +495,9 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
                    "conv3x3_fwd: GroupNorm statistics need Cout = 32 * 2^k >= 64, Ho*Wo >= 128 and no `add` (Cout=%d Ho*Wo=%d)", Cout, Ho * Wo);
     MAED_CHECK_ARG(w_layout == 0 || w_layout == 1, MAED_ERR_ARG, "conv3x3_fwd: w_layout must be 0 (Cout,3,3,Cin) or 1 (transposed image of the forward weight)");
     MAED_CHECK_ARG(x && w_taps && zero_page && y, MAED_ERR_ARG, "conv3x3_fwd: null pointer");
+    const int np_call = maed_x3_take_dtype(dtype);
     MAED_CHECK_ARG(dtype == MAED_BF16 || dtype == MAED_F32, MAED_ERR_ARG, "conv3x3_fwd: bad dtype %d", dtype);
-    const int x3np = dtype == MAED_F32 ? maed_x3_planes() : 0;
+    const int x3np = dtype == MAED_F32 ? (np_call ? np_call : maed_x3_planes()) : 0;
     MAED_CHECK_ARG(dtype == MAED_BF16 || x3np, MAED_ERR_UNSUPPORTED, "conv3x3_fwd: f32 needs the split-bf16 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL, 1 or 2))");
     MAED_CHECK_ARG(F >= 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride >= 1 && pad_top >= 0 && pad_left >= 0, MAED_ERR_SHAPE, "conv3x3_fwd: bad extents");
     MAED_CHECK_ARG(Cin % (dtype == MAED_F32 ? 32 : GM_BK) == 0 && Cout % 8 == 0, MAED_ERR_SHAPE, "conv3x3_fwd: need Cin %% 64 == 0 (f32: 32) and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
@@ -594,8 +595,7 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         // (ts_attn, the decoder head: M = frames) keep the exact split-K VALU route below -- a 128-row tile would leave most of the chip idle.
         const int np = impl == MAED_IMPL_X3 ? 2 : impl == MAED_IMPL_X6 ? 3 : impl == MAED_IMPL_AUTO ? maed_x3_planes() : 0;
         if (np) {
-            const bool ok = maed_x3_nt_shape_ok(A, lda, B, ldb, K);
-            MAED_CHECK_ARG(ok || impl == MAED_IMPL_AUTO, MAED_ERR_ALIGN, "gemm_nt(x3): need K%%32==0 (K=%lld), lda/ldb%%4==0, 16-B aligned A/B", (long long)K);
+            const bool ok = maed_x3_nt_shape_ok(A, lda, B, ldb, K);       // (otherwise: the exact kernel below -- never less accurate than asked for)
             const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
             if (ok && (impl != MAED_IMPL_AUTO || tiles128 >= 48 || EPI == MAED_EPI_ATOMIC_F32))
                 return maed_gemm_nt_x3_launch(EPI, np, A, lda, B, ldb, M, N, K, e, splitk, s);
@@ -663,12 +663,13 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
 extern "C" int maed_conv1x1_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int Cout, int Cin, void* y, int64_t ldy, int hw,
                                 double* gn_sums, int dtype, void* stream) {
     MAED_CHECK_ARG(x && w && y, MAED_ERR_ARG, "conv1x1_fwd: null pointer");
+    const int np_call = maed_x3_take_dtype(dtype);
     MAED_CHECK_ARG(dtype == MAED_BF16 || dtype == MAED_F32, MAED_ERR_ARG, "conv1x1_fwd: bad dtype %d", dtype);
     MAED_CHECK_ARG(is_aligned(x, 16) && is_aligned(w, 16) && is_aligned(y, 16), MAED_ERR_ALIGN, "conv1x1_fwd: 16-B alignment");
     MAED_CHECK_ARG(!gn_sums || gn_stats_shape_ok(Cout, hw), MAED_ERR_SHAPE, "conv1x1_fwd: GroupNorm statistics need Cout = 32 * 2^k >= 64 and hw >= 128 (Cout=%d hw=%d)", Cout, hw);
     EpiArgs e{nullptr, y, ldy, nullptr, nullptr, 0, gn_sums, hw};
     if (dtype == MAED_F32) {        // fp32 operands on the split-bf16 MFMA kernel (gemm_x3.hip)
-        const int x3np = maed_x3_planes();
+        const int x3np = np_call ? np_call : maed_x3_planes();
         MAED_CHECK_ARG(x3np, MAED_ERR_UNSUPPORTED, "conv1x1_fwd: f32 needs the split-bf16 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL, 1 or 2))");
         MAED_CHECK_ARG(M >= 0 && Cout > 0 && Cin > 0 && ldx >= Cin && ldw >= Cin && ldy >= Cout && ldy % 4 == 0 && maed_x3_nt_shape_ok(x, ldx, w, ldw, Cin), MAED_ERR_SHAPE,
                        "conv1x1_fwd(f32): need Cin %% 32 == 0 and 4-element aligned strides (Cin=%d Cout=%d)", Cin, Cout);
@@ -691,6 +692,10 @@ extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
                             int dtype, int epilogue, const float* bias, void* out, int64_t ldo, void* out2,
                             const void* aux, int64_t ldaux, int splitk, int impl, void* stream) {
     MAED_CHECK_ARG(A && B && out, MAED_ERR_ARG, "gemm_nt: null pointer");
+    {   // MAED_F32X3 / MAED_F32X6: fp32 storage with an explicit engine = MAED_F32 + impl MAED_IMPL_X3 / _X6
+        const int np_call = maed_x3_take_dtype(dtype);
+        if (np_call && impl == MAED_IMPL_AUTO) impl = np_call == 2 ? MAED_IMPL_X3 : MAED_IMPL_X6;
+    }
     MAED_CHECK_ARG(dtype == MAED_F32 || dtype == MAED_BF16, MAED_ERR_ARG, "gemm_nt: bad dtype %d", dtype);
     MAED_CHECK_ARG(M >= 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldo >= N, MAED_ERR_SHAPE, "gemm_nt: bad extents M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     if (splitk < 1) splitk = 1;

@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
 extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw,
                                   float* dbias, int dtype, void* stream) {
     MAED_CHECK_ARG(Y && X && dW, MAED_ERR_ARG, "gemm_tn_wgrad: null pointer");
+    const int np_call = maed_x3_take_dtype(dtype);
     if (dtype == MAED_F32) {        // fp32 operands on the split-bf16 MFMA kernel (gemm_x3.hip)
-        const int np = maed_x3_planes();
+        const int np = np_call ? np_call : maed_x3_planes();
         MAED_CHECK_ARG(np, MAED_ERR_UNSUPPORTED, "gemm_tn_wgrad: f32 needs the split-bf16 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL, 1 or 2)); the exact mode uses "
                                                  "transposed copies + gemm_nt");
         MAED_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldw >= K, MAED_ERR_SHAPE,
@@ -267,13 +268,14 @@ extern "C" int maed_conv3x3_tapmask(void* mask, int F, int H, int W, void* strea
 extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tapmask, const void* zero_page, float* dW, int F, int H, int W, int Cin,
                                   int Cout, int dtype, void* stream) {
     MAED_CHECK_ARG(dy && x && tapmask && zero_page && dW, MAED_ERR_ARG, "conv3x3_wgrad: null pointer");
+    const int np_call = maed_x3_take_dtype(dtype);
     MAED_CHECK_ARG(dtype == MAED_BF16 || dtype == MAED_F32, MAED_ERR_ARG, "conv3x3_wgrad: bad dtype %d", dtype);
     const int64_t M = (int64_t)F * H * W;
     const int N = Cout, K = 9 * Cin;
     if (dtype == MAED_F32) {        // fp32 operands on the split-bf16 MFMA kernel (gemm_x3.hip)
-        const int np = maed_x3_planes();
+        const int np = np_call ? np_call : maed_x3_planes();
         MAED_CHECK_ARG(np, MAED_ERR_UNSUPPORTED, "conv3x3_wgrad: f32 needs the split-bf16 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL, 1 or 2))");
-        MAED_CHECK_ARG(M > 0 && M % 32 == 0 && Cin % 4 == 0 && Cout % 4 == 0, MAED_ERR_SHAPE, "conv3x3_wgrad(f32): F*H*W = %lld must be a multiple of 32, Cin / Cout of 4", (long long)M);
+        MAED_CHECK_ARG(M > 0 && Cin % 4 == 0 && Cout % 4 == 0, MAED_ERR_SHAPE, "conv3x3_wgrad(f32): Cin / Cout must be multiples of 4 (Cin=%d Cout=%d)", Cin, Cout);
         MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16) && is_aligned(tapmask, 16), MAED_ERR_ALIGN, "conv3x3_wgrad: 16-B alignment");
         const X3TnConv cv{(const uint16_t*)tapmask, Cin, W};
         MAED_PROPAGATE(maed_gemm_tn_x3_launch(np, dy, (int64_t)Cout, x, (int64_t)Cin, M, N, K, dW, (int64_t)K, nullptr, &cv, 384, (hipStream_t)stream));

@@ -28,20 +28,6 @@
 
 namespace {
 
-// 4 consecutive fp32 -> NP planes of 4 bf16 (2 dwords per plane)
-template <int NP>
-__device__ __forceinline__ void split4(float r0, float r1, float r2, float r3, uint2 (&pl)[NP]) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const uint32_t w0 = pack_bf2(r0, r1), w1 = pack_bf2(r2, r3);
-        pl[p] = make_uint2(w0, w1);
-        if (p + 1 < NP) {
-            r0 -= __uint_as_float(w0 << 16); r1 -= __uint_as_float(w0 & 0xffff0000u);
-            r2 -= __uint_as_float(w1 << 16); r3 -= __uint_as_float(w1 & 0xffff0000u);
-        }
-    }
-}
-
 // one K step (16) of a wave's 2x2 (or 1x2) block of 32x32 tiles from the split LDS planes; TR: accumulators hold the transposed tiles
 template <int NP, bool TR, bool HALF_ROWS>
 __device__ __forceinline__ void x3_kstep(const unsigned short* Ap, const unsigned short* Bp, int plane_elems, f32x16_t& acc00, f32x16_t& acc01,

@@ -21,13 +21,15 @@ from .vision_transformer import vit_custom_resnet50_224_in21k
 class MAED(nn.Module):
     def __init__(self, encoder='ste', num_blocks=6, num_heads=12, st_mode='parallel', decoder='ktd', hidden_dim=1024,
                  embed_dim=768, max_seqlen=16, img_size=224, compute_dtype=torch.bfloat16, impl=L.IMPL_AUTO,
-                 smpl_arrays=None, **kwargs):
+                 smpl_arrays=None, backbone_f32_matmul=None, **kwargs):
         super().__init__()
         self.encoder_type = encoder
         if encoder.lower() != 'ste':
             raise NotImplementedError(encoder)       # maed.py:41 ('cnn' = stage-1 torchvision ResNet-50: out of scope)
         self.encoder = vit_custom_resnet50_224_in21k(num_blocks, num_heads, st_mode, embed_dim=embed_dim, img_size=img_size,
                                                      max_seqlen=max_seqlen, compute_dtype=compute_dtype, impl=impl)
+        # compute_dtype = float32: the backbone's own fp32 matmul engine (resnetv2.ResNetV2.f32_matmul); None = the process-wide mode
+        self.encoder.patch_embed.backbone.f32_matmul = backbone_f32_matmul
         self.decoder_type = decoder
         if decoder.lower() == 'ktd':                 # maed.py:24-29
             self.decoder = KTD(feat_dim=self.encoder.num_features, hidden_dim=hidden_dim, smpl_arrays=smpl_arrays)

@@ -59,9 +59,18 @@ def f32_split():
     return L.get_option(L.OPT_F32_MATMUL) != 0
 
 
-def lib_matmul_dtype(dtype):
-    """dtypes whose matrix products have library kernels for every role (forward, input gradient, weight gradient straight from row-major operands)"""
-    return dtype == torch.bfloat16 or (dtype == torch.float32 and f32_split())
+def lib_matmul_dtype(dtype, prec=None):
+    """dtypes whose matrix products have library kernels for every role (forward, input gradient, weight gradient straight from row-major operands);
+    prec: a module's own fp32 engine ("bf16x3" / "bf16x6", see mm_code), which counts like the process-wide mode"""
+    return dtype == torch.bfloat16 or (dtype == torch.float32 and (f32_split() or prec in ("bf16x3", "bf16x6")))
+
+
+def mm_code(dtype, prec=None):
+    """dtype code for the matrix-product entry points: fp32 tensors of a module with its own engine (ResNetV2.f32_matmul) go as MAED_F32X3 / MAED_F32X6,
+    everything else as dt_code (fp32 then follows the process-wide mode)"""
+    if dtype == torch.float32 and prec in ("bf16x3", "bf16x6"):
+        return L.F32X3 if prec == "bf16x3" else L.F32X6
+    return dt_code(dtype)
 
 
 def dt_code(dtype):
@@ -190,17 +199,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
     return (dx, dgamma, dbeta, twin) if want_twin else (dx, dgamma, dbeta)
 
 
-def gemm_tn_wgrad(Y, X, dW=None, dbias=None):
-    """dW[N,K] += Y[M,N]^T X[M,K]; dbias[N] += colsum(Y)   (bf16 operands, fp32 accumulators)"""
+def gemm_tn_wgrad(Y, X, dW=None, dbias=None, prec=None):
+    """dW[N,K] += Y[M,N]^T X[M,K]; dbias[N] += colsum(Y)   (bf16 operands, or fp32 ones on the split-bf16 kernels; fp32 accumulators)"""
     M, N = Y.shape
     K = X.shape[1]
     dW = torch.zeros(N, K, dtype=torch.float32, device=Y.device) if dW is None else dW
-    check(L.lib().maed_gemm_tn_wgrad(_p(Y), Y.stride(0), _p(X), X.stride(0), M, N, K, _p(dW), dW.stride(0), _p(dbias), dt_code(Y.dtype), _stream()),
+    check(L.lib().maed_gemm_tn_wgrad(_p(Y), Y.stride(0), _p(X), X.stride(0), M, N, K, _p(dW), dW.stride(0), _p(dbias), mm_code(Y.dtype, prec), _stream()),
           "gemm_tn_wgrad")
     return dW
 
 
-def gemm_nt(A, B, epilogue=L.EPI_STORE, bias=None, out=None, out2=None, aux=None, splitk=1, impl=L.IMPL_AUTO, M=None, K=None):
+def gemm_nt(A, B, epilogue=L.EPI_STORE, bias=None, out=None, out2=None, aux=None, splitk=1, impl=L.IMPL_AUTO, M=None, K=None, prec=None):
     """out = epilogue(A[M,K] @ B[N,K]^T).  A/B in the compute dtype (f32 or bf16); bias fp32.
     EPI_ADD: out2 (optional, uint8) = 1 bit per element of aux: aux is masked by it before the add (GroupNormFn's lazily masked residual gradient)."""
     assert A.dim() == 2 and B.dim() == 2 and A.dtype == B.dtype
@@ -213,7 +222,7 @@ def gemm_nt(A, B, epilogue=L.EPI_STORE, bias=None, out=None, out2=None, aux=None
         out = (torch.zeros if epilogue == L.EPI_ATOMIC_F32 else torch.empty)(M, N, dtype=odt, device=A.device)
     if epilogue == L.EPI_GELU and out2 is None:
         out2 = torch.empty_like(out)
-    check(L.lib().maed_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, dt_code(A.dtype), epilogue, _p(bias),
+    check(L.lib().maed_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, mm_code(A.dtype, prec), epilogue, _p(bias),
                                _p(out), out.stride(0), _p(out2), _p(aux), aux.stride(0) if aux is not None else 0,
                                splitk, impl, _stream()), "gemm_nt")
     return (out, out2) if epilogue == L.EPI_GELU else out
@@ -565,7 +574,7 @@ class WeightStdFn(ReportingFn):
         weights = [_c(w) for w in weights]
         # convolutions that run on the library's own kernels: they also get the transposed image and an fp32 dW slice
         direct = getattr(owner, "_direct_convs", None)
-        gemm = set((direct if direct is not None else getattr(owner, "_gemm_convs", ())) or ()) if lib_matmul_dtype(dtype) else set()
+        gemm = set((direct if direct is not None else getattr(owner, "_gemm_convs", ())) or ()) if lib_matmul_dtype(dtype, getattr(owner, "f32_matmul", None)) else set()
         tab, _, nf, total, t_offs = _ws_table(weights, transposed=gemm)
         dev = weights[0].device
         out = torch.empty(total, dtype=dtype, device=dev)
@@ -751,7 +760,7 @@ class Conv1x1Fn(torch.autograd.Function):
     forward 1.01 vs 2.33 ms, input gradient 1.02 vs 1.88 ms, weight gradient 1.47 vs 2.63 ms per step."""
 
     @staticmethod
-    def forward(ctx, x, w, wt, dw, fork=False, gn_sums=None, stride=1, lazy_short=False):
+    def forward(ctx, x, w, wt, dw, fork=False, gn_sums=None, stride=1, lazy_short=False, prec=None):
         """gn_sums (optional, pre-zeroed (N,32,2) f64): GroupNorm statistics of the output, accumulated by the GEMM's epilogue.
         x (N,I,H,W) channels_last; w (O,I,1,1) standardised weight (an output of WeightStdFn: the autograd edge orders
         its backward after ours); wt (I,O) transposed image; dw (O,I) fp32 accumulator (None when no gradient is wanted).
@@ -775,12 +784,12 @@ class Conv1x1Fn(torch.autograd.Function):
             A = x.permute(0, 2, 3, 1).reshape(N * H * W, I)
         if gn_sums is not None:
             y = torch.empty(N * Ho * Wo, O, dtype=x.dtype, device=x.device)
-            check(L.lib().maed_conv1x1_fwd(_p(A), A.stride(0), _p(w2), w2.stride(0), N * Ho * Wo, O, I, _p(y), O, Ho * Wo, _p(gn_sums), dt_code(x.dtype),
+            check(L.lib().maed_conv1x1_fwd(_p(A), A.stride(0), _p(w2), w2.stride(0), N * Ho * Wo, O, I, _p(y), O, Ho * Wo, _p(gn_sums), mm_code(x.dtype, prec),
                                            _stream()), "conv1x1_fwd")
         else:
-            y = gemm_nt(A, w2, L.EPI_STORE)
+            y = gemm_nt(A, w2, L.EPI_STORE, prec=prec)
         ctx.save_for_backward(A, wt)
-        ctx.dw, ctx.geom, ctx.stride = dw, (N, I, H, W, O, Ho, Wo), stride
+        ctx.dw, ctx.geom, ctx.stride, ctx.prec = dw, (N, I, H, W, O, Ho, Wo), stride, prec
         ctx.lazy_short = bool(lazy_short) and fork      # the shortcut's gradient will arrive unmasked, its ReLU bits registered in LAZY_RES
         ctx.set_materialize_grads(False)
         y = y.view(N, Ho, Wo, O).permute(0, 3, 1, 2)
@@ -801,24 +810,24 @@ class Conv1x1Fn(torch.autograd.Function):
         if dy is None:              # only the shortcut carried a gradient
             if mask is not None:
                 raise RuntimeError("Conv1x1Fn: lazily masked shortcut gradient without a gradient for the convolution itself")
-            return g_short, None, None, None, None, None, None, None
+            return g_short, None, None, None, None, None, None, None, None
         Y = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(N * Ho * Wo, O)
         if ctx.needs_input_grad[0]:
             if g_short is not None:
                 G = g_short.contiguous(memory_format=torch.channels_last).to(Y.dtype).permute(0, 2, 3, 1).reshape(N * H * W, I)
-                dx = gemm_nt(Y, wt, L.EPI_ADD, aux=G, out2=mask)
+                dx = gemm_nt(Y, wt, L.EPI_ADD, aux=G, out2=mask, prec=ctx.prec)
             else:
-                dx = gemm_nt(Y, wt, L.EPI_STORE)
+                dx = gemm_nt(Y, wt, L.EPI_STORE, prec=ctx.prec)
             if ctx.stride == 2:
                 g, dx = dx, torch.empty(N * H * W, I, dtype=dx.dtype, device=dx.device)
                 check(L.lib().maed_subsample2_bwd(_p(g), _p(dx), N, H, W, I, dt_code(dx.dtype), _stream()), "subsample2_bwd")
             dx = dx.view(N, H, W, I).permute(0, 3, 1, 2)
         if ctx.dw is not None:
-            dw = ctx.dw
-            side_stream_run(lambda: gemm_tn_wgrad(Y, A, dW=dw), Y, A, dw)
+            dw, prec = ctx.dw, ctx.prec
+            side_stream_run(lambda: gemm_tn_wgrad(Y, A, dW=dw, prec=prec), Y, A, dw)
         if mask is not None and dx is None:
             raise RuntimeError("Conv1x1Fn: lazily masked shortcut gradient but no input gradient requested")
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 
@@ -834,7 +843,7 @@ def _zero_page(device):
     return _ZERO_PAGE[key]
 
 
-def conv3x3(x, w_taps, stride=1, add=None, w_layout=0, gn_sums=None):
+def conv3x3(x, w_taps, stride=1, add=None, w_layout=0, gn_sums=None, prec=None):
     """y = conv3x3_SAME(x, w) on channels_last bf16 tensors through maed_conv3x3_fwd.  x (N,Cin,H,W) channels_last,
     w_taps: storage (Cout, 3, 3, Cin) contiguous (w_layout 0), or the transposed image (3, 3, Cout, Cin) of the FORWARD convolution whose
     input gradient this call computes (w_layout 1).  TF-SAME padding from the input size (resnetv2.py:51-59)."""
@@ -847,7 +856,7 @@ def conv3x3(x, w_taps, stride=1, add=None, w_layout=0, gn_sums=None):
     if add is not None:
         add = add.contiguous(memory_format=torch.channels_last)
     check(L.lib().maed_conv3x3_fwd(_p(x), _p(w_taps), _p(_zero_page(x.device)), _p(y), N, H, W, I, O, stride, ph // 2, pw // 2, Ho, Wo, _p(add),
-                                   w_layout, dt_code(x.dtype), _p(gn_sums), _stream()), "conv3x3_fwd")
+                                   w_layout, mm_code(x.dtype, prec), _p(gn_sums), _stream()), "conv3x3_fwd")
     return y
 
 
@@ -865,14 +874,14 @@ def _tapmask(N, H, W, device):
     return _TAPMASKS[key]
 
 
-def conv3x3_wgrad(dy, x, out=None):
+def conv3x3_wgrad(dy, x, out=None, prec=None):
     """fp32 dW (O, 3, 3, I) of the stride-1 3x3 SAME convolution from channels_last bf16 dy (N,O,H,W) and x (N,I,H,W); accumulates
     into `out` (any (O, 9*I)-sized contiguous fp32 tensor) when given"""
     N, I, H, W = x.shape
     O = dy.shape[1]
     dW = torch.zeros(O, 3, 3, I, dtype=torch.float32, device=x.device) if out is None else out
     check(L.lib().maed_conv3x3_wgrad(_p(dy), _p(x), _p(_tapmask(N, H, W, x.device)), _p(_zero_page(x.device)), _p(dW), N, H, W, I, O,
-                                     dt_code(x.dtype), _stream()), "conv3x3_wgrad")
+                                     mm_code(x.dtype, prec), _stream()), "conv3x3_wgrad")
     return dW
 
 
@@ -885,18 +894,18 @@ class Conv3x3Fn(torch.autograd.Function):
     place (no flipped copy) -- and the fp32 (O, 9*I) slice the weight gradient accumulates into (autograd then carries no dW)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, wt=None, dw=None, gn_sums=None):
+    def forward(ctx, x, w, stride, wt=None, dw=None, gn_sums=None, prec=None):
         x = x.contiguous(memory_format=torch.channels_last)
         w_taps = w.permute(0, 2, 3, 1)
         w_taps = w_taps if w_taps.is_contiguous() else w_taps.contiguous()
         ctx.save_for_backward(x, w)
-        ctx.stride, ctx.wt, ctx.dw = stride, wt, dw
-        return conv3x3(x, w_taps, stride, gn_sums=gn_sums)
+        ctx.stride, ctx.wt, ctx.dw, ctx.prec = stride, wt, dw, prec
+        return conv3x3(x, w_taps, stride, gn_sums=gn_sums, prec=prec)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        s, wt, dw_slice = ctx.stride, ctx.wt, ctx.dw
+        s, wt, dw_slice, prec = ctx.stride, ctx.wt, ctx.dw, ctx.prec
         dy = dy.contiguous(memory_format=torch.channels_last)
         N, I, H, W = x.shape
         O = w.shape[0]
@@ -908,15 +917,15 @@ class Conv3x3Fn(torch.autograd.Function):
         own_dx = need_x and s == 1 and O % 64 == 0               # (the gathered operand's channel count is O here)
         if own_dx:
             if wt is not None:                                   # in place from the transposed image: tap flip = negative tap stride
-                dx = conv3x3(dy, wt, 1, w_layout=1)
+                dx = conv3x3(dy, wt, 1, w_layout=1, prec=prec)
             else:                                                # dX = conv3x3(dY, w'), w'[ci][ky][kx][co] = w[co][ci][2-ky][2-kx]
-                dx = conv3x3(dy, w.flip(2, 3).permute(1, 2, 3, 0).contiguous(), 1)
-        own_dw = need_w and s == 1 and (N * H * W) % 64 == 0 and I % 8 == 0 and O % 8 == 0
+                dx = conv3x3(dy, w.flip(2, 3).permute(1, 2, 3, 0).contiguous(), 1, prec=prec)
+        own_dw = need_w and s == 1 and ((N * H * W) % 64 == 0 or x.dtype == torch.float32) and I % 8 == 0 and O % 8 == 0      # (the bf16 kernel has no ragged tile)
         if own_dw:                                               # TN GEMM over gathered rows; fp32, (O,3,3,I) like w's storage
             if dw_slice is not None:
-                side_stream_run(lambda: conv3x3_wgrad(dy, x, out=dw_slice), dy, x, dw_slice)
+                side_stream_run(lambda: conv3x3_wgrad(dy, x, out=dw_slice, prec=prec), dy, x, dw_slice)
             else:
-                dw = conv3x3_wgrad(dy, x).permute(0, 3, 1, 2)
+                dw = conv3x3_wgrad(dy, x, prec=prec).permute(0, 3, 1, 2)
             need_w = False
         if need_w or (need_x and not own_dx):
             sym = ph % 2 == 0 and pw % 2 == 0
@@ -931,4 +940,4 @@ class Conv3x3Fn(torch.autograd.Function):
                     dw = gw
             if need_x and not own_dx:
                 dx = gx if sym else gx[:, :, ph // 2:ph // 2 + H, pw // 2:pw // 2 + W]
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None

@@ -65,6 +65,10 @@ class _WsGroup:
         self._ws_on_side = False
         self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
 
+    @property
+    def f32_matmul(self):
+        return self.parent.f32_matmul
+
     def conv_weights(self):
         return [self.parent._convs[i].weight for i in self.conv_idx]
 
@@ -106,6 +110,7 @@ class StdConv2dSame(nn.Conv2d):
     _w_std = None  # set by ResNetV2 for the duration of a forward: weight standardised by the batched HIP kernel
     _w_t = None    # 1x1 stride-1 convolutions in bf16 mode: transposed standardised weight (I, O) -> the GEMM path
     _dw = None     # ... and the fp32 slice their weight gradient accumulates into
+    _prec = None   # fp32 matrix-product engine of the owning backbone (ResNetV2.f32_matmul), None = the process-wide mode
 
     @staticmethod
     def _gn_sums_for(gn, x_shape, out_channels, stride):
@@ -128,13 +133,14 @@ class StdConv2dSame(nn.Conv2d):
         if w is not None and self._w_t is not None and self.kernel_size == (1, 1):
             # 1x1, stride 1, bf16: three GEMMs on libmaed_hip instead of MIOpen's implicit-GEMM solvers (which zero-fill the
             # output and cast weight gradients through an fp32 workspace first): ops.Conv1x1Fn
-            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]), self.stride[0], lazy_short)
+            return ops.Conv1x1Fn.apply(x, w, self._w_t, self._dw, fork, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]), self.stride[0], lazy_short,
+                                       self._prec)
         assert not fork
-        if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and ops.lib_matmul_dtype(x.dtype)
+        if (w is not None and _OWN_CONV3X3 and self.kernel_size == (3, 3) and ops.on_library_device(x) and ops.lib_matmul_dtype(x.dtype, self._prec)
                 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and self.dilation == (1, 1) and self.groups == 1):
             # implicit-GEMM forward / stride-1 input gradient on libmaed_hip instead of MIOpen
             # (_w_t / _dw: transposed image and fp32 dW slice from WeightStdFn for the stride-1 ones, see ResNetV2._own3x3)
-            return ops.Conv3x3Fn.apply(x, w, self.stride[0], self._w_t, self._dw, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]))
+            return ops.Conv3x3Fn.apply(x, w, self.stride[0], self._w_t, self._dw, self._gn_sums_for(gn, x.shape, self.out_channels, self.stride[0]), self._prec)
         if w is None:  # stand-alone use / CPU: per-conv ATen composition
             w = self.get_weight().to(x.dtype)
             if ops.on_library_device(x):
@@ -250,9 +256,15 @@ class ResNetStage(nn.Module):
 class ResNetV2(nn.Module):
     """resnetv2.py:277-348 restricted to what the STE uses: preact=False, stem_type='same', no head."""
 
-    def __init__(self, layers=(3, 4, 9), channels=(256, 512, 1024), in_chans=3, stem_chs=64, compute_dtype=torch.float32, **_):
+    def __init__(self, layers=(3, 4, 9), channels=(256, 512, 1024), in_chans=3, stem_chs=64, compute_dtype=torch.float32, f32_matmul=None, **_):
         super().__init__()
         self.compute_dtype = compute_dtype
+        # compute_dtype = float32 only: this module's own engine for its fp32 matrix products -- None (follow the process-wide mode,
+        # ops.set_float32_matmul_precision), "bf16x3" or "bf16x6".  Why a backbone may want more than the rest of the model: its 52 GroupNorms after
+        # weight-standardised convolutions make the gradients of a freshly initialised network ill-conditioned (the fp32 reference arithmetic itself sits
+        # 1.5e-2 from fp64 there, bf16x3 7e-2, bf16x6 1.6e-2: scripts/x3_probe.py, profiles/r03_x3_probe.txt)
+        assert f32_matmul in (None, "bf16x3", "bf16x6"), f32_matmul
+        self.f32_matmul = f32_matmul
         self.stem = nn.Sequential(OrderedDict([
             ("conv", StdConv2dSame(in_chans, stem_chs, 7, stride=2)),
             ("norm", GroupNormAct(stem_chs)),
@@ -321,7 +333,7 @@ class ResNetV2(nn.Module):
         try:
             if ws is not None:
                 for i, (c, w) in enumerate(zip(self._convs, ws)):
-                    c._w_std, c._w_t, c._dw = w, self._w_std_t.get(i), self._dw_slices.get(i)
+                    c._w_std, c._w_t, c._dw, c._prec = w, self._w_std_t.get(i), self._dw_slices.get(i), self.f32_matmul
             off = 0
             for i, m in enumerate(self._norms):
                 m._sums_buf = sums[i]
@@ -335,7 +347,7 @@ class ResNetV2(nn.Module):
                 wg = ops.WeightStdFn.apply(g, self.compute_dtype, self._convs[0].eps, *g.conv_weights())   # then fires right after its backward
                 for k, (ci, w) in enumerate(zip(g.conv_idx, wg)):
                     c = self._convs[ci]
-                    c._w_std, c._w_t, c._dw = w, g._w_std_t.get(k), g._dw_slices.get(k)
+                    c._w_std, c._w_t, c._dw, c._prec = w, g._w_std_t.get(k), g._dw_slices.get(k), self.f32_matmul
                 x = self.stages[0](self.stem(x)) if gi == 0 else self.stages[gi](x)
             # backward order is last stage first: every group but the one that runs last may finish on the side stream (ops.WeightStdFn.backward)
             runs = [g for g in self._ws_groups if g._pending_backwards > 0]
@@ -344,7 +356,7 @@ class ResNetV2(nn.Module):
             return x
         finally:
             for c in self._convs:
-                c._w_std = c._w_t = c._dw = None
+                c._w_std = c._w_t = c._dw = c._prec = None
             for m in self._norms:
                 m._sums_buf = m._ab_buf = None
 

@@ -69,9 +69,11 @@ def main():
     summarize("fp32 oracle", g32)
     for mode in modes:
         dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+        glob, _, bb = mode.partition("+bb:")          # "bf16x3+bb:bf16x6" = process-wide bf16x3, the backbone on its own bf16x6 engine
         if mode != "bf16":
-            maed_amd.set_float32_matmul_precision(mode)
-        m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["H"], embed_dim=C, hidden_dim=CFG["hidden"], img_size=CFG["img"], compute_dtype=dtype)
+            maed_amd.set_float32_matmul_precision(glob)
+        m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["H"], embed_dim=C, hidden_dim=CFG["hidden"], img_size=CFG["img"], compute_dtype=dtype,
+                          backbone_f32_matmul=bb or None)
         m.load_state_dict(params, strict=False)
         m = m.to(dev).train()
         m.decoder.drop1.p = 0.0

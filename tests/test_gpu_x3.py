@@ -103,7 +103,7 @@ def test_conv3x3_x3_fwd_dgrad_wgrad(mode, stride, H, Cin, Cout):
     transposed image, stride-1 weight gradient"""
     from maed_amd import ops
     name, tol = mode
-    N = 4
+    N = 3                                                   # (14 x 14 x 3 = 588 rows: the weight-gradient kernel's ragged last tile)
     x = rnd(N, Cin, H, H, seed=30).contiguous(memory_format=torch.channels_last)
     w = rnd(Cout, Cin, 3, 3, seed=31, scale=(9 * Cin) ** -0.5)
     ref = _conv_ref(x, w, stride)
@@ -138,3 +138,23 @@ def test_conv1x1_x3_groupnorm_statistics(mode):
     report(f"conv1x1 {name}", y, ref, rtol=0, atol=tol * ref.abs().max().item())
     g = y.double().cpu().view(Fr, hw, 32, Cout // 32)
     report(f"conv1x1 {name} GroupNorm sums", sums, torch.stack([g.sum((1, 3)), (g * g).sum((1, 3))], -1), rtol=1e-5, atol=1e-2)
+
+
+@pytest.mark.parametrize("Fr,P,H", [(3, 197, 8), (2, 257, 2), (1, 600, 1), (2, 5, 2)])
+def test_attn_spatial_x3_fwd_bwd_vs_fp64(mode, Fr, P, H):
+    """fp32 q/k/v, split-bf16 contractions (csrc/attn_x3.hip; vision_transformer.py:206-214) against fp64 autograd through the oracle"""
+    from maed_amd import ops
+    from oracle import maed_ref as R
+    name, tol = mode
+    qkv = rnd(Fr, P, 3 * 64 * H, seed=P)
+    do = rnd(Fr, P, 64 * H, seed=4)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_spatial(qq, kk, vv, 64 ** -0.5)
+    lse_ref = torch.logsumexp((qq @ kk.transpose(-2, -1)) * 64 ** -0.5, dim=-1)
+    oref.backward(do.double())
+    o, lse = ops.attn_spatial_fwd(qkv.to(DEV), H)
+    dqkv = ops.attn_spatial_bwd(qkv.to(DEV), o, do.to(DEV), lse, H)
+    report(f"attn_spatial {name} fwd [F{Fr} P{P} H{H}]", o, oref.detach(), rtol=0, atol=2 * tol * oref.abs().max().item())
+    report(f"attn_spatial {name} lse", lse, lse_ref.detach(), rtol=0, atol=20 * tol)
+    report(f"attn_spatial {name} bwd", dqkv, x.grad, rtol=0, atol=4 * tol * x.grad.abs().max().item())

@@ -187,3 +187,28 @@ def test_f32_library_convolutions_need_the_split_mode():
     with patched():
         with pytest.raises(L.MaedHipError, match="split-bf16"):
             ops.gemm_tn_wgrad(Y, X)
+
+
+# ---- attention: fp32 q/k/v, split-bf16 contractions (csrc/attn_x3.hip) ------------------------------------------------------------------
+@pytest.mark.parametrize("impl,tol", [(L.IMPL_X3, 2e-4), (L.IMPL_X6, 5e-6)])
+@pytest.mark.parametrize("Fr,L_,H", [(2, 5, 2), (1, 197, 2), (1, 64, 1), (1, 130, 1)])
+def test_attn_x3_fwd_bwd_vs_fp64_oracle(impl, tol, Fr, L_, H):
+    """the K/V-tiled kernels on fp32 operands: one partial tile; cfg3's 197 tokens (2 row tiles x 4 streamed tiles, ragged ends); exactly one full
+    tile; a third wave with 2 rows.  Forward, log-sum-exp, dq / dk / dv and the accumulate flag against fp64 autograd through the oracle."""
+    from oracle import maed_ref as R
+    qkv = rnd(Fr, L_, 3 * 64 * H, seed=L_)
+    do = rnd(Fr, L_, 64 * H, seed=4)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_spatial(qq, kk, vv, 64 ** -0.5)
+    lse_ref = torch.logsumexp((qq @ kk.transpose(-2, -1)) * 64 ** -0.5, dim=-1)
+    oref.backward(do.double())
+    with patched():
+        o, lse = ops.attn_spatial_fwd(qkv, H, impl)
+        dqkv = ops.attn_spatial_bwd(qkv, o, do, lse, H, impl=impl)
+        acc = ops.attn_spatial_bwd(qkv, o, do, lse, H, dqkv=dqkv.clone(), accumulate=True, impl=impl)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    assert rel(o, oref.detach()) <= tol, rel(o, oref.detach())
+    assert (lse.double() - lse_ref.detach()).abs().max() <= 10 * tol
+    assert rel(dqkv, x.grad) <= 2 * tol, rel(dqkv, x.grad)
+    assert rel(acc, 2 * x.grad) <= 2 * tol
