@@ -141,6 +141,7 @@ class GradBucketer:
         self._seen = [False] * len(arena.params)      # parameters that reported a gradient since the last finish()
         self.unmarked = []                             # ... and the ones that did not, as of the last finish() (FusedAdam skips them like torch.optim.Adam)
         self._works = []
+        self._finished = False                         # finish() ran and nothing was reported since: a second finish() is a no-op
         self._fused = set()
         self._fused_modules = []
         for m in model.modules():  # modules whose kernels write parameter gradients directly (STE Block, ResNetV2)
@@ -158,6 +159,7 @@ class GradBucketer:
         if i is None:
             return
         self._seen[i] = True
+        self._finished = False
         b = self.bucket_of[i]
         self._pending[b] -= 1
         if self._pending[b] == 0:
@@ -183,7 +185,10 @@ class GradBucketer:
 
     def finish(self):
         """Launch whatever has not fired (parameters without a gradient this step), then make the
-        current stream wait for every bucket.  Call once per step, before the optimizer."""
+        current stream wait for every bucket.  Once per step, before the optimizer -- FusedAdam.step() calls it; calling it yourself first (to clip or
+        inspect the reduced gradients) is fine: until a new gradient is reported or the optimizer has consumed the step, further calls change nothing."""
+        if self._finished:
+            return
         for b in range(len(self.buckets)):
             self._launch(b)
         for w in self._works:
@@ -193,10 +198,27 @@ class GradBucketer:
             self.comm.wait()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        # kernel-written gradients are reported by the module's LAST backward kernel (ResNetV2: the weight-standardisation backward).  A module that ran a
+        # grad-enabled forward but whose reporter cannot run -- a backbone with frozen convolution weights and trainable GroupNorm parameters -- still
+        # produced gradients: count its trainable parameters as seen instead of freezing them
+        for m in self._fused_modules:
+            if getattr(m, "_grad_forward_seen", False):
+                for p in m.fused_parameters():
+                    i = self.arena.index.get(id(p))
+                    if i is not None:
+                        self._seen[i] = True
+                m._grad_forward_seen = False
         self.unmarked = [i for i, seen in enumerate(self._seen) if not seen]
         self._seen = [False] * len(self._seen)
         for m in self._fused_modules:       # a backward that never ran (an exception, a detached output) must not poison the next step
             m._pending_backwards = 0
+            for g in getattr(m, "_ws_groups", ()):      # per-stage weight standardisation: the stage owners count their own backwards
+                g._pending_backwards = 0
+        self._finished = True
+
+    def consumed(self):
+        """the optimizer has applied this step: the next finish() evaluates afresh (also when no gradient at all is reported before it)"""
+        self._finished = False
 
     def broadcast_parameters(self, src=0):
         """train.py:113 DDP construction broadcasts rank 0's parameters once."""
@@ -226,6 +248,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(arena.flat)
         self.exp_avg_sq = torch.zeros_like(arena.flat)
         self.step_count = 0
+        self._stepped = set()       # arena indices that have received at least one update (torch.optim.Adam keeps no state for the others)
 
     # kept as attributes for callers that read them
     lr = property(lambda self: self.param_groups[0]["lr"])
@@ -252,6 +275,9 @@ class FusedAdam(torch.optim.Optimizer):
         # torch.optim.Adam skips parameters whose .grad is None (ts_attn in the non-parallel st_modes, any unused parameter): no moment decay, no weight
         # decay.  The arena's gradients are never None, so "received no gradient this step" comes from the bucketer's readiness reports.
         skip = set(self.bucketer.unmarked) if self.bucketer is not None else set()
+        if self.bucketer is not None:
+            self.bucketer.consumed()
+        self._stepped.update(i for i in range(len(a.params)) if i not in skip)
         if self._uniform():     # the reference's case: every group shares the schedule -> one launch over the whole arena (or per run of active tensors)
             g = self.param_groups[0]
             runs = [(0, a.numel)]
@@ -284,8 +310,12 @@ class FusedAdam(torch.optim.Optimizer):
         return self.exp_avg[o:o + p.numel()].view(p.shape), self.exp_avg_sq[o:o + p.numel()].view(p.shape)
 
     def state_dict(self):
+        # (one step count for every tensor that has state: a parameter that starts receiving gradients late is bias-corrected with the global count, where
+        # torch keeps a per-tensor count -- the reference's models have no such parameter)
         if self.step_count > 0:
             for i in self._order:
+                if i not in self._stepped:      # never updated: no state, as torch.optim.Adam
+                    continue
                 m, v = self._views(i)
                 self.state[self.arena.params[i]] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
         try:
@@ -304,6 +334,7 @@ class FusedAdam(torch.optim.Optimizer):
             m.copy_(st["exp_avg"])
             v.copy_(st["exp_avg_sq"])
             steps.append(int(float(st["step"])))
+            self._stepped.add(i)
         if steps:
             assert len(set(steps)) == 1, "per-tensor step counts differ: not an Adam state this optimizer can represent"
             self.step_count = steps[0]

@@ -298,6 +298,7 @@ class ResNetV2(nn.Module):
                         and c.in_channels % 64 == 0 and c.out_channels % 64 == 0]
         self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
         self._pending_backwards = 0
+        self._grad_forward_seen = False     # a grad-enabled forward ran since the bucketer last looked (ddp.GradBucketer.finish)
         self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
         # per-stage groups (MAED_WS_PER_STAGE): the stem rides with stage 0
         conv_pos = {id(c): i for i, c in enumerate(self._convs)}
@@ -328,6 +329,8 @@ class ResNetV2(nn.Module):
         N = x.shape[0]
         sums = torch.zeros(len(self._norms), N, 32, 2, dtype=torch.float64, device=x.device)
         ab = None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.fused_parameters()):
+            self._grad_forward_seen = True
         if torch.is_grad_enabled() and any(p.requires_grad for p in (self._norms[0].weight, self._convs[0].weight)):
             ab = torch.zeros(N * 2 * sum(m.num_channels for m in self._norms), dtype=torch.float32, device=x.device)
         try:

@@ -110,7 +110,15 @@ class SMPL(nn.Module):
         self.faces = None
         self._ps_t = None
         self._derived_key = self._base_key()
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_derived(force=True))
+        # `synthetic` is cleared only when a state_dict really delivered the model arrays (not by device moves or in-place version bumps: ADVICE r2)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._after_load(incompatible))
+
+    def _after_load(self, incompatible):
+        base = ("v_template", "shapedirs", "posedirs", "J_regressor")
+        missing = {k.rsplit(".", 1)[-1] for k in incompatible.missing_keys}
+        self.refresh_derived(force=True)
+        if not missing.intersection(base):      # the state_dict carried the model arrays (the reference's loaders filter decoder.smpl.* out: eval.py:29)
+            self.synthetic = False
 
     def _base_key(self):
         return tuple((t.data_ptr(), t._version) for t in (self.v_template, self.shapedirs, self.posedirs, self.J_regressor))
@@ -125,8 +133,6 @@ class SMPL(nn.Module):
                 self.J_shapedirs = torch.einsum('jv,vcl->jcl', self.J_regressor, self.shapedirs).contiguous()
             self._ps_t = None
             self._derived_key = self._base_key()
-            if changed:
-                self.synthetic = False
 
     def pose_shape_dirs(self):
         """(207+10, 20670) = [posedirs ; shapedirs^T]: the K-contiguous B operand of the LBS backward's GEMM (tail.SmplTailFn)"""
