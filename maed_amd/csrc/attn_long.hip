@@ -16,7 +16,8 @@
 // lse (items, H, L) natural log, dqkv like qkv.  Selected by maed_attn_spatial_{fwd,bwd} when the sequence does not fit the
 // whole-head kernels, or explicitly with impl = MAED_IMPL_MFMA_LONG.  One LDS buffer, two barriers per tile; the next tile's global
 // loads are issued into registers before the current tile is consumed (register prefetch), so only the LDS write sits between the
-// barriers.  Not yet measured on hardware (written after the round-1 GPU budget was spent; scripts/attn_long_micro.py).
+// barriers.  Measured on MI355X in round 2 (profiles/r02_attn_long_micro_v2.txt): P = 197 forward 30.4 us, backward 108 us; since then the default
+// for every sequence length.
 #include "attn_mfma.cuh"
 
 #define D HEAD_DIM

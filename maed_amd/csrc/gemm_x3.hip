@@ -13,12 +13,9 @@
 // pieces into registers, splits them on the VALU (v_cvt_pk_bf16_f32 + exact residual) and writes the NP planes of the LDS image, so the
 // split costs no extra memory pass and -- because staging goes through registers anyway -- gathered rows (implicit-GEMM 3x3 convolution)
 // and transposing staging (weight gradients, reduction over rows) come for free: the fragments a MFMA lane needs are picked element by
-// element while packing.  LDS image per operand and plane: 128 rows x 32 k (bf16) = unpadded 64-byte rows whose 16-byte chunk index is XOR-ed
-// with (row >> 2) & 3 (conflict-free ds_read_b128 fragments).  Software pipeline: TWO LDS buffers and two register sets -- while the MFMAs of
-// tile t run out of one buffer, the same basic block splits tile t+1 (VALU work in the MFMAs' shadow: ~4 VALU per MFMA) and writes it into the
-// other buffer, and the global loads of tile t+3 are issued; one barrier per tile.  (The first version -- one buffer, split between two
-// barriers -- ran the VALU and MFMA phases of a wave back to back: 225 TFLOP/s at the qkv shape, profiles/r03_x3_micro_v1.txt.)
-// LDS-shuffled epilogue as in gemm.hip (all fused epilogues, GroupNorm statistics), XCD-aware tile order.
+// element while packing.  LDS image per operand and plane: 128 rows x 32 k (bf16), rows padded to 80 B (20 dwords = 4 x odd:
+// conflict-free ds_read_b128 fragments and ds_write_b128 rows).  One LDS buffer, the next K tile's global loads in flight under the
+// current tile's MFMAs, LDS-shuffled epilogue as in gemm.hip (all fused epilogues, GroupNorm statistics), XCD-aware tile order.
 //
 //   gemm_nt_x3_kernel   out = epi(A[M,K] B[N,K]^T)      nn.Linear forward / input gradients, 1x1 convolutions; CONV: 3x3 implicit GEMM
 //   gemm_tn_x3_kernel   dW[N,K] += Y[M,N]^T X[M,K]      weight gradients (reduction over rows), CONV: 3x3 weight gradient over gathered rows
@@ -27,59 +24,44 @@
 #include "gemm_x3.h"
 
 #define X3_BK 32
-#define X3_LD 32     // unpadded rows: 64 B
+#define X3_LD 40
 
 namespace {
 
-// All MFMAs of one 128 x 128 x 32 tile step for a wave's 2x2 (or 1x2) block of 32x32 tiles, out of the split LDS planes, with the OTHER work of the
-// step (split + LDS writes of the next tile, refill loads) placed between the MFMA groups by hand: after each group of 4 (2) MFMAs on different
-// accumulators -- 128 (64) cycles of matrix-pipe time -- `filler(g)` emits a slice of that work, fenced by sched_barriers so that the compiler keeps
-// the order.  (Left to itself hipcc emitted "all VALU, then all MFMAs" for the step, and sched_group_barrier pipelines did not change that: the ISA
-// notes in profiles/r03_x3_isa_notes.txt.)  TR: accumulators hold the transposed tiles.  Groups: (X3_BK/16) * (3 or 6).
-template <int NP, bool TR, bool HALF_ROWS, typename F>
-__device__ __forceinline__ void x3_tile_mfma(const unsigned short* tb, int a_row, int b_row, int hi, int fsw, int plane_elems, f32x16_t& acc00,
-                                             f32x16_t& acc01, f32x16_t& acc10, f32x16_t& acc11, F&& filler) {
-    int g = 0;
+// one K step (16) of a wave's 2x2 (or 1x2) block of 32x32 tiles from the split LDS planes; TR: accumulators hold the transposed tiles
+template <int NP, bool TR, bool HALF_ROWS>
+__device__ __forceinline__ void x3_kstep(const unsigned short* Ap, const unsigned short* Bp, int plane_elems, f32x16_t& acc00, f32x16_t& acc01,
+                                         f32x16_t& acc10, f32x16_t& acc11) {
+    bf16x8_t a0[NP], a1[NP], b0[NP], b1[NP];
 #pragma unroll
-    for (int kk = 0; kk < X3_BK / 16; ++kk) {
-        const int co = ((kk * 2 + hi) ^ fsw) << 3;
-        const unsigned short* Ap = tb + a_row + co;
-        const unsigned short* Bp = tb + b_row + co;
-        bf16x8_t a0[NP], a1[NP], b0[NP], b1[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            a0[p] = *reinterpret_cast<const bf16x8_t*>(Ap + p * plane_elems);
-            b0[p] = *reinterpret_cast<const bf16x8_t*>(Bp + p * plane_elems);
-            b1[p] = *reinterpret_cast<const bf16x8_t*>(Bp + p * plane_elems + 32 * X3_LD);
-            if constexpr (!HALF_ROWS) a1[p] = *reinterpret_cast<const bf16x8_t*>(Ap + p * plane_elems + 32 * X3_LD);
-        }
-        // smallest partial products first, the leading a0 b0 last
-#pragma unroll
-        for (int ord = NP - 1; ord >= 0; --ord)
-#pragma unroll
-            for (int pa = 0; pa <= ord; ++pa) {
-                const int pb = ord - pa;
-                if constexpr (TR) {
-                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[pb], a0[pa], acc00, 0, 0, 0);
-                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[pb], a0[pa], acc01, 0, 0, 0);
-                    if constexpr (!HALF_ROWS) {
-                        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[pb], a1[pa], acc10, 0, 0, 0);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[pb], a1[pa], acc11, 0, 0, 0);
-                    }
-                } else {
-                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[pa], b0[pb], acc00, 0, 0, 0);
-                    acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[pa], b1[pb], acc01, 0, 0, 0);
-                    if constexpr (!HALF_ROWS) {
-                        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[pa], b0[pb], acc10, 0, 0, 0);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[pa], b1[pb], acc11, 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                filler(g);
-                __builtin_amdgcn_sched_barrier(0);
-                ++g;
-            }
+    for (int p = 0; p < NP; ++p) {
+        a0[p] = *reinterpret_cast<const bf16x8_t*>(Ap + p * plane_elems);
+        b0[p] = *reinterpret_cast<const bf16x8_t*>(Bp + p * plane_elems);
+        b1[p] = *reinterpret_cast<const bf16x8_t*>(Bp + p * plane_elems + 32 * X3_LD);
+        if constexpr (!HALF_ROWS) a1[p] = *reinterpret_cast<const bf16x8_t*>(Ap + p * plane_elems + 32 * X3_LD);
     }
+    // smallest partial products first, the leading a0 b0 last
+#pragma unroll
+    for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int pa = 0; pa <= ord; ++pa) {
+            const int pb = ord - pa;
+            if constexpr (TR) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[pb], a0[pa], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[pb], a0[pa], acc01, 0, 0, 0);
+                if constexpr (!HALF_ROWS) {
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[pb], a1[pa], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[pb], a1[pa], acc11, 0, 0, 0);
+                }
+            } else {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[pa], b0[pb], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[pa], b1[pb], acc01, 0, 0, 0);
+                if constexpr (!HALF_ROWS) {
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[pa], b0[pb], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[pa], b1[pb], acc11, 0, 0, 0);
+                }
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -93,8 +75,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restr
                                                             int64_t M, int64_t N, int64_t K, int tiles_n, int ktiles_per_split, X3ConvDims d,
                                                             EpiArgs e) {
     constexpr int kPlane = 128 * X3_LD;
-    constexpr int kTileElems = 2 * NP * kPlane, kStageElems = 4 * 32 * GL_ST * 2;                  // one buffer: [A | B][plane]; two buffers
-    constexpr int kMainElems = 2 * kTileElems > kStageElems ? 2 * kTileElems : kStageElems;
+    constexpr int kTileElems = 2 * NP * kPlane, kStageElems = 4 * 32 * GL_ST * 2;
+    constexpr int kMainElems = kTileElems > kStageElems ? kTileElems : kStageElems;
     __shared__ __attribute__((aligned(16))) unsigned short lds_raw[kMainElems + (GN ? GN_TAB_FLOATS * 2 : 0)];
     double* const gn_tab = reinterpret_cast<double*>(lds_raw + kMainElems);
     if (GN && threadIdx.x < GN_TAB_FLOATS / 2) gn_tab[threadIdx.x] = 0.0;                       // (published by the main loop's barriers)
@@ -130,97 +112,62 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restr
             bp[i] = B + br * ldb + skc;
         }
     }
-    // ONE register set, refilled piece by piece: right after piece i of tile t+1 has been split and written to LDS, the same registers receive piece i
-    // of tile t+2 -- every load then has a whole tile step to land, and the step (MFMAs of tile t, split of tile t+1, loads of tile t+2) is one
-    // basic block without branches: loads past the last tile re-read the last tile (harmless), out-of-image taps of the gathered operand load a
-    // valid address and are zeroed by a select.
     float4 ra[4], rb[4];
-    int ty = 0, tx = 0, c0 = 0;                                     // CONV: (tap, channel chunk) of the NEXT tile to load; advanced without branches
+    int ty = 0, tx = 0, c0 = 0;                                     // CONV: K tile -> (tap, channel chunk), advanced with the loads
     if constexpr (CONV) { const int k = kt_beg * X3_BK; const int tap = k / d.Cin; ty = tap / 3; tx = tap % 3; c0 = k - tap * d.Cin; }
-    int kt_load = kt_beg;                                           // next tile to load (clamped to the last one)
-    int64_t a_off = 0, b_off = 0;                                   // element offsets of that tile (wave-uniform)
-    auto tile_offsets = [&]() {
-        if constexpr (CONV) { a_off = ((int64_t)ty * d.W + tx) * d.Cin + c0; b_off = (int64_t)(ty * 3 + tx) * d.b_tap + c0; }
-        else { a_off = b_off = (int64_t)kt_load * X3_BK; }
-    };
-    auto advance_tile = [&]() {                                     // scalar selects only
-        const bool adv = kt_load + 1 < kt_end;
-        kt_load += adv ? 1 : 0;
+    auto load_tile = [&](int kt) {
         if constexpr (CONV) {
-            const int c1 = c0 + X3_BK;
-            const bool w1 = adv && (c1 == d.Cin);
-            c0 = adv ? (w1 ? 0 : c1) : c0;
-            const int t1 = tx + (w1 ? 1 : 0);
-            const bool w2 = t1 == 3;
-            tx = w2 ? 0 : t1;
-            ty += w2 ? 1 : 0;
-        }
-        tile_offsets();
-    };
-    auto load_a = [&](int i) {
-        if constexpr (CONV) {
-            const bool ok = (unsigned)(iy[i] + ty) < (unsigned)d.H && (unsigned)(ix[i] + tx) < (unsigned)d.W;
-            const float* p = ok ? ap[i] + a_off : A + skc;          // (always a valid address)
-            const float4 v = *reinterpret_cast<const float4*>(p);
-            ra[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            const int64_t toff = ((int64_t)ty * d.W + tx) * d.Cin + c0, k0 = (int64_t)(ty * 3 + tx) * d.b_tap + c0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (unsigned)(iy[i] + ty) < (unsigned)d.H && (unsigned)(ix[i] + tx) < (unsigned)d.W;
+                ra[i] = ok ? *reinterpret_cast<const float4*>(ap[i] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!NARROW || i < 2) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+            }
+            c0 += X3_BK;
+            if (c0 == d.Cin) { c0 = 0; if (++tx == 3) { tx = 0; ++ty; } }
         } else {
-            ra[i] = *reinterpret_cast<const float4*>(ap[i] + a_off);
+            const int64_t k0 = (int64_t)kt * X3_BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const float4*>(ap[i] + k0);
+                if (!NARROW || i < 2) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+            }
         }
     };
-    auto load_b = [&](int i) { rb[i] = *reinterpret_cast<const float4*>(bp[i] + b_off); };
-    // LDS offset of this thread's 8-byte piece: row srow (+ 32 i), 16-byte chunk ((tid & 7) >> 1) ^ swizzle(row), half (tid & 1)
-    const int st_off = srow * X3_LD + (((((tid & 7) >> 1) ^ ((srow >> 2) & 3))) << 3) + (tid & 1) * 4;
-    auto store_a = [&](int i, int buf) {
-        uint2 pl[NP];
-        split4<NP>(ra[i].x, ra[i].y, ra[i].z, ra[i].w, pl);
+    auto store_tile = [&]() {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(lds_raw + buf * kTileElems + st_off + p * kPlane + 32 * i * X3_LD) = pl[p];
-    };
-    auto store_b = [&](int i, int buf) {
-        uint2 pl[NP];
-        split4<NP>(rb[i].x, rb[i].y, rb[i].z, rb[i].w, pl);
+        for (int i = 0; i < 4; ++i) {
+            const int off = (srow + 32 * i) * X3_LD + skc;
+            uint2 pl[NP];
+            split4<NP>(ra[i].x, ra[i].y, ra[i].z, ra[i].w, pl);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(lds_raw + buf * kTileElems + st_off + (NP + p) * kPlane + 32 * i * X3_LD) = pl[p];
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(lds_raw + p * kPlane + off) = pl[p];
+            if (!NARROW || i < 2) {
+                split4<NP>(rb[i].x, rb[i].y, rb[i].z, rb[i].w, pl);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(lds_raw + (NP + p) * kPlane + off) = pl[p];
+            }
+        }
     };
-    constexpr int NB = NARROW ? 2 : 4;                              // pieces of the B operand per thread
 
     constexpr bool TR = (EPI != MAED_EPI_ATOMIC_F32);
     f32x16_t acc00, acc01, acc10, acc11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
-    const int fsw = (l31 >> 2) & 3;                                 // swizzle term of this lane's fragment rows
-    const int a_row = (wr * (NARROW ? 32 : 64) + l31) * X3_LD, b_row = NP * kPlane + (wc * 64 + l31) * X3_LD;
-    constexpr int kGroups = (X3_BK / 16) * (NP == 2 ? 3 : 6);       // MFMA groups per tile step
+    const unsigned short* const Afrag = lds_raw + (wr * (NARROW ? 32 : 64) + l31) * X3_LD + hi * 8;
+    const unsigned short* const Bfrag = lds_raw + NP * kPlane + (wc * 64 + l31) * X3_LD + hi * 8;
 
-    // prologue: tile 0 -> buffer 0, registers <- tile 1
-    tile_offsets();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { load_a(i); if (i < NB) load_b(i); }
-    advance_tile();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { store_a(i, 0); load_a(i); if (i < NB) { store_b(i, 0); load_b(i); } }
-    advance_tile();
-    __syncthreads();
-    int buf = 0;
-    for (int kt = kt_beg; kt + 1 < kt_end; ++kt) {
-        // buffer `buf` holds tile kt, the registers tile kt+1 (landed or landing); a_off / b_off point at tile kt+2.  The 4 + NB pieces of tile kt+1 are
-        // split / written / refilled between the MFMA groups of tile kt
-        const int nb = buf ^ 1;
-        x3_tile_mfma<NP, TR, NARROW>(lds_raw + buf * kTileElems, a_row, b_row, hi, fsw, kPlane, acc00, acc01, acc10, acc11, [&](int g) {
-            // pieces 0 .. 4+NB-1 spread over the kGroups slots (first slots take two when there are fewer slots than pieces)
-            constexpr int kPieces = 4 + NB;
-#pragma unroll
-            for (int pc = 0; pc < kPieces; ++pc) {
-                if (pc * kGroups / kPieces != g) continue;
-                if (pc < 4) { store_a(pc, nb); load_a(pc); }
-                else { store_b(pc - 4, nb); load_b(pc - 4); }
-            }
-        });
-        advance_tile();
+    load_tile(kt_beg);
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        __syncthreads();                                    // every wave is done with the previous tile's fragments
+        store_tile();
         __syncthreads();
-        buf = nb;
+        if (kt + 1 < kt_end) load_tile(kt + 1);             // in flight under this tile's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < X3_BK / 16; ++kk)
+            x3_kstep<NP, TR, NARROW>(Afrag + kk * 16, Bfrag + kk * 16, kPlane, acc00, acc01, acc10, acc11);
     }
-    x3_tile_mfma<NP, TR, NARROW>(lds_raw + buf * kTileElems, a_row, b_row, hi, fsw, kPlane, acc00, acc01, acc10, acc11, [](int) {});
 
     if constexpr (!TR) {
         // natural orientation: D[row m][col n], col = lane & 31 -> the 32 lanes of a half-wave hit 32 consecutive columns (coalesced atomics)
@@ -277,8 +224,8 @@ template <int NP, bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ X, int64_t ldx,
                                                             int64_t M, int N, int K, float* __restrict__ dW, int64_t ldw,
                                                             float* __restrict__ dbias, int tiles_k, int mtiles_per_split, X3TnConv cv) {
-    constexpr int kPlane = 128 * X3_LD, kTileElems = 2 * NP * kPlane;
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * kTileElems];      // [buffer][Y^T | X^T][plane][column][m]
+    constexpr int kPlane = 128 * X3_LD;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * NP * kPlane];     // [Y^T | X^T][plane][column][m]
     __shared__ float lcs[4][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
@@ -304,85 +251,54 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
     if constexpr (CONV) {
         if (side) { tap = col_in / cv.Cin; col_in -= tap * cv.Cin; shift = (tap / 3 - 1) * cv.Wimg + (tap % 3 - 1); }
     }
-    const float* const lane_src = src + ((int64_t)(mg * 8 + shift)) * ld + col_in;      // (col_in = 0 for columns past N / K: a valid address)
-    // row nc*4 + jj, 16-byte chunk mg ^ swizzle(row) with swizzle = (row >> 2) & 3 = nc & 3
-    unsigned short* const my_lds = lds + side * NP * kPlane + (nc * 4) * X3_LD + ((mg ^ (nc & 3)) << 3);
+    const float* const lane_src = src + ((int64_t)(mg * 8 + shift)) * ld + col_in;
+    unsigned short* const my_lds = lds + side * NP * kPlane + (nc * 4) * X3_LD + mg * 8;
     const bool bias_blk = (dbias != nullptr) && (tile_k == (int)(bz % tiles_k));   // block-uniform: the K tile that takes the column sums rotates
-    const float bias_w = (bias_blk && side == 0) ? 1.f : 0.f;      // (a multiply, not a branch: the split and the MFMAs of a step stay one basic block)
+    const bool do_bias = bias_blk && (side == 0);
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // one register set, refilled row by row right after its split (see gemm_nt_x3_kernel); unconditional loads from always-valid addresses: columns
-    // past N / K read column 0 (their LDS rows only feed outputs that are never stored), rows past M and masked taps are zeroed by a select
     float4 r[8];
-    const int nfull = (int)(M / X3_BK);                      // tiles without rows past M
-    int mt_load = mt_beg;
-    auto load_row = [&](int j) {
-        const int64_t row0 = (int64_t)mt_load * X3_BK + mg * 8;
-        const float* tb = lane_src + (int64_t)mt_load * X3_BK * ld;
-        bool ok = (mt_load < nfull) || (row0 + j < M);       // (only the globally last tile can be ragged)
-        if constexpr (CONV) {                               // X side: the tap's shifted pixel must lie inside the image (no branch: the Y side reads the mask too)
-            const uint32_t mw = reinterpret_cast<const uint32_t*>(cv.tapmask + row0)[j >> 1];
-            ok = ok && (side == 0 || ((mw >> ((j & 1) * 16 + tap)) & 1u));
-        }
-        const float* p = ok ? tb + (int64_t)j * ld : src;   // (always a valid address)
-        const float4 v = *reinterpret_cast<const float4*>(p);
-        r[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-    };
-    auto advance_tile = [&]() { mt_load += (mt_load + 1 < mt_end) ? 1 : 0; };
-    // split + transpose + LDS writes of the 8 x 4 block in r[] (tile in flight in the registers) into buffer `buf`, then refill r[] from tile mt_load
-    float4 q[8];                                            // the block being split (a copy: r[] is refilled while q[] is consumed)
-    auto take_and_refill = [&](bool refill) {
+    auto load_tile = [&](int mt) {
+        const int64_t row0 = (int64_t)mt * X3_BK + mg * 8;
+        const float* tb = lane_src + (int64_t)mt * X3_BK * ld;
+        uint32_t mw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        bool masked = false;
+        if constexpr (CONV) masked = side != 0;
+        if (masked) { const uint4 mk = *reinterpret_cast<const uint4*>(cv.tapmask + row0); mw[0] = mk.x; mw[1] = mk.y; mw[2] = mk.z; mw[3] = mk.w; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) q[j] = r[j];
-        if (refill) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) load_row(j);
+        for (int j = 0; j < 8; ++j) {
+            bool ok = col_ok && (row0 + j < M);
+            if (masked) ok = ok && ((mw[j >> 1] >> ((j & 1) * 16 + tap)) & 1u);
+            r[j] = ok ? *reinterpret_cast<const float4*>(tb + (int64_t)j * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    // column jj of the block: 8 m-values -> NP x 16 bytes of LDS row nc*4 + jj (the transpose is the choice of registers), + the bias partial sum
-    auto store_col = [&](int jj, int buf) {
-        unsigned short* const dst = my_lds + buf * kTileElems + jj * X3_LD;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = jj == 0 ? q[j].x : jj == 1 ? q[j].y : jj == 2 ? q[j].z : q[j].w;
-        uint2 p0[NP], p1[NP];
-        split4<NP>(v[0], v[1], v[2], v[3], p0);
-        split4<NP>(v[4], v[5], v[6], v[7], p1);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(dst + p * kPlane) = make_uint4(p0[p].x, p0[p].y, p1[p].x, p1[p].y);
-        cs[jj] += bias_w * (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+    auto store_tile = [&]() {
+#define X3_TN_COL(COMP, jj_) { \
+            uint2 p0[NP], p1[NP]; \
+            split4<NP>(r[0].COMP, r[1].COMP, r[2].COMP, r[3].COMP, p0); split4<NP>(r[4].COMP, r[5].COMP, r[6].COMP, r[7].COMP, p1); \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) \
+                *reinterpret_cast<uint4*>(my_lds + p * kPlane + (jj_) * X3_LD) = make_uint4(p0[p].x, p0[p].y, p1[p].x, p1[p].y); \
+            if (do_bias) cs[jj_] += ((r[0].COMP + r[1].COMP) + (r[2].COMP + r[3].COMP)) + ((r[4].COMP + r[5].COMP) + (r[6].COMP + r[7].COMP)); }
+        X3_TN_COL(x, 0) X3_TN_COL(y, 1) X3_TN_COL(z, 2) X3_TN_COL(w, 3)
+#undef X3_TN_COL
     };
 
     f32x16_t acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
-    const int fsw = (l31 >> 2) & 3;
-    const int a_row = (wr * 64 + l31) * X3_LD, b_row = NP * kPlane + (wc * 64 + l31) * X3_LD;
-    constexpr int kGroups = (X3_BK / 16) * (NP == 2 ? 3 : 6);
+    for (int q = 0; q < 16; ++q) { acc00[q] = 0.f; acc01[q] = 0.f; acc10[q] = 0.f; acc11[q] = 0.f; }
+    const unsigned short* const Afrag = lds + (wr * 64 + l31) * X3_LD + hi * 8;
+    const unsigned short* const Bfrag = lds + NP * kPlane + (wc * 64 + l31) * X3_LD + hi * 8;
 
-#pragma unroll
-    for (int j = 0; j < 8; ++j) load_row(j);
-    advance_tile();
-    take_and_refill(mt_beg + 1 < mt_end);           // tile 0 -> buffer 0, registers <- tile 1
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) store_col(jj, 0);
-    advance_tile();
-    __syncthreads();
-    int buf = 0;
-    for (int mt = mt_beg; mt + 1 < mt_end; ++mt) {
-        // buffer `buf` holds tile mt, the registers tile mt+1; mt_load points at tile mt+2 (clamped: the last tile is re-read, its copy never stored)
-        const int nb = buf ^ 1;
-        take_and_refill(true);
-        x3_tile_mfma<NP, false, false>(lds + buf * kTileElems, a_row, b_row, hi, fsw, kPlane, acc00, acc01, acc10, acc11, [&](int g) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jj * kGroups / 4 == g) store_col(jj, nb);
-        });
-        advance_tile();
+    load_tile(mt_beg);
+    for (int mt = mt_beg; mt < mt_end; ++mt) {
         __syncthreads();
-        buf = nb;
+        store_tile();
+        __syncthreads();
+        if (mt + 1 < mt_end) load_tile(mt + 1);
+#pragma unroll
+        for (int kk = 0; kk < X3_BK / 16; ++kk)
+            x3_kstep<NP, false, false>(Afrag + kk * 16, Bfrag + kk * 16, kPlane, acc00, acc01, acc10, acc11);
     }
-    x3_tile_mfma<NP, false, false>(lds + buf * kTileElems, a_row, b_row, hi, fsw, kPlane, acc00, acc01, acc10, acc11, [](int) {});
 
     // D[row n][col k]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*hi -> atomics of a half-wave hit 32 consecutive k
 #define X3_TN_EPI(acc_, i_, j_) { const int kcol = k0 + wc * 64 + (j_) * 32 + l31; \

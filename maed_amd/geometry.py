@@ -1,6 +1,6 @@
 """6D rotation / axis-angle helpers (reference: lib/utils/geometry.py:320-334,58-87,143-223,90-140) as
-differentiable ATen compositions.  They carry the TRAINING graph of the decoder tail ((F*24) tiny
-rows) on the GPU; the inference path uses the fused HIP kernel maed_rot6d_pose_fwd instead."""
+differentiable ATen compositions for HOST tensors: what the `-m "not gpu"` suite compares the kernels with.  On a library device both the inference
+and the training path run maed_rot6d_pose_fwd / _bwd (tail.SmplTailFn)."""
 import torch
 import torch.nn.functional as F
 

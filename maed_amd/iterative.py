@@ -57,6 +57,8 @@ class Regressor(nn.Module):
         self.register_buffer('init_shape', mp['shape'].reshape(1, NSHAPE))
         self.register_buffer('init_cam', mp['cam'].reshape(1, NCAM))
         self._packed_key, self._packed = None, None
+        # fp32 [out,in] masters + transposed images for the training head's library GEMMs (one cache per weight view: WeightCache keys on the tensors it is given)
+        self._caches = {k: ops.WeightCache() for k in ("fc1x", "fc1p", "fc2", "pose", "shape", "cam")}
 
     # the tail and its dispatch predicates are KTD's (same attributes: fc1, smpl, training)
     get_output = KTD.get_output
@@ -92,6 +94,25 @@ class Regressor(nn.Module):
             prm = ops.gemm_nt(h2, w_dec, L.EPI_STORE, bias=b_dec).add_(prm)
         return prm[:, :NPOSE].contiguous(), prm[:, NPOSE:NPOSE + NSHAPE].contiguous(), prm[:, NPOSE + NSHAPE:].contiguous()
 
+    def _regress_train(self, x, pose, shape, cam, n_iter):
+        """the differentiable head on the library (spin.py:53-76): every nn.Linear through ste_modes.LinearTokFn (maed_gemm_nt forward / input gradient,
+        maed_gemm_tn_wgrad or transposed copies for the weight gradient), Dropout through maed_dropout; fc1's iteration-invariant feature part hoisted
+        out of the three rounds as in _regress_hip.  What stays on ATen are the (F,157) adds and concatenations between the GEMMs."""
+        from . import ste_modes
+        lin = ste_modes.LinearTokFn.apply
+        fd, c = self.feat_dim, self._caches
+        x = x.float().contiguous()
+        w1 = self.fc1.weight
+        hx = lin(x, w1[:, :fd], self.fc1.bias, c["fc1x"], True)
+        for _ in range(n_iter):
+            prm = torch.cat([pose, shape, cam], dim=1).float().contiguous()
+            xc = ste_modes.dropout(hx + lin(prm, w1[:, fd:], None, c["fc1p"], True), self.drop1.p, self.drop1.training)
+            xc = ste_modes.dropout(lin(xc, self.fc2.weight, self.fc2.bias, c["fc2"], True), self.drop2.p, self.drop2.training)
+            pose = lin(xc, self.decpose.weight, self.decpose.bias, c["pose"], True) + pose
+            shape = lin(xc, self.decshape.weight, self.decshape.bias, c["shape"], True) + shape
+            cam = lin(xc, self.deccam.weight, self.deccam.bias, c["cam"], True) + cam
+        return pose, shape, cam
+
     def _regress_torch(self, x, pose, shape, cam, n_iter):
         fd = self.feat_dim
         hx = F.linear(x, self.fc1.weight[:, :fd], self.fc1.bias)
@@ -109,7 +130,9 @@ class Regressor(nn.Module):
         pose, shape, cam = self._init(x.shape[0], init_pose, init_shape, init_cam)
         if self._use_hip(x):
             return self._regress_hip(x, pose, shape, cam, n_iter)
-        return self._regress_torch(x.float(), pose, shape, cam, n_iter)
+        if ops.on_library_device(x):                 # differentiable, on the device: library Functions (no ATen twin on a GPU)
+            return self._regress_train(x, pose, shape, cam, n_iter)
+        return self._regress_torch(x.float(), pose, shape, cam, n_iter)     # host tensors: the ATen composition the CPU suite compares the kernels with
 
     def forward(self, x, seqlen, J_regressor=None, init_pose=None, init_shape=None, init_cam=None, n_iter=3, **kwargs):
         """spin.py:78-86.  The reference ignores its n_iter argument here and always runs 3 rounds (spin.py:83); so does this."""

@@ -79,7 +79,7 @@ class KTD(nn.Module):
         x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc2.weight, self.fc2.bias, self._fc_cache2, True), self.drop2.p, self.drop2.training)
         return tail.KtdChainFn.apply(x, self, *self.fused_parameters())
 
-    # ---- ATen path (training) -------------------------------------------------------------------
+    # ---- ATen composition for host tensors (the CPU suite's comparison arm; a library device takes _head_hip / _head_train) ----
     def _head_torch(self, x):
         x = self.drop1(self.fc1(x))
         x = self.drop2(self.fc2(x))

@@ -464,6 +464,7 @@ class EmbedAddFn(torch.autograd.Function):
 # uses the copy only if it receives THAT VERY tensor object as grad_output (identity, not data_ptr: allocator reuse).
 _TWIN = [None, None]
 TWIN_HITS = [0, 0]   # [hits, misses] -- diagnostics
+_TWIN_WARNED = [False]
 
 
 class ReportingFn(torch.autograd.Function):
@@ -520,6 +521,13 @@ class STEBlockFn(ReportingFn):
             ref, cand = _TWIN
             if ref is not None and ref() is dy and cand.shape == dy.shape and cand.dtype == cdt:
                 tw_in = cand
+            elif ref is not None and not _TWIN_WARNED[0]:
+                # a block handed its compute-dtype gradient copy on, but the tensor that arrives is not the one it returned (a hook that clones or rescales
+                # gradients, retain_graph replays, activation checkpointing ...): correct -- the copy is re-made from dy -- but a cast pass per block
+                _TWIN_WARNED[0] = True
+                import warnings
+                warnings.warn("maed_amd: the residual-gradient hand-off between consecutive STE blocks was bypassed (the gradient tensor arriving at a block is not "
+                              "the one the next block returned); falling back to one extra cast pass per block", RuntimeWarning, stacklevel=2)
             TWIN_HITS[0 if tw_in is not None else 1] += 1
         _TWIN[0], _TWIN[1] = None, None
         tw_out = torch.empty(dy.shape, dtype=cdt, device=dy.device) if cdt != torch.float32 else None

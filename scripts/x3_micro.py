@@ -12,6 +12,8 @@ from maed_amd import ops, _lib as L  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 groups = (sys.argv[2] if len(sys.argv) > 2 else "nt,tn,conv,attn").split(",")
+only = sys.argv[3].split(",") if len(sys.argv) > 3 and sys.argv[3] != "all" else None      # shape-name filter (nt / tn groups)
+only_modes = sys.argv[4].split(",") if len(sys.argv) > 4 else None                         # mode filter: bf16,bf16x3,bf16x6
 torch.manual_seed(0)
 M = 128 * 197
 dev = "cuda"
@@ -30,10 +32,12 @@ def timeit(fn, n=iters):
 
 
 def modes():
-    yield "bf16", torch.bfloat16
+    if only_modes is None or "bf16" in only_modes:
+        yield "bf16", torch.bfloat16
     for m in ("bf16x3", "bf16x6"):
-        maed_amd.set_float32_matmul_precision(m)
-        yield m, torch.float32
+        if only_modes is None or m in only_modes:
+            maed_amd.set_float32_matmul_precision(m)
+            yield m, torch.float32
     maed_amd.set_float32_matmul_precision("exact")
 
 
@@ -43,6 +47,8 @@ if "nt" in groups:
               "sq4k": (4096, 4096, 4096, L.EPI_STORE), "c3a": (25088, 256, 1024, L.EPI_STORE), "c3b": (25088, 1024, 256, L.EPI_STORE),
               "c2a": (100352, 128, 512, L.EPI_STORE), "c2b": (100352, 512, 128, L.EPI_STORE), "c1a": (401408, 64, 256, L.EPI_STORE), "c1b": (401408, 256, 64, L.EPI_STORE)}
     for name, (m, n, k, epi) in shapes.items():
+        if only and name not in only:
+            continue
         line = f"nt {name:5s} {m}x{n}x{k}:"
         for mode, dt in modes():
             A = [torch.randn(m, k, device=dev).to(dt) for _ in range(2)]
@@ -65,6 +71,8 @@ if "tn" in groups:
            ("c1 56 64->256", 401408, 256, 64), ("c1 56 256->64", 401408, 64, 256), ("c2 28 128->512", 100352, 512, 128), ("c2 28 512->128", 100352, 128, 512),
            ("c3 14 256->1024", 25088, 1024, 256), ("c3 14 1024->256", 25088, 256, 1024)]
     for name, m, n, k in ste:
+        if only and name.split()[0] not in only:
+            continue
         line = f"tn {name:16s} M={m} N={n} K={k}:"
         for mode, dt in modes():
             Y, X = torch.randn(m, n, device=dev).to(dt), torch.randn(m, k, device=dev).to(dt)

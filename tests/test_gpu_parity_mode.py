@@ -1,0 +1,93 @@
+"""The fp32-accurate mode at MFMA speed, at FULL module size (BASELINE.json cfg2 / cfg3 dimensions: C = 512, H = 8, depth 6, 224^2, T = 16; one clip):
+compute_dtype = float32, fp32 matrix products on the split-bf16 kernels (process-wide "bf16x3", the backbone on its own "bf16x6" engine -- MAED(
+backbone_f32_matmul=...)), every convolution but the 7x7 stem and the two strided 3x3 backward passes on the library's own kernels.
+
+  * outputs vs the fp32 CPU oracle (north_star: 1e-3 relative on SMPL parameters)
+  * EVERY parameter gradient of the whole model vs fp64 autograd through the oracle:
+      - outside the backbone: 1e-3 of the tensor's largest gradient, per parameter
+      - inside the backbone the fp32 REFERENCE ARITHMETIC ITSELF is 1.5e-2 (median over a stage's parameters) / 3.5e-2 (worst) away from fp64 on a freshly
+        initialised network -- 52 GroupNorms behind weight-standardised convolutions amplify fp32 rounding (measured here every run: the fp32 oracle vs the
+        fp64 oracle).  No fp32 implementation can be closer to fp64 than fp32 arithmetic is; the bar is therefore the reference's own distance: per
+        stage, median and worst error at most 1.5x the fp32 oracle's (+1e-3).  bf16x6 meets it (1.0x); bf16x3 in the backbone does not (4x:
+        profiles/r03_x3_probe_call2_mixed.txt), which is why the backbone carries its own engine.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import maed_ref as R
+
+pytestmark = pytest.mark.gpu
+
+from _util import DEV, note, report, rnd  # noqa: E402
+
+CFG = dict(depth=6, H=8, img=224, hidden=1024, T=16)
+WTS = {"theta": 1.0, "kp_3d": 1.0, "kp_2d": 0.01}
+
+
+def _group(name):
+    if "backbone" in name:
+        s = name.split("backbone.")[1]
+        return "backbone." + (s.split(".")[0] if s.startswith("stem") else ".".join(s.split(".")[:2]))
+    return "ste+decoder"
+
+
+def _oracle(params, clip, sp, dtype):
+    pd = {k: v.clone().to(dtype).requires_grad_(True) for k, v in params.items()}
+    spd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sp.items()}
+    out = R.maed_forward(clip.to(dtype), pd, spd, depth=CFG["depth"], H=CFG["H"])
+    sum(w * (out[k] ** 2).mean() for k, w in WTS.items()).backward()
+    return {k: v.detach() for k, v in out.items()}, {k: v.grad for k, v in pd.items() if v.grad is not None}
+
+
+def test_cfg3_full_size_parity_mode_outputs_and_every_gradient():
+    import maed_amd
+    from maed_amd import ops
+    C, P = 64 * CFG["H"], (CFG["img"] // 16) ** 2 + 1
+    params = R.make_params(embed_dim=C, depth=CFG["depth"], hidden_dim=CFG["hidden"], n_tokens=P, seed=7)
+    sp = R.make_synthetic_smpl(0)
+    clip = rnd(1, CFG["T"], 3, CFG["img"], CFG["img"], seed=21)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    o64, g64 = _oracle(params, clip, sp, torch.float64)
+    o32, g32 = _oracle(params, clip, sp, torch.float32)
+    rel = lambda a, b: float((a.double().cpu() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+    old = ops.get_float32_matmul_precision()
+    calls = {"c1": 0, "c3": 0}
+    real_c1, real_c3 = ops.Conv1x1Fn.forward, ops.conv3x3
+    try:
+        ops.set_float32_matmul_precision("bf16x3")
+        ops.Conv1x1Fn.forward = staticmethod(lambda ctx, *a: (calls.__setitem__("c1", calls["c1"] + 1), real_c1(ctx, *a))[1])
+        ops.conv3x3 = lambda *a, **k: (calls.__setitem__("c3", calls["c3"] + 1), real_c3(*a, **k))[1]
+        m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["H"], embed_dim=C, hidden_dim=CFG["hidden"], img_size=CFG["img"], compute_dtype=torch.float32,
+                          backbone_f32_matmul="bf16x6")
+        m.load_state_dict(params, strict=False)
+        m = m.to(DEV).train()
+        m.decoder.drop1.p = 0.0
+        m.decoder.drop2.p = 0.0
+        out = m(clip.to(DEV))
+        sum(w * (out[k] ** 2).mean() for k, w in WTS.items()).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_float32_matmul_precision(old)
+        ops.Conv1x1Fn.forward, ops.conv3x3 = real_c1, real_c3
+    # the library's own convolutions carried the backbone: 35 1x1 (33 stride-1 + 2 packed stride-2 shortcuts), 16 3x3 forward + 13 stride-1 input gradients
+    assert calls["c1"] == 35 and calls["c3"] == 16 + 13, calls
+
+    for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts"):
+        report(f"parity mode (f32, bf16x3 / backbone bf16x6) cfg3 full size {k} vs fp32 oracle", out[k].detach().float(), o32[k], rtol=0, atol=1e-3 * o32[k].abs().max().item())
+    by_mine, by_ref = {}, {}
+    for n, p in m.named_parameters():
+        assert p.grad is not None and n in g64, n
+        by_mine.setdefault(_group(n), []).append((rel(p.grad, g64[n]), n))
+        by_ref.setdefault(_group(n), []).append((rel(g32[n], g64[n]), n))
+    for grp in sorted(by_mine):
+        a, b = sorted(by_mine[grp]), sorted(by_ref[grp])
+        med_a, med_b, w_a, w_b = a[len(a) // 2][0], b[len(b) // 2][0], a[-1][0], b[-1][0]
+        note(f"parity mode gradients vs fp64, {grp:20s} n={len(a):3d}: ours median {med_a:.2e} worst {w_a:.2e} ({a[-1][1]});  fp32 oracle median {med_b:.2e} worst {w_b:.2e}")
+        if grp == "ste+decoder":
+            assert w_a <= 1e-3, (grp, a[-1])
+        else:
+            assert med_a <= 1.5 * med_b + 1e-3 and w_a <= 1.5 * w_b + 1e-3, (grp, med_a, med_b, w_a, w_b)

@@ -20,8 +20,14 @@ def _checks():
 
 @pytest.mark.parametrize("part", ["conv3x3", "long_attention", "modes", "iterative", "evaluation"])
 def test_new_path_parity_on_gpu(part):
+    """every comparison of the part runs (a mismatch does not hide the ones behind it), each goes into the parity report, and the failure message names
+    exactly the comparisons that are out of tolerance"""
+    from _util import note
     mod = _checks()
-    try:
-        getattr(mod, part)()
-    except SystemExit as e:          # check() exits on the first mismatch
-        pytest.fail(f"{part}: parity check failed (exit {e.code}); see the captured output")
+    mod.RESULTS.clear()
+    getattr(mod, part)()
+    assert mod.RESULTS, f"{part}: no comparison ran"
+    for name, err, tol, ok in mod.RESULTS:
+        note(f"{'ok  ' if ok else 'FAIL'} [{part}] {name:70s} rel err {err:.3e} (tol {tol:.0e})")
+    bad = [f"{name}: rel err {err:.3e} > {tol:.0e}" for name, err, tol, ok in mod.RESULTS if not ok]
+    assert not bad, f"{part}: {len(bad)} of {len(mod.RESULTS)} comparisons out of tolerance:\n  " + "\n  ".join(bad)
