@@ -145,6 +145,23 @@ def parity_probe(dev):
     return out
 
 
+class _SimModel(torch.nn.Module):
+    """--simulate only: a CPU stand-in with MAED's output contract (clip (N,T,3,H,W) -> dict of (N,T,...) tensors).  The real model's kernels on the
+    host simulator take minutes per step; what --simulate exercises is the driver around the model (process group, broadcast, autograd-hook readiness,
+    bucketed all-reduce, FusedAdam and the fused loss on the simulator, profiling steps, barriers, JSON)."""
+
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Linear(3, 64)
+        self.mid = torch.nn.Linear(64, 64)
+        self.dec = torch.nn.Linear(64, 49 * 2 + 49 * 3 + 85)
+
+    def forward(self, x, J_regressor=None):
+        N, T = x.shape[:2]
+        o = self.dec(torch.tanh(self.mid(torch.tanh(self.enc(x.mean(dim=(-1, -2)))))))
+        return dict(kp_2d=o[..., :98].reshape(N, T, 49, 2), kp_3d=o[..., 98:245].reshape(N, T, 49, 3), theta=o[..., 245:])
+
+
 def parity_mode_line(dev, steps=4):
     """the fp32-accurate mode beside the headline bf16 line: compute_dtype = float32 with the fp32 matrix products on the split-bf16 MFMA kernels
     (process-wide bf16x3, the backbone on bf16x6 -- DESIGN.md section 4), the SAME cfg3 train step (8 clips x 16 frames, fwd + bwd + Adam) timed over a few
@@ -209,12 +226,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="cfg2: inference forward instead of the train step")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"], help="cfg3 = BASELINE's metric workload (default); cfg5 = long-clip stress")
+    ap.add_argument("--simulate", action="store_true",
+                    help="TEST ONLY (tests/test_bench_world2.py): the whole driver -- process group, broadcast, bucketed all-reduce overlapped with backward, "
+                         "extra profiling steps, barriers, JSON -- on CPU tensors with the kernels on the host simulator and the gloo backend, tiny workload; "
+                         "the number it prints is meaningless")
     ap.add_argument("--backbone-f32-matmul", default=None, choices=["bf16x3", "bf16x6"],
                     help="--dtype f32 only: the backbone's own engine (MAED(backbone_f32_matmul=...)); default: the process-wide mode")
     args = ap.parse_args()
 
     if args.workload == "cfg5":   # BASELINE.json configs[4]: long-clip stress (per-GPU clips stated in config.workload)
         CFG.update(clips=2, T=64, img=256, depth=12, heads=12, dim=768)
+    sim = args.simulate
+    if sim:                       # tiny model, host simulator, gloo: exercises the orchestration, not the kernels' speed
+        CFG.update(clips=1, T=2, img=32, depth=1, heads=2, dim=128, hidden=64)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _hostsim
+        sim_ctx = _hostsim.patched()
+        sim_ctx.__enter__()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -224,10 +252,15 @@ def main():
     force_coll = os.environ.get("MAED_FORCE_COLLECTIVES", "0") == "1"
     if world > 1 or (force_coll and "RANK" in os.environ and "MASTER_PORT" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if sim:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if not sim:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if sim else torch.device("cuda", local_rank)
+    cuda_sync = (lambda: None) if sim else torch.cuda.synchronize
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     from maed_amd import _lib as L
@@ -239,7 +272,7 @@ def main():
         maed_amd.set_float32_matmul_precision(args.f32_matmul)
 
     log(f"building model ({args.dtype}) on {dev}")
-    model = build_model(dtype, dev, args.backbone_f32_matmul)
+    model = _SimModel() if sim else build_model(dtype, dev, args.backbone_f32_matmul)
     gen = torch.Generator().manual_seed(1000 + rank)
     clip = torch.randn(CFG["clips"], CFG["T"], 3, CFG["img"], CFG["img"], generator=gen).to(dev)
     tgt = make_targets(CFG["clips"], CFG["T"], dev, gen)
@@ -254,10 +287,10 @@ def main():
         model.train()
         arena = ParamArena(model)
         comm = None
-        if os.environ.get("MAED_COMM", "torch") == "direct":   # the library's own RCCL communicator + side stream (maed_comm_*)
+        if os.environ.get("MAED_COMM", "torch") == "direct" and not sim:   # the library's own RCCL communicator + side stream (maed_comm_*)
             from maed_amd.ddp import RcclComm
             comm = RcclComm()
-        bucketer = GradBucketer(arena, model, comm=comm, force_collectives=force_coll)
+        bucketer = GradBucketer(arena, model, comm=comm, force_collectives=force_coll, **(dict(bucket_bytes=16 << 10) if sim else {}))
         bucketer.broadcast_parameters(0)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=bucketer)  # configs/config_stage2.yaml:63-66
         criterion = LossVideo(**LOSS_W)                                        # lib/core/loss.py via maed_loss_fwd_bwd
@@ -269,26 +302,32 @@ def main():
             opt.step()
 
     def fence():
-        torch.cuda.synchronize()
+        cuda_sync()
         if dist.is_available() and dist.is_initialized():
             dist.barrier()
-        torch.cuda.synchronize()
+        cuda_sync()
 
     # setup, not a benchmark step: the first pass through the model makes MIOpen search its convolution algorithms (~20 s) and
     # loads every code object; it is kept out of the W warm-up steps so that a small --warmup cannot put it next to the timed region
     t1 = time.perf_counter()
     step()
-    torch.cuda.synchronize()
+    cuda_sync()
     log(f"setup pass (MIOpen algorithm search, code-object loading): {time.perf_counter() - t1:.3f}s")
     for i in range(args.warmup):
         t1 = time.perf_counter()
         step()
-        torch.cuda.synchronize()
+        cuda_sync()
         log(f"warm-up step {i}: {time.perf_counter() - t1:.3f}s")
     fence()
     # the contract's number: K steps bracketed by barrier + synchronize; beside it one event per step boundary on the launch stream
     # (every kernel of a step is enqueued on torch's current stream) for the per-step median / p10 / p90
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    class _HostMark:       # --simulate: host clock in place of hipEvents
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return 1e3 * (other.t - self.t)
+    marks = [(_HostMark() if sim else torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -316,12 +355,12 @@ def main():
     # EVERY rank runs the extra steps (a train step contains the gradient all-reduce: a rank stepping alone would wait for
     # collectives nobody else issues); only rank 0 brackets its launches with events and reports
     nprof = 3
-    if rank == 0:
+    if rank == 0 and not sim:
         lib.maed_prof_enable(1)
     for _ in range(nprof):
         step()
     fence()
-    if rank == 0:
+    if rank == 0 and not sim:
         ntags = lib.maed_prof_ntags()
         ms = (ctypes.c_double * ntags)()
         cnt = (ctypes.c_int * ntags)()
@@ -403,7 +442,7 @@ def main():
 
     log(f"kernel timing done: {json.dumps(kernels)}")
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sim:
         try:
             cpu = cpu_baseline()
         except Exception as e:  # the baseline must never take the bench line down
@@ -435,6 +474,11 @@ def main():
                        "loss": "lib/core/loss.py LossVideo (config_stage2 weights) on synthetic labels, fused fwd+bwd kernel",
                        "smpl": "synthetic SMPL-shaped parameters (licensed model file unavailable)"},
             "step_time": step_stats,
+            # data-parallel diagnostics (N > 1 or forced collectives): transport, ranks, gradient buckets and when each was launched in the last backward
+            "ddp": (None if args.forward_only else dict(transport="maed_comm (own RCCL communicator)" if comm is not None else ("torch.distributed/" + (dist.get_backend() if dist.is_initialized() else "none")),
+                                                     rccl_ranks=world, collectives=bool(bucketer.collectives), gradient_dtype="f32",
+                                                     buckets=[dict(mbytes=round(4 * (e - s) / 2 ** 20, 2), params=n) for s, e, n in bucketer.buckets],
+                                                     bucket_launch_order=list(bucketer.launch_order), per_stage_weight_std=bool(bucketer.world > 1))),
             "roofline": roofline, "roofline_attention": roofline_attention, "roofline_wgrad": roofline_wgrad, "kernels": kernels, "kernel_groups": groups,
             "cpu_baseline": cpu,
             "parity_err_bf16": (cpu or {}).get("parity_probe", {}).get("rel_err", {}).get("bf16") if cpu and (cpu.get("parity_probe") or {}).get("rel_err") else None,

@@ -89,6 +89,10 @@ typedef enum {
     MAED_OPT_ABLATE = 3,        /* diagnostic builds (-DMAED_GEMM_ABLATE) only: bit mask of pipeline stages to drop */
     MAED_OPT_COUNT
 } maed_option;
+/* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's
+ * architecture in maed_last_error() -- the host calls it once after loading the library, so that a wrong device fails here and not as an "invalid device
+ * function" at the first launch.  The library keeps no per-device state. */
+int maed_init(int device);
 int maed_set_option(int key, int value);   /* MAED_OK or MAED_ERR_ARG */
 int maed_get_option(int key);              /* the value, or MAED_ERR_ARG (negative) for an unknown key */
 

@@ -59,6 +59,7 @@ KTD_W_ANC = 3420
 SIGNATURES = {
     "maed_last_error": (C.c_char_p, []),
     "maed_version": (i32, []),
+    "maed_init": (i32, [i32]),
     "maed_set_option": (i32, [i32, i32]),
     "maed_get_option": (i32, [i32]),
     "maed_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i32, vp, vp, i64, i32, f32, vp]),
@@ -146,6 +147,9 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = handle
         apply_options(handle)
+        import torch
+        if torch.cuda.is_available():        # a GPU that is not gfx950 fails here, with its name, instead of at the first launch
+            check(handle.maed_init(torch.cuda.current_device()), "maed_init")
     return _lib
 
 

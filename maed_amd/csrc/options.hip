@@ -4,6 +4,7 @@
 #include "common.cuh"
 #include "gemm_x3.h"
 #include <atomic>
+#include <string.h>
 
 static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {0},      // MAED_OPT_F32_MATMUL: exact
@@ -11,6 +12,20 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {384},    // MAED_OPT_TN_TARGET_WGS
     {0},      // MAED_OPT_ABLATE
 };
+
+extern "C" int maed_init(int device) {
+#ifndef MAED_HOSTSIM
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); maed_set_error("init: no HIP device %d", device); return MAED_ERR_ARG; }
+    if (!strstr(prop.gcnArchName, "gfx950")) {
+        maed_set_error("init: device %d is %s; libmaed_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return MAED_ERR_UNSUPPORTED;
+    }
+#else
+    (void)device;
+#endif
+    return MAED_OK;
+}
 
 extern "C" int maed_set_option(int key, int value) {
     MAED_CHECK_ARG(key >= 0 && key < MAED_OPT_COUNT, MAED_ERR_ARG, "set_option: unknown option %d", key);

@@ -121,6 +121,17 @@ class GradBucketer:
         # stream/event plumbing on a single GPU: tests/test_gpu_model.py)
         self.collectives = (self.world > 1) or (force_collectives and (comm is not None or (dist.is_available() and dist.is_initialized())))
         cap = max(1, bucket_bytes // 4)
+        # Bucket boundaries also fall where a group of kernel-written gradients that is reported as ONE unit begins (the backbone's per-stage
+        # weight-standardisation groups: last stage first, stem + first stage last): a bucket then never waits for a LATER report than its own group's,
+        # and what remains exposed at the end of the backward is the all-reduce of the small stem + stage-1 group (0.9 MB at cfg3), not of a 32 MiB
+        # bucket that happens to contain it.
+        cuts = set()
+        if self.world > 1 or force_collectives:
+            for m in model.modules():
+                for g in getattr(m, "_ws_groups", ()):
+                    idx = [arena.index[id(p)] for p in g.fused_parameters() if id(p) in arena.index]
+                    if idx:
+                        cuts.add(min(idx))
         # buckets are built from the END of the arena (first to complete in backward)
         self.buckets = []  # [start, end, n_params]
         self.bucket_of = [0] * len(arena.params)
@@ -134,6 +145,9 @@ class GradBucketer:
             cur_start = o
             cur_n += 1
             self.bucket_of[i] = len(self.buckets)
+            if i in cuts and i > 0:             # first parameter of a reporting group: the parameters in front of it belong to an earlier-in-forward group
+                self.buckets.append([cur_start, end, cur_n])
+                end, cur_n = cur_start, 0
         if cur_n:
             self.buckets.append([cur_start, end, cur_n])
         self._pending = [b[2] for b in self.buckets]
@@ -141,6 +155,7 @@ class GradBucketer:
         self._seen = [False] * len(arena.params)      # parameters that reported a gradient since the last finish()
         self.unmarked = []                             # ... and the ones that did not, as of the last finish() (FusedAdam skips them like torch.optim.Adam)
         self._works = []
+        self.launch_order = []                         # bucket indices in the order they were launched in the last step (diagnostics: bench.py "ddp")
         self._finished = False                         # finish() ran and nothing was reported since: a second finish() is a no-op
         self._fused = set()
         self._fused_modules = []
@@ -176,6 +191,9 @@ class GradBucketer:
         if self._launched[b]:
             return
         self._launched[b] = True
+        if not any(self._launched[i] for i in range(len(self._launched)) if i != b):
+            self.launch_order = []
+        self.launch_order.append(b)
         if self.collectives:
             s, e, _ = self.buckets[b]
             if self.comm is not None:
