@@ -87,7 +87,6 @@ typedef enum {
     MAED_OPT_SIDE_STREAM = 1,   /* 1 (default): weight-gradient GEMMs / temporal attention of the fused STE block on the library's side stream */
     MAED_OPT_TN_TARGET_WGS = 2, /* workgroups a weight-gradient GEMM is split into along M (default 384; tuning knob of scripts/gpu_tn_sweep.sh) */
     MAED_OPT_ABLATE = 3,        /* diagnostic builds (-DMAED_GEMM_ABLATE) only: bit mask of pipeline stages to drop */
-    MAED_OPT_TN_KERNEL = 4,     /* bf16 weight-gradient GEMM: 1 (default) DMA-staged tiles + transposing LDS fragment reads, 0 the register-staged kernel */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's

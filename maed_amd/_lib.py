@@ -18,7 +18,7 @@ IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
 IMPL_X3, IMPL_X6 = 7, 8  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
-OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_TN_KERNEL = range(5)   # maed_option (include/maed_hip.h)
+OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE = range(4)   # maed_option (include/maed_hip.h)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -160,7 +160,6 @@ _OPTIONS = {
     OPT_SIDE_STREAM: int(os.environ.get("MAED_WGRAD_SIDE_STREAM", "1") == "1"),
     OPT_TN_TARGET_WGS: max(64, int(os.environ.get("MAED_TN_TARGET_WGS", "384"))),
     OPT_ABLATE: int(os.environ.get("MAED_GEMM_ABLATE", "0")),
-    OPT_TN_KERNEL: int(os.environ.get("MAED_TN_KERNEL", "1")),
 }
 
 

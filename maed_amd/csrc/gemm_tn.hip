@@ -12,7 +12,6 @@
 #include "common.cuh"
 #include "gemm_epilogue.cuh"      // xcd_remap
 #include "gemm_x3.h"
-#include "attn_mfma.cuh"
 #include <stdlib.h>
 
 static int tn_remap() { return 1; }     // XCD-aware (split, tile) order: -6...8 % and 292 -> 189 MB of HBM traffic per launch (profiles/r02_pmc)
@@ -200,114 +199,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Round 3: the same product with NO register staging at all.  The kernel above spends its time on the LDS side (per 64-row tile a wave does 8
-// transposing ds_write_b128 after 32 v_perm, a barrier, 16 ds_read_b128 + 16 MFMA: profiles/r02_gemm_tn_ablation.txt -- MFMA + LDS transposes
-// alone are 3/4 of its time, at two workgroups per CU).  Here the row-major operand tiles [64 m][128 columns] go global -> LDS by DMA
-// (global_load_lds_dwordx4: no VGPRs, no VALU, no ds_write) and the M-contiguous MFMA fragments come out of the row-major image with
-// ds_read_b64_tr_b16 (attn_mfma.cuh lds_frag_tr_rm: a 16-lane group reads a 4 x 16 block and receives its columns), so a tile step is
-// 8 DMAs + 32 transposing reads + 16 MFMAs per wave, ~100 VGPRs, 32 KB of LDS -> 4 workgroups per CU hide the DMA latency (the NT kernel's
-// one-buffer recipe).  256-byte rows would put the 4 rows of a transposing read on the same banks: the 16-byte chunk index is XOR-ed with
-// (row & 3) << 2 -- applied, as in gemm_nt_glds_bf16_kernel, to the SOURCE address of each DMA lane.
-// Bias gradient: the Y tile never passes through registers, so the column sums are one more MFMA per 32 Y^T rows against a fragment of ones,
-// (the wave of column half wc takes the wc-th 32-row block of its Y^T rows: one extra accumulator per wave), for every tiles_k-th M tile (rotating with the K tile index: each (N tile, M tile) pair exactly once).
-// Needs M % 64 == 0 (no ragged tile) and 32-bit byte offsets inside a tile; the kernel above remains for everything else and for the
-// gathered-row convolution weight gradient.
-// ------------------------------------------------------------------------------------------------------------------------------------
-#define TG_LD 128     // LDS row (elements): one 256-byte tile row, unpadded
-
-__device__ __forceinline__ bf16x8_t tg_frag_tr(const unsigned short* X, int key_base, int e_base, int lane) {
-    // lds_frag_tr_rm on the swizzled 256-byte-row image: element column e of row r lives in chunk (e >> 3) ^ ((r & 3) << 2)
-    const int i = lane & 15;
-    const int r = key_base + 4 * (lane >> 5) + (i >> 2);
-    const int e = e_base + (lane & 16) + 4 * (i & 3);
-    const unsigned short* p = X + r * TG_LD + ((((e >> 3) ^ ((r & 3) << 2))) << 3) + (e & 7);
-    union { bf16x8_t v; uint2 u[2]; } f;
-    auto lo = MAED_DS_READ_TR16(p);
-    auto hi = MAED_DS_READ_TR16(p + 8 * TG_LD);             // (row + 8: same swizzle term)
-    __builtin_memcpy(&f.u[0], &lo, 8);
-    __builtin_memcpy(&f.u[1], &hi, 8);
-    return f.v;
-}
-
-__global__ __launch_bounds__(256, 4) void gemm_tn_glds_bf16_kernel(const bf16* __restrict__ Y, int64_t ldy, const bf16* __restrict__ X, int64_t ldx,
-                                                                   int64_t M, int N, int K, float* __restrict__ dW, int64_t ldw,
-                                                                   float* __restrict__ dbias, int tiles_k, int mtiles_per_split) {
-    __shared__ __attribute__((aligned(1024))) unsigned short lds[2][64 * TG_LD];      // [Y | X][m][column]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
-    const int lin = xcd_remap((int)(blockIdx.z * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.z));
-    const int bx = lin % (int)gridDim.x, bz = lin / (int)gridDim.x;
-    const int tile_n = bx / tiles_k, tile_k = bx % tiles_k;
-    const int n0 = tile_n * 128, k0 = tile_k * 128;
-    const int nmt = (int)(M / 64);
-    const int mt_beg = bz * mtiles_per_split;
-    int mt_end = mt_beg + mtiles_per_split;
-    if (mt_end > nmt) mt_end = nmt;
-    if (mt_beg >= mt_end) return;
-
-    // staging: waves 0,1 bring the Y tile (rows 0..31 / 32..63), waves 2,3 the X tile; DMA i of a wave covers rows 4i..4i+3 of its half:
-    // lane l -> row (l >> 4), LDS chunk (l & 15), i.e. global chunk (l & 15) ^ ((l >> 4) << 2).  Columns past N / K read column 0 (a valid
-    // address; those LDS columns only feed outputs that are never stored).
-    const int op = wave >> 1, half = wave & 1;
-    const bf16* const src = op ? X : Y;
-    const int64_t ld = op ? ldx : ldy;
-    const int cmax = op ? K : N, cbase = op ? k0 : n0;
-    const int rin = lane >> 4;
-    int gcol = cbase + (((lane & 15) ^ (rin << 2)) << 3);
-    if (gcol >= cmax) gcol = 0;
-    uint32_t voff[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) voff[i] = (uint32_t)((((int64_t)(32 * half + 4 * i + rin)) * ld + gcol) * 2);
-    const char* const src_b = reinterpret_cast<const char*>(src);
-    unsigned short* const my_rows = &lds[op][(32 * half) * TG_LD];
-
-    f32x16_t acc00, acc01, acc10, acc11, accb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; accb[r] = 0.f; }
-    union { bf16x8_t v; uint32_t u[4]; } ones;
-    ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3f803f80u;                         // bf16 1.0 x 8
-    const bool bias_wave = dbias != nullptr;
-
-    for (int mt = mt_beg; mt < mt_end; ++mt) {
-        const char* const tb = src_b + (int64_t)mt * 64 * ld * 2;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) MAED_LDS_DMA16(tb, voff[i], my_rows + 4 * i * TG_LD);
-        MAED_WAIT_VMCNT0();
-        __syncthreads();
-        const bool bias_now = bias_wave && (mt % tiles_k == tile_k);                      // wave-uniform
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8_t a0 = tg_frag_tr(lds[0], kk * 16, wr * 64, lane), a1 = tg_frag_tr(lds[0], kk * 16, wr * 64 + 32, lane);
-            const bf16x8_t b0 = tg_frag_tr(lds[1], kk * 16, wc * 64, lane), b1 = tg_frag_tr(lds[1], kk * 16, wc * 64 + 32, lane);
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);
-            if (bias_now) {                                                             // (wave-uniform branches)
-                if (wc) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ones.v, accb, 0, 0, 0);
-                else accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ones.v, accb, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-    // D[row n][col k]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*hi -> atomics of a half-wave hit 32 consecutive k
-#define TG_EPI(acc_, i_, j_) { const int kcol = k0 + wc * 64 + (j_) * 32 + l31; \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int nrow = n0 + wr * 64 + (i_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; \
-            if (nrow < N && kcol < K) atomicAdd(dW + (int64_t)nrow * ldw + kcol, acc_[r]); } }
-    TG_EPI(acc00, 0, 0) TG_EPI(acc01, 0, 1) TG_EPI(acc10, 1, 0) TG_EPI(acc11, 1, 1)
-#undef TG_EPI
-    if (bias_wave && l31 == 0) {                           // every column of the ones-product holds the column sum: take column 0
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = n0 + wr * 64 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (row < N) atomicAdd(dbias + row, accb[r]);
-        }
-    }
-}
-
 extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw,
                                   float* dbias, int dtype, void* stream) {
     MAED_CHECK_ARG(Y && X && dW, MAED_ERR_ARG, "gemm_tn_wgrad: null pointer");
@@ -338,14 +229,6 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     if (splits < 1) splits = 1;
     const int per = (nmt + splits - 1) / splits;
     const int z = (nmt + per - 1) / per;
-    // round 3: DMA-staged kernel with transposing fragment reads (no register staging) whenever its preconditions hold; MAED_OPT_TN_KERNEL = 0 keeps
-    // the register-staged kernel (A/B knob of scripts/x3_micro.py / wgrad_micro.py)
-    if (maed_opt(MAED_OPT_TN_KERNEL) == 1 && M % 64 == 0 && (uint64_t)64 * (uint64_t)(ldy > ldx ? ldy : ldx) * 2 < (1ull << 31)) {
-        hipLaunchKernelGGL(gemm_tn_glds_bf16_kernel, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M, N, K, dW, ldw,
-                           dbias, tk, per);
-        MAED_CHECK_LAUNCH("gemm_tn_wgrad(glds)");
-        return MAED_OK;
-    }
 #ifdef MAED_GEMM_ABLATE
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
                        N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap(), maed_opt(MAED_OPT_ABLATE));

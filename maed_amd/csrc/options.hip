@@ -11,7 +11,6 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {1},      // MAED_OPT_SIDE_STREAM
     {384},    // MAED_OPT_TN_TARGET_WGS
     {0},      // MAED_OPT_ABLATE
-    {1},      // MAED_OPT_TN_KERNEL
 };
 
 extern "C" int maed_init(int device) {

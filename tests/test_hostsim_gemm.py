@@ -73,25 +73,6 @@ def test_gemm_nt_splitk_atomic():
     assert torch.allclose(out, A.float() @ B.float().t(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("kernel", [0, 1])      # MAED_OPT_TN_KERNEL: register-staged / DMA-staged with transposing fragment reads (needs M % 64 == 0: else falls back)
-@pytest.mark.parametrize("M,N,K", [(256, 136, 72), (192, 264, 392), (128, 8, 8), (64, 128, 128)])
-def test_gemm_tn_wgrad_kernels_agree_with_torch(kernel, M, N, K):
-    """both bf16 weight-gradient kernels at shapes the DMA-staged one accepts: ragged N / K tiles (columns past the edge are fetched from column 0 and never
-    stored), 3 K tiles (the bias column sums rotate over them), several M tiles; accumulation into existing dW / dbias"""
-    Y, X = rnd(M, N, seed=12).bfloat16(), rnd(M, K, seed=13).bfloat16()
-    dW0, db0 = rnd(N, K, seed=14), rnd(N, seed=15)
-    dW, db = dW0.clone(), db0.clone()
-    old = L.get_option(L.OPT_TN_KERNEL)
-    try:
-        L.set_option(L.OPT_TN_KERNEL, kernel)
-        with patched():
-            ops.gemm_tn_wgrad(Y, X, dW=dW, dbias=db)
-    finally:
-        L.set_option(L.OPT_TN_KERNEL, old)
-    assert torch.allclose(dW, dW0 + Y.float().t() @ X.float(), rtol=1e-4, atol=1e-3)
-    assert torch.allclose(db, db0 + Y.float().sum(0), rtol=1e-4, atol=1e-3)
-
-
 @pytest.mark.parametrize("M,N,K", [(200, 136, 72), (64, 128, 128), (37, 8, 8), (130, 64, 256)])
 def test_gemm_tn_wgrad_and_bias(M, N, K):
     Y, X = rnd(M, N, seed=12).bfloat16(), rnd(M, K, seed=13).bfloat16()
