@@ -65,6 +65,13 @@ def lib_matmul_dtype(dtype, prec=None):
     return dtype == torch.bfloat16 or (dtype == torch.float32 and (f32_split() or prec in ("bf16x3", "bf16x6")))
 
 
+def wgrad_prec(prec):
+    """engine of a WEIGHT-gradient product inside a module that runs its other products on "bf16x6": bf16x3.  A weight gradient is a leaf of the backward pass --
+    its rounding error (~2^-16 of |dy||x|, i.e. ~1e-5 of the largest entry) goes nowhere else, unlike the forward / input-gradient products whose errors the
+    following GroupNorms amplify (which is what bf16x6 is for).  Measured: scripts/x3_probe.py, profiles/r03_x3_probe_wgrad_x3.txt."""
+    return "bf16x3" if prec == "bf16x6" else prec
+
+
 def mm_code(dtype, prec=None):
     """dtype code for the matrix-product entry points: fp32 tensors of a module with its own engine (ResNetV2.f32_matmul) go as MAED_F32X3 / MAED_F32X6,
     everything else as dt_code (fp32 then follows the process-wide mode)"""
@@ -832,7 +839,7 @@ class Conv1x1Fn(torch.autograd.Function):
             dx = dx.view(N, H, W, I).permute(0, 3, 1, 2)
         if ctx.dw is not None:
             dw, prec = ctx.dw, ctx.prec
-            side_stream_run(lambda: gemm_tn_wgrad(Y, A, dW=dw, prec=prec), Y, A, dw)
+            side_stream_run(lambda: gemm_tn_wgrad(Y, A, dW=dw, prec=wgrad_prec(prec)), Y, A, dw)
         if mask is not None and dx is None:
             raise RuntimeError("Conv1x1Fn: lazily masked shortcut gradient but no input gradient requested")
         return dx, None, None, None, None, None, None, None, None
@@ -931,9 +938,9 @@ class Conv3x3Fn(torch.autograd.Function):
         own_dw = need_w and s == 1 and ((N * H * W) % 64 == 0 or x.dtype == torch.float32) and I % 8 == 0 and O % 8 == 0      # (the bf16 kernel has no ragged tile)
         if own_dw:                                               # TN GEMM over gathered rows; fp32, (O,3,3,I) like w's storage
             if dw_slice is not None:
-                side_stream_run(lambda: conv3x3_wgrad(dy, x, out=dw_slice, prec=prec), dy, x, dw_slice)
+                side_stream_run(lambda: conv3x3_wgrad(dy, x, out=dw_slice, prec=wgrad_prec(prec)), dy, x, dw_slice)
             else:
-                dw = conv3x3_wgrad(dy, x, prec=prec).permute(0, 3, 1, 2)
+                dw = conv3x3_wgrad(dy, x, prec=wgrad_prec(prec)).permute(0, 3, 1, 2)
             need_w = False
         if need_w or (need_x and not own_dx):
             sym = ph % 2 == 0 and pw % 2 == 0
