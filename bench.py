@@ -348,22 +348,40 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     log(f"timed {args.steps} steps: {ms_per_step:.2f} ms/step")
 
+    # ---- host enqueue time of one step (extra steps, untimed region): the wall time step() takes to RETURN when the GPU queue is empty, i.e. what the host
+    # needs to issue a step's ~700 launches; the step is GPU-bound as long as this stays below ms_per_step
+    host_ms = []
+    for _ in range(3):
+        fence()
+        t1 = time.perf_counter()
+        step()
+        host_ms.append(1e3 * (time.perf_counter() - t1))
+    fence()
+    host_enqueue_ms = round(sorted(host_ms)[1], 3)
+    log(f"host enqueue per step: {host_ms}")
+
     # ---- in-situ kernel timing for the rooflines (extra steps, events on the launch stream) ---------------
     kernels = {}
-    roofline = roofline_attention = roofline_wgrad = None
+    roofline = roofline_nt = roofline_attention = roofline_wgrad = None
     groups = None
     # EVERY rank runs the extra steps (a train step contains the gradient all-reduce: a rank stepping alone would wait for
     # collectives nobody else issues); only rank 0 brackets its launches with events and reports
     nprof = 3
-    if rank == 0 and not sim:
+    from maed_amd import ops as _ops
+    side_was = _ops._SIDE_ON
+    _ops._SIDE_ON = False            # profiling steps on ONE stream (every rank alike): kernel durations are then not inflated by concurrency and agree with a
+    if rank == 0 and not sim:        # single-stream rocprofv3 summary of the same command (MAED_WGRAD_SIDE_STREAM=0); the C++ block driver does the same under maed_prof_enable
         lib.maed_prof_enable(1)
     for _ in range(nprof):
         step()
     fence()
+    _ops._SIDE_ON = side_was
     if rank == 0 and not sim:
         ntags = lib.maed_prof_ntags()
         ms = (ctypes.c_double * ntags)()
         cnt = (ctypes.c_int * ntags)()
+        pflops = (ctypes.c_double * ntags)()
+        lib.maed_prof_flops(pflops)
         lib.maed_prof_collect(ms, cnt)
         lib.maed_prof_enable(0)
         Fr, P, C_, T = CFG["clips"] * CFG["T"], (CFG["img"] // 16) ** 2 + 1, CFG["dim"], CFG["T"]
@@ -419,8 +437,9 @@ def main():
             return fl / (tot_ms * 1e-3) / 1e12, 1e3 * tot_ms / n, n, tot_ms / nprof
 
         nt = fam(["gemm_qkv", "gemm_proj_resid", "gemm_fc1_gelu", "gemm_fc2_resid", "gemm_dgrad(all)"])
-        if nt:   # the step's dominant kernel family by time (rocprofv3: profiles/r02_*steady*): the NT GEMMs
-            roofline = dict(kernel="bf16 NT GEMM family of the STE (gemm_nt_glds_bf16_kernel 128x128 + gemm_nt_256_bf16_kernel 256x256: qkv, proj, fc1+GELU, "
+        roofline_nt = None
+        if nt:   # the NT GEMM family of the STE (second by time in the single-stream rocprofv3 summary)
+            roofline_nt = dict(kernel="bf16 NT GEMM family of the STE (gemm_nt_glds_bf16_kernel 128x128 + gemm_nt_256_bf16_kernel 256x256: qkv, proj, fc1+GELU, "
                                    "fc2+residual and the four input-gradient GEMMs of every block; the same kernels run the backbone's 1x1 convolutions)",
                             bound="mfma", achieved=round(nt[0], 2), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=round(nt[0] / MFMA_BF16_PEAK_TF, 4),
                             traffic=traffic_db.get("gemm_nt"), avg_us=round(nt[1], 2), launches=nt[2], ms_per_step=round(nt[3], 3),
@@ -431,6 +450,21 @@ def main():
             roofline_wgrad = dict(kernel="gemm_tn_mfma_bf16_kernel (weight gradients dW += Y^T X of the STE, five per block)", bound="mfma", achieved=k["tflops"],
                                   peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"], traffic=traffic_db.get("gemm_tn"), avg_us=k["avg_us"],
                                   note="flops averaged over the five shapes; in-situ hipEvent timing")
+        # THE roofline object: the kernel with the most time in the step's rocprofv3 summary -- the TN weight-gradient GEMM (gemm_tn_mfma_bf16_kernel<false>:
+        # STE Linear layers AND the backbone's 1x1 convolutions) -- over EVERY launch of it (tag 11: maed_gemm_tn_wgrad brackets itself and declares 2*M*N*K)
+        TN_ALL = 11
+        if ntags > TN_ALL and cnt[TN_ALL] > 0:
+            us = 1e3 * ms[TN_ALL] / cnt[TN_ALL]
+            tf = pflops[TN_ALL] / (ms[TN_ALL] * 1e-3) / 1e12
+            roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_mfma_bf16_kernel<false>") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
+                                   "5 per STE block + the backbone's 1x1 convolutions)", bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                            frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=traffic_db.get("gemm_tn"), avg_us=round(us, 2), launches=cnt[TN_ALL] // nprof,
+                            ms_per_step=round(ms[TN_ALL] / nprof, 3),
+                            note="the kernel with the most time in the single-stream rocprofv3 summary of this command (profiles/); achieved = sum of 2*M*N*K declared by every "
+                                 f"launch / sum of their hipEvent durations on the launch stream ({nprof} extra single-stream steps); the NT GEMM family and the attention forward "
+                                 "are under roofline_nt / roofline_attention" + traffic_note)
+        else:
+            roofline = roofline_nt
         if "attn_spatial_fwd" in kernels:   # the kernel north_star names
             k = kernels["attn_spatial_fwd"]
             roofline_attention = dict(kernel="STE spatial attention forward (the kernel north_star names)", bound="hbm", achieved=k["algorithmic_gbs"], peak=HBM_PEAK_GBS,
@@ -473,13 +507,14 @@ def main():
                        "global_batch_clips": clips, "frames_per_clip": CFG["T"], "parallelism": f"dp{world}",
                        "loss": "lib/core/loss.py LossVideo (config_stage2 weights) on synthetic labels, fused fwd+bwd kernel",
                        "smpl": "synthetic SMPL-shaped parameters (licensed model file unavailable)"},
-            "step_time": step_stats,
+            "step_time": step_stats, "host_enqueue_ms": host_enqueue_ms,
             # data-parallel diagnostics (N > 1 or forced collectives): transport, ranks, gradient buckets and when each was launched in the last backward
             "ddp": (None if args.forward_only else dict(transport="maed_comm (own RCCL communicator)" if comm is not None else ("torch.distributed/" + (dist.get_backend() if dist.is_initialized() else "none")),
                                                      rccl_ranks=world, collectives=bool(bucketer.collectives), gradient_dtype="f32",
                                                      buckets=[dict(mbytes=round(4 * (e - s) / 2 ** 20, 2), params=n) for s, e, n in bucketer.buckets],
                                                      bucket_launch_order=list(bucketer.launch_order), per_stage_weight_std=bool(bucketer.world > 1))),
-            "roofline": roofline, "roofline_attention": roofline_attention, "roofline_wgrad": roofline_wgrad, "kernels": kernels, "kernel_groups": groups,
+            "roofline": roofline, "roofline_nt": roofline_nt, "roofline_attention": roofline_attention, "roofline_wgrad": roofline_wgrad, "kernels": kernels,
+            "kernel_groups": groups,
             "cpu_baseline": cpu,
             "parity_err_bf16": (cpu or {}).get("parity_probe", {}).get("rel_err", {}).get("bf16") if cpu and (cpu.get("parity_probe") or {}).get("rel_err") else None,
             "parity_mode": (cpu or {}).pop("parity_mode", None) if cpu else None,

@@ -220,6 +220,9 @@ int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, con
 int maed_prof_enable(int on);
 int maed_prof_ntags(void);
 int maed_prof_collect(double* ms_total_host, int* count_host);
+/* tags 11 / 12: EVERY maed_gemm_tn_wgrad / maed_conv3x3_wgrad launch (STE and backbone).  maed_prof_flops fills flops_host[n] with the algorithmic FLOPs
+ * (2 M N K per launch) the tagged launches declared since the last collect -- call it before maed_prof_collect, which clears them. */
+int maed_prof_flops(double* flops_host);
 
 /* ---- K10: KTD joint chain (ktd.py:81-86) ------------------------------------------------------- */
 /* base[f32](F,144) = x W_feat^T + b for the 1024-wide feature part of all 24 regressors has been

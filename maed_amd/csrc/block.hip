@@ -10,27 +10,29 @@
 //           into the caller's gradient arena), bias gradients fall out of the transposes.
 #include "common.cuh"
 #include "gemm_x3.h"
+#include "prof.h"
 #include <hip/hip_runtime.h>
 #include <utility>
 #include <vector>
 
-// ---- in-situ kernel timing (measurement only; off by default) -----------------------------------------
-// When enabled, the composite block calls bracket selected launches with hipEvents recorded on the SAME
-// stream the kernel is launched on; maed_prof_collect() synchronises the events and returns total ms and
-// launch counts per tag.  bench.py uses this for the roofline numbers.
-enum { PROF_ATTN_SP_FWD = 0, PROF_ATTN_TM_FWD, PROF_GEMM_QKV, PROF_GEMM_FC1, PROF_GEMM_FC2, PROF_ATTN_SP_BWD, PROF_ATTN_TM_BWD, PROF_GEMM_WGRAD,
-       PROF_GEMM_PROJ, PROF_GEMM_DGRAD /* the four input-gradient GEMMs of a block */, PROF_LAYERNORM /* fwd + bwd */, PROF_NTAGS };
+// ---- in-situ kernel timing (csrc/prof.h): storage and entry points ----------------------------------------------
 static bool g_prof = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_NTAGS];
-struct ProfScope {
-    int tag; hipStream_t s; hipEvent_t a, b; bool on;
-    ProfScope(int tag_, void* stream) : tag(tag_), s((hipStream_t)stream), on(g_prof) {
-        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
-    }
-    ~ProfScope() { if (on) { hipEventRecord(b, s); g_prof_ev[tag].emplace_back(a, b); } }
-};
+static double g_prof_flops[PROF_NTAGS];
+bool maed_prof_on() { return g_prof; }
+void maed_prof_open(int tag, hipStream_t s, hipEvent_t* a) { (void)tag; hipEventCreate(a); hipEventRecord(*a, s); }
+void maed_prof_close(int tag, hipStream_t s, hipEvent_t a, double flops) {
+    hipEvent_t b;
+    hipEventCreate(&b); hipEventRecord(b, s);
+    g_prof_ev[tag].emplace_back(a, b);
+    g_prof_flops[tag] += flops;
+}
 extern "C" int maed_prof_enable(int on) { g_prof = on != 0; return MAED_OK; }
 extern "C" int maed_prof_ntags(void) { return PROF_NTAGS; }
+extern "C" int maed_prof_flops(double* flops) {              // FLOPs declared by the tagged launches since the last collect (call BEFORE maed_prof_collect)
+    for (int t = 0; t < PROF_NTAGS; ++t) if (flops) flops[t] = g_prof_flops[t];
+    return MAED_OK;
+}
 extern "C" int maed_prof_collect(double* ms_total, int* count) {
     for (int t = 0; t < PROF_NTAGS; ++t) {
         double tot = 0.0;
@@ -44,6 +46,7 @@ extern "C" int maed_prof_collect(double* ms_total, int* count) {
         if (ms_total) ms_total[t] = tot;
         if (count) count[t] = (int)g_prof_ev[t].size();
         g_prof_ev[t].clear();
+        g_prof_flops[t] = 0.0;
     }
     return MAED_OK;
 }
