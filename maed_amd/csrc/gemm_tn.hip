@@ -70,14 +70,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     // global_load_dwordx4 v, v_off, s[base] with a loop-invariant 32-bit lane offset.  The first version recomputed 64-bit
     // row*ld products and branched on a row bound for every load: ~10 VALU/SALU instructions per MFMA.
     const int side = __builtin_amdgcn_readfirstlane(tid >> 7), st = tid & 127;
-    const int nc = st & 15, mg = st >> 4;                      // column chunk (8 cols), row group (8 rows)
+    // column chunk (8 cols) nc = consecutive lanes (16 lanes cover a 256-byte row segment: coalesced), row group (8 rows) mg.
+    // LDS image: column c of the tile lives in LDS row R(c) = (c & ~31) | ((c & 7) << 2) | ((c >> 3) & 3) -- inside every block of 32 columns the 4 chunks
+    // are interleaved -- and its 16-byte slots are XOR-ed with 4 * ((c >> 5) & 1).  The 8 lanes a transposing ds_write_b128 is serviced with (8 consecutive
+    // chunks, one j) then hit 8 distinct bank groups, and a fragment = 32 consecutive LDS rows with one constant slot term is conflict-free under the
+    // hardware's real ds_read_b128 lane grouping ({0-3,12-15,20-27}, ...: every residue mod 16; 144-byte rows).  The round-1 layout (row = column, slot XOR-ed
+    // with (row >> 3) & 7) was conflict-free for the writes only: SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE
+    // (profiles/r03_tn_bf16_sq_counters_before_lane_remap.txt).  The epilogue undoes R(): lanes still cover 32 consecutive k per atomic instruction.
+    const int nc = st & 15, mg = st >> 4;
     const bf16* src = side ? X : Y;
     const int64_t lds_src = side ? ldx : ldy;
     const int c0 = (side ? k0 : n0) + nc * 8;
     const int cmax = side ? K : N;
     const bool col_ok = c0 < cmax;                            // N, K are multiples of 8 (checked by the launcher); loop-invariant
     unsigned short* my_lds_base = &lds[0][side][0];
-    const int wr_off = (nc * 8) * TN_LD + ((mg ^ (nc & 7)) << 3);   // row (nc*8 + j), swizzled 16-B slot mg ^ ((row>>3)&7)
+    const int wr_off = ((nc >> 2) * 32 + (nc & 3)) * TN_LD + ((mg ^ (((nc >> 2) & 1) << 2)) << 3);   // column nc*8 + j -> LDS row (nc>>2)*32 + 4j + (nc&3): step 4 rows per j
     // the column sums of a Y tile are needed once per (N-tile, M-split): the K-tile that takes them rotates with the split
     // index so the extra VALU work is spread over all workgroups instead of making the K-tile-0 ones stragglers
     const bool bias_blk = (dbias != nullptr) && (tile_k == (int)(bz % tiles_k));   // block-uniform
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                *reinterpret_cast<uint4*>(my_lds_base + (size_t)b * (2 * 128 * TN_LD) + wr_off + j * TN_LD) = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(my_lds_base + (size_t)b * (2 * 128 * TN_LD) + wr_off + 4 * j * TN_LD) = make_uint4(0u, 0u, 0u, 0u);
     }
 
     uint4 r0_0, r0_1, r0_2, r0_3, r0_4, r0_5, r0_6, r0_7, r1_0, r1_1, r1_2, r1_3, r1_4, r1_5, r1_6, r1_7;
@@ -127,24 +134,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
 #define TN_CS(S, COMP, j0) { const uint32_t w__[8] = {r##S##_0.COMP, r##S##_1.COMP, r##S##_2.COMP, r##S##_3.COMP, r##S##_4.COMP, r##S##_5.COMP, r##S##_6.COMP, r##S##_7.COMP}; \
         _Pragma("unroll") for (int i__ = 0; i__ < 8; ++i__) { cs[j0] += __uint_as_float(w__[i__] << 16); cs[j0 + 1] += __uint_as_float(w__[i__] & 0xffff0000u); } }
 #define TN_STORE(S, buf_) if (col_ok && !(ablate & 8)) { unsigned short* d__ = my_lds_base + (size_t)(buf_) * (2 * 128 * TN_LD) + wr_off; \
-        *reinterpret_cast<uint4*>(d__ + 0 * TN_LD) = TN_ROW(S, x, perm_lo); *reinterpret_cast<uint4*>(d__ + 1 * TN_LD) = TN_ROW(S, x, perm_hi); \
-        *reinterpret_cast<uint4*>(d__ + 2 * TN_LD) = TN_ROW(S, y, perm_lo); *reinterpret_cast<uint4*>(d__ + 3 * TN_LD) = TN_ROW(S, y, perm_hi); \
-        *reinterpret_cast<uint4*>(d__ + 4 * TN_LD) = TN_ROW(S, z, perm_lo); *reinterpret_cast<uint4*>(d__ + 5 * TN_LD) = TN_ROW(S, z, perm_hi); \
-        *reinterpret_cast<uint4*>(d__ + 6 * TN_LD) = TN_ROW(S, w, perm_lo); *reinterpret_cast<uint4*>(d__ + 7 * TN_LD) = TN_ROW(S, w, perm_hi); \
+        *reinterpret_cast<uint4*>(d__ + 0 * TN_LD) = TN_ROW(S, x, perm_lo); *reinterpret_cast<uint4*>(d__ + 4 * TN_LD) = TN_ROW(S, x, perm_hi); \
+        *reinterpret_cast<uint4*>(d__ + 8 * TN_LD) = TN_ROW(S, y, perm_lo); *reinterpret_cast<uint4*>(d__ + 12 * TN_LD) = TN_ROW(S, y, perm_hi); \
+        *reinterpret_cast<uint4*>(d__ + 16 * TN_LD) = TN_ROW(S, z, perm_lo); *reinterpret_cast<uint4*>(d__ + 20 * TN_LD) = TN_ROW(S, z, perm_hi); \
+        *reinterpret_cast<uint4*>(d__ + 24 * TN_LD) = TN_ROW(S, w, perm_lo); *reinterpret_cast<uint4*>(d__ + 28 * TN_LD) = TN_ROW(S, w, perm_hi); \
         if (do_bias) { TN_CS(S, x, 0) TN_CS(S, y, 2) TN_CS(S, z, 4) TN_CS(S, w, 6) } }
 
     f32x16_t acc00, acc01, acc10, acc11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
-    // fragment reads: row = sub-tile base + l31, logical 16-B slot 2*kk + hi, physical slot ^ ((row >> 3) & 7)
+    // fragment reads: 32 consecutive LDS rows of one 32-column block, 16-B slot (2*kk + hi) ^ 4 * (block & 1): the second sub-tile of a wave is the odd block
     const int arow0 = wr * 64 + l31, arow1 = arow0 + 32, brow0 = wc * 64 + l31, brow1 = brow0 + 32;
-    const int asw0 = (arow0 >> 3) & 7, asw1 = (arow1 >> 3) & 7, bsw0 = (brow0 >> 3) & 7, bsw1 = (brow1 >> 3) & 7;
 #define TN_COMPUTE(buf_) if (!(ablate & 4)) { const unsigned short* A__ = &lds[buf_][0][0]; const unsigned short* B__ = &lds[buf_][1][0]; \
         _Pragma("unroll") for (int kk = 0; kk < TN_BM / 16; ++kk) { const int sl = 2 * kk + hi; \
-            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(A__ + arow0 * TN_LD + ((sl ^ asw0) << 3)); \
-            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(A__ + arow1 * TN_LD + ((sl ^ asw1) << 3)); \
-            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(B__ + brow0 * TN_LD + ((sl ^ bsw0) << 3)); \
-            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(B__ + brow1 * TN_LD + ((sl ^ bsw1) << 3)); \
+            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(A__ + arow0 * TN_LD + (sl << 3)); \
+            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(A__ + arow1 * TN_LD + ((sl ^ 4) << 3)); \
+            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(B__ + brow0 * TN_LD + (sl << 3)); \
+            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(B__ + brow1 * TN_LD + ((sl ^ 4) << 3)); \
             acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0); \
             acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0); \
             acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0); \
@@ -179,9 +185,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
         TN_COMPUTE(0);
     }
 
-    // D[row n][col k]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*hi -> atomics of a half-wave hit 32 consecutive k
-#define TN_EPI(acc_, i_, j_) { const int kcol = k0 + wc * 64 + (j_) * 32 + l31; \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int nrow = n0 + wr * 64 + (i_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; \
+    // D[LDS row of n][LDS row of k]: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*hi; LDS row r5 of a 32-column block is column ((r5 & 3) << 3) + (r5 >> 2):
+    // the atomics of a half-wave still hit 32 consecutive k (one 128-byte line), in interleaved order
+#define TN_UNR(r5_) ((((r5_) & 3) << 3) + ((r5_) >> 2))
+#define TN_EPI(acc_, i_, j_) { const int kcol = k0 + wc * 64 + (j_) * 32 + TN_UNR(l31); \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int nrow = n0 + wr * 64 + (i_) * 32 + TN_UNR((r & 3) + 8 * (r >> 2) + 4 * hi); \
             if (nrow < N && kcol < K && !(ablate & 1)) atomicAdd(dW + (int64_t)nrow * ldw + kcol, acc_[r]); } }
     TN_EPI(acc00, 0, 0) TN_EPI(acc01, 0, 1) TN_EPI(acc10, 1, 0) TN_EPI(acc11, 1, 1)
 

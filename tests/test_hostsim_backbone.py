@@ -143,7 +143,7 @@ def test_conv3x3_implicit_gemm_matches_aten(N, I, O, H, W, stride, monkeypatch):
     from maed_amd.resnetv2 import _same_pad
     own_wgrad = []
     real = ops.conv3x3_wgrad
-    monkeypatch.setattr(ops, "conv3x3_wgrad", lambda dy_, x_: (own_wgrad.append(1), real(dy_, x_))[1])
+    monkeypatch.setattr(ops, "conv3x3_wgrad", lambda dy_, x_, **k: (own_wgrad.append(1), real(dy_, x_, **k))[1])
     g = torch.Generator().manual_seed(H * 100 + W)
     bf = torch.bfloat16
     x = torch.randn(N, I, H, W, generator=g).to(bf).float()
