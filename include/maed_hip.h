@@ -85,7 +85,7 @@ typedef enum {
                                  * Entry points that have no exact fp32 kernel (maed_conv1x1_fwd, maed_conv3x3_fwd, maed_gemm_tn_wgrad,
                                  * maed_conv3x3_wgrad) accept MAED_F32 only with 1 or 2. */
     MAED_OPT_SIDE_STREAM = 1,   /* 1 (default): weight-gradient GEMMs / temporal attention of the fused STE block on the library's side stream */
-    MAED_OPT_TN_TARGET_WGS = 2, /* workgroups a weight-gradient GEMM is split into along M (default 384; tuning knob of scripts/gpu_tn_sweep.sh) */
+    MAED_OPT_TN_TARGET_WGS = 2, /* workgroups a weight-gradient GEMM is split into along M: 0 (default) = built-in heuristic, >= 64 = that target (sweep knob) */
     MAED_OPT_ABLATE = 3,        /* diagnostic builds (-DMAED_GEMM_ABLATE) only: bit mask of pipeline stages to drop */
     MAED_OPT_COUNT
 } maed_option;

@@ -159,7 +159,7 @@ def lib():
 _OPTIONS = {
     OPT_F32_MATMUL: {"exact": 0, "0": 0, "bf16x3": 1, "1": 1, "bf16x6": 2, "2": 2}[os.environ.get("MAED_F32_MATMUL", "exact")],
     OPT_SIDE_STREAM: int(os.environ.get("MAED_WGRAD_SIDE_STREAM", "1") == "1"),
-    OPT_TN_TARGET_WGS: max(64, int(os.environ.get("MAED_TN_TARGET_WGS", "384"))),
+    OPT_TN_TARGET_WGS: int(os.environ.get("MAED_TN_TARGET_WGS", "0")),
     OPT_ABLATE: int(os.environ.get("MAED_GEMM_ABLATE", "0")),
 }
 

@@ -15,6 +15,17 @@
 #include "prof.h"
 #include <stdlib.h>
 
+// M-splits of a weight-gradient GEMM with `tiles` output tiles of 128 x 128.  The kernel runs two workgroups per CU; the sweep after the LDS layout fix
+// (profiles/r03_tn_split_sweep_after_layout.txt) says: large outputs (>= 32 tiles: qkv, fc1, fc2) want the grid to fill the chip exactly twice -- as many
+// splits as fit in 512 workgroups, never more (a 513th workgroup starts a second round: qkv 63.6 us at 480 workgroups, 88.2 at 528) -- while small
+// outputs (proj, the convolutions) are cheaper with ~256: every split adds a pass of fp32 atomics over the output and a prologue / epilogue per workgroup.
+// MAED_OPT_TN_TARGET_WGS > 0 overrides with a plain target (the sweep knob).
+int maed_tn_splits(int tiles) {
+    const int target = maed_opt(MAED_OPT_TN_TARGET_WGS);
+    if (target > 0) return (target + tiles - 1) / tiles;
+    if (tiles >= 32) return 512 / tiles > 0 ? 512 / tiles : 1;
+    return (256 + tiles - 1) / tiles;
+}
 static int tn_remap() { return 1; }     // XCD-aware (split, tile) order: -6...8 % and 292 -> 189 MB of HBM traffic per launch (profiles/r02_pmc)
 
 #define TN_BM 64      // reduction rows per LDS tile
@@ -220,7 +231,7 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
         MAED_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ldw >= K, MAED_ERR_SHAPE,
                        "gemm_tn_wgrad(f32): need N, K, ldy, ldx multiples of 4 (N=%d K=%d)", N, K);
         MAED_CHECK_ARG(is_aligned(Y, 16) && is_aligned(X, 16), MAED_ERR_ALIGN, "gemm_tn_wgrad: Y/X must be 16-B aligned");
-        MAED_PROPAGATE(maed_gemm_tn_x3_launch(np, Y, ldy, X, ldx, M, N, K, dW, ldw, dbias, nullptr, maed_opt(MAED_OPT_TN_TARGET_WGS), (hipStream_t)stream));
+        MAED_PROPAGATE(maed_gemm_tn_x3_launch(np, Y, ldy, X, ldx, M, N, K, dW, ldw, dbias, nullptr, 0, (hipStream_t)stream));
         MAED_CHECK_LAUNCH("gemm_tn_wgrad(x3)");
         return MAED_OK;
     }
@@ -231,10 +242,7 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     MAED_CHECK_ARG(ldy < (1 << 24) && ldx < (1 << 24), MAED_ERR_SHAPE, "gemm_tn_wgrad: row strides must be < 2^24 elements");
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     const int nmt = (int)((M + TN_BM - 1) / TN_BM);
-    const int target = maed_opt(MAED_OPT_TN_TARGET_WGS);     // measurement knob for the split heuristic (default 384)
-    // ~384 workgroups (1.5 per CU): measured optimum at the STE and backbone shapes (profiles/r01_tn_split_sweep.txt) -- every
-    // extra split adds a 128x128 tile of fp32 atomics, and the kernel runs at two workgroups per CU anyway
-    int splits = (target + tn * tk - 1) / (tn * tk);
+    int splits = maed_tn_splits(tn * tk);
     if (splits > (nmt + 3) / 4) splits = (nmt + 3) / 4;      // at least 4 M-tiles per workgroup
     if (splits < 1) splits = 1;
     const int per = (nmt + splits - 1) / splits;
@@ -289,7 +297,7 @@ extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tap
         MAED_CHECK_ARG(M > 0 && Cin % 4 == 0 && Cout % 4 == 0, MAED_ERR_SHAPE, "conv3x3_wgrad(f32): Cin / Cout must be multiples of 4 (Cin=%d Cout=%d)", Cin, Cout);
         MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16) && is_aligned(tapmask, 16), MAED_ERR_ALIGN, "conv3x3_wgrad: 16-B alignment");
         const X3TnConv cv{(const uint16_t*)tapmask, Cin, W};
-        MAED_PROPAGATE(maed_gemm_tn_x3_launch(np, dy, (int64_t)Cout, x, (int64_t)Cin, M, N, K, dW, (int64_t)K, nullptr, &cv, 384, (hipStream_t)stream));
+        MAED_PROPAGATE(maed_gemm_tn_x3_launch(np, dy, (int64_t)Cout, x, (int64_t)Cin, M, N, K, dW, (int64_t)K, nullptr, &cv, 0, (hipStream_t)stream));
         MAED_CHECK_LAUNCH("conv3x3_wgrad(x3)");
         return MAED_OK;
     }
@@ -298,7 +306,7 @@ extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tap
     MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16) && is_aligned(tapmask, 16) && is_aligned(zero_page, 16), MAED_ERR_ALIGN, "conv3x3_wgrad: 16-B alignment");
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     const int nmt = (int)(M / TN_BM);
-    int splits = (384 + tn * tk - 1) / (tn * tk);
+    int splits = maed_tn_splits(tn * tk);
     if (splits > (nmt + 3) / 4) splits = (nmt + 3) / 4;
     if (splits < 1) splits = 1;
     const int per = (nmt + splits - 1) / splits;

@@ -35,6 +35,7 @@ struct X3TnConv { const uint16_t* tapmask; int Cin, Wimg; };
 
 // number of bf16 planes of the process-wide fp32 matmul mode (maed_set_option(MAED_OPT_F32_MATMUL)): 0 = exact VALU kernels, 2 = bf16x3, 3 = bf16x6
 int maed_x3_planes(void);
+int maed_tn_splits(int tiles);          // gemm_tn.hip: M-split heuristic of the weight-gradient GEMMs
 // dtype codes MAED_F32X3 / MAED_F32X6 = fp32 storage with an explicit engine: returns the plane count they ask for (0 for plain MAED_F32 / MAED_BF16)
 // and rewrites `dtype` to MAED_F32
 static inline int maed_x3_take_dtype(int& dtype) {

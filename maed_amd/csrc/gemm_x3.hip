@@ -402,7 +402,10 @@ int maed_gemm_tn_x3_launch(int np, const void* Y, int64_t ldy, const void* X, in
                            const X3TnConv* conv, int target_wgs, hipStream_t s) {
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     const int nmt = (int)((M + X3_BK - 1) / X3_BK);
-    int splits = (target_wgs + tn * tk - 1) / (tn * tk);
+    // large outputs: fill the chip exactly twice like the bf16 kernel (maed_tn_splits); small ones keep ~384 workgroups -- this kernel runs three
+    // workgroups per CU and measured slower with the bf16 kernel's 256 (profiles/r03_x3_tn_split_ab.txt: proj 73 vs 93 us, 56x56 1x1 148 vs 189 us)
+    const int tiles = tn * tk;
+    int splits = target_wgs > 0 ? (target_wgs + tiles - 1) / tiles : tiles >= 32 ? maed_tn_splits(tiles) : (384 + tiles - 1) / tiles;
     if (splits > (nmt + 7) / 8) splits = (nmt + 7) / 8;      // at least 8 M-tiles (256 rows) per workgroup
     if (splits < 1) splits = 1;
     const int per = (nmt + splits - 1) / splits;

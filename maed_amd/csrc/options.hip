@@ -9,7 +9,7 @@
 static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {0},      // MAED_OPT_F32_MATMUL: exact
     {1},      // MAED_OPT_SIDE_STREAM
-    {384},    // MAED_OPT_TN_TARGET_WGS
+    {0},      // MAED_OPT_TN_TARGET_WGS: 0 = the built-in heuristic (gemm_tn.hip maed_tn_splits)
     {0},      // MAED_OPT_ABLATE
 };
 
@@ -30,7 +30,7 @@ extern "C" int maed_init(int device) {
 extern "C" int maed_set_option(int key, int value) {
     MAED_CHECK_ARG(key >= 0 && key < MAED_OPT_COUNT, MAED_ERR_ARG, "set_option: unknown option %d", key);
     if (key == MAED_OPT_F32_MATMUL) MAED_CHECK_ARG(value >= 0 && value <= 2, MAED_ERR_ARG, "set_option: MAED_OPT_F32_MATMUL takes 0 (exact), 1 (bf16x3) or 2 (bf16x6)");
-    if (key == MAED_OPT_TN_TARGET_WGS) MAED_CHECK_ARG(value >= 64, MAED_ERR_ARG, "set_option: MAED_OPT_TN_TARGET_WGS must be >= 64");
+    if (key == MAED_OPT_TN_TARGET_WGS) MAED_CHECK_ARG(value == 0 || value >= 64, MAED_ERR_ARG, "set_option: MAED_OPT_TN_TARGET_WGS must be 0 (heuristic) or >= 64");
     g_opt[key].store(value, std::memory_order_relaxed);
     return MAED_OK;
 }
