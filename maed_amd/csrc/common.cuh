@@ -36,6 +36,35 @@ typedef short maed_v4i16_t __attribute__((ext_vector_type(4)));
 #define MAED_DS_READ_TR16(p_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) maed_v4i16_t*)(p_))
 #endif
 
+// ---- buffer loads: 16 bytes per lane at (wave-uniform 128-bit resource: base + extent) + 32-bit lane byte offset + wave-uniform byte offset.  No 64-bit lane
+// arithmetic per load (hipcc keeps 64-bit lane pointers for global_load: two VALU instructions each), and the hardware range-checks the LANE offset against the
+// extent: a lane whose offset lies past it reads zeros -- rows past the end of a tensor and out-of-image convolution taps (lane offset = MAED_BUF_OOB) cost no
+// select and no branch.  (The uniform offset is NOT part of the check: callers keep it inside the tensor.)
+#define MAED_BUF_OOB 0xfffffff0u
+#ifdef MAED_HOSTSIM
+struct maed_buf_t { const char* base; uint32_t bytes; };
+static inline maed_buf_t maed_make_buf(const void* p, uint64_t bytes) { return maed_buf_t{(const char*)p, (uint32_t)(bytes > 0xffffffffull ? 0xffffffffull : bytes)}; }
+static inline uint4 maed_buf_load16(const maed_buf_t& r, uint32_t lane_off, uint32_t uniform_off) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if ((uint64_t)lane_off + 16 <= r.bytes) memcpy(&v, r.base + lane_off + uniform_off, 16);
+    return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t maed_buf_t;
+typedef unsigned int maed_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ maed_buf_t maed_make_buf(const void* p, uint64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(uint32_t)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 maed_buf_load16(maed_buf_t r, uint32_t lane_off, uint32_t uniform_off) {
+    const maed_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)uniform_off, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+#endif
+__device__ __forceinline__ float4 maed_buf_load_f4(const maed_buf_t& r, uint32_t lane_off, uint32_t uniform_off) {
+    const uint4 v = maed_buf_load16(r, lane_off, uniform_off);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // dynamic LDS of a kernel (the host simulator of tests/hostsim substitutes its own definition)
 #ifndef MAED_DYN_SHARED
 #define MAED_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]

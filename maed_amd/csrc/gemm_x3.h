@@ -6,15 +6,29 @@
 
 // 4 consecutive fp32 -> NP planes of 4 bf16 (2 dwords per plane): x = x0 + x1 (+ x2), x0 = bf16(x) (round to nearest even), x1 = bf16(x - x0), ...
 // (every subtraction is exact in fp32)
+// v_cvt_pk_bf16_f32 as an opaque operation: through the __bf16 vector cast hipcc re-converts the LOW element on its own to form float(x0) (it folds
+// "(pack << 16)" back into a scalar conversion): 6 converter instructions per 4 values instead of 4 (ISA of the first build, profiles/r03_x3_isa_notes.txt)
+__device__ __forceinline__ uint32_t x3_pack_bf2(float lo, float hi) {
+#ifdef MAED_HOSTSIM
+    return pack_bf2(lo, hi);
+#else
+    uint32_t w;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(lo), "v"(hi));
+    return w;
+#endif
+}
+typedef float x3_f32x2_t __attribute__((ext_vector_type(2)));
 template <int NP>
 __device__ __forceinline__ void split4(float r0, float r1, float r2, float r3, uint2 (&pl)[NP]) {
+    x3_f32x2_t a = {r0, r1}, b = {r2, r3};                   // (pairs: the residual subtraction is one v_pk_add_f32 per pair)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const uint32_t w0 = pack_bf2(r0, r1), w1 = pack_bf2(r2, r3);
+        const uint32_t w0 = x3_pack_bf2(a.x, a.y), w1 = x3_pack_bf2(b.x, b.y);
         pl[p] = make_uint2(w0, w1);
         if (p + 1 < NP) {
-            r0 -= __uint_as_float(w0 << 16); r1 -= __uint_as_float(w0 & 0xffff0000u);
-            r2 -= __uint_as_float(w1 << 16); r3 -= __uint_as_float(w1 & 0xffff0000u);
+            const x3_f32x2_t ha = {__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)}, hb = {__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+            a -= ha;
+            b -= hb;
         }
     }
 }

@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restr
     // staging map: a 128 x 32 fp32 tile = 1024 16-byte pieces, 4 per thread: row (tid >> 3) + 32 i, k offset (tid & 7) * 4 -- 8 lanes cover one
     // 128-byte row segment
     const int srow = tid >> 3, skc = (tid & 7) * 4;
-    const float* ap[4]; const float* bp[4];
+    // buffer loads (common.cuh): resource of the operand + loop-invariant 32-bit lane BYTE offsets + the K tile's uniform byte offset -- no 64-bit lane arithmetic
+    // in the loop (the first build spent 16 v_lshl_add_u64 per tile step on it), and an out-of-image tap is a lane offset past the extent (reads zeros).
+    // The launchers check that an operand spans < 4 GB.
+    uint32_t ao[4], bo[4];
     int iy[4], ix[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -104,34 +107,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x3_kernel(const float* __restr
             const int ox = (int)(m % d.Wo), oy = (int)((m / d.Wo) % d.Ho);
             const int64_t f = m / ((int64_t)d.Wo * d.Ho);
             iy[i] = oy * d.stride - d.pad_top; ix[i] = ox * d.stride - d.pad_left;
-            ap[i] = A + ((f * d.H + iy[i]) * d.W + ix[i]) * (int64_t)d.Cin + skc;
-            bp[i] = B + d.b_base + br * d.b_row + skc;
+            // (top-left tap of a border pixel lies before its image: the offsets carry a constant bias of the padding so that they are non-negative; the tile base
+            // below subtracts it again -- base + offset is a valid address whenever the tap is inside the image)
+            ao[i] = (uint32_t)((((f * d.H + iy[i]) * d.W + ix[i] + (int64_t)d.pad_top * d.W + d.pad_left) * (int64_t)d.Cin + skc) * 4);
+            bo[i] = (uint32_t)((br * d.b_row + skc) * 4);
         } else {
             iy[i] = 0; ix[i] = 0;
-            ap[i] = A + m * lda + skc;
-            bp[i] = B + br * ldb + skc;
+            ao[i] = (uint32_t)((m * lda + skc) * 4);
+            bo[i] = (uint32_t)((br * ldb + skc) * 4);
         }
     }
+    // CONV: the image resource starts `bias` elements in front of the tensor (see ao[]); the weight resource is the whole (Cout, 9, Cin) tensor
+    const int64_t a_bias = CONV ? ((int64_t)d.pad_top * d.W + d.pad_left) * d.Cin : 0;
+    const maed_buf_t Abuf = maed_make_buf(A - a_bias, CONV ? ((int64_t)d.F * d.H * d.W * d.Cin + a_bias) * 4 : ((M - 1) * lda + K) * 4);
+    const maed_buf_t Bbuf = maed_make_buf(B, CONV ? 9 * N * (int64_t)d.Cin * 4 : ((N - 1) * ldb + K) * 4);
     float4 ra[4], rb[4];
     int ty = 0, tx = 0, c0 = 0;                                     // CONV: K tile -> (tap, channel chunk), advanced with the loads
     if constexpr (CONV) { const int k = kt_beg * X3_BK; const int tap = k / d.Cin; ty = tap / 3; tx = tap % 3; c0 = k - tap * d.Cin; }
     auto load_tile = [&](int kt) {
         if constexpr (CONV) {
-            const int64_t toff = ((int64_t)ty * d.W + tx) * d.Cin + c0, k0 = (int64_t)(ty * 3 + tx) * d.b_tap + c0;
+            const uint32_t ak = (uint32_t)((((int64_t)ty * d.W + tx) * d.Cin + c0) * 4);                      // tap + channel-chunk offset (the bias in ao[] stands for -pad)
+            const uint32_t bk = (uint32_t)((d.b_base + (int64_t)(ty * 3 + tx) * d.b_tap + c0) * 4);            // (non-negative for both weight layouts)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = (unsigned)(iy[i] + ty) < (unsigned)d.H && (unsigned)(ix[i] + tx) < (unsigned)d.W;
-                ra[i] = ok ? *reinterpret_cast<const float4*>(ap[i] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!NARROW || i < 2) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+                ra[i] = maed_buf_load_f4(Abuf, ok ? ao[i] : MAED_BUF_OOB, ak);
+                if (!NARROW || i < 2) rb[i] = maed_buf_load_f4(Bbuf, bo[i], bk);
             }
             c0 += X3_BK;
             if (c0 == d.Cin) { c0 = 0; if (++tx == 3) { tx = 0; ++ty; } }
         } else {
-            const int64_t k0 = (int64_t)kt * X3_BK;
+            const uint32_t kb = (uint32_t)kt * (X3_BK * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const float4*>(ap[i] + k0);
-                if (!NARROW || i < 2) rb[i] = *reinterpret_cast<const float4*>(bp[i] + k0);
+                ra[i] = maed_buf_load_f4(Abuf, ao[i], kb);
+                if (!NARROW || i < 2) rb[i] = maed_buf_load_f4(Bbuf, bo[i], kb);
             }
         }
     };
@@ -255,7 +265,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
     if constexpr (CONV) {
         if (side) { tap = col_in / cv.Cin; col_in -= tap * cv.Cin; shift = (tap / 3 - 1) * cv.Wimg + (tap % 3 - 1); }
     }
-    const float* const lane_src = src + ((int64_t)(mg * 8 + shift)) * ld + col_in;
+    // buffer loads (common.cuh): one resource per side; the lane's BYTE offset of row j of tile mt = row_off[j] + mt * tile_bytes is range-checked by the hardware
+    // against the tensor's extent, so rows past M read zeros by themselves (a ragged last tile needs no predicate) and a masked tap or a column past N / K is the
+    // out-of-range offset.  CONV: a tap shifts the X rows by up to Wimg + 1 rows either way -- the resource starts that many rows in front of the tensor.
+    const int64_t row_bias = (CONV && side) ? (int64_t)cv.Wimg + 1 : 0;
+    const maed_buf_t buf = maed_make_buf(src - row_bias * ld, ((M - 1 + row_bias) * ld + (side ? (CONV ? cv.Cin : K) : N)) * 4);
+    const uint32_t lane_off0 = (uint32_t)((((int64_t)(mg * 8 + shift) + row_bias) * ld + col_in) * 4);
+    const uint32_t row_bytes = (uint32_t)(ld * 4), tile_bytes = (uint32_t)(X3_BK * ld * 4);
     unsigned short* const my_lds = lds + side * NP * kPlane + ((nc >> 3) * 32 + (nc & 7)) * X3_LD + mg * 8;     // column nc*4 + jj -> LDS row (nc>>3)*32 + 8 jj + (nc&7)
     const bool bias_blk = (dbias != nullptr) && (tile_k == (int)(bz % tiles_k));   // block-uniform: the K tile that takes the column sums rotates
     const bool do_bias = bias_blk && (side == 0);
@@ -263,17 +279,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
 
     float4 r[8];
     auto load_tile = [&](int mt) {
-        const int64_t row0 = (int64_t)mt * X3_BK + mg * 8;
-        const float* tb = lane_src + (int64_t)mt * X3_BK * ld;
+        const uint32_t t_off = lane_off0 + (uint32_t)mt * tile_bytes;     // (in the lane offset, not the uniform one: the range check sees it)
         uint32_t mw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         bool masked = false;
         if constexpr (CONV) masked = side != 0;
-        if (masked) { const uint4 mk = *reinterpret_cast<const uint4*>(cv.tapmask + row0); mw[0] = mk.x; mw[1] = mk.y; mw[2] = mk.z; mw[3] = mk.w; }
+        if (masked) { const uint4 mk = *reinterpret_cast<const uint4*>(cv.tapmask + (int64_t)mt * X3_BK + mg * 8); mw[0] = mk.x; mw[1] = mk.y; mw[2] = mk.z; mw[3] = mk.w; }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            bool ok = col_ok && (row0 + j < M);
-            if (masked) ok = ok && ((mw[j >> 1] >> ((j & 1) * 16 + tap)) & 1u);
-            r[j] = ok ? *reinterpret_cast<const float4*>(tb + (int64_t)j * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t off = col_ok ? t_off + (uint32_t)j * row_bytes : MAED_BUF_OOB;
+            if (masked) off = ((mw[j >> 1] >> ((j & 1) * 16 + tap)) & 1u) ? off : MAED_BUF_OOB;
+            r[j] = maed_buf_load_f4(buf, off, 0u);
         }
     };
     auto store_tile = [&]() {
@@ -333,6 +348,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float* __restr
 bool maed_x3_nt_shape_ok(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t K) {
     return K % X3_BK == 0 && lda % 4 == 0 && ldb % 4 == 0 && is_aligned(A, 16) && is_aligned(B, 16);
 }
+// buffer loads with 32-bit byte offsets: every operand must span less than 4 GB
+static bool x3_fits32(int64_t rows_a, int64_t lda, int64_t rows_b, int64_t ldb) {
+    return (uint64_t)rows_a * (uint64_t)lda * 4 < 0xfffffff0ull && (uint64_t)rows_b * (uint64_t)ldb * 4 < 0xfffffff0ull;
+}
 
 template <int EPI, int NP, bool NARROW, bool CONV, bool GN>
 static void launch_nt(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const X3ConvDims& d, const EpiArgs& e,
@@ -357,6 +376,7 @@ static void launch_nt_np(int np, const float* A, int64_t lda, const float* B, in
 int maed_gemm_nt_x3_launch(int epilogue, int np, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e,
                            int splitk, hipStream_t s) {
     const float* a = (const float*)A; const float* b = (const float*)B;
+    MAED_CHECK_ARG(x3_fits32(M, lda, N, ldb), MAED_ERR_SHAPE, "gemm_nt(x3): an operand larger than 4 GB");
     switch (epilogue) {
         case MAED_EPI_STORE: launch_nt_np<MAED_EPI_STORE>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
         case MAED_EPI_GELU: launch_nt_np<MAED_EPI_GELU>(np, a, lda, b, ldb, M, N, K, e, 1, s); break;
@@ -375,6 +395,7 @@ int maed_gemm_nt_x3_launch(int epilogue, int np, const void* A, int64_t lda, con
 int maed_conv1x1_x3_launch(int np, const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int Cout, int Cin, const EpiArgs& e, bool gn, hipStream_t s) {
     const X3ConvDims d{};
     const float* a = (const float*)x; const float* b = (const float*)w;
+    MAED_CHECK_ARG(x3_fits32(M, ldx, Cout, ldw), MAED_ERR_SHAPE, "conv1x1(x3): an operand larger than 4 GB");
     const bool narrow = Cout <= 64;
 #define X3_C1(NP_, NARROW_, GN_) launch_nt<MAED_EPI_STORE, NP_, NARROW_, false, GN_>(a, ldx, b, ldw, M, Cout, Cin, d, e, 1, s)
     if (np == 3) { if (gn) { if (narrow) X3_C1(3, true, true); else X3_C1(3, false, true); } else { if (narrow) X3_C1(3, true, false); else X3_C1(3, false, false); } }
@@ -386,6 +407,7 @@ int maed_conv1x1_x3_launch(int np, const void* x, int64_t ldx, const void* w, in
 // 3x3 implicit GEMM: STORE (+ GN) or ADD epilogue
 int maed_conv3x3_x3_launch(int np, const void* x, const void* w, const X3ConvDims& d, int64_t M, int Cout, const EpiArgs& e, bool add, bool gn, hipStream_t s) {
     const float* a = (const float*)x; const float* b = (const float*)w;
+    MAED_CHECK_ARG(x3_fits32((int64_t)d.F * d.H * d.W + (int64_t)d.pad_top * d.W + d.pad_left, d.Cin, 9 * (int64_t)Cout, d.Cin), MAED_ERR_SHAPE, "conv3x3(x3): an operand larger than 4 GB");
     const bool narrow = Cout <= 64;
 #define X3_C3(EPI_, NP_, NARROW_, GN_) launch_nt<EPI_, NP_, NARROW_, true, GN_>(a, 0, b, 0, M, Cout, 9 * (int64_t)d.Cin, d, e, 1, s)
 #define X3_C3_NP(NP_) \
