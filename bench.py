@@ -163,9 +163,10 @@ class _SimModel(torch.nn.Module):
 
 
 def parity_mode_line(dev, steps=4):
-    """the fp32-accurate mode beside the headline bf16 line: compute_dtype = float32 with the fp32 matrix products on the split-bf16 MFMA kernels
-    (process-wide bf16x3, the backbone on bf16x6 -- DESIGN.md section 4), the SAME cfg3 train step (8 clips x 16 frames, fwd + bwd + Adam) timed over a few
-    steps, and the error of that mode's forward at full module size (one clip) against the fp32 CPU oracle.  north_star: 1e-3 relative on SMPL parameters."""
+    """the fp32-accurate mode beside the headline bf16 line: compute_dtype = float32 with the fp32 matrix products on the split-bf16 MFMA kernels, the SAME cfg3
+    train step (8 clips x 16 frames, fwd + bwd + Adam) timed over a few steps, and the error of that mode's forward at full module size (one clip) against the
+    fp32 CPU oracle (north_star: 1e-3 relative on SMPL parameters).  Two variants: "bf16x3" everywhere, and the backbone on "bf16x6" (its forward / input-gradient
+    products; gradient parity at the fp32 reference's own level, DESIGN.md section 4 -- the mode tests/test_gpu_parity_mode.py checks)."""
     import maed_amd
     from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
     from maed_amd.loss import LossVideo
@@ -173,44 +174,51 @@ def parity_mode_line(dev, steps=4):
     old = maed_amd.get_float32_matmul_precision()
     maed_amd.set_float32_matmul_precision("bf16x3")
     try:
-        model = build_model(torch.float32, dev, "bf16x6").train()
         gen = torch.Generator().manual_seed(1000)
         clip = torch.randn(CFG["clips"], CFG["T"], 3, CFG["img"], CFG["img"], generator=gen).to(dev)
         tgt = make_targets(CFG["clips"], CFG["T"], dev, gen)
-        arena = ParamArena(model)
-        opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=GradBucketer(arena, model))
-        criterion = LossVideo(**LOSS_W)
-
-        def step():
-            opt.zero_grad()
-            loss, _ = criterion(model(clip), tgt, None)
-            loss.backward()
-            opt.step()
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / steps
-        del model, arena, opt
-        # forward parity at full module size, one clip, against the fp32 oracle
         P = (CFG["img"] // 16) ** 2 + 1
         params = R.make_params(embed_dim=CFG["dim"], depth=CFG["depth"], hidden_dim=CFG["hidden"], n_tokens=P, seed=7)
         one = torch.randn(1, CFG["T"], 3, CFG["img"], CFG["img"], generator=torch.Generator().manual_seed(21))
         with torch.no_grad():
             ref = R.maed_forward(one, params, R.make_synthetic_smpl(0), depth=CFG["depth"], H=CFG["heads"])
-            m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["heads"], embed_dim=CFG["dim"], hidden_dim=CFG["hidden"], img_size=CFG["img"],
-                              max_seqlen=max(16, CFG["T"]), compute_dtype=torch.float32, backbone_f32_matmul="bf16x6")
-            m.load_state_dict(params, strict=False)
-            o = m.to(dev).eval()(one.to(dev))
-        err = {k: float((o[k].float().cpu() - ref[k]).abs().max() / ref[k].abs().max()) for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts")}
-        return dict(compute_dtype="f32", f32_matmul="bf16x3", backbone_f32_matmul="bf16x6", ms_per_step=round(ms, 3), clips_per_sec=round(CFG["clips"] * 1e3 / ms, 2),
-                    steps=steps, theta_rel_err=err["theta"], rel_err=err,
-                    note="same cfg3 train step in the fp32-accurate mode: fp32 activations / weights, matrix products split into bf16 terms on the matrix cores "
-                         "(csrc/gemm_x3.hip, attn_x3.hip: 3 MFMAs per product, 6 in the backbone), library convolutions; rel_err = max |out - fp32 oracle| / max |oracle| "
-                         "of the forward at full module size on one clip (north_star bar: 1e-3 on SMPL parameters); every-gradient parity: tests/test_gpu_parity_mode.py")
+        variants = {}
+        for name, bb in (("bf16x3", None), ("bf16x3_backbone_bf16x6", "bf16x6")):
+            model = build_model(torch.float32, dev, bb).train()
+            arena = ParamArena(model)
+            opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=GradBucketer(arena, model))
+            criterion = LossVideo(**LOSS_W)
+
+            def step():
+                opt.zero_grad()
+                loss, _ = criterion(model(clip), tgt, None)
+                loss.backward()
+                opt.step()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            del model, arena, opt
+            with torch.no_grad():       # forward parity at full module size, one clip, against the fp32 oracle
+                m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["heads"], embed_dim=CFG["dim"], hidden_dim=CFG["hidden"], img_size=CFG["img"],
+                                  max_seqlen=max(16, CFG["T"]), compute_dtype=torch.float32, backbone_f32_matmul=bb)
+                m.load_state_dict(params, strict=False)
+                o = m.to(dev).eval()(one.to(dev))
+            err = {k: float((o[k].float().cpu() - ref[k]).abs().max() / ref[k].abs().max()) for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts")}
+            variants[name] = dict(ms_per_step=round(ms, 3), clips_per_sec=round(CFG["clips"] * 1e3 / ms, 2), theta_rel_err=err["theta"], rel_err=err)
+            del m
+        main_v = variants["bf16x3"]
+        return dict(compute_dtype="f32", f32_matmul="bf16x3", ms_per_step=main_v["ms_per_step"], clips_per_sec=main_v["clips_per_sec"], theta_rel_err=main_v["theta_rel_err"],
+                    steps=steps, variants=variants,
+                    note="same cfg3 train step in the fp32-accurate mode: fp32 activations / weights, every matrix product split into bf16 terms on the matrix cores "
+                         "(csrc/gemm_x3.hip, attn_x3.hip: 3 MFMAs per product), library convolutions; rel_err = max |out - fp32 oracle| / max |oracle| of the forward at "
+                         "full module size on one clip (north_star bar: 1e-3 on SMPL parameters).  variants.bf16x3_backbone_bf16x6: the backbone's forward / "
+                         "input-gradient products with 6 MFMAs -- parameter gradients then sit as close to fp64 as the reference's own fp32 arithmetic "
+                         "(tests/test_gpu_parity_mode.py: every gradient of the full-size model)")
     finally:
         maed_amd.set_float32_matmul_precision(old)
 
