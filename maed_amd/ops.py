@@ -65,10 +65,12 @@ def lib_matmul_dtype(dtype, prec=None):
     return dtype == torch.bfloat16 or (dtype == torch.float32 and (f32_split() or prec in ("bf16x3", "bf16x6")))
 
 
-def wgrad_prec(prec):
-    """engine of a WEIGHT-gradient product inside a module that runs its other products on "bf16x6": bf16x3.  A weight gradient is a leaf of the backward pass --
-    its rounding error (~2^-16 of |dy||x|, i.e. ~1e-5 of the largest entry) goes nowhere else, unlike the forward / input-gradient products whose errors the
-    following GroupNorms amplify (which is what bf16x6 is for).  Measured: scripts/x3_probe.py, profiles/r03_x3_probe_wgrad_x3.txt."""
+def bwd_prec(prec):
+    """engine of the BACKWARD products (input gradient, weight gradient) of a module whose forward runs on "bf16x6": bf16x3.  What bf16x6 buys is the forward:
+    rounding errors of the activations are re-normalised -- and amplified -- by every following GroupNorm, and the backward pass differentiates THOSE activations.
+    The backward products themselves are linear in dy; their ~2^-16 error is not amplified (a weight gradient is even a leaf).  Measured on the full-size model
+    against fp64 (scripts/x3_probe.py, profiles/r03_x3_probe_*.txt): backbone gradients with forward bf16x6 + backward bf16x3 sit exactly where all-bf16x6 does
+    (median 1.60e-2 / 1.38e-2 / 2.7e-3 per stage = the fp32 oracle's own distance), all-bf16x3 at 7.0e-2 / 5.8e-2 / 7.9e-3; the step 50.8 -> 48.7 ms."""
     return "bf16x3" if prec == "bf16x6" else prec
 
 
@@ -830,16 +832,16 @@ class Conv1x1Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if g_short is not None:
                 G = g_short.contiguous(memory_format=torch.channels_last).to(Y.dtype).permute(0, 2, 3, 1).reshape(N * H * W, I)
-                dx = gemm_nt(Y, wt, L.EPI_ADD, aux=G, out2=mask, prec=ctx.prec)
+                dx = gemm_nt(Y, wt, L.EPI_ADD, aux=G, out2=mask, prec=bwd_prec(ctx.prec))
             else:
-                dx = gemm_nt(Y, wt, L.EPI_STORE, prec=ctx.prec)
+                dx = gemm_nt(Y, wt, L.EPI_STORE, prec=bwd_prec(ctx.prec))
             if ctx.stride == 2:
                 g, dx = dx, torch.empty(N * H * W, I, dtype=dx.dtype, device=dx.device)
                 check(L.lib().maed_subsample2_bwd(_p(g), _p(dx), N, H, W, I, dt_code(dx.dtype), _stream()), "subsample2_bwd")
             dx = dx.view(N, H, W, I).permute(0, 3, 1, 2)
         if ctx.dw is not None:
             dw, prec = ctx.dw, ctx.prec
-            side_stream_run(lambda: gemm_tn_wgrad(Y, A, dW=dw, prec=wgrad_prec(prec)), Y, A, dw)
+            side_stream_run(lambda: gemm_tn_wgrad(Y, A, dW=dw, prec=bwd_prec(prec)), Y, A, dw)
         if mask is not None and dx is None:
             raise RuntimeError("Conv1x1Fn: lazily masked shortcut gradient but no input gradient requested")
         return dx, None, None, None, None, None, None, None, None
@@ -932,15 +934,15 @@ class Conv3x3Fn(torch.autograd.Function):
         own_dx = need_x and s == 1 and O % 64 == 0               # (the gathered operand's channel count is O here)
         if own_dx:
             if wt is not None:                                   # in place from the transposed image: tap flip = negative tap stride
-                dx = conv3x3(dy, wt, 1, w_layout=1, prec=prec)
+                dx = conv3x3(dy, wt, 1, w_layout=1, prec=bwd_prec(prec))
             else:                                                # dX = conv3x3(dY, w'), w'[ci][ky][kx][co] = w[co][ci][2-ky][2-kx]
-                dx = conv3x3(dy, w.flip(2, 3).permute(1, 2, 3, 0).contiguous(), 1, prec=prec)
+                dx = conv3x3(dy, w.flip(2, 3).permute(1, 2, 3, 0).contiguous(), 1, prec=bwd_prec(prec))
         own_dw = need_w and s == 1 and ((N * H * W) % 64 == 0 or x.dtype == torch.float32) and I % 8 == 0 and O % 8 == 0      # (the bf16 kernel has no ragged tile)
         if own_dw:                                               # TN GEMM over gathered rows; fp32, (O,3,3,I) like w's storage
             if dw_slice is not None:
-                side_stream_run(lambda: conv3x3_wgrad(dy, x, out=dw_slice, prec=wgrad_prec(prec)), dy, x, dw_slice)
+                side_stream_run(lambda: conv3x3_wgrad(dy, x, out=dw_slice, prec=bwd_prec(prec)), dy, x, dw_slice)
             else:
-                dw = conv3x3_wgrad(dy, x, prec=wgrad_prec(prec)).permute(0, 3, 1, 2)
+                dw = conv3x3_wgrad(dy, x, prec=bwd_prec(prec)).permute(0, 3, 1, 2)
             need_w = False
         if need_w or (need_x and not own_dx):
             sym = ph % 2 == 0 and pw % 2 == 0
