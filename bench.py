@@ -390,6 +390,14 @@ def main():
         cnt = (ctypes.c_int * ntags)()
         pflops = (ctypes.c_double * ntags)()
         lib.maed_prof_flops(pflops)
+        # every launch of the roofline kernel (tag 11) with its own duration, FLOPs and algorithmic bytes: each launch is priced against ITS bound below
+        TN_ALL = 11
+        tn_recs = []
+        if ntags > TN_ALL:
+            cap = 4096
+            r_us, r_fl, r_by = (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+            nrec = min(cap, lib.maed_prof_records(TN_ALL, r_us, r_fl, r_by, cap))
+            tn_recs = [(r_us[i], r_fl[i], r_by[i]) for i in range(nrec)]
         lib.maed_prof_collect(ms, cnt)
         lib.maed_prof_enable(0)
         Fr, P, C_, T = CFG["clips"] * CFG["T"], (CFG["img"] // 16) ** 2 + 1, CFG["dim"], CFG["T"]
@@ -460,14 +468,29 @@ def main():
                                   note="flops averaged over the five shapes; in-situ hipEvent timing")
         # THE roofline object: the kernel with the most time in the step's rocprofv3 summary -- the TN weight-gradient GEMM (gemm_tn_mfma_bf16_kernel<false>:
         # STE Linear layers AND the backbone's 1x1 convolutions) -- over EVERY launch of it (tag 11: maed_gemm_tn_wgrad brackets itself and declares 2*M*N*K)
-        TN_ALL = 11
         if ntags > TN_ALL and cnt[TN_ALL] > 0:
             us = 1e3 * ms[TN_ALL] / cnt[TN_ALL]
             tf = pflops[TN_ALL] / (ms[TN_ALL] * 1e-3) / 1e12
+            # The launches of this kernel are not all bound by the same resource: the backbone's stage-1/2 weight gradients reduce over 100-400 K pixels into a
+            # 64..512-wide output (50-100 FLOP per byte: HBM-bound), the STE's are MFMA-bound.  Per launch: t_bound = max(FLOPs x MFMAs-per-product / MFMA peak,
+            # algorithmic bytes / HBM peak); launch_bound.frac = sum t_bound / sum duration -- how far the family as a whole is from ITS roofline.
+            mult = 1.0 if args.dtype == "bf16" else {"bf16x3": 3.0, "bf16x6": 6.0}.get(args.f32_matmul, 1.0)
+            shapes, tb_sum, dur_sum, n_hbm = {}, 0.0, 0.0, 0
+            for u, fl, by in tn_recs:
+                t_m, t_h = fl * mult / (MFMA_BF16_PEAK_TF * 1e6), by / (HBM_PEAK_GBS * 1e3)       # us
+                tb_sum += max(t_m, t_h); dur_sum += u; n_hbm += t_h > t_m
+                e = shapes.setdefault((fl, by), [0, 0.0, t_m, t_h])
+                e[0] += 1; e[1] += u
+            by_shape = [dict(gflop=round(fl / 1e9, 2), mbytes=round(by / 1e6, 1), launches_per_step=round(e[0] / nprof, 2), avg_us=round(e[1] / e[0], 1),
+                             tflops=round(fl * e[0] / e[1] / 1e6, 1), gbs=round(by * e[0] / e[1] / 1e3, 1), bound="hbm" if e[3] > e[2] else "mfma",
+                             frac_of_bound=round(max(e[2], e[3]) * e[0] / e[1], 3))
+                        for (fl, by), e in sorted(shapes.items(), key=lambda kv: -kv[1][1])]
+            launch_bound = dict(frac=round(tb_sum / dur_sum, 4) if dur_sum else None, hbm_bound_launches_per_step=round(n_hbm / nprof, 1),
+                                mfma_bound_launches_per_step=round((len(tn_recs) - n_hbm) / nprof, 1), mfma_ops_per_product=mult, by_shape=by_shape[:12])
             roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_mfma_bf16_kernel<false>") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
                                    "5 per STE block + the backbone's 1x1 convolutions)", bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                             frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=traffic_db.get("gemm_tn"), avg_us=round(us, 2), launches=cnt[TN_ALL] // nprof,
-                            ms_per_step=round(ms[TN_ALL] / nprof, 3),
+                            ms_per_step=round(ms[TN_ALL] / nprof, 3), launch_bound=launch_bound,
                             note="the kernel with the most time in the single-stream rocprofv3 summary of this command (profiles/); achieved = sum of 2*M*N*K declared by every "
                                  f"launch / sum of their hipEvent durations on the launch stream ({nprof} extra single-stream steps); the NT GEMM family and the attention forward "
                                  "are under roofline_nt / roofline_attention" + traffic_note)

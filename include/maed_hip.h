@@ -223,6 +223,9 @@ int maed_prof_collect(double* ms_total_host, int* count_host);
 /* tags 11 / 12: EVERY maed_gemm_tn_wgrad / maed_conv3x3_wgrad launch (STE and backbone).  maed_prof_flops fills flops_host[n] with the algorithmic FLOPs
  * (2 M N K per launch) the tagged launches declared since the last collect -- call it before maed_prof_collect, which clears them. */
 int maed_prof_flops(double* flops_host);
+/* per-launch records of one tag in launch order (before maed_prof_collect): duration [us], declared FLOPs, algorithmic HBM bytes (operands read once, result written
+ * once); returns the number of records held, writes at most cap of them.  bench.py prices every launch against ITS bound (MFMA or HBM) with these. */
+int maed_prof_records(int tag, double* us_host, double* flops_host, double* bytes_host, int cap);
 
 /* ---- K10: KTD joint chain (ktd.py:81-86) ------------------------------------------------------- */
 /* base[f32](F,144) = x W_feat^T + b for the 1024-wide feature part of all 24 regressors has been

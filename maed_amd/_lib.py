@@ -88,6 +88,7 @@ SIGNATURES = {
     "maed_prof_ntags": (i32, []),
     "maed_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i32)]),
     "maed_prof_flops": (i32, [C.POINTER(C.c_double)]),
+    "maed_prof_records": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
     "maed_ktd_chain_fwd": (i32, [vp, vp, vp, i32, vp]),
     "maed_rot6d_pose_fwd": (i32, [vp, vp, vp, i64, vp]),
     "maed_smpl_lbs_fwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, vp, i32, vp]),

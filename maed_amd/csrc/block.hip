@@ -17,36 +17,56 @@
 
 // ---- in-situ kernel timing (csrc/prof.h): storage and entry points ----------------------------------------------
 static bool g_prof = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_NTAGS];
-static double g_prof_flops[PROF_NTAGS];
+struct ProfRec { hipEvent_t a, b; double flops, bytes; };
+static std::vector<ProfRec> g_prof_ev[PROF_NTAGS];
 bool maed_prof_on() { return g_prof; }
 void maed_prof_open(int tag, hipStream_t s, hipEvent_t* a) { (void)tag; hipEventCreate(a); hipEventRecord(*a, s); }
-void maed_prof_close(int tag, hipStream_t s, hipEvent_t a, double flops) {
+void maed_prof_close(int tag, hipStream_t s, hipEvent_t a, double flops, double bytes) {
     hipEvent_t b;
     hipEventCreate(&b); hipEventRecord(b, s);
-    g_prof_ev[tag].emplace_back(a, b);
-    g_prof_flops[tag] += flops;
+    g_prof_ev[tag].push_back(ProfRec{a, b, flops, bytes});
 }
 extern "C" int maed_prof_enable(int on) { g_prof = on != 0; return MAED_OK; }
 extern "C" int maed_prof_ntags(void) { return PROF_NTAGS; }
 extern "C" int maed_prof_flops(double* flops) {              // FLOPs declared by the tagged launches since the last collect (call BEFORE maed_prof_collect)
-    for (int t = 0; t < PROF_NTAGS; ++t) if (flops) flops[t] = g_prof_flops[t];
+    for (int t = 0; t < PROF_NTAGS; ++t) {
+        double tot = 0.0;
+        for (auto& r : g_prof_ev[t]) tot += r.flops;
+        if (flops) flops[t] = tot;
+    }
     return MAED_OK;
+}
+// per-launch records of one tag, in launch order (call BEFORE maed_prof_collect): duration, declared FLOPs and algorithmic bytes; returns the number of records
+// the tag holds (at most `cap` are written)
+extern "C" int maed_prof_records(int tag, double* us, double* flops, double* bytes, int cap) {
+    if (tag < 0 || tag >= PROF_NTAGS) return 0;
+    int i = 0;
+    for (auto& r : g_prof_ev[tag]) {
+        if (i < cap) {
+            hipEventSynchronize(r.b);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, r.a, r.b);
+            if (us) us[i] = 1e3 * (double)ms;
+            if (flops) flops[i] = r.flops;
+            if (bytes) bytes[i] = r.bytes;
+        }
+        ++i;
+    }
+    return i;
 }
 extern "C" int maed_prof_collect(double* ms_total, int* count) {
     for (int t = 0; t < PROF_NTAGS; ++t) {
         double tot = 0.0;
-        for (auto& ev : g_prof_ev[t]) {
-            hipEventSynchronize(ev.second);
+        for (auto& r : g_prof_ev[t]) {
+            hipEventSynchronize(r.b);
             float ms = 0.f;
-            hipEventElapsedTime(&ms, ev.first, ev.second);
+            hipEventElapsedTime(&ms, r.a, r.b);
             tot += ms;
-            hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+            hipEventDestroy(r.a); hipEventDestroy(r.b);
         }
         if (ms_total) ms_total[t] = tot;
         if (count) count[t] = (int)g_prof_ev[t].size();
         g_prof_ev[t].clear();
-        g_prof_flops[t] = 0.0;
     }
     return MAED_OK;
 }

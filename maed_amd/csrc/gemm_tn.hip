@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
 extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw,
                                   float* dbias, int dtype, void* stream) {
     MAED_CHECK_ARG(Y && X && dW, MAED_ERR_ARG, "gemm_tn_wgrad: null pointer");
-    ProfScope prof__(PROF_TN_ALL, stream, 2.0 * (double)M * N * K);
+    const double es__ = (dtype == MAED_BF16) ? 2.0 : 4.0;
+    ProfScope prof__(PROF_TN_ALL, stream, 2.0 * (double)M * N * K, es__ * (double)M * ((double)N + K) + 4.0 * (double)N * K);
     const int np_call = maed_x3_take_dtype(dtype);
     if (dtype == MAED_F32) {        // fp32 operands on the split-bf16 MFMA kernel (gemm_x3.hip)
         const int np = np_call ? np_call : maed_x3_planes();
@@ -286,7 +287,8 @@ extern "C" int maed_conv3x3_tapmask(void* mask, int F, int H, int W, void* strea
 extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tapmask, const void* zero_page, float* dW, int F, int H, int W, int Cin,
                                   int Cout, int dtype, void* stream) {
     MAED_CHECK_ARG(dy && x && tapmask && zero_page && dW, MAED_ERR_ARG, "conv3x3_wgrad: null pointer");
-    ProfScope prof__(PROF_TN_CONV, stream, 2.0 * (double)F * H * W * Cout * 9 * Cin);
+    const double es__ = (dtype == MAED_BF16) ? 2.0 : 4.0;
+    ProfScope prof__(PROF_TN_CONV, stream, 2.0 * (double)F * H * W * Cout * 9 * Cin, es__ * (double)F * H * W * ((double)Cout + Cin) + 36.0 * (double)Cout * Cin);
     const int np_call = maed_x3_take_dtype(dtype);
     MAED_CHECK_ARG(dtype == MAED_BF16 || dtype == MAED_F32, MAED_ERR_ARG, "conv3x3_wgrad: bad dtype %d", dtype);
     const int64_t M = (int64_t)F * H * W;

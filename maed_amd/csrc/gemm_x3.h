@@ -7,7 +7,7 @@
 // 4 consecutive fp32 -> NP planes of 4 bf16 (2 dwords per plane): x = x0 + x1 (+ x2), x0 = bf16(x) (round to nearest even), x1 = bf16(x - x0), ...
 // (every subtraction is exact in fp32)
 // v_cvt_pk_bf16_f32 as an opaque operation: through the __bf16 vector cast hipcc re-converts the LOW element on its own to form float(x0) (it folds
-// "(pack << 16)" back into a scalar conversion): 6 converter instructions per 4 values instead of 4 (ISA of the first build, profiles/r03_x3_isa_notes.txt)
+// "(pack << 16)" back into a scalar conversion): 6 converter instructions per 4 values instead of 4 (ISA of the first build, profiles/r03_isa_audit_x3.txt)
 __device__ __forceinline__ uint32_t x3_pack_bf2(float lo, float hi) {
 #ifdef MAED_HOSTSIM
     return pack_bf2(lo, hi);

@@ -1,6 +1,6 @@
 // In-situ kernel timing (measurement only; off by default): selected launches are bracketed with hipEvents recorded on the SAME stream the kernel
 // is launched on; maed_prof_collect() synchronises the events and returns total ms and launch counts per tag, maed_prof_flops() the algorithmic
-// FLOPs the tagged launches declared.  bench.py uses this for the roofline numbers.  Storage and entry points: csrc/block.hip.
+// FLOPs the tagged launches declared, maed_prof_records() duration / FLOPs / algorithmic bytes of every launch of one tag.  bench.py uses this for the roofline numbers.  Storage and entry points: csrc/block.hip.
 #pragma once
 #include "common.cuh"
 
@@ -10,12 +10,13 @@ enum { PROF_ATTN_SP_FWD = 0, PROF_ATTN_TM_FWD, PROF_GEMM_QKV, PROF_GEMM_FC1, PRO
 
 bool maed_prof_on();
 void maed_prof_open(int tag, hipStream_t s, hipEvent_t* a);
-void maed_prof_close(int tag, hipStream_t s, hipEvent_t a, double flops);
+void maed_prof_close(int tag, hipStream_t s, hipEvent_t a, double flops, double bytes);
 
 struct ProfScope {
-    int tag; hipStream_t s; hipEvent_t a; bool on; double flops;
-    ProfScope(int tag_, void* stream, double flops_ = 0.0) : tag(tag_), s((hipStream_t)stream), a(nullptr), on(maed_prof_on()), flops(flops_) {
+    int tag; hipStream_t s; hipEvent_t a; bool on; double flops, bytes;      // bytes: algorithmic HBM bytes of the launch (operands once, results once)
+    ProfScope(int tag_, void* stream, double flops_ = 0.0, double bytes_ = 0.0)
+        : tag(tag_), s((hipStream_t)stream), a(nullptr), on(maed_prof_on()), flops(flops_), bytes(bytes_) {
         if (on) maed_prof_open(tag, s, &a);
     }
-    ~ProfScope() { if (on) maed_prof_close(tag, s, a, flops); }
+    ~ProfScope() { if (on) maed_prof_close(tag, s, a, flops, bytes); }
 };
