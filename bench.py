@@ -464,7 +464,7 @@ def main():
         if "gemm_wgrad(all)" in kernels:
             k = kernels["gemm_wgrad(all)"]
             roofline_wgrad = dict(kernel="gemm_tn_mfma_bf16_kernel (weight gradients dW += Y^T X of the STE, five per block)", bound="mfma", achieved=k["tflops"],
-                                  peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"], traffic=traffic_db.get("gemm_tn"), avg_us=k["avg_us"],
+                                  peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"], traffic=traffic_db.get("gemm_tn_ste_shapes", traffic_db.get("gemm_tn")), avg_us=k["avg_us"],
                                   note="flops averaged over the five shapes; in-situ hipEvent timing")
         # THE roofline object: the kernel with the most time in the step's rocprofv3 summary -- the TN weight-gradient GEMM (gemm_tn_mfma_bf16_kernel<false>:
         # STE Linear layers AND the backbone's 1x1 convolutions) -- over EVERY launch of it (tag 11: maed_gemm_tn_wgrad brackets itself and declares 2*M*N*K)
@@ -490,7 +490,8 @@ def main():
             roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_mfma_bf16_kernel<false>") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
                                    "5 per STE block + the backbone's 1x1 convolutions)", bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                             frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=traffic_db.get("gemm_tn"), avg_us=round(us, 2), launches=cnt[TN_ALL] // nprof,
-                            ms_per_step=round(ms[TN_ALL] / nprof, 3), launch_bound=launch_bound,
+                            ms_per_step=round(ms[TN_ALL] / nprof, 3), algorithmic_bytes=(int(sum(r[2] for r in tn_recs) / len(tn_recs)) if tn_recs else None),
+                            launch_bound=launch_bound,
                             note="the kernel with the most time in the single-stream rocprofv3 summary of this command (profiles/); achieved = sum of 2*M*N*K declared by every "
                                  f"launch / sum of their hipEvent durations on the launch stream ({nprof} extra single-stream steps); the NT GEMM family and the attention forward "
                                  "are under roofline_nt / roofline_attention" + traffic_note)
