@@ -41,9 +41,8 @@ __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return __b
 // feature-map size), and a masked row loads a page of zeros instead.  Needs M % 64 == 0 (no ragged tile).  Opt-in path.
 struct TnConv { const uint16_t* tapmask; const bf16* zero_page; int Cin, Wimg; };
 
-// SB (single LDS buffer, one register set, 3 workgroups per CU instead of 2): experiment, selected by bit 16 of MAED_OPT_ABLATE
-template <bool CONV, bool SB = false>
-__global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_tn_mfma_bf16_kernel(const bf16* __restrict__ Y, int64_t ldy, const bf16* __restrict__ X,
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* __restrict__ Y, int64_t ldy, const bf16* __restrict__ X,
                                                                    int64_t ldx, int64_t M, int N, int K, float* __restrict__ dW,
                                                                    int64_t ldw, float* __restrict__ dbias, int tiles_k, int mtiles_per_split,
                                                                    TnConv cv, int remap
@@ -54,8 +53,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_tn_mfma_bf16_kernel(cons
 #ifndef MAED_GEMM_ABLATE
     constexpr int ablate = 0;
 #endif
-    constexpr int NBUF = SB ? 1 : 2;
-    __shared__ __attribute__((aligned(16))) unsigned short lds[NBUF][2][128 * TN_LD];  // [buf][Y^T | X^T][row n|k][m]
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][128 * TN_LD];  // [buf][Y^T | X^T][row n|k][m]
     __shared__ float lcs[8][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, hi = lane >> 5;
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_tn_mfma_bf16_kernel(cons
               vo6 = vo5 + ldi, vo7 = vo6 + ldi;               // fits 32 bits: the launcher checks ld < 2^24
     if (!col_ok) {
 #pragma unroll
-        for (int b = 0; b < NBUF; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 *reinterpret_cast<uint4*>(my_lds_base + (size_t)b * (2 * 128 * TN_LD) + wr_off + 4 * j * TN_LD) = make_uint4(0u, 0u, 0u, 0u);
@@ -172,23 +170,6 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_tn_mfma_bf16_kernel(cons
     __syncthreads();                            // (zeroed LDS rows of out-of-range columns are in place)
     // (a four-set variant -- loads issued three tile times ahead instead of one -- measured the same or slower: the loop is not waiting on
     // vmcnt; profiles/r02_gemm_tn_ablation.txt: MFMA + LDS transposes alone take 3/4 of the kernel's time)
-    if constexpr (SB) {
-        if (mt_beg < mt_endf) {
-            TN_LOAD(0, mt_beg);
-            TN_STORE(0, 0);
-            __syncthreads();
-            for (int mt = mt_beg; mt < mt_endf; ++mt) {
-                const bool more = mt + 1 < mt_endf;       // block-uniform
-                if (more) TN_LOAD(0, mt + 1);
-                TN_COMPUTE(0);
-                if (more) {
-                    __syncthreads();
-                    TN_STORE(0, 0);
-                    __syncthreads();
-                }
-            }
-        }
-    } else
     if (mt_beg < mt_endf) {
         TN_LOAD(0, mt_beg);
         TN_LOAD(1, mt_beg + 1);
@@ -271,10 +252,6 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
                        N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap(), maed_opt(MAED_OPT_ABLATE));
 #else
-    if (maed_opt(MAED_OPT_ABLATE) & 16)
-        hipLaunchKernelGGL((gemm_tn_mfma_bf16_kernel<false, true>), dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
-                           N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap());
-    else
     hipLaunchKernelGGL(gemm_tn_mfma_bf16_kernel<false>, dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)Y, ldy, (const bf16*)X, ldx, M,
                        N, K, dW, ldw, dbias, tk, per, TnConv{nullptr, nullptr, 0, 0}, tn_remap());
 #endif
