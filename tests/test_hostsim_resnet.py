@@ -223,7 +223,8 @@ def test_two_stage_backbone_downsample_shortcut_runs_on_packed_pixels():
         assert p.grad is not None and cos(p.grad, q.grad) > 0.93, (n, cos(p.grad, q.grad))
 
 
-@pytest.mark.parametrize("mode,tol_y,tol_g", [("bf16x3", 2e-4, 2e-3), ("bf16x6", 2e-5, 2e-4), ("module:bf16x6", 2e-5, 2e-4)])
+# (the process-wide "bf16x6" runs the same kernels as "module:bf16x6" forward and as "bf16x3" backward; kernel-level bf16x6 cases: test_hostsim_x3.py)
+@pytest.mark.parametrize("mode,tol_y,tol_g", [("bf16x3", 2e-4, 2e-3), ("module:bf16x6", 2e-5, 2e-4)])
 def test_backbone_f32_split_mode_runs_on_library_convolutions(mode, tol_y, tol_g, monkeypatch):
     """compute_dtype=float32 with the split-bf16 matmul mode: the fp32 backbone takes the bf16 mode's code path -- 1x1 convolutions on
     maed_gemm_nt / maed_conv1x1_fwd (+ GroupNorm statistics from the epilogue), 3x3 on the implicit-GEMM kernel incl. its transposed-image input
@@ -237,7 +238,7 @@ def test_backbone_f32_split_mode_runs_on_library_convolutions(mode, tol_y, tol_g
     sim = copy.deepcopy(ref)
     if mode.startswith("module:"):                    # the process-wide mode stays exact; the backbone carries its own engine (MAED_F32X6 dtype codes per call)
         sim.f32_matmul, mode = mode.split(":")[1], "exact"
-    x = torch.randn(2, 3, 64, 64)                     # stem /4 -> 16 x 16 = 256 pixels per frame (GroupNorm statistics from the epilogues)
+    x = torch.randn(1, 3, 64, 64)                     # stem /4 -> 16 x 16 = 256 pixels per frame (GroupNorm statistics from the epilogues)
     yr = ref(x)
     gout = torch.randn_like(yr)
     (yr * gout).sum().backward()
