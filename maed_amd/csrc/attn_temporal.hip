@@ -6,6 +6,7 @@
 // of the same (n,h,p) are shared by T neighbouring threads through L1.  fp32 math for both dtypes.
 #include "common.cuh"
 #include "attn_mfma.cuh"
+#include "gemm_x3.h"
 #include <stdlib.h>
 
 #define D HEAD_DIM
@@ -845,6 +846,12 @@ extern "C" int maed_attn_temporal_fwd(const void* qkv, void* o, float* lse, int 
     if (total == 0) return MAED_OK;
     dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == MAED_BF16 && launch_tm_fwd_mfma(qkv, o, lse, F, P, H, T, scale, (hipStream_t)stream)) { MAED_CHECK_LAUNCH("attn_temporal_fwd"); return MAED_OK; }
+    // fp32 operands, split-bf16 contractions on the matrix cores (attn_x3.hip): MAED_F32X3 per call or the process-wide fp32 matmul mode; bf16x6 keeps the exact kernels
+    const int np_call = maed_x3_take_dtype(dtype);
+    if (dtype == MAED_F32 && maed_attn_tm_x3_fwd_launch(np_call ? np_call : maed_x3_planes(), qkv, o, lse, F, P, H, T, scale, (hipStream_t)stream)) {
+        MAED_CHECK_LAUNCH("attn_temporal_fwd(x3)");
+        return MAED_OK;
+    }
     MAED_DISPATCH_DTYPE(dtype, TT, {
         if (!launch_tm_fwd_lds<TT>(qkv, o, lse, F, P, H, T, scale, (hipStream_t)stream))
             hipLaunchKernelGGL((attn_tm_fwd_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, (TT*)o, lse, total, P, H, T, scale);
@@ -862,6 +869,11 @@ extern "C" int maed_attn_temporal_bwd(const void* qkv, const void* o, const void
     dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == MAED_BF16 && launch_tm_bwd_mfma(qkv, o, d_o, lse, dqkv, accumulate, F, P, H, T, scale, (hipStream_t)stream)) {
         MAED_CHECK_LAUNCH("attn_temporal_bwd");
+        return MAED_OK;
+    }
+    const int np_call = maed_x3_take_dtype(dtype);
+    if (dtype == MAED_F32 && maed_attn_tm_x3_bwd_launch(np_call ? np_call : maed_x3_planes(), qkv, o, d_o, lse, dqkv, accumulate, F, P, H, T, scale, (hipStream_t)stream)) {
+        MAED_CHECK_LAUNCH("attn_temporal_bwd(x3)");
         return MAED_OK;
     }
     MAED_DISPATCH_DTYPE(dtype, TT, {

@@ -407,6 +407,234 @@ __global__ __launch_bounds__(256, 2) void attn_x3_bwd_dkv(const float* __restric
     }
 }
 
+
+// ==================================================================================================
+// Temporal attention (Attention.forward_temporal, vision_transformer.py:216-228) in the fp32-accurate mode: the one-tile kernels of attn_temporal.hip
+// (attn_tm_fwd_mfma / attn_tm_bwd_mfma_l32) on fp32 operands with split-bf16 contractions.  A one-wave workgroup owns one (clip n, head h, group of
+// G = 32 / T tokens): its 32 rows r = g*T + t are the T frames of G tokens (cfg3: T = 16, two tokens per tile); row r lives at frame n*T + t, token
+// tg*G + g of the (F, P, 3C) qkv tensor.  With a single tile the "other side" of every product is the wave's own 32 rows: row-major operands (Q, K, V,
+// dO fragments) are loaded straight from global memory as fp32, split once into NP register planes; only the A operands of the products that
+// contract over rows (V^T; K^T, Q^T, dO^T) go through LDS, as row-major plane images read back transposed by ds_read_b64_tr_b16.  Keys of another
+// token are masked (block-diagonal attention over the virtual sequence).  The f32 VALU kernels these replace in the split modes: 129 / 283 us per cfg3
+// launch (forward / backward).
+// ==================================================================================================
+constexpr int TPLANE = 32 * KLD;    // one bf16 plane of a 32-row image
+
+template <int NP>
+__device__ __forceinline__ void tm_frag_tr_planes(const unsigned short* X, int key_base, int e_base, int lane, bf16x8_t (&out)[NP]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) out[q] = lds_frag_tr_rm(X + q * TPLANE, key_base, e_base, lane);
+}
+// 8 consecutive fp32 of the lane's row -> NP register fragment planes (+ optionally the same planes into a row-major LDS image at dst)
+template <int NP, bool TO_LDS>
+__device__ __forceinline__ void tm_load_split(const float* p, bool ok, bf16x8_t (&out)[NP], unsigned short* dst) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (ok) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    uint2 pa[NP], pb[NP];
+    split4<NP>(a.x, a.y, a.z, a.w, pa);
+    split4<NP>(b.x, b.y, b.z, b.w, pb);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        union { bf16x8_t v; uint4 u; } f;
+        f.u = make_uint4(pa[q].x, pa[q].y, pb[q].x, pb[q].y);
+        out[q] = f.v;
+        if constexpr (TO_LDS) *reinterpret_cast<uint4*>(dst + q * TPLANE) = f.u;
+    }
+}
+
+#define TMX_ROW_OK(r) (p0 + (r) / Tn < P)
+#define TMX_TOK(r) (((int64_t)n * Tn + (r) % Tn) * P + p0 + (r) / Tn)
+
+template <int NP>
+__global__ __launch_bounds__(64, 4) void attn_tm_x3_fwd(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse, int P, int H, int Tn,
+                                                        int G, int ngroups, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[NP * TPLANE];
+    const int C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    const int tg = bid % ngroups; bid /= ngroups;
+    const int h = bid % H, n = bid / H;
+    const int p0 = tg * G;
+    const int row = l31;
+    const bool row_ok = TMX_ROW_OK(row);
+    const int64_t tok = row_ok ? TMX_TOK(row) : 0;
+    const float* rp = qkv + tok * ld + h * D;
+    bf16x8_t qf[4][NP], kf[4][NP];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e0 = t * 16 + hi * 8;
+        bf16x8_t vtmp[NP];
+        tm_load_split<NP, false>(rp + e0, row_ok, qf[t], nullptr);
+        tm_load_split<NP, false>(rp + C + e0, row_ok, kf[t], nullptr);
+        tm_load_split<NP, true>(rp + 2 * C + e0, row_ok, vtmp, Vs + row * KLD + e0);     // rows of absent tokens are staged as zeros
+    }
+    __syncthreads();
+    f32x16_t s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s = mfma_split<NP>(kf[t], qf[t], s);                     // S^T: lane = query, registers = keys
+    const int rg = row / Tn;
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool ok = TMX_ROW_OK(k) && (k / Tn == rg);
+        s[r] = ok ? s[r] * scale_log2e : -INFINITY;
+        m = fmaxf(m, s[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float msafe = (m == -INFINITY) ? 0.f : m;                                      // (a query row of an absent token: everything masked)
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - msafe); l += s[r]; }
+    l += __shfl_xor(l, 32, 64);
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {                                                     // O^T = V^T P^T, 16 keys per step
+        bf16x8_t pf[NP];
+        split_frag<NP>(s, st, pf);
+#pragma unroll
+        for (int et = 0; et < 2; ++et) {
+            bf16x8_t vf[NP];
+            tm_frag_tr_planes<NP>(Vs, 16 * st, et * 32, lane, vf);
+            oacc[et] = mfma_split<NP>(vf, pf, oacc[et]);
+        }
+    }
+    if (row_ok) {
+        const float inv = 1.f / l;
+        float* orow = o + tok * C + h * D;
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(orow + et * 32 + 8 * g + 4 * hi) =
+                    make_float4(oacc[et][4 * g] * inv, oacc[et][4 * g + 1] * inv, oacc[et][4 * g + 2] * inv, oacc[et][4 * g + 3] * inv);
+        if (hi == 0) lse[(((int64_t)n * Tn + row % Tn) * H + h) * P + p0 + rg] = (m + log2f(l)) * 0.69314718055994530942f;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(64, 2) void attn_tm_x3_bwd(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ d_o,
+                                                        const float* __restrict__ lse, float* __restrict__ dqkv, int accumulate, int P, int H, int Tn, int G,
+                                                        int ngroups, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[NP * TPLANE], Ks[NP * TPLANE], dOs[NP * TPLANE];
+    __shared__ float Ls[32], Ds[32];
+    const int C = H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    const int tg = bid % ngroups; bid /= ngroups;
+    const int h = bid % H, n = bid / H;
+    const int p0 = tg * G;
+    const int row = l31;
+    const bool row_ok = TMX_ROW_OK(row);
+    const int64_t tok = row_ok ? TMX_TOK(row) : 0;
+    const float* rp = qkv + tok * ld + h * D;
+    const float* gp = d_o + tok * C + h * D;
+    const float* op = o + tok * C + h * D;
+    const float l2e = 1.44269504088896340736f;
+    bf16x8_t qf[4][NP], kf[4][NP], vf[4][NP], dof[4][NP];
+    float dsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e0 = t * 16 + hi * 8;
+        tm_load_split<NP, true>(rp + e0, row_ok, qf[t], Qs + row * KLD + e0);            // (rows of absent tokens: zeros)
+        tm_load_split<NP, true>(rp + C + e0, row_ok, kf[t], Ks + row * KLD + e0);
+        tm_load_split<NP, false>(rp + 2 * C + e0, row_ok, vf[t], nullptr);
+        tm_load_split<NP, true>(gp + e0, row_ok, dof[t], dOs + row * KLD + e0);
+        if (row_ok) {
+            float a[8], b[8];
+            ld8(gp + e0, a); ld8(op + e0, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum = fmaf(a[j], b[j], dsum);
+        }
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    const float Dq = dsum;
+    const int rg = row / Tn;
+    const float L2 = row_ok ? lse[(((int64_t)n * Tn + row % Tn) * H + h) * P + p0 + rg] * l2e : 0.f;
+    if (hi == 0) { Ds[row] = Dq; Ls[row] = L2; }
+    __syncthreads();
+
+    const float sl2e = scale * l2e;
+    float* drow = dqkv + tok * ld + h * D;
+    {   // ---- pass A: lane = query;  S^T = K Q^T, dP^T = V dO^T ----
+        f32x16_t sa, dp, dq[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = -Dq; dq[0][r] = 0.f; dq[1][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sa = mfma_split<NP>(kf[t], qf[t], sa);
+            dp = mfma_split<NP>(vf[t], dof[t], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool ok = row_ok && TMX_ROW_OK(k) && (k / Tn == rg);
+            const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sa[r], sl2e, -L2)) : 0.f;
+            sa[r] = pr * dp[r];                      // dS / scale
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8_t dsf[NP];
+            split_frag<NP>(sa, st, dsf);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                bf16x8_t ktf[NP];
+                tm_frag_tr_planes<NP>(Ks, 16 * st, et * 32, lane, ktf);
+                dq[et] = mfma_split<NP>(ktf, dsf, dq[et]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
+        if (row_ok) store_rowT_f32(drow, dq, hi, accumulate);
+    }
+    {   // ---- pass B: lane = key;  S = Q K^T, dP = dO V^T ----
+        f32x16_t sb, dp, dk[2], dv[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sb[r] = 0.f; dp[r] = -Ds[(r & 3) + 8 * (r >> 2) + 4 * hi]; dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sb = mfma_split<NP>(qf[t], kf[t], sb);
+            dp = mfma_split<NP>(dof[t], vf[t], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool ok = row_ok && TMX_ROW_OK(qq) && (qq / Tn == rg);
+            const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(sb[r], sl2e, -Ls[qq])) : 0.f;
+            dp[r] *= pr;                             // dS / scale
+            sb[r] = pr;                              // P
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8_t pf[NP], dsf[NP];
+            split_frag<NP>(sb, st, pf);
+            split_frag<NP>(dp, st, dsf);
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                bf16x8_t dotf[NP], qtf[NP];
+                tm_frag_tr_planes<NP>(dOs, 16 * st, et * 32, lane, dotf);
+                tm_frag_tr_planes<NP>(Qs, 16 * st, et * 32, lane, qtf);
+                dv[et] = mfma_split<NP>(dotf, pf, dv[et]);       // dV^T += dO^T P
+                dk[et] = mfma_split<NP>(qtf, dsf, dk[et]);       // dK^T += Q^T dS
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[0][r] *= scale; dk[1][r] *= scale; }
+        if (row_ok) {
+            store_rowT_f32(drow + C, dk, hi, accumulate);
+            store_rowT_f32(drow + 2 * C, dv, hi, accumulate);
+        }
+    }
+}
+#undef TMX_ROW_OK
+#undef TMX_TOK
+
 }  // namespace
 
 int maed_attn_x3_fwd_launch(int np, const void* qkv, void* o, float* lse, int F, int L, int H, float scale, hipStream_t s) {
@@ -432,4 +660,25 @@ int maed_attn_x3_bwd_launch(int np, const void* qkv, const void* o, const void* 
 #undef X3_BWD
     MAED_CHECK_LAUNCH("attn_x3_bwd");
     return MAED_OK;
+}
+
+// temporal attention, one-tile virtual sequences (32 % T == 0: T = 16 packs two tokens per tile), bf16x3 only (two planes): false = not this shape / engine,
+// the caller keeps its exact kernels (never less accurate than asked for)
+bool maed_attn_tm_x3_fwd_launch(int np, const void* qkv, void* o, float* lse, int F, int P, int H, int T, float scale, hipStream_t s) {
+    if (np != 2 || T > 32 || 32 % T != 0) return false;
+    const int G = 32 / T, ngroups = (P + G - 1) / G;
+    if ((int64_t)(F / T) * H * ngroups >= (1ll << 31)) return false;
+    hipLaunchKernelGGL(attn_tm_x3_fwd<2>, dim3((unsigned)((F / T) * H * ngroups)), dim3(64), 0, s, (const float*)qkv, (float*)o, lse, P, H, T, G, ngroups,
+                       scale * 1.44269504088896340736f);
+    return true;
+}
+
+bool maed_attn_tm_x3_bwd_launch(int np, const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int P, int H, int T,
+                                float scale, hipStream_t s) {
+    if (np != 2 || T > 32 || 32 % T != 0) return false;
+    const int G = 32 / T, ngroups = (P + G - 1) / G;
+    if ((int64_t)(F / T) * H * ngroups >= (1ll << 31)) return false;
+    hipLaunchKernelGGL(attn_tm_x3_bwd<2>, dim3((unsigned)((F / T) * H * ngroups)), dim3(64), 0, s, (const float*)qkv, (const float*)o, (const float*)d_o, lse,
+                       (float*)dqkv, accumulate, P, H, T, G, ngroups, scale);
+    return true;
 }

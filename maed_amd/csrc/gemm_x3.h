@@ -67,5 +67,9 @@ int maed_conv3x3_x3_launch(int np, const void* x, const void* w, const X3ConvDim
 int maed_attn_x3_fwd_launch(int np, const void* qkv, void* o, float* lse, int F, int L, int H, float scale, hipStream_t s);
 int maed_attn_x3_bwd_launch(int np, const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int L, int H, float scale,
                             hipStream_t s);
+// temporal attention on one-tile virtual sequences (32 % T == 0), two planes only: false = shape / engine not covered (the caller runs its exact kernels)
+bool maed_attn_tm_x3_fwd_launch(int np, const void* qkv, void* o, float* lse, int F, int P, int H, int T, float scale, hipStream_t s);
+bool maed_attn_tm_x3_bwd_launch(int np, const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate, int F, int P, int H, int T,
+                                float scale, hipStream_t s);
 int maed_gemm_tn_x3_launch(int np, const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw, float* dbias,
                            const X3TnConv* conv, int target_wgs, hipStream_t s);

@@ -268,22 +268,23 @@ def attn_spatial_bwd(qkv, o, d_o, lse, H, dqkv=None, accumulate=False, impl=L.IM
     return dqkv
 
 
-def attn_temporal_fwd(qkv, H, T):
+def attn_temporal_fwd(qkv, H, T, prec=None):
+    """prec (fp32 only): "bf16x3" = split-bf16 contractions on the matrix cores for this call (one-tile sequences: 32 % T == 0), None = the process-wide mode"""
     F_, P, C3 = qkv.shape
     C_ = C3 // 3
     qkv = _c(qkv)
     o = torch.empty(F_, P, C_, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(F_, H, P, dtype=torch.float32, device=qkv.device)
-    check(L.lib().maed_attn_temporal_fwd(_p(qkv), _p(o), _p(lse), F_, P, H, T, 1.0 / math.sqrt(C_ // H), dt_code(qkv.dtype), _stream()),
+    check(L.lib().maed_attn_temporal_fwd(_p(qkv), _p(o), _p(lse), F_, P, H, T, 1.0 / math.sqrt(C_ // H), mm_code(qkv.dtype, prec), _stream()),
           "attn_temporal_fwd")
     return o, lse
 
 
-def attn_temporal_bwd(qkv, o, d_o, lse, H, T, dqkv=None, accumulate=False):
+def attn_temporal_bwd(qkv, o, d_o, lse, H, T, dqkv=None, accumulate=False, prec=None):
     F_, P, C3 = qkv.shape
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
     check(L.lib().maed_attn_temporal_bwd(_p(_c(qkv)), _p(_c(o)), _p(_c(d_o)), _p(lse), _p(dqkv), int(accumulate), F_, P, H, T,
-                                         1.0 / math.sqrt(C3 // 3 // H), dt_code(qkv.dtype), _stream()), "attn_temporal_bwd")
+                                         1.0 / math.sqrt(C3 // 3 // H), mm_code(qkv.dtype, prec), _stream()), "attn_temporal_bwd")
     return dqkv
 
 

@@ -116,3 +116,17 @@ if "attn" in groups:
             line += f"  {mode} fwd {uf:7.1f} us ({fl / uf / 1e6:5.0f} TF) bwd {ub:7.1f} us"
             del qkv, do, o, dq
         print(line, flush=True)
+    for P, H, N, T in ((197, 8, 8, 16),):
+        line = f"attn temporal P={P} H={H} N={N} T={T}:"
+        for mode, dt in modes():
+            qkv = torch.randn(N * T, P, 3 * 64 * H, device=dev).to(dt)
+            do = torch.randn(N * T, P, 64 * H, device=dev).to(dt)
+            o, lse = ops.attn_temporal_fwd(qkv, H, T)
+            dq = torch.empty_like(qkv)
+            uf = timeit(lambda: ops.attn_temporal_fwd(qkv, H, T))
+            ub = timeit(lambda: ops.attn_temporal_bwd(qkv, o, do, lse, H, T, dqkv=dq))
+            gb = (4 + 8) * qkv.numel() / 3 * qkv.element_size() / 1e3          # fwd: q,k,v + o; bwd: q,k,v,o,dO + dq,dk,dv
+            line += f"  {mode} fwd {uf:7.1f} us bwd {ub:7.1f} us ({gb / (uf + ub):5.0f} GB/s algorithmic)"
+            del qkv, do, o, dq
+        print(line, flush=True)
+

@@ -158,3 +158,29 @@ def test_attn_spatial_x3_fwd_bwd_vs_fp64(mode, Fr, P, H):
     report(f"attn_spatial {name} fwd [F{Fr} P{P} H{H}]", o, oref.detach(), rtol=0, atol=2 * tol * oref.abs().max().item())
     report(f"attn_spatial {name} lse", lse, lse_ref.detach(), rtol=0, atol=20 * tol)
     report(f"attn_spatial {name} bwd", dqkv, x.grad, rtol=0, atol=4 * tol * x.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("N,T,P,H", [(8, 16, 197, 8), (2, 16, 9, 2), (3, 8, 5, 1), (1, 32, 33, 2)])
+def test_attn_temporal_x3_fwd_bwd_vs_fp64(N, T, P, H):
+    """temporal attention (vision_transformer.py:216-228) on fp32 operands with split-bf16 contractions (attn_tm_x3_fwd / _bwd: one-tile virtual sequences,
+    bf16x3 only) at the cfg3 shape and at ragged token counts, against fp64 autograd through the oracle; the split kernel must really be the one that ran"""
+    from maed_amd import ops
+    from oracle import maed_ref as R
+    tol = 1e-4
+    Fr = N * T
+    qkv = rnd(Fr, P, 3 * 64 * H, seed=P)
+    do = rnd(Fr, P, 64 * H, seed=4)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_temporal(qq, kk, vv, T, 64 ** -0.5)
+    oref.backward(do.double())
+    o, lse = ops.attn_temporal_fwd(qkv.to(DEV), H, T, prec="bf16x3")
+    dqkv = ops.attn_temporal_bwd(qkv.to(DEV), o, do.to(DEV), lse, H, T, prec="bf16x3")
+    acc = ops.attn_temporal_bwd(qkv.to(DEV), o, do.to(DEV), lse, H, T, dqkv=dqkv.clone(), accumulate=True, prec="bf16x3")
+    o_exact, lse_exact = ops.attn_temporal_fwd(qkv.to(DEV), H, T)
+    assert not torch.equal(o, o_exact), "the split kernel did not run"
+    report(f"attn_temporal bf16x3 fwd [N{N} T{T} P{P} H{H}]", o, oref.detach(), rtol=0, atol=2 * tol * oref.abs().max().item())
+    report("attn_temporal bf16x3 lse vs exact kernel", lse, lse_exact, rtol=0, atol=20 * tol)
+    report("attn_temporal bf16x3 bwd", dqkv, x.grad, rtol=0, atol=4 * tol * x.grad.abs().max().item())
+    report("attn_temporal bf16x3 bwd accumulate", acc, 2 * x.grad, rtol=0, atol=8 * tol * x.grad.abs().max().item())
+

@@ -212,3 +212,49 @@ def test_attn_x3_fwd_bwd_vs_fp64_oracle(impl, tol, Fr, L_, H):
     assert (lse.double() - lse_ref.detach()).abs().max() <= 10 * tol
     assert rel(dqkv, x.grad) <= 2 * tol, rel(dqkv, x.grad)
     assert rel(acc, 2 * x.grad) <= 2 * tol
+
+
+@pytest.mark.parametrize("N,T,P,H", [(1, 16, 9, 1), (2, 8, 5, 2), (1, 32, 3, 1), (2, 16, 2, 2)])
+def test_attn_temporal_x3_fwd_bwd_vs_fp64_oracle(N, T, P, H):
+    """temporal attention on one-tile virtual sequences with split-bf16 contractions (attn_tm_x3_fwd / _bwd): two tokens x 16 frames per tile with an odd
+    token count (the last tile holds one token: absent rows are masked), four tokens x 8 frames, one token x 32 frames; forward, log-sum-exp, dq / dk / dv
+    and the accumulate flag against fp64 autograd through the oracle -- per call ("bf16x3" dtype code) and through the process-wide mode"""
+    from oracle import maed_ref as R
+    Fr = N * T
+    qkv = rnd(Fr, P, 3 * 64 * H, seed=T + P)
+    do = rnd(Fr, P, 64 * H, seed=4)
+    x = qkv.double().requires_grad_(True)
+    qq, kk, vv = R.split_qkv(x, H)
+    oref = R.attention_temporal(qq, kk, vv, T, 64 ** -0.5)
+    oref.backward(do.double())
+    with patched():
+        o, lse = ops.attn_temporal_fwd(qkv, H, T, prec="bf16x3")
+        dqkv = ops.attn_temporal_bwd(qkv, o, do, lse, H, T, prec="bf16x3")
+        acc = ops.attn_temporal_bwd(qkv, o, do, lse, H, T, dqkv=dqkv.clone(), accumulate=True, prec="bf16x3")
+        o_exact, lse_exact = ops.attn_temporal_fwd(qkv, H, T)                  # process-wide mode = exact: the VALU kernels
+        old = ops.get_float32_matmul_precision()
+        try:
+            ops.set_float32_matmul_precision("bf16x3")
+            o_mode, _ = ops.attn_temporal_fwd(qkv, H, T)
+        finally:
+            ops.set_float32_matmul_precision(old)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    tol = 2e-4
+    assert rel(o, oref.detach()) <= tol, rel(o, oref.detach())
+    assert 1e-7 < rel(o, o_exact), "the split kernel did not run (bit-identical to the exact kernel)"
+    assert torch.equal(o_mode, o)
+    assert (lse - lse_exact).abs().max() <= 10 * tol
+    assert rel(dqkv, x.grad) <= 2 * tol, rel(dqkv, x.grad)
+    assert rel(acc, 2 * x.grad) <= 2 * tol
+
+
+def test_attn_temporal_x3_other_frame_counts_and_bf16x6_keep_the_exact_kernels():
+    """T = 3 does not tile into 32 rows and bf16x6 has no temporal split kernel: both run the exact fp32 kernels (never less accurate than asked for)"""
+    qkv = rnd(6, 5, 3 * 64, seed=1)
+    with patched():
+        ref, _ = ops.attn_temporal_fwd(qkv, 1, 3)
+        a, _ = ops.attn_temporal_fwd(qkv, 1, 3, prec="bf16x3")
+        b, _ = ops.attn_temporal_fwd(qkv[:4].contiguous(), 1, 2, prec="bf16x6")
+        bref, _ = ops.attn_temporal_fwd(qkv[:4].contiguous(), 1, 2)
+    assert torch.equal(a, ref) and torch.equal(b, bref)
+
