@@ -538,7 +538,9 @@ def main():
                        + ("train step fwd+bwd+allreduce+Adam" if not args.forward_only else "inference forward"),
                        "global_batch_clips": clips, "frames_per_clip": CFG["T"], "parallelism": f"dp{world}",
                        "loss": "lib/core/loss.py LossVideo (config_stage2 weights) on synthetic labels, fused fwd+bwd kernel",
-                       "smpl": "synthetic SMPL-shaped parameters (licensed model file unavailable)"},
+                       "smpl": "synthetic SMPL-shaped parameters (licensed model file unavailable)",
+                       "input": "one synthetic clip batch resident in HBM, reused by every step: no host-to-device copy in the timed region (DESIGN.md section 5: a 77 MB fp32 "
+                                "batch is ~1.4 ms over PCIe Gen5 when not overlapped)"},
             "step_time": step_stats, "host_enqueue_ms": host_enqueue_ms,
             # data-parallel diagnostics (N > 1 or forced collectives): transport, ranks, gradient buckets and when each was launched in the last backward
             "ddp": (None if args.forward_only else dict(transport="maed_comm (own RCCL communicator)" if comm is not None else ("torch.distributed/" + (dist.get_backend() if dist.is_initialized() else "none")),
