@@ -472,7 +472,7 @@ class EmbedAddFn(torch.autograd.Function):
 
 # (weakref to the residual-gradient tensor a Block backward returned, its compute-dtype copy).  The next Block backward
 # uses the copy only if it receives THAT VERY tensor object as grad_output (identity, not data_ptr: allocator reuse).
-_TWIN = [None, None]
+_TWIN = [None, None, None]      # [weakref to dx, its compute-dtype copy, chain index of the block that left it (Block._chain_index, None if unknown)]
 TWIN_HITS = [0, 0]   # [hits, misses] -- diagnostics
 _TWIN_WARNED = [False]
 
@@ -509,6 +509,8 @@ class STEBlockFn(ReportingFn):
         check(lib.maed_ste_block_fwd(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _stream()), "ste_block_fwd")
         ctx.block, ctx.dims = block, dims
         ctx.save_for_backward(x, saved)
+        # a hand-off left by the LAST block of an earlier backward pass (nobody consumes block 0's) is stale once a new forward runs: dropping it here frees its tensor
+        _TWIN[0], _TWIN[1], _TWIN[2] = None, None, None
         if ReportingFn.will_run_backward(ctx):        # a forward under no_grad has no backward to pair with
             block._pending_backwards += 1
         return y
@@ -528,10 +530,12 @@ class STEBlockFn(ReportingFn):
         cdt = block.compute_dtype
         tw_in = None
         if cdt != torch.float32:
-            ref, cand = _TWIN
+            ref, cand, producer = _TWIN
+            mine = getattr(block, "_chain_index", None)
             if ref is not None and ref() is dy and cand.shape == dy.shape and cand.dtype == cdt:
                 tw_in = cand
-            elif ref is not None and not _TWIN_WARNED[0]:
+            elif ref is not None and producer is not None and mine is not None and producer == mine + 1 and not _TWIN_WARNED[0]:
+                # (only when the hand-off was meant for THIS block: the first block of a backward chain legitimately finds the previous chain's last one)
                 # a block handed its compute-dtype gradient copy on, but the tensor that arrives is not the one it returned (a hook that clones or rescales
                 # gradients, retain_graph replays, activation checkpointing ...): correct -- the copy is re-made from dy -- but a cast pass per block
                 _TWIN_WARNED[0] = True
@@ -539,12 +543,12 @@ class STEBlockFn(ReportingFn):
                 warnings.warn("maed_amd: the residual-gradient hand-off between consecutive STE blocks was bypassed (the gradient tensor arriving at a block is not "
                               "the one the next block returned); falling back to one extra cast pass per block", RuntimeWarning, stacklevel=2)
             TWIN_HITS[0 if tw_in is not None else 1] += 1
-        _TWIN[0], _TWIN[1] = None, None
+        _TWIN[0], _TWIN[1], _TWIN[2] = None, None, None
         tw_out = torch.empty(dy.shape, dtype=cdt, device=dy.device) if cdt != torch.float32 else None
         check(lib.maed_ste_block_bwd(C.byref(d), C.byref(pr), C.byref(gr), _p(x), _p(dy), _p(dx), _p(saved), _p(scratch),
                                      _p(tw_in), _p(tw_out), _stream()), "ste_block_bwd")
         if tw_out is not None:
-            _TWIN[0], _TWIN[1] = weakref.ref(dx), tw_out
+            _TWIN[0], _TWIN[1], _TWIN[2] = weakref.ref(dx), tw_out, getattr(block, "_chain_index", None)
         block._pending_backwards -= 1
         if block._pending_backwards == 0 and block.grads_ready is not None:
             block.grads_ready(block)

@@ -229,6 +229,8 @@ class VisionTransformer(nn.Module):
             Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
                   norm_layer=norm_layer, st_mode=st_mode, compute_dtype=compute_dtype, impl=impl)
             for _ in range(depth)])
+        for i, blk in enumerate(self.blocks):
+            blk._chain_index = i        # position in the chain: ops.STEBlockFn's residual-gradient hand-off knows which block a copy was left for
         self.norm = norm_layer(embed_dim)
         self.st_mode = st_mode
         if representation_size:

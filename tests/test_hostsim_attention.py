@@ -100,6 +100,51 @@ def test_ste_block_forward_backward_vs_oracle(dtype, f32_mode, rows):
         close(prm.grad, ref, rtol=1e-3 if f32 else 5e-2, atol=(1e-4 if f32 else 3e-2) * scale)
 
 
+def test_residual_gradient_hand_off_between_blocks_is_used_and_a_bypass_is_loud():
+    """bf16 blocks hand the compute-dtype copy of their residual gradient to the previous block (ops._TWIN, keyed on tensor identity).  Two training steps of a
+    two-block chain: the hand-off is used on every second block backward and nothing warns (the copy the LAST block leaves is stale, not a bypass); a hook
+    that replaces the gradient between the blocks is a real bypass: same result through the extra cast pass, one RuntimeWarning."""
+    import warnings
+    from functools import partial
+    import torch.nn as nn
+    from maed_amd.vision_transformer import Block
+    torch.manual_seed(0)
+    C, H, T, P = 128, 2, 2, 5
+    blocks = [Block(C, H, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", compute_dtype=torch.bfloat16, impl=0) for _ in range(2)]
+    for i, b in enumerate(blocks):
+        b._chain_index = i
+    x = rnd(T, P, C, seed=1)
+    dy = rnd(T, P, C, seed=2)
+
+    def run(hook):
+        for b in blocks:
+            for prm in b.parameters():
+                prm.grad = None
+        xg = x.clone().requires_grad_(True)
+        h = blocks[0](xg, T)
+        if hook:
+            h.register_hook(lambda g: g.clone())
+        blocks[1](h, T).backward(dy)
+        return xg.grad.clone()
+
+    ops._TWIN_WARNED[0] = False
+    with patched():
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            h0 = list(ops.TWIN_HITS)
+            g1 = run(False)
+            g2 = run(False)
+            assert not [m for m in w if "hand-off" in str(m.message)], [str(m.message) for m in w]
+            assert ops.TWIN_HITS[0] - h0[0] == 2 and ops.TWIN_HITS[1] - h0[1] == 2, (h0, ops.TWIN_HITS)
+            assert torch.equal(g1, g2)
+            g3 = run(True)
+            assert len([m for m in w if "hand-off" in str(m.message) and issubclass(m.category, RuntimeWarning)]) == 1
+            run(True)
+            assert len([m for m in w if "hand-off" in str(m.message)]) == 1        # once per process
+    assert torch.allclose(g3, g1, rtol=2e-2, atol=2e-2 * float(g1.abs().max()))
+    ops._TWIN_WARNED[0] = False
+
+
 # ---- long-sequence (K/V-tiled) kernels: attn_long.hip ------------------------------------------------------------------
 @pytest.mark.parametrize("Fr,L_,H,impl", [
     (2, 5, 2, L.IMPL_MFMA_LONG),          # one partial tile, one partially filled wave
