@@ -592,7 +592,7 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         MAED_CHECK_ARG(impl == MAED_IMPL_AUTO || impl == MAED_IMPL_VALU || impl == MAED_IMPL_X3 || impl == MAED_IMPL_X6, MAED_ERR_UNSUPPORTED,
                        "gemm_nt: f32 runs on the exact-f32 VALU kernel (MAED_IMPL_VALU) or the split-bf16 MFMA kernel (MAED_IMPL_X3 / _X6); impl=%d", impl);
         // split-bf16 MFMA kernel (gemm_x3.hip): explicitly, or when the process-wide fp32 matmul mode asks for it.  GEMMs with few output tiles
-        // (ts_attn, the decoder head: M = frames) keep the exact split-K VALU route below -- a 128-row tile would leave most of the chip idle.
+        // (ts_attn, the decoder head: M = frames) take the split-K route below -- a 128-row tile per workgroup would leave most of the chip idle.
         const int np = impl == MAED_IMPL_X3 ? 2 : impl == MAED_IMPL_X6 ? 3 : impl == MAED_IMPL_AUTO ? maed_x3_planes() : 0;
         if (np) {
             const bool ok = maed_x3_nt_shape_ok(A, lda, B, ldb, K);       // (otherwise: the exact kernel below -- never less accurate than asked for)
@@ -613,6 +613,13 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
                 if (sk > 1) {
                     hipLaunchKernelGGL(bias_fill_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, (float*)e.out, e.ldo, e.bias, M, N);
                     EpiArgs ea{nullptr, e.out, e.ldo, nullptr, nullptr, 0};
+                    // split modes: the K slices on the split-bf16 MFMA kernel (128 x 128 tiles, atomic epilogue) -- 128 x 1024 x 1024: 32 -> 12 us
+                    if (np && maed_x3_nt_shape_ok(A, lda, B, ldb, K)) {
+                        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
+                        int sk3 = (int)(256 / t128);
+                        if (sk3 > K / 64) sk3 = (int)(K / 64);
+                        if (sk3 >= 1) return maed_gemm_nt_x3_launch(MAED_EPI_ATOMIC_F32, np, A, lda, B, ldb, M, N, K, ea, sk3, s);
+                    }
                     return launch_valu<MAED_EPI_ATOMIC_F32, float>(A, lda, B, ldb, M, N, K, ea, sk, s);
                 }
             }

@@ -89,11 +89,15 @@ def test_gemm_nt_x3_splitk_atomic_and_auto_dispatch(x3_mode):
     with patched():
         out = ops.gemm_nt(A, B, L.EPI_ATOMIC_F32, splitk=2)                  # AUTO + mode bf16x3 -> the split kernel, K range per z
         exact = ops.gemm_nt(A, B, L.EPI_STORE, impl=L.IMPL_VALU)            # the exact kernel stays selectable
-        few = ops.gemm_nt(A, B, L.EPI_STORE)                                # few tiles: AUTO keeps the exact split-K route
+        few = ops.gemm_nt(A, B, L.EPI_STORE)                                # few tiles, K >= 256: bias fill + K slices on the split kernel (atomic epilogue)
+        fewb = ops.gemm_nt(A, B, L.EPI_STORE, bias=rnd(N, seed=14))
         Ab, Bb = rnd(1024, 64, seed=12), rnd(768, 64, seed=13)
         many = ops.gemm_nt(Ab, Bb, L.EPI_STORE)                             # 48 tiles: AUTO takes the split kernel
     assert (out.double() - ref).abs().max() <= 1e-4 * ref.abs().max()
-    assert torch.allclose(exact.double(), ref, rtol=1e-5, atol=1e-5) and torch.allclose(few.double(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(exact.double(), ref, rtol=1e-5, atol=1e-5)
+    errf = (few.double() - ref).abs().max()
+    assert 1e-8 * ref.abs().max() < errf <= 1e-4 * ref.abs().max(), errf      # split arithmetic
+    assert (fewb.double() - ref - rnd(N, seed=14).double()).abs().max() <= 1e-4 * ref.abs().max()
     refm = Ab.double() @ Bb.double().t()
     errm = (many.double() - refm).abs().max()
     assert 1e-7 * refm.abs().max() < errm <= 1e-4 * refm.abs().max()          # split arithmetic, not the exact kernel and not bf16
