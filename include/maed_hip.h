@@ -140,7 +140,9 @@ int maed_attn_spatial_bwd(const void* qkv, const void* o, const void* d_o, const
                           int dtype, int impl, void* stream);
 
 /* ---- K4: Attention.forward_temporal (vision_transformer.py:216-228) -------------------------- */
-/* per (clip, head, token): attention across the T frames of the clip; no transposed copies. */
+/* per (clip, head, token): attention across the T frames of the clip; no transposed copies.
+ * dtype MAED_F32 in the bf16x3 mode (MAED_OPT_F32_MATMUL = 1, or dtype = MAED_F32X3 for this call) with 32 % T == 0: split-bf16 contractions on the
+ * matrix cores (csrc/attn_x3.hip); every other fp32 case (other T, bf16x6) runs the exact fp32 kernels. */
 int maed_attn_temporal_fwd(const void* qkv, void* o, float* lse, int F, int P, int H, int T,
                            float scale, int dtype, void* stream);
 int maed_attn_temporal_bwd(const void* qkv, const void* o, const void* d_o, const float* lse,

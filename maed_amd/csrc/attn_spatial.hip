@@ -584,17 +584,17 @@ extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F
         const size_t lds = ((size_t)P * 64 + (size_t)D * (Pk + 4)) * 2;
         MAED_CHECK_ARG(lds <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_fwd(mfma): LDS %zu B", lds);
         static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void*)attn_sp_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_sp_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         hipLaunchKernelGGL(attn_sp_fwd_mfma, dim3(F * H), dim3(64 * (Pk / 32)), lds, s, (const bf16*)qkv, (bf16*)o, lse, P, H,
                            scale * 1.44269504088896340736f);
     } else {
         const size_t lds = valu_lds_bytes(P, false);
         if (lds > 160 * 1024) return maed_attn_long_fwd_valu_launch(qkv, o, lse, F, P, H, scale, dtype, s);   // K/V do not fit: tiled
         if (dtype == MAED_F32) {
-            hipFuncSetAttribute((const void*)attn_sp_fwd_valu<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_sp_fwd_valu<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((attn_sp_fwd_valu<float>), dim3(F * H), dim3(256), lds, s, (const float*)qkv, (float*)o, lse, P, H, scale);
         } else if (dtype == MAED_BF16) {
-            hipFuncSetAttribute((const void*)attn_sp_fwd_valu<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_sp_fwd_valu<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((attn_sp_fwd_valu<bf16>), dim3(F * H), dim3(256), lds, s, (const bf16*)qkv, (bf16*)o, lse, P, H, scale);
         } else { maed_set_error("attn_spatial_fwd: bad dtype"); return MAED_ERR_ARG; }
     }
@@ -605,8 +605,8 @@ extern "C" int maed_attn_spatial_fwd(const void* qkv, void* o, float* lse, int F
 template <typename T>
 static void launch_bwd_valu(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, int accumulate,
                             int F, int P, int H, float scale, hipStream_t s) {
-    hipFuncSetAttribute((const void*)attn_sp_bwd_dq_valu<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)attn_sp_bwd_dkv_valu<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_sp_bwd_dq_valu<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_sp_bwd_dkv_valu<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((attn_sp_bwd_dq_valu<T>), dim3(F * H), dim3(256), valu_lds_bytes(P, false), s, (const T*)qkv, (const T*)o,
                        (const T*)d_o, lse, (T*)dqkv, accumulate, P, H, scale);
     hipLaunchKernelGGL((attn_sp_bwd_dkv_valu<T>), dim3(F * H), dim3(256), valu_lds_bytes(P, true), s, (const T*)qkv, (const T*)o,
@@ -639,8 +639,8 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
         MAED_CHECK_ARG(lds_dkv <= 160 * 1024, MAED_ERR_SHAPE, "attn_spatial_bwd(mfma): P=%d needs %zu B LDS", P, lds_dkv);
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)attn_sp_bwd_dq_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)attn_sp_bwd_dkv_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_sp_bwd_dq_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_sp_bwd_dkv_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
         hipStream_t s = (hipStream_t)stream;

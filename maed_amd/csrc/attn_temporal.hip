@@ -326,7 +326,7 @@ static bool launch_tm_fwd_lds(const void* qkv, void* o, float* lse, int F, int P
     const size_t lds = 2 * ((size_t)256 * RowGeom<T>::RS + GP * 16);
     if (lds > 160 * 1024) return false;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)attn_tm_fwd_lds<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_tm_fwd_lds<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const int chunks = (P + GP - 1) / GP;
     hipLaunchKernelGGL((attn_tm_fwd_lds<T>), dim3((unsigned)((F / Tn) * H * chunks)), dim3(256), lds, s, (const T*)qkv, (T*)o, lse, P, H, Tn, GP, scale);
     return true;
@@ -339,7 +339,7 @@ static bool launch_tm_bwd_lds(const void* qkv, const void* o, const void* d_o, c
     const size_t lds = 4 * ((size_t)128 * RowGeom<T>::RS + GP * 16) + 2 * 128 * sizeof(float);
     if (lds > 160 * 1024) return false;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)attn_tm_bwd_lds<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_tm_bwd_lds<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const int chunks = (P + GP - 1) / GP;
     hipLaunchKernelGGL((attn_tm_bwd_lds<T>), dim3((unsigned)((F / Tn) * H * chunks)), dim3(256), lds, s, (const T*)qkv, (const T*)o, (const T*)d_o,
                        lse, (T*)dqkv, accumulate, P, H, Tn, GP, scale);
@@ -801,8 +801,8 @@ static bool launch_tm_bwd_mfma(const void* qkv, const void* o, const void* d_o, 
     if (lds > 160 * 1024) return false;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)attn_tm_bwd_mfma<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)attn_tm_bwd_mfma<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_tm_bwd_mfma<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_tm_bwd_mfma<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     const int ngroups = (P + G - 1) / G;
@@ -830,7 +830,7 @@ static bool launch_tm_fwd_mfma(const void* qkv, void* o, float* lse, int F, int 
     const size_t lds = ((size_t)Lk * 64 + (size_t)D * (Lk + 4)) * 2;
     if (lds > 160 * 1024) return false;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)attn_tm_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_tm_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const int ngroups = (P + G - 1) / G;
     hipLaunchKernelGGL(attn_tm_fwd_mfma, dim3((unsigned)((F / Tn) * H * ngroups)), dim3(64 * (Lk / 32)), lds, s, (const bf16*)qkv, (bf16*)o, lse, P, H,
                        Tn, G, ngroups, scale * 1.44269504088896340736f);

@@ -356,7 +356,7 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
     hipStream_t s = (hipStream_t)stream;
     const int rows = gn_rows_per_wg(N, HW, C);
     dim3 grid((HW + rows - 1) / rows, N);
-    if (!sums_zeroed) hipMemsetAsync(sums, 0, (size_t)N * GN_G * 2 * sizeof(double), s);
+    if (!sums_zeroed) MAED_HIP(hipMemsetAsync(sums, 0, (size_t)N * GN_G * 2 * sizeof(double), s), "groupnorm_fwd: memset");
     MAED_DISPATCH_DTYPE(dtype, T, {
         if (sums_zeroed != 2)       // 2: the producing convolution's epilogue accumulated the statistics already (maed_conv1x1_fwd / maed_conv3x3_fwd)
             hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)x, sums, HW, C, rows);
@@ -382,7 +382,7 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
     // the reduction pass ends with 4C atomics per workgroup: fewer, fatter workgroups (~768: 3 per CU) keep it HBM-bound
     const int rrows = gn_rows_per_wg(N, HW, C, 768);
     dim3 rgrid((HW + rrows - 1) / rrows, N);
-    if (!ab_zeroed) hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s);
+    if (!ab_zeroed) MAED_HIP(hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s), "groupnorm_bwd: memset");
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
     const bool ymask = relu && relu_mask;      // residual added before the ReLU: the forward's bit mask (dres may be NULL: not materialised)
     // dgamma / dbeta from per-workgroup partials + a closing column sum instead of contended atomics in the reduction pass
@@ -400,11 +400,11 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
             hipStream_t sa = s;
             if (aux_stream) {
                 static hipEvent_t ring[32]; static int next = -1;
-                if (next < 0) { for (int i = 0; i < 32; ++i) hipEventCreateWithFlags(&ring[i], hipEventDisableTiming); next = 0; }
+                if (next < 0) { for (int i = 0; i < 32; ++i) MAED_HIP(hipEventCreateWithFlags(&ring[i], hipEventDisableTiming), "groupnorm_bwd: event ring"); next = 0; }
                 hipEvent_t e = ring[next]; next = (next + 1) & 31;
-                hipEventRecord(e, s);
+                MAED_HIP(hipEventRecord(e, s), "groupnorm_bwd: event");
                 sa = (hipStream_t)aux_stream;
-                hipStreamWaitEvent(sa, e, 0);
+                MAED_HIP(hipStreamWaitEvent(sa, e, 0), "groupnorm_bwd: stream wait");
             }
             hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 63) / 64, (N + 63) / 64), dim3(256), 0, sa, ab_scratch, dgamma, dbeta, N, C);
         }

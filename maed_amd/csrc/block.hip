@@ -20,10 +20,10 @@ static bool g_prof = false;
 struct ProfRec { hipEvent_t a, b; double flops, bytes; };
 static std::vector<ProfRec> g_prof_ev[PROF_NTAGS];
 bool maed_prof_on() { return g_prof; }
-void maed_prof_open(int tag, hipStream_t s, hipEvent_t* a) { (void)tag; hipEventCreate(a); hipEventRecord(*a, s); }
+void maed_prof_open(int tag, hipStream_t s, hipEvent_t* a) { (void)tag; (void)hipEventCreate(a); (void)hipEventRecord(*a, s); }
 void maed_prof_close(int tag, hipStream_t s, hipEvent_t a, double flops, double bytes) {
     hipEvent_t b;
-    hipEventCreate(&b); hipEventRecord(b, s);
+    (void)hipEventCreate(&b); (void)hipEventRecord(b, s);
     g_prof_ev[tag].push_back(ProfRec{a, b, flops, bytes});
 }
 extern "C" int maed_prof_enable(int on) { g_prof = on != 0; return MAED_OK; }
@@ -43,9 +43,9 @@ extern "C" int maed_prof_records(int tag, double* us, double* flops, double* byt
     int i = 0;
     for (auto& r : g_prof_ev[tag]) {
         if (i < cap) {
-            hipEventSynchronize(r.b);
+            (void)hipEventSynchronize(r.b);
             float ms = 0.f;
-            hipEventElapsedTime(&ms, r.a, r.b);
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
             if (us) us[i] = 1e3 * (double)ms;
             if (flops) flops[i] = r.flops;
             if (bytes) bytes[i] = r.bytes;
@@ -58,11 +58,11 @@ extern "C" int maed_prof_collect(double* ms_total, int* count) {
     for (int t = 0; t < PROF_NTAGS; ++t) {
         double tot = 0.0;
         for (auto& r : g_prof_ev[t]) {
-            hipEventSynchronize(r.b);
+            (void)hipEventSynchronize(r.b);
             float ms = 0.f;
-            hipEventElapsedTime(&ms, r.a, r.b);
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
             tot += ms;
-            hipEventDestroy(r.a); hipEventDestroy(r.b);
+            (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
         }
         if (ms_total) ms_total[t] = tot;
         if (count) count[t] = (int)g_prof_ev[t].size();
@@ -94,8 +94,8 @@ struct SideStream {
     // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
     void fence(hipStream_t from, hipStream_t to) {
         hipEvent_t e = ev[next]; next = (next + 1) % 62;               // slots 62 / 63 are named fences, outside the ring
-        hipEventRecord(e, from);
-        hipStreamWaitEvent(to, e, 0);
+        (void)hipEventRecord(e, from);            // (a failure surfaces as the launch error of the kernels that follow)
+        (void)hipStreamWaitEvent(to, e, 0);
     }
 };
 static SideStream* side_stream() {
@@ -264,7 +264,7 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
         TO_SIDE();
         WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, wst));
-        if (ss) hipEventRecord(ss->ev[63], ss->s);                       // "fc1 weight gradient done" (named slot, outside the ring)
+        if (ss) MAED_HIP(hipEventRecord(ss->ev[63], ss->s), "ste_block_bwd: event");                       // "fc1 weight gradient done" (named slot, outside the ring)
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
         // LayerNorm dgamma/dbeta via partials in the (here unused) transpose slot instead of contended atomics (measured on MI355X,
         // profiles/r02_call2_steady_*.csv: 0.629 -> 0.503 + 0.080 ms per step)
@@ -281,7 +281,7 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         WGRAD(maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dt, wst));
         MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
         MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
-        if (ss) hipStreamWaitEvent(main_s, ss->ev[63], 0);               // the attention backward overwrites bigA, which the fc1 weight gradient reads
+        if (ss) MAED_HIP(hipStreamWaitEvent(main_s, ss->ev[63], 0), "ste_block_bwd: stream wait");               // the attention backward overwrites bigA, which the fc1 weight gradient reads
         PROF(PROF_ATTN_TM_BWD, maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
         PROF(PROF_ATTN_SP_BWD, maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
                                                      MAED_IMPL_AUTO, stream));

@@ -82,6 +82,9 @@ void maed_set_error(const char* fmt, ...);
 #define MAED_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
     maed_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return MAED_ERR_LAUNCH; } } while (0)
 #define MAED_PROPAGATE(expr) do { int rc__ = (expr); if (rc__ != MAED_OK) return rc__; } while (0)
+// a HIP runtime call inside an entry point (memset, event, stream wait): its failure is the entry point's failure
+#define MAED_HIP(expr, name) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
+    maed_set_error("%s: %s", name, hipGetErrorString(e__)); return MAED_ERR_LAUNCH; } } while (0)
 
 // process-wide options (csrc/options.hip; maed_set_option in include/maed_hip.h)
 int maed_opt(int key);

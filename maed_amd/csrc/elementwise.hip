@@ -109,7 +109,7 @@ extern "C" int maed_st_colmean(const void* x_s, const void* x_t, void* means, fl
     if (F == 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)F * 2 * C;
-    hipMemsetAsync(ws, 0, n * sizeof(float), s);
+    MAED_HIP(hipMemsetAsync(ws, 0, n * sizeof(float), s), "memset");
     dim3 grid((C / 4 + 63) / 64, F, 2 * CM_SPLIT);
     MAED_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL((st_colmean_kernel<T>), grid, dim3(64), 0, s, (const T*)x_s, (const T*)x_t, ws, P, C);
@@ -138,7 +138,7 @@ extern "C" int maed_st_mix_bwd_reduce(const void* dmix, const void* x_s, const v
     if (F == 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = (int64_t)F * 2 * C;
-    hipMemsetAsync(ws, 0, n * sizeof(float), s);
+    MAED_HIP(hipMemsetAsync(ws, 0, n * sizeof(float), s), "memset");
     dim3 grid((C / 4 + 63) / 64, F, CM_SPLIT);
     MAED_DISPATCH_DTYPE(dtype, T, {
         hipLaunchKernelGGL((st_mix_bwd_reduce_kernel<T>), grid, dim3(64), 0, s, (const T*)dmix, (const T*)x_s, (const T*)x_t, ws, P, C);

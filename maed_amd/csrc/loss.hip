@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void loss_accl_kernel(const float* __restrict_
 extern "C" int maed_loss_accl_fwd_bwd(const float* pred_kp3d, const float* gt_kp3d, int N, int T, float weight, double* loss, float* d_kp3d, void* stream) {
     MAED_CHECK_ARG(pred_kp3d && gt_kp3d && loss && d_kp3d, MAED_ERR_ARG, "loss_accl_fwd_bwd: null pointer");
     MAED_CHECK_ARG(N >= 0 && T >= 3, MAED_ERR_SHAPE, "loss_accl_fwd_bwd: needs clips of at least 3 frames (T=%d)", T);
-    hipMemsetAsync(loss, 0, sizeof(double), (hipStream_t)stream);
+    MAED_HIP(hipMemsetAsync(loss, 0, sizeof(double), (hipStream_t)stream), "loss: memset");
     if (N == 0) return MAED_OK;
     const int64_t total = (int64_t)N * T * 49;
     hipLaunchKernelGGL(loss_accl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred_kp3d, gt_kp3d, N, T, weight, d_kp3d, loss);

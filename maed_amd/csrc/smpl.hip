@@ -279,7 +279,7 @@ extern "C" int maed_joint_regress_fwd(const float* Jreg, int J, const float* ver
     MAED_CHECK_ARG(J > 0 && J <= 32, MAED_ERR_SHAPE, "joint_regress_fwd: J=%d must be in 1..32", J);
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
-    hipMemsetAsync(out, 0, (size_t)F * J * 3 * sizeof(float), s);
+    MAED_HIP(hipMemsetAsync(out, 0, (size_t)F * J * 3 * sizeof(float), s), "memset");
     hipLaunchKernelGGL(joint_regress_kernel, dim3((NV + JR_KC - 1) / JR_KC, (F + JR_FG - 1) / JR_FG), dim3(64), 0, s, Jreg, J, verts, out, F);
     MAED_CHECK_LAUNCH("joint_regress_fwd");
     return MAED_OK;
