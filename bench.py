@@ -162,9 +162,9 @@ class _SimModel(torch.nn.Module):
         return dict(kp_2d=o[..., :98].reshape(N, T, 49, 2), kp_3d=o[..., 98:245].reshape(N, T, 49, 3), theta=o[..., 245:])
 
 
-def parity_mode_line(dev, steps=4):
+def parity_mode_line(dev, steps=5):
     """the fp32-accurate mode beside the headline bf16 line: compute_dtype = float32 with the fp32 matrix products on the split-bf16 MFMA kernels, the SAME cfg3
-    train step (8 clips x 16 frames, fwd + bwd + Adam) timed over a few steps, and the error of that mode's forward at full module size (one clip) against the
+    train step (8 clips x 16 frames, fwd + bwd + Adam), median of a few steps, and the error of that mode's forward at full module size (one clip) against the
     fp32 CPU oracle (north_star: 1e-3 relative on SMPL parameters).  Two variants: "bf16x3" everywhere, and the backbone on "bf16x6" (its forward / input-gradient
     products; gradient parity at the fp32 reference's own level, DESIGN.md section 4 -- the mode tests/test_gpu_parity_mode.py checks)."""
     import maed_amd
@@ -194,14 +194,19 @@ def parity_mode_line(dev, steps=4):
                 loss, _ = criterion(model(clip), tgt, None)
                 loss.backward()
                 opt.step()
-            for _ in range(2):
+            for _ in range(3):
                 step()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
+            # one event per step boundary on the launch stream, median step: a one-off stall inside these few steps (a lazily compiled MIOpen solver, an allocator
+            # growth) would otherwise be averaged into the figure (observed once: 370 ms "per step" over 4 steps on a box whose previous run measured 45.2)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            evs[0].record()
+            for i in range(steps):
                 step()
+                evs[i + 1].record()
             torch.cuda.synchronize()
-            ms = 1e3 * (time.perf_counter() - t0) / steps
+            per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+            ms = per[len(per) // 2] if steps % 2 else 0.5 * (per[steps // 2 - 1] + per[steps // 2])
             del model, arena, opt
             with torch.no_grad():       # forward parity at full module size, one clip, against the fp32 oracle
                 m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["heads"], embed_dim=CFG["dim"], hidden_dim=CFG["hidden"], img_size=CFG["img"],
