@@ -49,7 +49,7 @@ typedef enum {
 /* GEMM epilogues (out = epilogue(acc = A * B^T)) */
 typedef enum {
     MAED_EPI_STORE = 0,      /* out[T]   = acc + bias                                              */
-    MAED_EPI_GELU = 1,       /* out2[T]  = acc + bias ; out[T] = gelu_erf(out2)  (nn.GELU)          */
+    MAED_EPI_GELU = 1,       /* out2[T]  = acc + bias ; out[T] = gelu_erf(out2)  (nn.GELU); out2 = NULL: only out is written */
     MAED_EPI_RESID_F32 = 2,  /* out[f32] = aux[f32] + acc + bias   (residual add fused)             */
     MAED_EPI_MUL_DGELU = 3,  /* out[T]   = acc * gelu_erf'(aux[T]) (backward through GELU)          */
     MAED_EPI_ATOMIC_F32 = 4, /* out[f32] += acc  (atomic; weight gradients, split-K allowed)        */
@@ -207,6 +207,10 @@ size_t maed_ste_block_scratch_bytes(const maed_block_dims* d);
  * handed unchanged to maed_ste_block_bwd.  x_out may alias x_in only if no backward is wanted. */
 int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in,
                        float* x_out, void* saved, void* stream);
+/* the same forward when no backward will follow (inference): `work` = maed_ste_block_saved_bytes of scratch; what only the backward would read
+ * (fc1's pre-activation: 103 MB per block at cfg3) is not written.  x_out may alias x_in. */
+int maed_ste_block_infer(const maed_block_dims* d, const maed_block_params* p, const float* x_in,
+                         float* x_out, void* work, void* stream);
 /* dx_in[f32] = dBlock/dx_in(dx_out); parameter gradients are accumulated into g. dx_in may alias dx_out.
  * dx_out_twin (optional, in): dx_out already in the compute dtype; dx_in_twin (optional, out): dx_in in the compute
  * dtype -- consecutive blocks hand the bf16 copy along so no cast pass is needed. */

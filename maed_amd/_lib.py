@@ -80,6 +80,7 @@ SIGNATURES = {
     "maed_ste_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_scratch_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
+    "maed_ste_block_infer": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
     "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp, vp, vp]),
     "maed_loss_accl_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp]),
     "maed_dropout": (i32, [vp, vp, i64, f32, C.c_uint64, vp]),

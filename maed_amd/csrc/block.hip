@@ -194,8 +194,7 @@ int wgrad(const void* Yt, const void* Xt, int64_t No, int64_t Ko, int64_t Mp, fl
 extern "C" size_t maed_ste_block_saved_bytes(const maed_block_dims* d) { return d ? saved_layout(*d).total : 0; }
 extern "C" size_t maed_ste_block_scratch_bytes(const maed_block_dims* d) { return d ? scratch_layout(*d).total : 0; }
 
-extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out,
-                                  void* saved, void* stream) {
+static int block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved, bool for_backward, void* stream) {
     MAED_PROPAGATE(check_dims(d, "ste_block_fwd"));
     MAED_CHECK_ARG(p && x_in && x_out && saved, MAED_ERR_ARG, "ste_block_fwd: null pointer");
     MAED_CHECK_ARG(is_aligned(saved, 256), MAED_ERR_ALIGN, "ste_block_fwd: saved buffer must be 256-B aligned");
@@ -222,9 +221,17 @@ extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_par
     MAED_PROPAGATE(maed_st_mix_fwd(sv + L.xs, sv + L.xt, logits, sv + L.mix, d->F, d->P, C, dt, stream));
     PROF(PROF_GEMM_PROJ, maed_gemm_nt(sv + L.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, sv + L.xmid, C, nullptr, x_in, C, 1, gi, stream));
     MAED_PROPAGATE(maed_layernorm_fwd((const float*)(sv + L.xmid), C, p->ln2_g, p->ln2_b, sv + L.ln2, dt, (float*)(sv + L.mean2), (float*)(sv + L.rstd2), M, C, d->eps, stream));
-    PROF(PROF_GEMM_FC1, maed_gemm_nt(sv + L.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, sv + L.hact, Hd, sv + L.hpre, nullptr, 0, 1, gi, stream));
+    PROF(PROF_GEMM_FC1, maed_gemm_nt(sv + L.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, sv + L.hact, Hd, for_backward ? sv + L.hpre : nullptr /* only GELU' reads it */, nullptr, 0, 1, gi, stream));
     PROF(PROF_GEMM_FC2, maed_gemm_nt(sv + L.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, sv + L.xmid, C, 1, gi, stream));
     return MAED_OK;
+}
+
+extern "C" int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved, void* stream) {
+    return block_fwd(d, p, x_in, x_out, saved, true, stream);
+}
+// the same forward when no backward will follow (inference): what only the backward reads is not written -- fc1's pre-activation, 103 MB per block at cfg3
+extern "C" int maed_ste_block_infer(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* work, void* stream) {
+    return block_fwd(d, p, x_in, x_out, work, false, stream);
 }
 
 extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, const maed_block_grads* g,

@@ -713,8 +713,7 @@ extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
     int rc;
     switch (epilogue) {
         case MAED_EPI_STORE: rc = dispatch<MAED_EPI_STORE>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
-        case MAED_EPI_GELU:
-            MAED_CHECK_ARG(out2, MAED_ERR_ARG, "gemm_nt: GELU epilogue needs out2");
+        case MAED_EPI_GELU:            // (out2 = NULL: the pre-activation is not stored -- inference)
             rc = dispatch<MAED_EPI_GELU>(A, lda, B, ldb, M, N, K, dtype, e, splitk, impl, s); break;
         case MAED_EPI_RESID_F32:
             MAED_CHECK_ARG(aux, MAED_ERR_ARG, "gemm_nt: RESID epilogue needs aux");

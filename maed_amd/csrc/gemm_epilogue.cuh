@@ -20,7 +20,7 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int6
         stf((T*)e.out + r * e.ldo + c, acc + (e.bias ? e.bias[c] : 0.f));
     } else if constexpr (EPI == MAED_EPI_GELU) {
         const float pre = acc + (e.bias ? e.bias[c] : 0.f);
-        stf((T*)e.out2 + r * e.ldo + c, pre);
+        if (e.out2) stf((T*)e.out2 + r * e.ldo + c, pre);          // (out2 = NULL: nobody will ask for GELU', inference)
         stf((T*)e.out + r * e.ldo + c, gelu_fwd<T>(round_to<T>(pre)));  // activation of the STORED (rounded) pre-activation
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         ((float*)e.out)[r * e.ldo + c] = ((const float*)e.aux)[r * e.ldaux + c] + (acc + (e.bias ? e.bias[c] : 0.f));
@@ -59,7 +59,7 @@ __device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int
     if constexpr (EPI == MAED_EPI_STORE) {
         st4((T*)e.out + r * e.ldo + c0, v);
     } else if constexpr (EPI == MAED_EPI_GELU) {
-        st4((T*)e.out2 + r * e.ldo + c0, v);
+        if (e.out2) st4((T*)e.out2 + r * e.ldo + c0, v);
         // activation of the STORED (rounded) pre-activation, as the backward sees it -- rounded in registers, not read back
         float a[4] = {gelu_fwd<T>(round_to<T>(v[0])), gelu_fwd<T>(round_to<T>(v[1])), gelu_fwd<T>(round_to<T>(v[2])), gelu_fwd<T>(round_to<T>(v[3]))};
         st4((T*)e.out + r * e.ldo + c0, a);
@@ -108,7 +108,7 @@ __device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int
     if constexpr (EPI == MAED_EPI_STORE) {
         st8((T*)e.out + r * e.ldo + c0, v);
     } else if constexpr (EPI == MAED_EPI_GELU) {
-        st8((T*)e.out2 + r * e.ldo + c0, v);
+        if (e.out2) st8((T*)e.out2 + r * e.ldo + c0, v);
         float a[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = gelu_fwd<T>(round_to<T>(v[j]));   // activation of the STORED (rounded) pre-activation

@@ -506,7 +506,9 @@ class STEBlockFn(ReportingFn):
         pr = block._c_params(x.dtype if False else block.compute_dtype)
         saved = _aligned_bytes(lib.maed_ste_block_saved_bytes(C.byref(d)), x.device)
         y = torch.empty_like(x)
-        check(lib.maed_ste_block_fwd(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _stream()), "ste_block_fwd")
+        # no backward will follow (torch.no_grad / nothing requires grad): the inference entry point leaves out what only the backward reads
+        entry = lib.maed_ste_block_fwd if ReportingFn.will_run_backward(ctx) else lib.maed_ste_block_infer
+        check(entry(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _stream()), "ste_block_fwd")
         ctx.block, ctx.dims = block, dims
         ctx.save_for_backward(x, saved)
         # a hand-off left by the LAST block of an earlier backward pass (nobody consumes block 0's) is stale once a new forward runs: dropping it here frees its tensor

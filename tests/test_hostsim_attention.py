@@ -100,6 +100,38 @@ def test_ste_block_forward_backward_vs_oracle(dtype, f32_mode, rows):
         close(prm.grad, ref, rtol=1e-3 if f32 else 5e-2, atol=(1e-4 if f32 else 3e-2) * scale)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_forward_without_backward_takes_the_inference_entry_point_and_equals_the_training_forward(dtype):
+    """under torch.no_grad the Block runs maed_ste_block_infer (fc1's pre-activation, which only GELU' reads, is not stored): same output bit for bit"""
+    from functools import partial
+    import torch.nn as nn
+    from maed_amd.vision_transformer import Block
+    torch.manual_seed(0)
+    C, H, T, P = 128, 2, 2, 7
+    blk = Block(C, H, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", compute_dtype=dtype, impl=0)
+    x = rnd(T, P, C, seed=1)
+    with patched() as h:
+        calls = {"fwd": 0, "infer": 0}
+        real_f, real_i = h.maed_ste_block_fwd, h.maed_ste_block_infer
+
+        class Spy:
+            def __init__(self, fn, key):
+                self.fn, self.key = fn, key
+
+            def __call__(self, *a):
+                calls[self.key] += 1
+                return self.fn(*a)
+        h.maed_ste_block_fwd, h.maed_ste_block_infer = Spy(real_f, "fwd"), Spy(real_i, "infer")
+        try:
+            y_train = blk(x.clone().requires_grad_(True), T)
+            with torch.no_grad():
+                y_eval = blk(x, T)
+        finally:
+            h.maed_ste_block_fwd, h.maed_ste_block_infer = real_f, real_i
+    assert calls == {"fwd": 1, "infer": 1}, calls
+    assert torch.equal(y_train.detach(), y_eval)
+
+
 def test_residual_gradient_hand_off_between_blocks_is_used_and_a_bypass_is_loud():
     """bf16 blocks hand the compute-dtype copy of their residual gradient to the previous block (ops._TWIN, keyed on tensor identity).  Two training steps of a
     two-block chain: the hand-off is used on every second block backward and nothing warns (the copy the LAST block leaves is stale, not a bypass); a hook
