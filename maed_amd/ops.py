@@ -91,7 +91,9 @@ def dt_code(dtype):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of the current stream of the current device: one C call (torch.cuda.current_stream() builds a Stream object and resolves the device index
+    # through Python -- 11 us a piece, 130 of them per train step: scripts/host_profile.py)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 # ---- side stream for the backbone's weight-gradient GEMMs -----------------------------------------------------------------------------

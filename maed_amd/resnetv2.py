@@ -253,6 +253,12 @@ class ResNetStage(nn.Module):
         return self.blocks(x)
 
 
+def _slots(module, **values):
+    """per-pass hand-over slots of a layer (standardised weight, scratch slices): plain instance attributes, set without nn.Module.__setattr__'s parameter / buffer /
+    submodule bookkeeping -- 750 assignments per train step, 2 us each through the Module (scripts/host_profile.py)"""
+    module.__dict__.update(values)
+
+
 class ResNetV2(nn.Module):
     """resnetv2.py:277-348 restricted to what the STE uses: preact=False, stem_type='same', no head."""
 
@@ -336,13 +342,13 @@ class ResNetV2(nn.Module):
         try:
             if ws is not None:
                 for i, (c, w) in enumerate(zip(self._convs, ws)):
-                    c._w_std, c._w_t, c._dw, c._prec = w, self._w_std_t.get(i), self._dw_slices.get(i), self.f32_matmul
+                    _slots(c, _w_std=w, _w_t=self._w_std_t.get(i), _dw=self._dw_slices.get(i), _prec=self.f32_matmul)
             off = 0
             for i, m in enumerate(self._norms):
-                m._sums_buf = sums[i]
+                _slots(m, _sums_buf=sums[i])
                 if ab is not None:
                     n = N * 2 * m.num_channels
-                    m._ab_buf = ab[off:off + n].view(N, m.num_channels, 2)
+                    _slots(m, _ab_buf=ab[off:off + n].view(N, m.num_channels, 2))
                     off += n
             if ws is not None:
                 return self.stages(self.stem(x))
@@ -350,7 +356,7 @@ class ResNetV2(nn.Module):
                 wg = ops.WeightStdFn.apply(g, self.compute_dtype, self._convs[0].eps, *g.conv_weights())   # then fires right after its backward
                 for k, (ci, w) in enumerate(zip(g.conv_idx, wg)):
                     c = self._convs[ci]
-                    c._w_std, c._w_t, c._dw, c._prec = w, g._w_std_t.get(k), g._dw_slices.get(k), self.f32_matmul
+                    _slots(c, _w_std=w, _w_t=g._w_std_t.get(k), _dw=g._dw_slices.get(k), _prec=self.f32_matmul)
                 x = self.stages[0](self.stem(x)) if gi == 0 else self.stages[gi](x)
             # backward order is last stage first: every group but the one that runs last may finish on the side stream (ops.WeightStdFn.backward)
             runs = [g for g in self._ws_groups if g._pending_backwards > 0]
@@ -359,9 +365,9 @@ class ResNetV2(nn.Module):
             return x
         finally:
             for c in self._convs:
-                c._w_std = c._w_t = c._dw = c._prec = None
+                _slots(c, _w_std=None, _w_t=None, _dw=None, _prec=None)
             for m in self._norms:
-                m._sums_buf = m._ab_buf = None
+                _slots(m, _sums_buf=None, _ab_buf=None)
 
     def forward(self, x, seqlen=8):
         return self.forward_features(x)
