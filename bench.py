@@ -246,6 +246,11 @@ def main():
     ap.add_argument("--backbone-f32-matmul", default=None, choices=["bf16x3", "bf16x6"],
                     help="--dtype f32 only: the backbone's own engine (MAED(backbone_f32_matmul=...)); default: the process-wide mode")
     args = ap.parse_args()
+    # stdout carries ONE line, the JSON: native libraries print there too (RCCL writes a five-line version banner to stdout when a communicator is created), so
+    # file descriptor 1 points at stderr until the line is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     if args.workload == "cfg5":   # BASELINE.json configs[4]: long-clip stress (per-GPU clips stated in config.workload)
         CFG.update(clips=2, T=64, img=256, depth=12, heads=12, dim=768)
@@ -558,9 +563,15 @@ def main():
             "parity_err_bf16": (cpu or {}).get("parity_probe", {}).get("rel_err", {}).get("bf16") if cpu and (cpu.get("parity_probe") or {}).get("rel_err") else None,
             "parity_mode": (cpu or {}).pop("parity_mode", None) if cpu else None,
         }
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
 
 
 if __name__ == "__main__":

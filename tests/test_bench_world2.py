@@ -22,6 +22,8 @@ def test_bench_main_two_ranks_gloo_simulator():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE JSON line
+    # ... and nothing else reaches stdout from bench.py: native libraries' prints (RCCL's version banner at communicator creation) go to stderr
+    assert [l for l in out.stdout.splitlines() if l.strip() and not l.startswith("{")] == [] or "torch.distributed" in out.stdout, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 2 * 1 * 1e3 / d["ms_per_step"]) < 0.05 * d["value"]      # whole-job clips/s: 2 ranks x 1 clip
