@@ -128,6 +128,44 @@ def _small_maed(dtype, depth=2, H=2, img=64, hidden=64, seed=5):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_without_grad_takes_the_inference_entry_point_and_equals_the_training_forward(dtype):
+    """under torch.no_grad a Block runs maed_ste_block_infer (fc1's pre-activation, which only the backward reads, is not stored): the output equals the
+    grad-enabled forward's bit for bit (the block forward has no atomics) -- cfg3 token geometry, 2 clips"""
+    from functools import partial
+    import torch.nn as nn
+    from maed_amd import _lib as L
+    from maed_amd.vision_transformer import Block
+    torch.manual_seed(0)
+    C, H, T, P = 512, 8, 16, 197
+    blk = Block(C, H, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", compute_dtype=dtype, impl=0).to(DEV)
+    x = rnd(2 * T, P, C, seed=1).to(DEV)
+    lib = L.lib()
+    calls = {"fwd": 0, "infer": 0}
+    real_f, real_i = lib.maed_ste_block_fwd, lib.maed_ste_block_infer
+
+    class Spy:
+        def __init__(self, fn, key):
+            self.fn, self.key = fn, key
+
+        def __call__(self, *a):
+            calls[self.key] += 1
+            return self.fn(*a)
+    lib.maed_ste_block_fwd, lib.maed_ste_block_infer = Spy(real_f, "fwd"), Spy(real_i, "infer")
+    try:
+        y_grad = blk(x.clone().requires_grad_(True), T)
+        with torch.no_grad():
+            y_nograd = blk(x, T)
+    finally:
+        lib.maed_ste_block_fwd, lib.maed_ste_block_infer = real_f, real_i
+    assert calls == {"fwd": 1, "infer": 1}, calls
+    if dtype == torch.bfloat16:
+        assert torch.equal(y_grad.detach(), y_nograd)
+    else:       # fp32: the ts_attn GEMM (32 x 1024 x 1024: few tiles, long K) sums its K slices with fp32 atomics -- same kernels, order-dependent last bits
+        report("Block forward f32: maed_ste_block_infer vs maed_ste_block_fwd", y_nograd, y_grad.detach(), rtol=1e-5, atol=1e-5)
+    note(f"Block forward [{dtype}, 32 frames x 197 tokens x 512]: maed_ste_block_infer output == maed_ste_block_fwd output")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maed_forward_small_vs_oracle(dtype):
     m, params = _small_maed(dtype)
     m.eval()
