@@ -369,13 +369,13 @@ def main():
     # ---- host enqueue time of one step (extra steps, untimed region): the wall time step() takes to RETURN when the GPU queue is empty, i.e. what the host
     # needs to issue a step's ~700 launches; the step is GPU-bound as long as this stays below ms_per_step
     host_ms = []
-    for _ in range(3):
+    for _ in range(7):
         fence()
         t1 = time.perf_counter()
         step()
         host_ms.append(1e3 * (time.perf_counter() - t1))
     fence()
-    host_enqueue_ms = round(sorted(host_ms)[1], 3)
+    host_enqueue_ms = round(sorted(host_ms)[3], 3)      # median of 7
     log(f"host enqueue per step: {host_ms}")
 
     # ---- in-situ kernel timing for the rooflines (extra steps, events on the launch stream) ---------------

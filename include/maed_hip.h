@@ -218,6 +218,10 @@ int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_params* p, con
                        const float* x_in, const float* dx_out, float* dx_in, void* saved, void* scratch,
                        const void* dx_out_twin, void* dx_in_twin, void* stream);
 
+/* stream ordering helper for hosts that put single launches on a second stream of their own: everything enqueued on from_stream so far happens before whatever
+ * is enqueued on to_stream from now on (one event record + one stream wait; the events come from a ring the library owns). */
+int maed_stream_fence(void* from_stream, void* to_stream);
+
 /* measurement only: bracket selected launches inside the composite block calls with hipEvents on the
  * launch stream.  Tags: 0 attn_spatial_fwd, 1 attn_temporal_fwd, 2 qkv GEMM, 3 fc1 GEMM, 4 fc2 GEMM,
  * 5 attn_spatial_bwd, 6 attn_temporal_bwd, 7 weight-gradient GEMMs, 8 proj GEMM, 9 the four input-gradient GEMMs of a block,

@@ -85,6 +85,7 @@ SIGNATURES = {
     "maed_loss_accl_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp]),
     "maed_dropout": (i32, [vp, vp, i64, f32, C.c_uint64, vp]),
     "maed_tanh_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "maed_stream_fence": (i32, [vp, vp]),
     "maed_prof_enable": (i32, [i32]),
     "maed_prof_ntags": (i32, []),
     "maed_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i32)]),

@@ -12,6 +12,8 @@
 #include "gemm_x3.h"
 #include "prof.h"
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -102,6 +104,26 @@ static SideStream* side_stream() {
     if (!maed_opt(MAED_OPT_SIDE_STREAM) || g_prof) return nullptr;      // (before the static: with the option off the stream is never created)
     static SideStream ss;
     return ss.ok ? &ss : nullptr;
+}
+
+// "everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on": one event record + one stream wait from a ring of timing-less
+// events the library owns.  For hosts that run single launches on a second stream of their own (maed_amd/ops.py: the backbone's weight-gradient GEMMs): the same
+// fence through the framework costs a Python-level event object, a record and a wait per use.
+extern "C" int maed_stream_fence(void* from_stream, void* to_stream) {
+    static hipEvent_t ring[64];
+    static std::once_flag once;
+    static std::atomic<unsigned> next{0};
+    static bool ok = false;
+    std::call_once(once, [] {
+        ok = true;
+        for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) { ok = false; break; }
+    });
+    MAED_CHECK_ARG(ok, MAED_ERR_LAUNCH, "stream_fence: event ring could not be created");
+    if (from_stream == to_stream) return MAED_OK;
+    hipEvent_t e = ring[next.fetch_add(1, std::memory_order_relaxed) & 63];
+    MAED_HIP(hipEventRecord(e, (hipStream_t)from_stream), "stream_fence: record");
+    MAED_HIP(hipStreamWaitEvent((hipStream_t)to_stream, e, 0), "stream_fence: wait");
+    return MAED_OK;
 }
 
 namespace {

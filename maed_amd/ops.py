@@ -7,6 +7,7 @@ is no PyTorch/CPU fallback (a CPU tensor or a missing library is an error).
 import ctypes as C
 import math
 import os
+import threading
 import weakref
 
 import numpy as _np
@@ -90,7 +91,13 @@ def dt_code(dtype):
     raise TypeError(f"maed_amd: unsupported compute dtype {dtype}")
 
 
+_TLS = threading.local()     # .stream: raw handle the wrappers launch on instead of the current stream (side_stream_run), per thread
+
+
 def _stream():
+    s = getattr(_TLS, "stream", None)
+    if s is not None:
+        return s
     # raw handle of the current stream of the current device: one C call (torch.cuda.current_stream() builds a Stream object and resolves the device index
     # through Python -- 11 us a piece, 130 of them per train step: scripts/host_profile.py)
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
@@ -126,9 +133,16 @@ def side_stream_run(fn, *tensors):
     if st is None:
         st = _SIDE[t0.device] = [torch.cuda.Stream(device=t0.device), False]
     side = st[0]
-    side.wait_stream(torch.cuda.current_stream(t0.device))
-    with torch.cuda.stream(side):
+    # fn() is library launches only: they take the side stream's raw handle from _stream() (thread-local override) after one fence behind the caller's stream --
+    # no framework stream switch, no Python-level event (side.wait_stream + `with torch.cuda.stream(side)` cost 50 us per use, 49 uses per train step)
+    raw = side.cuda_stream
+    check(L.lib().maed_stream_fence(_stream(), raw), "stream_fence")
+    prev = getattr(_TLS, "stream", None)
+    _TLS.stream = raw
+    try:
         out = fn()
+    finally:
+        _TLS.stream = prev
     for t in tensors:
         t.record_stream(side)
     _join_at_end_of_backward(t0.device, st)

@@ -34,6 +34,10 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    torch.autograd.set_multithreading_enabled(False)      # the backward's Python functions in THIS thread, so that cProfile sees them
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(steps):
@@ -43,7 +47,7 @@ def main():
     for key in ("tottime", "cumtime"):
         print(f"==== top by {key} ({steps} steps) ====")
         st = pstats.Stats(pr)
-        st.sort_stats(key).print_stats(35)
+        st.sort_stats(key).print_stats(45)
 
 
 if __name__ == "__main__":
