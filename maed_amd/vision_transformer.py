@@ -108,6 +108,9 @@ class Attention(nn.Module):
         return out
 
 
+_LIN_FIELDS = [("w_" + n, "wt_" + n, "b_" + n) for n in ("qkv", "ts", "proj", "fc1", "fc2")]      # maed_block_params / maed_block_grads field names per Linear
+
+
 class Block(nn.Module):
     """vision_transformer.py:244-261.  forward = one fused call (ops.STEBlockFn) in 'parallel' mode, the staged
     composition of ste_modes.block otherwise."""
@@ -135,17 +138,28 @@ class Block(nn.Module):
     def _linears(self):
         return [self.attn.qkv, self.attn.ts_attn, self.attn.proj, self.mlp.fc1, self.mlp.fc2]
 
+    def _hot(self):
+        """(linears, LayerNorm parameters, fused parameter list) looked up once: the attribute chains below go through nn.Module.__getattr__ (2-3 us a hop), twelve
+        times per train step and block.  Parameters are replaced in place by load_state_dict / optimizers; a module surgery that swaps Parameter OBJECTS must
+        drop `_hot_cache` (ParamArena re-points .data, which keeps the objects)."""
+        c = self.__dict__.get("_hot_cache")
+        if c is None:
+            lin = self._linears()
+            ln = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias)
+            c = (lin, [l.weight for l in lin], [l.bias for l in lin], ln, list(ln) + [t for l in lin for t in (l.weight, l.bias) if t is not None])
+            self.__dict__["_hot_cache"] = c
+        return c
+
     def _c_params(self, dtype):
-        lin = self._linears()
-        w = self._cache.get([l.weight for l in lin], dtype)
-        self._keep = w
+        lin, weights, biases, ln, _ = self._hot()
+        w = self._cache.get(weights, dtype)
+        self.__dict__["_keep"] = w
         p = L.BlockParams()
-        p.ln1_g, p.ln1_b = self.norm1.weight.data_ptr(), self.norm1.bias.data_ptr()
-        p.ln2_g, p.ln2_b = self.norm2.weight.data_ptr(), self.norm2.bias.data_ptr()
-        for name, l, (wc, wt) in zip(["qkv", "ts", "proj", "fc1", "fc2"], lin, w):
-            setattr(p, "w_" + name, wc.data_ptr())
-            setattr(p, "wt_" + name, wt.data_ptr())
-            setattr(p, "b_" + name, l.bias.data_ptr() if l.bias is not None else None)
+        p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b = ln[0].data_ptr(), ln[1].data_ptr(), ln[2].data_ptr(), ln[3].data_ptr()
+        for name, b, (wc, wt) in zip(_LIN_FIELDS, biases, w):
+            setattr(p, name[0], wc.data_ptr())
+            setattr(p, name[1], wt.data_ptr())
+            setattr(p, name[2], b.data_ptr() if b is not None else None)
         return p
 
     def _c_grads(self):
@@ -158,19 +172,18 @@ class Block(nn.Module):
                 prm.grad = torch.zeros_like(prm)
             return prm.grad.data_ptr()
 
-        g.ln1_g, g.ln1_b = grad_ptr(self.norm1.weight), grad_ptr(self.norm1.bias)
-        g.ln2_g, g.ln2_b = grad_ptr(self.norm2.weight), grad_ptr(self.norm2.bias)
-        for name, l in zip(["qkv", "ts", "proj", "fc1", "fc2"], self._linears()):
-            setattr(g, "w_" + name, grad_ptr(l.weight))
-            setattr(g, "b_" + name, grad_ptr(l.bias))
+        _, weights, biases, ln, _ = self._hot()
+        g.ln1_g, g.ln1_b, g.ln2_g, g.ln2_b = grad_ptr(ln[0]), grad_ptr(ln[1]), grad_ptr(ln[2]), grad_ptr(ln[3])
+        for name, wgt, b in zip(_LIN_FIELDS, weights, biases):
+            setattr(g, name[0], grad_ptr(wgt))
+            setattr(g, name[2], grad_ptr(b))
         return g
 
     def fused_parameters(self):
         """parameters whose gradients the fused backward writes straight into .grad (none in the staged modes: autograd owns them)"""
         if not self.fused:
             return []
-        return [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias] + \
-               [t for l in self._linears() for t in (l.weight, l.bias) if t is not None]
+        return self._hot()[4]
 
     def forward(self, x, seqlen=1):
         if not self.fused:
