@@ -346,6 +346,7 @@ def main():
         def elapsed_time(self, other):
             return 1e3 * (other.t - self.t)
     marks = [(_HostMark() if sim else torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + 1)]
+    dev_allocs0 = 0 if sim else torch.cuda.memory_stats(dev).get("num_device_alloc", 0)     # hipMalloc calls of the caching allocator so far
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -353,12 +354,14 @@ def main():
         marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    dev_allocs = 0 if sim else torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - dev_allocs0
     in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     log("per-step ms (hipEvents, in order): " + " ".join(f"{t:.1f}" for t in in_order))
     per_step = sorted(in_order)
     pct = lambda q: per_step[min(len(per_step) - 1, max(0, int(round(q * (len(per_step) - 1)))))]
     step_stats = dict(median_ms=round(pct(0.5), 3), p10_ms=round(pct(0.1), 3), p90_ms=round(pct(0.9), 3), min_ms=round(per_step[0], 3),
-                      max_ms=round(per_step[-1], 3), how="hipEvent per step boundary on the launch stream, this rank")
+                      max_ms=round(per_step[-1], 3), how="hipEvent per step boundary on the launch stream, this rank",
+                      device_allocations_in_timed_region=dev_allocs)     # > 0: the caching allocator was still growing (hipMalloc inside the timed steps: more --warmup)
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -107,8 +107,8 @@ def _stream():
 # dW += Y^T X of a convolution depends only on tensors that exist when its backward runs, and nothing reads dW before the batched
 # weight-standardisation backward.  On the caller's stream the TN kernel (bound by its LDS-side pipeline) sits between
 # the input-gradient GEMM and the GroupNorm backward of the layer in front (HBM-bound): on a second stream it runs beside them.
-# record_stream keeps the caching allocator from handing the operands' memory out while the side stream still reads them;
-# side_stream_join() orders the caller's stream after everything issued so far (WeightStdFn.backward calls it before it reads the dW slices).
+# The operands stay referenced until side_stream_join() has ordered the caller's stream after everything issued so far (_keep_until_join; WeightStdFn.backward
+# joins before it reads the dW slices, and one join is queued for the end of every backward pass), so the caching allocator cannot hand their memory out early.
 # MAED_WGRAD_SIDE_STREAM=0: everything on the caller's stream (A/B knob; the STE blocks' C++ driver reads the same variable).
 _SIDE_ON = L.get_option(L.OPT_SIDE_STREAM) == 1
 _SIDE = {}
@@ -143,8 +143,7 @@ def side_stream_run(fn, *tensors):
         out = fn()
     finally:
         _TLS.stream = prev
-    for t in tensors:
-        t.record_stream(side)
+    _keep_until_join(t0.device, st, tensors)
     _join_at_end_of_backward(t0.device, st)
     st[1] = True
     return out
@@ -158,11 +157,25 @@ def side_stream_handle(device, *tensors):
     st = _SIDE.get(device)
     if st is None:
         st = _SIDE[device] = [torch.cuda.Stream(device=device), False]
-    for t in tensors:
-        t.record_stream(st[0])
+    _keep_until_join(device, st, tensors)
     _join_at_end_of_backward(device, st)
     st[1] = True
     return st[0].cuda_stream
+
+
+def _keep_until_join(device, st, tensors):
+    """what a side-stream launch reads / writes stays referenced until the caller's stream has been ordered behind the side stream (side_stream_join): freed
+    after that, the caching allocator hands the memory out for work that is enqueued behind the join.  Tensor.record_stream would do the same job per tensor, but
+    defers the reuse until the side stream's EVENT has completed on the device: a host that runs several steps ahead of the GPU (13 ms of enqueue against a 22 ms
+    step) then finds nothing reusable and the allocator keeps growing -- 10 -> 30 GB reserved over 12 free-running steps, with hipMalloc stalls of 100+ ms in the
+    fp32 modes (scripts/alloc_probe.py)."""
+    keep = _KEEP.setdefault(device, [])
+    keep.extend(tensors)
+    if len(keep) > 4096:                # nobody joined for a long time (direct calls outside a backward pass): join now
+        side_stream_join(device)
+
+
+_KEEP = {}
 
 
 def side_stream_join(device):
@@ -170,6 +183,9 @@ def side_stream_join(device):
     if st is not None and st[1]:
         torch.cuda.current_stream(device).wait_stream(st[0])
         st[1] = False
+    keep = _KEEP.get(device)
+    if keep:
+        keep.clear()
 
 
 def _p(t):
@@ -658,10 +674,8 @@ class WeightStdFn(ReportingFn):
             return WeightStdFn._backward_body(ctx, gouts)
         side = st[0]
         side.wait_stream(torch.cuda.current_stream(dev))     # gradients autograd carried here (MIOpen convolutions), p.grad zero-fills
+        _keep_until_join(dev, st, [g for g in gouts if g is not None])
         with torch.cuda.stream(side):
-            for g in gouts:
-                if g is not None:
-                    g.record_stream(side)
             return WeightStdFn._backward_body(ctx, gouts)
 
     @staticmethod
