@@ -17,7 +17,7 @@ from oracle import maed_ref as R
 
 pytestmark = pytest.mark.gpu
 
-from _util import DEV, q, report, rnd, tol  # noqa: E402
+from _util import DEV, note, q, report, rnd, tol  # noqa: E402
 
 
 def _ops():
@@ -561,3 +561,26 @@ def test_conv1x1_stride2_on_packed_pixels(N, I, O, H, W):
     report(f"conv1x1s2 fwd{tag}", y.float(), ref, **tol(torch.bfloat16, 2))
     report(f"conv1x1s2 dx{tag}", xg.grad.float(), xd.grad, **tol(torch.bfloat16, 2))
     report(f"conv1x1s2 dw{tag}", dw - 1.0, wd.grad.reshape(O, I), rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())
+
+
+def test_stream_fence_orders_two_streams():
+    """maed_stream_fence(from, to): everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on (the fence the host uses for
+    side-stream launches instead of framework events).  A long fill on stream A, the fence, a read on stream B: B must see the fill -- 20 rounds, fresh values."""
+    from maed_amd import _lib as L, ops
+    lib = L.lib()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.zeros(64 << 20, dtype=torch.float32, device=DEV)          # 256 MB: the fill takes ~100 us
+    y = torch.empty(1, dtype=torch.float32, device=DEV)
+    torch.cuda.synchronize()
+    for k in range(1, 21):
+        with torch.cuda.stream(a):
+            x.fill_(float(k))
+        ops.check(lib.maed_stream_fence(a.cuda_stream, b.cuda_stream), "stream_fence")
+        with torch.cuda.stream(b):
+            y.copy_(x[-1:])
+        ops.check(lib.maed_stream_fence(b.cuda_stream, a.cuda_stream), "stream_fence")      # (the next fill must not overtake the read)
+        b.synchronize()
+        assert y.item() == float(k), (k, y.item())
+    assert lib.maed_stream_fence(a.cuda_stream, a.cuda_stream) == 0                          # same stream: nothing to do
+    note("maed_stream_fence: 20 producer/consumer rounds across two streams in order")
+
