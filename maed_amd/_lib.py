@@ -132,6 +132,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_init_pending = False      # maed_init still to be called (lib(): as soon as the framework has a device context)
 
 
 class MaedHipError(RuntimeError):
@@ -140,7 +141,7 @@ class MaedHipError(RuntimeError):
 
 def lib():
     """Load libmaed_hip.so (once).  Raises if it has not been built: there is no fallback path."""
-    global _lib
+    global _lib, _init_pending
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MaedHipError(f"{LIB_PATH} is missing: build it with `python -m maed_amd.build` "
@@ -151,9 +152,15 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = handle
         apply_options(handle)
+        _init_pending = True
+    if _init_pending:
+        # maed_init (architecture check: a GPU that is not gfx950 fails here, with its name, instead of at the first launch) needs a device context.  Binding the
+        # library must not CREATE one: a multi-rank launcher that binds before torch.cuda.set_device(local_rank) would put a context of every rank on GPU 0
+        #  -- so the check waits until the framework has initialised CUDA/HIP, and then looks at the device the caller selected.
         import torch
-        if torch.cuda.is_available():        # a GPU that is not gfx950 fails here, with its name, instead of at the first launch
-            check(handle.maed_init(torch.cuda.current_device()), "maed_init")
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            _init_pending = False
+            check(_lib.maed_init(torch.cuda.current_device()), "maed_init")
     return _lib
 
 

@@ -273,7 +273,9 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
     const float* logits = (const float*)(sv + L.logits);
     float* dxmid = (float*)(sc + S.dxmid);
 
-    if (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || maed_x3_planes())) {
+    // (f32: the split TN kernel needs N, K and the row strides -- C, 2C, 3C, hidden -- to be multiples of 4; C = 64 H always is, a hidden width that is not falls
+    //  through to the exact transposed-copy path below, never less accurate than asked for, as maed_gemm_nt does)
+    if (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || (maed_x3_planes() && d->hidden % 4 == 0))) {
         // ---- bf16, and f32 in the split-bf16 matmul mode: weight gradients straight from the row-major operands (maed_gemm_tn_wgrad), no transposed copies ----
         const void* dyc = dt == MAED_F32 ? (const void*)dx_out : dx_out_twin;   // dx_out in the compute dtype
         if (!dyc) {                                                      // first block of the backward: cast once
@@ -288,6 +290,9 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
 #define FROM_SIDE() do { if (ss) ss->fence(ss->s, main_s); } while (0) /* the chain waits for the weight gradients issued so far */
 #define WGRAD(expr) do { ProfScope ps__(PROF_GEMM_WGRAD, wst); MAED_PROPAGATE(expr); } while (0)
         // MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
+        // ALIASING (the header lets dx_in alias dx_out): in f32 the fc2 weight gradient reads dx_out ITSELF on the side stream, and dx_in is written only by the
+        // closing layernorm_bwd_ws.  What orders the two: ev[63] is recorded on the side stream behind the fc1 weight gradient (hence behind this one) and the
+        // caller's stream waits for it before the attention backward -- long before the closing LayerNorm.  Keep that wait if the order below is ever changed.
         TO_SIDE();
         WGRAD(maed_gemm_tn_wgrad(dyc, C, sv + L.hact, Hd, M, C, Hd, g->w_fc2, Hd, g->b_fc2, dt, wst));
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));

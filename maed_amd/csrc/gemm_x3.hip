@@ -422,6 +422,11 @@ int maed_conv3x3_x3_launch(int np, const void* x, const void* w, const X3ConvDim
 
 int maed_gemm_tn_x3_launch(int np, const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw, float* dbias,
                            const X3TnConv* conv, int target_wgs, hipStream_t s) {
+    // 32-bit byte offsets against a buffer extent clamped to 4 GB (as the NT / convolution launchers): a larger operand would wrap into range and read wrong rows.
+    // The gathered X rows of the 3x3 weight gradient reach one image row + one pixel past either end of the tensor (masked taps): counted in.
+    const int64_t x_rows = M + (conv ? 2 * ((int64_t)conv->Wimg + 1) : 0);
+    MAED_CHECK_ARG(x3_fits32(M, ldy, x_rows, ldx), MAED_ERR_SHAPE, "gemm_tn(x3): an operand larger than 4 GB (M=%lld ldy=%lld ldx=%lld): split the batch",
+                   (long long)M, (long long)ldy, (long long)ldx);
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     const int nmt = (int)((M + X3_BK - 1) / X3_BK);
     // large outputs: fill the chip exactly twice like the bf16 kernel (maed_tn_splits); small ones keep ~384 workgroups -- this kernel runs three

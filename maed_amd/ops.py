@@ -110,8 +110,13 @@ def _stream():
 # The operands stay referenced until side_stream_join() has ordered the caller's stream after everything issued so far (_keep_until_join; WeightStdFn.backward
 # joins before it reads the dW slices, and one join is queued for the end of every backward pass), so the caching allocator cannot hand their memory out early.
 # MAED_WGRAD_SIDE_STREAM=0: everything on the caller's stream (A/B knob; the STE blocks' C++ driver reads the same variable).
-_SIDE_ON = L.get_option(L.OPT_SIDE_STREAM) == 1
+_SIDE_ON = None      # None: follow the library option (read at USE time -- a later _lib.set_option(OPT_SIDE_STREAM) then moves the Python side with the C++ block driver);
+                     # True / False: override (bench.py's single-stream profiling steps, A/B scripts, tests)
 _SIDE = {}
+
+
+def _side_on():
+    return (L.get_option(L.OPT_SIDE_STREAM) == 1) if _SIDE_ON is None else _SIDE_ON
 
 
 def _join_at_end_of_backward(device, st):
@@ -127,7 +132,7 @@ def _join_at_end_of_backward(device, st):
 
 def side_stream_run(fn, *tensors):
     t0 = tensors[0]
-    if not (_SIDE_ON and t0.is_cuda):
+    if not (t0.is_cuda and _side_on()):
         return fn()
     st = _SIDE.get(t0.device)
     if st is None:
@@ -152,7 +157,7 @@ def side_stream_run(fn, *tensors):
 def side_stream_handle(device, *tensors):
     """raw handle of the side stream for entry points that fence a trailing kernel onto it themselves (maed_groupnorm_bwd aux_stream);
     None when the side stream is off.  `tensors`: what that kernel reads / writes (kept alive for it)."""
-    if not (_SIDE_ON and device.type == "cuda"):
+    if not (device.type == "cuda" and _side_on()):
         return None
     st = _SIDE.get(device)
     if st is None:
@@ -668,7 +673,7 @@ class WeightStdFn(ReportingFn):
         their kernel AND their readiness report on the side stream itself, behind that stage's weight gradients, so the caller's stream -- the
         dy -> dx chain of the next stage -- never waits for them; the last group's join covers them."""
         dev = ctx.weights[0].device
-        st = _SIDE.get(dev) if (_SIDE_ON and getattr(ctx.owner, "_ws_on_side", False)) else None
+        st = _SIDE.get(dev) if (_side_on() and getattr(ctx.owner, "_ws_on_side", False)) else None
         if st is None or not st[1]:
             side_stream_join(dev)
             return WeightStdFn._backward_body(ctx, gouts)

@@ -1,4 +1,5 @@
-"""STE temporal attention forward/backward in isolation (bf16) at the cfg3 and cfg5 shapes: MAED_TEMPORAL_MFMA=0/1 A/B."""
+"""STE temporal attention forward/backward in isolation (bf16, the MFMA kernels of csrc/attn_temporal.hip) at the cfg3 and cfg5 shapes.
+(The round-1 MAED_TEMPORAL_MFMA=0/1 A/B switch is gone with the LDS-staged bf16 kernels it selected: this script times ONE implementation.)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,4 +24,4 @@ for name, (F_, P, H, T) in {"cfg3": (128, 197, 8, 16), "cfg5": (128, 257, 12, 64
             fn(i)
         e1.record(); torch.cuda.synchronize()
         res[tag] = 1e3 * e0.elapsed_time(e1) / iters
-    print(f"temporal attention {name} (F={F_} P={P} H={H} T={T}) MFMA={os.environ.get('MAED_TEMPORAL_MFMA', '0')}: fwd {res['fwd']:7.1f} us  bwd {res['bwd']:7.1f} us", flush=True)
+    print(f"temporal attention {name} (F={F_} P={P} H={H} T={T}): fwd {res['fwd']:7.1f} us  bwd {res['bwd']:7.1f} us", flush=True)

@@ -2,7 +2,10 @@
 environment; the printed loss trajectory must agree (first step identical, second within bf16 / summation-order noise).
 
     python scripts/sim_e2e_flags.py
-    MAED_GN_DEFER_AFFINE=1 MAED_LN_DEFER_AFFINE=1 MAED_TAIL_PARALLEL=1 MAED_WS_PER_STAGE=1 MAED_CONV3X3=own python scripts/sim_e2e_flags.py
+    MAED_WS_PER_STAGE=1 MAED_GN_FUSE_STATS=0 MAED_GN_LAZY_DRES=0 MAED_CONV3X3=miopen python scripts/sim_e2e_flags.py
+
+(switches that still exist: README.md's table; the round-2 in-kernel switches MAED_GN_DEFER_AFFINE / MAED_LN_DEFER_AFFINE / MAED_TAIL_PARALLEL are gone with the
+variants that lost -- setting them changes nothing)
 
 Round-1 tree: [171.142578125, 162.39 +- 0.01] either way (atomics make the second step vary in the 5th digit from run to run)."""
 import os, sys, torch

@@ -184,6 +184,18 @@ def test_gemm_tn_x6_is_fp32_level():
     assert (dW.double() - ref).abs().max() <= 2e-6 * ref.abs().max()
 
 
+def test_gemm_tn_x3_rejects_operands_past_4gb(x3_mode):
+    """the split TN kernel addresses rows with 32-bit byte offsets against a 4 GB buffer extent -- an operand past that must be refused (as the NT /
+    convolution launchers do), not read wrapped.  A row stride of 2^26 floats makes 64 rows span 16 GB without allocating them: the check fires before any access."""
+    Y, X, dW = rnd(64, 8, seed=1), rnd(64, 8, seed=2), torch.zeros(8, 8)
+    with patched():
+        rc = L.lib().maed_gemm_tn_wgrad(ops._p(Y), 1 << 26, ops._p(X), 8, 64, 8, 8, ops._p(dW), 8, None, ops.mm_code(torch.float32), None)
+        assert rc != 0 and b"4 GB" in L.lib().maed_last_error()
+        rc = L.lib().maed_gemm_tn_wgrad(ops._p(Y), 8, ops._p(X), 1 << 26, 64, 8, 8, ops._p(dW), 8, None, ops.mm_code(torch.float32), None)
+        assert rc != 0 and b"4 GB" in L.lib().maed_last_error()
+    assert dW.abs().max() == 0
+
+
 def test_f32_library_convolutions_need_the_split_mode():
     """in the exact mode the entry points without an exact fp32 kernel refuse fp32 (loudly: no silent precision change)"""
     assert ops.get_float32_matmul_precision() == "exact"
