@@ -87,6 +87,7 @@ typedef enum {
     MAED_OPT_SIDE_STREAM = 1,   /* 1 (default): weight-gradient GEMMs / temporal attention of the fused STE block on the library's side stream */
     MAED_OPT_TN_TARGET_WGS = 2, /* workgroups a weight-gradient GEMM is split into along M: 0 (default) = built-in heuristic, >= 64 = that target (sweep knob) */
     MAED_OPT_ABLATE = 3,        /* diagnostic builds (-DMAED_GEMM_ABLATE) only: bit mask of pipeline stages to drop */
+    MAED_OPT_GN_BWD_ONEPASS = 4,/* 1 (default): maed_groupnorm_bwd with frame_sync reads x and dy once (register-resident slices + per-frame barrier); 0: two passes */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's
@@ -353,10 +354,15 @@ int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, 
  * added before the ReLU (optional: inference passes NULL), required by backward in that case -- without a residual the mask is
  * recomputed from x.  16x less traffic than re-reading the saved output in both backward passes.
  * dx (and dres = masked dy when dres != NULL; with a relu_mask dres may be NULL: the consumer masks dy itself, MAED_EPI_ADD with out2 = relu_mask);
- * dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats */
+ * dgamma/dbeta += (atomics); ab_scratch: N*C*2 floats.
+ * frame_sync (optional, N * MAED_GN_SYNC_WORDS 4-byte words that are ZERO at launch -- e.g. a slice of the same zero-filled arena as ab_scratch; single use):
+ * with it the backward reads x and dy ONCE -- the workgroups that share a frame keep their slices in registers between the reduction and the apply step,
+ * exchange their 2 x 32 group sums through frame_sync[n] and meet at its arrival counter (3 tensor streams instead of 5; MAED_OPT_GN_BWD_ONEPASS = 0 or
+ * NULL: the two-pass kernels) */
+#define MAED_GN_SYNC_WORDS 80
 int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
-                       int relu, int dtype, int ab_zeroed, void* aux_stream, void* stream);
+                       int relu, int dtype, int ab_zeroed, uint32_t* frame_sync, void* aux_stream, void* stream);
 /* aux_stream (optional): a second stream of the caller's on which the closing dgamma/dbeta column sum is enqueued (fenced after the reduction
  * pass on `stream`); the caller joins it before anybody reads dgamma/dbeta.  NULL: everything on `stream`. */
 

@@ -18,7 +18,7 @@ IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
 IMPL_X3, IMPL_X6 = 7, 8  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
-OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE = range(4)   # maed_option (include/maed_hip.h)
+OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS = range(5)   # maed_option (include/maed_hip.h)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -107,7 +107,7 @@ SIGNATURES = {
     "maed_weight_std_fwd": (i32, [vp, i32, i32, vp, i32, vp, f32, vp]),
     "maed_weight_std_bwd": (i32, [vp, i32, i32, i32, vp, f32, vp]),
     "maed_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp]),
-    "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp, vp]),
+    "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp, vp, vp]),
     "maed_comm_load": (i32, [C.c_char_p]),
     "maed_comm_unique_id": (i32, [vp]),
     "maed_comm_init": (i32, [i32, i32, vp]),
@@ -171,6 +171,7 @@ _OPTIONS = {
     OPT_SIDE_STREAM: int(os.environ.get("MAED_WGRAD_SIDE_STREAM", "1") == "1"),
     OPT_TN_TARGET_WGS: int(os.environ.get("MAED_TN_TARGET_WGS", "0")),
     OPT_ABLATE: int(os.environ.get("MAED_GEMM_ABLATE", "0")),
+    OPT_GN_BWD_ONEPASS: int(os.environ.get("MAED_GN_BWD_ONEPASS", "1")),      # A/B knob: 0 = the two-pass GroupNorm backward (2: 256-thread variant of the one-pass kernel)
 }
 
 

@@ -334,6 +334,192 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// ---- backward in ONE pass over x and dy (round 4) -------------------------------------------------------------------------------------------------
+// The two kernels above read x and dy twice: five tensor streams (2 + 2 reads, 1 write) for a result that needs three.  Nothing of a frame's dx can be written
+// before the frame's 2 x 32 group sums are complete -- but the operands do not have to go back to memory in between: here the S workgroups that share a
+// frame each load their slice of x and dy ONCE into registers (CH chunks of 8 channels per thread and tensor: 64 VGPRs of payload, two 512-thread workgroups
+// per CU hold 2 x 128 KB), reduce it, add their per-channel partials to ab[n] with device-scope atomics, meet at a per-frame arrival counter, read the frame's
+// totals back (returning atomics: served where the adds were performed, no L2 of another XCD in between) and apply straight from the registers.
+// HBM traffic 5 -> 3 streams.  The workgroups of a frame are consecutive in dispatch order (blockIdx.x = slice), a workgroup waits only for its own frame's
+// slices, and a frame is at most 64 workgroups against 512 resident ones: every waiting workgroup's peers are either resident or next in the queue.
+// `sync`: one arrival counter per frame, ZERO at launch (the caller hands in a slice of the same per-pass zero-filled arena as `ab`).
+// phase: 0 = the whole thing (GPU); 1 = reduction half only / 2 = apply half only, totals from ab -- the host simulator runs workgroups one after another, so
+// its launcher issues the two halves as two launches (tests/hostsim: everything but the spin itself is then checked on the host).
+#define GN1_NT 512
+template <typename T> struct GnChunk;
+template <> struct GnChunk<bf16> { uint4 v; };
+template <> struct GnChunk<float> { float4 a, b; };
+__device__ __forceinline__ void gn_chunk_ld(const bf16* p, GnChunk<bf16>& c) { c.v = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void gn_chunk_ld(const float* p, GnChunk<float>& c) { c.a = *reinterpret_cast<const float4*>(p); c.b = *reinterpret_cast<const float4*>(p + 4); }
+__device__ __forceinline__ void gn_chunk_st(bf16* p, const GnChunk<bf16>& c) { *reinterpret_cast<uint4*>(p) = c.v; }
+__device__ __forceinline__ void gn_chunk_st(float* p, const GnChunk<float>& c) { *reinterpret_cast<float4*>(p) = c.a; *reinterpret_cast<float4*>(p + 4) = c.b; }
+__device__ __forceinline__ void gn_chunk_zero(GnChunk<bf16>& c) { c.v = make_uint4(0u, 0u, 0u, 0u); }
+__device__ __forceinline__ void gn_chunk_zero(GnChunk<float>& c) { c.a = make_float4(0.f, 0.f, 0.f, 0.f); c.b = c.a; }
+__device__ __forceinline__ void gn_chunk_get(const GnChunk<bf16>& c, float (&o)[8]) {
+    o[0] = __uint_as_float(c.v.x << 16); o[1] = __uint_as_float(c.v.x & 0xffff0000u); o[2] = __uint_as_float(c.v.y << 16); o[3] = __uint_as_float(c.v.y & 0xffff0000u);
+    o[4] = __uint_as_float(c.v.z << 16); o[5] = __uint_as_float(c.v.z & 0xffff0000u); o[6] = __uint_as_float(c.v.w << 16); o[7] = __uint_as_float(c.v.w & 0xffff0000u);
+}
+__device__ __forceinline__ void gn_chunk_get(const GnChunk<float>& c, float (&o)[8]) {
+    o[0] = c.a.x; o[1] = c.a.y; o[2] = c.a.z; o[3] = c.a.w; o[4] = c.b.x; o[5] = c.b.y; o[6] = c.b.z; o[7] = c.b.w;
+}
+__device__ __forceinline__ void gn_chunk_put(GnChunk<bf16>& c, const float (&o)[8]) {
+    c.v = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+}
+__device__ __forceinline__ void gn_chunk_put(GnChunk<float>& c, const float (&o)[8]) {
+    c.a = make_float4(o[0], o[1], o[2], o[3]); c.b = make_float4(o[4], o[5], o[6], o[7]);
+}
+// device-scope accesses of the frame barrier (the simulator never reaches the spin: see `phase`)
+#ifdef MAED_HOSTSIM
+__device__ __forceinline__ bool gn_frame_arrive_and_wait(uint32_t* ctr, uint32_t S) { atomicAdd(ctr, 1u); return *ctr >= S; }
+__device__ __forceinline__ float gn_coherent_read(float* p) { return *p; }
+#else
+__device__ __forceinline__ bool gn_frame_arrive_and_wait(uint32_t* ctr, uint32_t S) {      // ONE lane; every wave has drained its atomics (vmcnt 0 + barrier) before
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S; ) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 21)) return false;                  // seconds: a peer never arrived (dirty counter, lost launch) -- poison the result instead of hanging the GPU
+    }
+    return true;
+}
+__device__ __forceinline__ float gn_coherent_read(float* p) { return __hip_atomic_fetch_add(p, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
+// GPC: groups an 8-channel chunk spans (C / 32 channels per group: 1 for C >= 256, 2 for C = 128, 4 for C = 64); CH: chunks a thread keeps per tensor.
+// What crosses the frame barrier is only what the apply step needs: 2 x 32 gamma-weighted GROUP sums per workgroup (64 atomics out, 64 returning atomics back),
+// in sync[n][16..79]; the per-channel partials ab[n] (dgamma / dbeta: read by the closing column-sum kernel, not here) are added while lane 0 waits at the counter.
+#define GN1_SYNC_WORDS 80                     /* per frame: [0] arrival counter, [16..79] group sums (their own cache lines) */
+template <typename T, bool RELU, bool YMASK, int GPC, int CH, int NT>
+__global__ __launch_bounds__(NT, 4) void gn_bwd_onepass_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask, const T* __restrict__ dy,
+                                                                   const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* ab /* [N][C][2], zero at launch */, T* __restrict__ dx, T* __restrict__ dres,
+                                                                   uint32_t* sync /* [N][GN1_SYNC_WORDS], zero at launch */, int HW, int C, float eps, int S,
+                                                                   int rows_per_wg, int phase) {
+    MAED_DYN_SHARED(float, lpart);       // [NT / cbn][C][2] per-row-lane partials (32 KB)
+    __shared__ float lmu[GN_G], lrs[GN_G], lgrp[GN_G * 2], lb[GN_G], lk[GN_G];
+    __shared__ int lfail;
+    const int n = blockIdx.y, tid = threadIdx.x, cpg = C / GN_G;
+    if (tid < GN_G) {
+        const double cnt = (double)HW * cpg;
+        const double m = sums[((int64_t)n * GN_G + tid) * 2] / cnt;
+        double var = sums[((int64_t)n * GN_G + tid) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        lmu[tid] = (float)m; lrs[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    if (tid < GN_G * 2) lgrp[tid] = 0.f;
+    if (tid == 0) lfail = 0;
+    __syncthreads();
+    const int cbn = C / 8, cb = tid % cbn, rsub = tid / cbn, rstep = NT / cbn;
+    constexpr int JS = 8 / GPC;                                    // channels of a chunk that share a group
+    const int g0 = cb * 8 / cpg;
+    float mu[GPC], rs[GPC];
+#pragma unroll
+    for (int q = 0; q < GPC; ++q) { mu[q] = lmu[g0 + q]; rs[q] = lrs[g0 + q]; }
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
+    const int64_t base = ((int64_t)n * HW) * C + cb * 8;
+    float* const gsum = (float*)(sync + (int64_t)n * GN1_SYNC_WORDS + 16);
+
+    // ---- all loads of the slice in flight at once ----
+    GnChunk<T> xr[CH], dr[CH];
+    uint32_t mb[(CH + 3) / 4];
+#pragma unroll
+    for (int k = 0; k < (CH + 3) / 4; ++k) mb[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int r = r0 + rsub + k * rstep;
+        if (r < r1) {
+            gn_chunk_ld(x + base + (int64_t)r * C, xr[k]);
+            gn_chunk_ld(dy + base + (int64_t)r * C, dr[k]);
+            if (RELU && YMASK) mb[k >> 2] |= (uint32_t)mask[((int64_t)n * HW + r) * cbn + cb] << (8 * (k & 3));
+        } else { gn_chunk_zero(xr[k]); gn_chunk_zero(dr[k]); }
+    }
+    // ---- reduction over the slice; dr becomes the MASKED dy (exact: an element or zero) ----
+    {
+        float sa[8], sb[8], ga[8], be[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sa[j] = 0.f; sb[j] = 0.f; ga[j] = 0.f; be[j] = 0.f; }
+        if (RELU && !YMASK) { ld8(gamma + cb * 8, ga); ld8(beta + cb * 8, be); }     // (otherwise gamma is needed only behind the loop: 8 registers less across it)
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (r0 + rsub + k * rstep >= r1) continue;
+            float v[8], d[8];
+            gn_chunk_get(xr[k], v); gn_chunk_get(dr[k], d);
+            const uint32_t bits = (mb[k >> 2] >> (8 * (k & 3))) & 0xffu;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (v[j] - mu[j / JS]) * rs[j / JS];
+                if (RELU) d[j] = (YMASK ? ((bits >> j) & 1u) != 0u : fmaf(xh, ga[j], be[j]) > 0.f) ? d[j] : 0.f;
+                sa[j] += d[j]; sb[j] = fmaf(d[j], xh, sb[j]);
+            }
+            if (RELU) gn_chunk_put(dr[k], d);
+        }
+        if (!(RELU && !YMASK)) ld8(gamma + cb * 8, ga);
+        if (phase != 2) {
+            float* mine = lpart + ((size_t)rsub * C + cb * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mine[2 * j] = sa[j]; mine[2 * j + 1] = sb[j]; }
+            // gamma-weighted group partials of this thread -> the workgroup's 2 x 32 table
+#pragma unroll
+            for (int q = 0; q < GPC; ++q) {
+                float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                for (int j = q * JS; j < (q + 1) * JS; ++j) { p1 = fmaf(ga[j], sa[j], p1); p2 = fmaf(ga[j], sb[j], p2); }
+                // narrow layers (C < 512): 64 / cbn lanes of a wave hold the same chunk column -- fold them first (C = 64: 64 threads of the workgroup would
+                // otherwise queue at each of 8 x 8 LDS addresses: measured slower than the two-pass kernels)
+                for (int m = cbn; m < 64; m <<= 1) { p1 += __shfl_xor(p1, m, 64); p2 += __shfl_xor(p2, m, 64); }
+                if ((tid & 63) < cbn) { atomicAdd(&lgrp[(g0 + q) * 2], p1); atomicAdd(&lgrp[(g0 + q) * 2 + 1], p2); }
+            }
+        }
+    }
+    __syncthreads();
+    if (phase != 2) {
+        if (tid < GN_G * 2 && (S > 1 || phase == 1)) atomicAdd(gsum + tid, lgrp[tid]);
+        if (phase == 0 && S > 1) {
+            MAED_WAIT_VMCNT0();                                    // the 64 group-sum atomics have been performed
+            __syncthreads();
+            if (tid == 0 && !gn_frame_arrive_and_wait(sync + (int64_t)n * GN1_SYNC_WORDS, (uint32_t)S)) lfail = 1;
+        }
+        // per-channel partials for dgamma / dbeta (nobody in this kernel reads them): under lane 0's wait
+        for (int i = tid; i < 2 * C; i += NT) {
+            float t = 0.f;
+            for (int k = 0; k < rstep; ++k) t += lpart[(size_t)k * 2 * C + i];
+            atomicAdd(ab + (int64_t)n * C * 2 + i, t);
+        }
+        if (phase == 1) return;
+        __syncthreads();
+    }
+    if (tid < GN_G * 2 && (S > 1 || phase == 2)) lgrp[tid] = gn_coherent_read(gsum + tid);
+    __syncthreads();
+    if (tid < GN_G) {
+        const float cnt = (float)((double)HW * cpg);
+        const float poison = lfail ? __uint_as_float(0x7fc00000u) : 0.f;
+        lb[tid] = lrs[tid] * (lgrp[2 * tid] / cnt) + poison; lk[tid] = lrs[tid] * (lgrp[2 * tid + 1] / cnt);
+    }
+    __syncthreads();
+    // ---- apply from the registers: dx = rstd * (gamma * dy_eff - m1 - xhat * m2) ----
+    float A[8], B[GPC], K[GPC];
+    {
+        float gg[8];
+        ld8(gamma + cb * 8, gg);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A[j] = rs[j / JS] * gg[j];
+#pragma unroll
+        for (int q = 0; q < GPC; ++q) { B[q] = lb[g0 + q]; K[q] = lk[g0 + q]; }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int r = r0 + rsub + k * rstep;
+        if (r >= r1) continue;
+        float v[8], d[8], o[8];
+        gn_chunk_get(xr[k], v); gn_chunk_get(dr[k], d);
+        if (dres) gn_chunk_st(dres + base + (int64_t)r * C, dr[k]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(A[j], d[j], -fmaf((v[j] - mu[j / JS]) * rs[j / JS], K[j / JS], B[j / JS]));
+        GnChunk<T> oc;
+        gn_chunk_put(oc, o);
+        gn_chunk_st(dx + base + (int64_t)r * C, oc);
+    }
+}
+
 static int gn_check(int C, int HW, const char* who) {
     MAED_CHECK_ARG(C % GN_G == 0 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, MAED_ERR_SHAPE, "%s: C=%d unsupported (need C%%32==0, C/8 a power of two <= 256)", who, C);
     MAED_CHECK_ARG(HW > 0, MAED_ERR_SHAPE, "%s: HW=%d", who, HW);
@@ -371,7 +557,7 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
 
 extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                                   void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
-                                  int relu, int dtype, int ab_zeroed, void* aux_stream, void* stream) {
+                                  int relu, int dtype, int ab_zeroed, uint32_t* frame_sync, void* aux_stream, void* stream) {
     MAED_CHECK_ARG(x && dy && sums && gamma && beta && dx && dgamma && dbeta && ab_scratch, MAED_ERR_ARG, "groupnorm_bwd: null pointer");
     MAED_CHECK_ARG(!(relu && dres) || relu_mask, MAED_ERR_ARG, "groupnorm_bwd: the forward's relu_mask is needed when a residual was added before the ReLU");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_bwd"));
@@ -384,16 +570,42 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
     dim3 rgrid((HW + rrows - 1) / rrows, N);
     if (!ab_zeroed) MAED_HIP(hipMemsetAsync(ab_scratch, 0, (size_t)N * C * 2 * sizeof(float), s), "groupnorm_bwd: memset");
     const size_t lds = (size_t)(256 / (C / 8)) * 2 * C * sizeof(float);
-    const bool ymask = relu && relu_mask;      // residual added before the ReLU: the forward's bit mask (dres may be NULL: not materialised)
     // dgamma / dbeta from per-workgroup partials + a closing column sum instead of contended atomics in the reduction pass
     // (timed on MI355X, profiles/r02_call2_steady_*.csv: reduction passes 2.15 -> 1.42 ms per step + 0.31 ms closing kernels)
     constexpr int defer = 1;
+    // one pass over x and dy (gn_bwd_onepass_kernel) when the caller provides the per-frame arrival counters (zero at launch) and a frame fits 64 workgroups
+    // chunks per thread and tensor: 64 payload VGPRs (bf16: 8 chunks, f32: 4); one fewer where the ReLU mask is recomputed from x (gamma and beta live through
+    // the reduction: 8 chunks spill 7-14 VGPRs to scratch at the 128-VGPR budget of two 512-thread workgroups per CU)
+    const bool ymask = relu && relu_mask;      // residual added before the ReLU: the forward's bit mask (dres may be NULL: not materialised)
+    const int cpg = C / GN_G, cbn1 = C / 8, ch1 = dtype == MAED_BF16 ? ((relu && !ymask) ? 7 : 8) : 4;
+    int S1 = 0, rows1 = 0;
+    const int nt1 = maed_opt(MAED_OPT_GN_BWD_ONEPASS) == 2 ? 256 : GN1_NT;      // (2: experiment -- 256-thread workgroups, four per CU)
+    bool onepass = frame_sync && maed_opt(MAED_OPT_GN_BWD_ONEPASS) && cpg >= 2 && cbn1 <= nt1;
+    if (onepass) {
+        const int rstep = nt1 / cbn1, cap = ch1 * rstep;
+        S1 = (HW + cap - 1) / cap;
+        rows1 = (((HW + S1 - 1) / S1) + rstep - 1) / rstep * rstep;      // balanced slices, whole row steps
+        onepass = S1 <= 64;
+    }
 #define GN_RED(RELU_, YM_) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, RELU_, YM_>), rgrid, dim3(256), lds, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, gamma, beta, ab_scratch, dgamma, dbeta, HW, C, eps, rrows, defer)
 #define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
+#define GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, NT_) hipLaunchKernelGGL((gn_bwd_onepass_kernel<T, RELU_, YM_, GPC_, CH_, NT_>), dim3(S1, N), dim3(NT_), lds1, s, (const T*)x, relu_mask, \
+        (const T*)dy, sums, gamma, beta, ab_scratch, (T*)dx, (T*)dres, frame_sync, HW, C, eps, S1, rows1, PH_)
+#define GN_ONE3(RELU_, YM_, GPC_, CH_, PH_) do { if (nt1 == 256) GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, 256); else GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, GN1_NT); } while (0)
+#define GN_ONE2(RELU_, YM_, CH_, PH_) do { if (cpg >= 8) GN_ONE3(RELU_, YM_, 1, CH_, PH_); else if (cpg == 4) GN_ONE3(RELU_, YM_, 2, CH_, PH_); else GN_ONE3(RELU_, YM_, 4, CH_, PH_); } while (0)
+#define GN_ONE(PH_) do { constexpr int CH_ = sizeof(T) == 2 ? 8 : 4, CHM_ = sizeof(T) == 2 ? 7 : 4; \
+        if (!relu) GN_ONE2(false, false, CH_, PH_); else if (ymask) GN_ONE2(true, true, CH_, PH_); else GN_ONE2(true, false, CHM_, PH_); } while (0)
+    const size_t lds1 = (size_t)(nt1 / cbn1) * 2 * C * sizeof(float);
     MAED_DISPATCH_DTYPE(dtype, T, {
-        if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);
+        if (onepass) {
+#ifdef MAED_HOSTSIM
+            GN_ONE(1); GN_ONE(2);       // workgroups run one after another on the host: the two halves as two launches
+#else
+            GN_ONE(0);
+#endif
+        } else if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);
         if (defer) {
             // dgamma / dbeta are read by nobody before the caller joins aux_stream (ops.side_stream_join): the small column-sum kernel leaves the
             // dy -> dx chain and runs beside the apply pass
@@ -408,10 +620,15 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
             }
             hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 63) / 64, (N + 63) / 64), dim3(256), 0, sa, ab_scratch, dgamma, dbeta, N, C);
         }
-        if (ymask) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);
+        if (onepass) { }
+        else if (ymask) GN_APP(true, true); else if (dres) GN_APP(true, false); else if (relu) GN_APP(false, true); else GN_APP(false, false);
     });
 #undef GN_RED
 #undef GN_APP
+#undef GN_ONE
+#undef GN_ONE2
+#undef GN_ONE3
+#undef GN_ONE4
     MAED_CHECK_LAUNCH("groupnorm_bwd");
     return MAED_OK;
 }

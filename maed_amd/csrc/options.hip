@@ -11,6 +11,7 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {1},      // MAED_OPT_SIDE_STREAM
     {0},      // MAED_OPT_TN_TARGET_WGS: 0 = the built-in heuristic (gemm_tn.hip maed_tn_splits)
     {0},      // MAED_OPT_ABLATE
+    {1},      // MAED_OPT_GN_BWD_ONEPASS
 };
 
 extern "C" int maed_init(int device) {

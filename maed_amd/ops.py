@@ -716,13 +716,16 @@ class WeightStdFn(ReportingFn):
 LAZY_RES = {}
 
 
+GN_SYNC_WORDS = 80      # MAED_GN_SYNC_WORDS (include/maed_hip.h): 4-byte words per frame of maed_groupnorm_bwd's frame_sync scratch
+
+
 class GroupNormFn(torch.autograd.Function):
     """y = act(GroupNorm32(x) * gamma + beta [+ residual]) on channels_last tensors (maed_groupnorm_fwd/bwd).
     direct=True: gamma/beta gradients are accumulated by the kernel straight into gamma.grad / beta.grad (the
     owner module reports them through its grads_ready callback) instead of travelling through autograd."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, relu, direct, sums=None, ab=None, stats_ready=False, lazy_res=False):
+    def forward(ctx, x, residual, gamma, beta, eps, relu, direct, sums=None, ab=None, stats_ready=False, lazy_res=False, sync=None):
         """sums (N,32,2) f64 / ab (N,C,2) f32: optional PRE-ZEROED scratch slices (ResNetV2 zeroes one arena per pass for all
         its 52 layers instead of one memset per layer and direction).  stats_ready: `sums` already holds the statistics of x (the
         producing convolution's epilogue accumulated them: Conv1x1Fn / Conv3x3Fn gn_sums) -- no statistics pass."""
@@ -741,6 +744,7 @@ class GroupNormFn(torch.autograd.Function):
         check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), _p(mask), N, H * W, C_, eps, int(relu),
                                          dt_code(x.dtype), 2 if (stats_ready and zeroed) else int(zeroed), _stream()), "groupnorm_fwd")
         ctx.ab = ab
+        ctx.sync = sync if ab is not None else None      # N * GN_SYNC_WORDS zero words (any 4-byte dtype): frame_sync of the one-pass backward, single use like ab
         ctx.save_for_backward(x, mask, sums)
         ctx.eps, ctx.relu, ctx.direct = eps, relu, direct
         # lazy_res: the residual's gradient (dy masked by the ReLU bits) is not materialised -- backward hands dy itself on and registers the bit mask
@@ -766,22 +770,24 @@ class GroupNormFn(torch.autograd.Function):
         else:
             dgamma = torch.zeros(C_, dtype=torch.float32, device=x.device)
             dbeta = torch.zeros(C_, dtype=torch.float32, device=x.device)
-        ab, ab_zeroed = ctx.ab, ctx.ab is not None
-        ctx.ab = None                                   # single use: a second backward through this node gets fresh scratch
+        ab, ab_zeroed, sync = ctx.ab, ctx.ab is not None, ctx.sync
+        ctx.ab = ctx.sync = None                        # single use: a second backward through this node gets fresh scratch
         if ab is None:
             ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
+        if sync is None:
+            sync = torch.zeros(N * GN_SYNC_WORDS, dtype=torch.int32, device=x.device)
         # kernel-written dgamma / dbeta are read only after WeightStdFn.backward's side_stream_join: their closing column sum goes to the side stream
         aux = side_stream_handle(x.device, ab) if ctx.direct else None
         check(L.lib().maed_groupnorm_bwd(_p(x), _p(mask), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
-                                         N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), aux, _stream()), "groupnorm_bwd")
+                                         N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), _p(sync), aux, _stream()), "groupnorm_bwd")
         if ctx.lazy_res:
             for k in [k for k, (r, _) in LAZY_RES.items() if r() is None]:      # announcements whose consumer never ran (an interrupted backward)
                 del LAZY_RES[k]
             LAZY_RES[dy.data_ptr()] = (weakref.ref(dy), mask)
             dres = dy
         if ctx.direct:
-            return dx, dres, None, None, None, None, None, None, None, None, None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+            return dx, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class MaxPool3s2SameFn(torch.autograd.Function):

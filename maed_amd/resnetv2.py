@@ -161,6 +161,7 @@ class GroupNormAct(nn.GroupNorm):
     _direct_grad = False  # set by ResNetV2: the kernels accumulate dgamma/dbeta straight into .grad
     _sums_buf = None      # set by ResNetV2 per pass: pre-zeroed (N,32,2) f64 / (N,C,2) f32 scratch slices
     _ab_buf = None
+    _sync_buf = None      # ... and the N * GN_SYNC_WORDS zero words of the one-pass backward (maed_groupnorm_bwd frame_sync: arrival counter + group sums per frame)
     _stats_ready = False  # set by the convolution in front when its epilogue filled _sums_buf (consumed by the next forward)
 
     def __init__(self, num_channels, num_groups=32, eps=1e-5, affine=True, apply_act=True):
@@ -172,7 +173,8 @@ class GroupNormAct(nn.GroupNorm):
         relu = self.apply_act if relu is None else relu
         if ops.on_library_device(x) and self.num_groups == 32:
             ready, self._stats_ready = self._stats_ready and self._sums_buf is not None, False
-            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad, self._sums_buf, self._ab_buf, ready, lazy_res)
+            return ops.GroupNormFn.apply(x, residual, self.weight, self.bias, self.eps, relu, self._direct_grad, self._sums_buf, self._ab_buf, ready, lazy_res,
+                                         self._sync_buf)
         x = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
         if residual is not None:
             x = x + residual
@@ -338,7 +340,9 @@ class ResNetV2(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.fused_parameters()):
             self._grad_forward_seen = True
         if torch.is_grad_enabled() and any(p.requires_grad for p in (self._norms[0].weight, self._convs[0].weight)):
-            ab = torch.zeros(N * 2 * sum(m.num_channels for m in self._norms), dtype=torch.float32, device=x.device)
+            # (+ N * GN_SYNC_WORDS zero words per layer behind the partial sums: per-frame arrival counter + group sums of the one-pass GroupNorm backward --
+            #  same fill, single use)
+            ab = torch.zeros(N * 2 * sum(m.num_channels for m in self._norms) + N * ops.GN_SYNC_WORDS * len(self._norms), dtype=torch.float32, device=x.device)
         try:
             if ws is not None:
                 for i, (c, w) in enumerate(zip(self._convs, ws)):
@@ -348,8 +352,8 @@ class ResNetV2(nn.Module):
                 _slots(m, _sums_buf=sums[i])
                 if ab is not None:
                     n = N * 2 * m.num_channels
-                    _slots(m, _ab_buf=ab[off:off + n].view(N, m.num_channels, 2))
-                    off += n
+                    _slots(m, _ab_buf=ab[off:off + n].view(N, m.num_channels, 2), _sync_buf=ab[off + n:off + n + N * ops.GN_SYNC_WORDS])
+                    off += n + N * ops.GN_SYNC_WORDS
             if ws is not None:
                 return self.stages(self.stem(x))
             for gi, g in enumerate(self._ws_groups):       # standardise a stage's weights right before it runs: its autograd node
@@ -367,7 +371,7 @@ class ResNetV2(nn.Module):
             for c in self._convs:
                 _slots(c, _w_std=None, _w_t=None, _dw=None, _prec=None)
             for m in self._norms:
-                _slots(m, _sums_buf=None, _ab_buf=None)
+                _slots(m, _sums_buf=None, _ab_buf=None, _sync_buf=None)
 
     def forward(self, x, seqlen=8):
         return self.forward_features(x)

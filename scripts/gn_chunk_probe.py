@@ -42,7 +42,7 @@ def main():
                     sl = slice(n0, n0 + chunk)
                     mk = mask[n0 * HW * C // 8:(n0 + chunk) * HW * C // 8] if res else None
                     ops.check(lib.maed_groupnorm_bwd(p(x[sl]), p(mk), p(dy[sl]), p(sums[sl]), p(gamma), p(beta), p(dx[sl]), None, p(dg), p(db), p(ab[sl]),
-                                                     chunk, HW, C, 1e-5, 1, L.BF16, 1, None, st), "bwd")
+                                                     chunk, HW, C, 1e-5, 1, L.BF16, 1, None, None, st), "bwd")      # (frame_sync = None: the two-pass kernels this probe is about)
                 e1.record()
                 torch.cuda.synchronize()
                 if it:

@@ -5,6 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from maed_amd import _lib as L
 from maed_amd import ops
 
 from _hostsim import patched
@@ -59,6 +60,56 @@ def test_groupnorm_fused_matches_aten(relu, res):
     assert torch.allclose(gs.grad, gr.grad, rtol=1e-3, atol=1e-3) and torch.allclose(bs.grad, br.grad, rtol=1e-3, atol=1e-3)
     if res:
         assert torch.allclose(rs.grad, rr.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 20, 21), (1, 128, 10, 13), (2, 256, 14, 14), (1, 1024, 6, 6)])
+def test_groupnorm_backward_one_pass_register_resident(dtype, relu, res, N, C, H, W):
+    """round 4: maed_groupnorm_bwd with frame_sync -- x and dy are read ONCE, the slices stay in registers between the reduction and the apply step, the workgroups
+    of a frame meet at a per-frame counter.  Every shape here splits a frame over several workgroups (2-4 slices, ragged last slice, 1 / 2 / 4 groups per
+    8-channel chunk); the simulator runs workgroups one after another, so its launcher issues the two halves of the kernel as two launches: everything but the spin
+    itself is checked here -- against fp64 autograd on the same (rounded) inputs, and against the two-pass kernels."""
+    torch.manual_seed(5)
+    x = torch.randn(N, C, H, W).to(dtype); r = torch.randn(N, C, H, W).to(dtype) if res else None
+    gamma, beta = torch.randn(C), torch.randn(C)
+    g = torch.randn(N, C, H, W).to(dtype)
+    xr, gr, br = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if res else None
+    ref = F.group_norm(xr, 32, gr, br, 1e-5)
+    if res:
+        ref = ref + rr
+    if relu:
+        ref = F.relu(ref)
+    ref.backward(g.double())
+    out = {}
+    for onepass in (1, 0):
+        xs = cl(x.clone()).requires_grad_(True)
+        rs = cl(r.clone()).requires_grad_(True) if res else None
+        gs, bs = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        old = L.get_option(L.OPT_GN_BWD_ONEPASS)
+        with patched():
+            L.set_option(L.OPT_GN_BWD_ONEPASS, onepass)
+            try:
+                y = ops.GroupNormFn.apply(xs, rs, gs, bs, 1e-5, relu, False)
+                y.backward(cl(g))
+            finally:
+                L.set_option(L.OPT_GN_BWD_ONEPASS, old)
+        out[onepass] = (xs.grad.double(), gs.grad.double(), bs.grad.double(), rs.grad.double() if res else None)
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    for k, (dx, dg, db, dr) in out.items():
+        # near a ReLU kink a bf16-rounded output may flip sign against the fp64 reference: compare where the reference is clear of zero
+        clear = (ref.detach().abs() > (0 if dtype == torch.float32 else 2e-2)) | (not relu)
+        assert ((dx - xr.grad).abs() * clear).max() <= tol * xr.grad.abs().max(), (k, "dx")
+        if dtype == torch.float32:
+            assert (dg - gr.grad).abs().max() <= 1e-4 * gr.grad.abs().max() and (db - br.grad).abs().max() <= 1e-4 * br.grad.abs().max(), (k, "affine")
+        if res and dtype == torch.float32:
+            assert (dr - rr.grad).abs().max() <= 1e-6 * rr.grad.abs().max(), (k, "dres")
+    # one pass vs two passes: the same arithmetic up to summation order
+    assert (out[1][0] - out[0][0]).abs().max() <= (1e-5 if dtype == torch.float32 else 8e-3) * out[0][0].abs().max()
+    assert (out[1][1] - out[0][1]).abs().max() <= 1e-4 * out[0][1].abs().max() and (out[1][2] - out[0][2]).abs().max() <= 1e-4 * out[0][2].abs().max()
+    if res:
+        assert torch.equal(out[1][3], out[0][3])
 
 
 def test_weight_standardisation_batched_matches_aten():
