@@ -305,9 +305,23 @@ def main():
         model.train()
         arena = ParamArena(model)
         comm = None
-        if os.environ.get("MAED_COMM", "torch") == "direct" and not sim:   # the library's own RCCL communicator + side stream (maed_comm_*)
+        # transport of the gradient all-reduce (train.py:113,182): round 4 -- the LIBRARY's communicator (maed_comm_*: RCCL bound by dlsym, own side stream, event fences)
+        # is the default whenever collectives run (a process group with more than one rank, or forced ones); MAED_COMM=torch selects torch.distributed's
+        # ProcessGroupNCCL (the same RCCL).  If the own communicator cannot be created on this box the run falls back to torch.distributed, says so on stderr and in
+        # the JSON line (ddp.transport) -- a scaling run must not die of a transport choice.
+        want_direct = os.environ.get("MAED_COMM", "direct") == "direct" and not sim and dist.is_available() and dist.is_initialized() and (world > 1 or force_coll)
+        if want_direct:
             from maed_amd.ddp import RcclComm
-            comm = RcclComm()
+            try:
+                comm = RcclComm()
+            except Exception as e:  # noqa: BLE001
+                log(f"MAED_COMM=direct: own RCCL communicator unavailable ({e}); falling back to torch.distributed")
+                comm = None
+            ok = torch.tensor([1.0 if comm is not None else 0.0], device=dev)          # every rank takes the same transport
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0.0 and comm is not None:
+                comm.destroy()
+                comm = None
         bucketer = GradBucketer(arena, model, comm=comm, force_collectives=force_coll, **(dict(bucket_bytes=16 << 10) if sim else {}))
         bucketer.broadcast_parameters(0)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=bucketer)  # configs/config_stage2.yaml:63-66

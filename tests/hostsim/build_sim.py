@@ -22,13 +22,14 @@ ASAN = os.environ.get("MAED_SIM_ASAN", "0") not in ("", "0")
 SAN = ["-fsanitize=thread"] if TSAN else ["-fsanitize=address"] if ASAN else []
 OUT_DIR = os.path.join(HERE, "_build_tsan" if TSAN else "_build_asan" if ASAN else "_build")
 OUT = os.path.join(OUT_DIR, "libmaed_hostsim.so")
-SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip", "attn_long.hip", "gemm_x3.hip", "options.hip", "attn_x3.hip"]
+SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip", "attn_long.hip", "gemm_x3.hip", "options.hip", "attn_x3.hip",
+           "comm.hip"]      # (the RCCL wrapper against tests/hostsim/rccl/rccl.h: streams / events are no-ops here, the NCCL entry points come from whatever library the test names)
 CLANG = os.environ.get("MAED_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 def build(force=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + [os.path.join(HERE, "sim_support.cpp")]
-    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))) + [
+    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "rccl", "rccl.h")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))) + [
         os.path.join(ROOT, "include", "maed_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
@@ -49,6 +50,16 @@ def build(force=False):
         objs = list(ex.map(compile_one, srcs))
     subprocess.run([CLANG, "-shared", "-pthread"] + (SAN + ["-shared-libsan"] if SAN else []) + ["-o", OUT] + objs, check=True)
     return OUT
+
+
+def build_fakerccl(force=False):
+    """libfakerccl.so (tests/hostsim/fakerccl.cpp): the NCCL subset csrc/comm.hip binds, over shared memory between processes of one host"""
+    src, out = os.path.join(HERE, "fakerccl.cpp"), os.path.join(OUT_DIR, "libfakerccl.so")
+    deps = [src, os.path.join(HERE, "rccl", "rccl.h")]
+    if force or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps):
+        os.makedirs(OUT_DIR, exist_ok=True)
+        subprocess.run([CLANG, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-I", HERE, src, "-o", out, "-lrt"], check=True)
+    return out
 
 
 if __name__ == "__main__":

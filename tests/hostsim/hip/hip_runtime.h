@@ -256,6 +256,8 @@ static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 0
 template <typename K> static inline hipError_t hipFuncSetAttribute(K, int, int) { return hipSuccess; }
 
