@@ -183,7 +183,9 @@ def parity_mode_line(dev, steps=5):
         with torch.no_grad():
             ref = R.maed_forward(one, params, R.make_synthetic_smpl(0), depth=CFG["depth"], H=CFG["heads"])
         variants = {}
-        for name, bb in (("bf16x3", None), ("bf16x3_backbone_bf16x6", "bf16x6")):
+        for name, bb in (("bf16x3", None), ("bf16x3_backbone_bf16x6", "bf16x6"), ("bf16x3_fwd_bf16_bwd", None)):
+            # third variant (round 4): the same forward, the backward's matrix products with ONE bf16 plane (MAED_F32X1): outputs as accurate as bf16x3, gradients bf16-level
+            maed_amd.set_float32_backward_precision("bf16x1" if name == "bf16x3_fwd_bf16_bwd" else None)
             model = build_model(torch.float32, dev, bb).train()
             arena = ParamArena(model)
             opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=GradBucketer(arena, model))
@@ -217,8 +219,10 @@ def parity_mode_line(dev, steps=5):
             variants[name] = dict(ms_per_step=round(ms, 3), clips_per_sec=round(CFG["clips"] * 1e3 / ms, 2), theta_rel_err=err["theta"], rel_err=err)
             del m
         main_v = variants["bf16x3"]
+        # the fastest variant that meets north_star's 1e-3 on SMPL parameters at full module size: first-class in the bench line
+        fast = min((v for v in variants.items() if v[1]["theta_rel_err"] <= 1e-3), key=lambda kv: kv[1]["ms_per_step"], default=("bf16x3", main_v))
         return dict(compute_dtype="f32", f32_matmul="bf16x3", ms_per_step=main_v["ms_per_step"], clips_per_sec=main_v["clips_per_sec"], theta_rel_err=main_v["theta_rel_err"],
-                    steps=steps, variants=variants,
+                    steps=steps, variants=variants, fastest_within_1e3=dict(name=fast[0], **{k: fast[1][k] for k in ("ms_per_step", "clips_per_sec", "theta_rel_err")}),
                     note="same cfg3 train step in the fp32-accurate mode: fp32 activations / weights, every matrix product split into bf16 terms on the matrix cores "
                          "(csrc/gemm_x3.hip, attn_x3.hip: 3 MFMAs per product), library convolutions; rel_err = max |out - fp32 oracle| / max |oracle| of the forward at "
                          "full module size on one clip (north_star bar: 1e-3 on SMPL parameters).  variants.bf16x3_backbone_bf16x6: the backbone's forward / "
@@ -226,6 +230,7 @@ def parity_mode_line(dev, steps=5):
                          "(tests/test_gpu_parity_mode.py: every gradient of the full-size model)")
     finally:
         maed_amd.set_float32_matmul_precision(old)
+        maed_amd.set_float32_backward_precision(None)
 
 
 def main():
@@ -243,6 +248,8 @@ def main():
                     help="TEST ONLY (tests/test_bench_world2.py): the whole driver -- process group, broadcast, bucketed all-reduce overlapped with backward, "
                          "extra profiling steps, barriers, JSON -- on CPU tensors with the kernels on the host simulator and the gloo backend, tiny workload; "
                          "the number it prints is meaningless")
+    ap.add_argument("--f32-backward", default=None, choices=["same", "bf16x1"],
+                    help="--dtype f32 only: engine of the backward matrix products (maed_amd.set_float32_backward_precision): bf16x1 = one bf16 plane per operand")
     ap.add_argument("--backbone-f32-matmul", default=None, choices=["bf16x3", "bf16x6"],
                     help="--dtype f32 only: the backbone's own engine (MAED(backbone_f32_matmul=...)); default: the process-wide mode")
     args = ap.parse_args()
@@ -288,6 +295,9 @@ def main():
     if args.f32_matmul:
         import maed_amd
         maed_amd.set_float32_matmul_precision(args.f32_matmul)
+    if args.f32_backward:
+        import maed_amd
+        maed_amd.set_float32_backward_precision(args.f32_backward)
 
     log(f"building model ({args.dtype}) on {dev}")
     model = _SimModel() if sim else build_model(dtype, dev, args.backbone_f32_matmul)

@@ -35,7 +35,11 @@ extern "C" {
 typedef enum { MAED_F32 = 0, MAED_BF16 = 1,
                /* fp32 STORAGE with an explicit matrix-product engine (the per-call form of MAED_OPT_F32_MATMUL; accepted by the matrix-product entry
                 * points maed_gemm_nt, maed_gemm_tn_wgrad, maed_conv1x1_fwd, maed_conv3x3_fwd, maed_conv3x3_wgrad): split-bf16 with 3 / 6 MFMAs per product */
-               MAED_F32X3 = 2, MAED_F32X6 = 3 } maed_dtype;
+               MAED_F32X3 = 2, MAED_F32X6 = 3,
+               /* fp32 storage, ONE bf16 plane per operand (one MFMA per product: bf16-level products, fp32 accumulation, no bf16 copy of the tensors): the
+                * BACKWARD products of the mixed mode "bf16x3 forward / bf16 backward" (maed_gemm_nt, maed_gemm_tn_wgrad, maed_conv3x3_fwd as an input gradient,
+                * maed_conv3x3_wgrad; the attention entry points keep two planes) */
+               MAED_F32X1 = 4 } maed_dtype;
 
 typedef enum {
     MAED_OK = 0,
@@ -65,6 +69,7 @@ typedef enum { MAED_IMPL_AUTO = 0, MAED_IMPL_VALU = 1, MAED_IMPL_MFMA = 2,
                MAED_IMPL_MFMA_GLDS1 = 3, MAED_IMPL_MFMA_GLDS2 = 4, /* gemm_nt only: direct global->LDS staging, 1 or 2 LDS buffers */
                MAED_IMPL_MFMA_LONG = 5, /* attn_spatial only: K/V-tiled long-sequence kernels (chosen automatically past 512 / 320 tokens) */
                MAED_IMPL_MFMA_256 = 6, /* gemm_nt only: 256x256 tiles, counted-vmcnt LDS-DMA pipeline (csrc/gemm256.hip) */
+               MAED_IMPL_X1 = 9, /* gemm_nt only: fp32 operands, ONE bf16 plane (what dtype MAED_F32X1 selects) */
                MAED_IMPL_X3 = 7, MAED_IMPL_X6 = 8 /* MAED_F32 matrix products on the bf16 matrix cores: every fp32 operand split into 2 / 3 bf16
                                                    * terms, 3 / 6 MFMAs per product, fp32 accumulation (csrc/gemm_x3.hip): |error| ~2^-16 / ~2^-23
                                                    * of |a||b| instead of bf16's 2^-8.  MAED_IMPL_AUTO takes them when MAED_OPT_F32_MATMUL says so. */
@@ -88,6 +93,8 @@ typedef enum {
     MAED_OPT_TN_TARGET_WGS = 2, /* workgroups a weight-gradient GEMM is split into along M: 0 (default) = built-in heuristic, >= 64 = that target (sweep knob) */
     MAED_OPT_ABLATE = 3,        /* diagnostic builds (-DMAED_GEMM_ABLATE) only: bit mask of pipeline stages to drop */
     MAED_OPT_GN_BWD_ONEPASS = 4,/* 1 (default): maed_groupnorm_bwd with frame_sync reads x and dy once (register-resident slices + per-frame barrier); 0: two passes */
+    MAED_OPT_F32_BWD_X1 = 5,    /* 1: the fused STE block's BACKWARD matrix products on fp32 tensors use one bf16 plane (MAED_F32X1) whatever the forward engine is;
+                                 * 0 (default): the process-wide engine.  The host sets it together with its own per-call dtype codes (ops.set_float32_backward_precision) */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's

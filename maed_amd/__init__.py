@@ -10,4 +10,4 @@ from .resnetv2 import ResNetV2  # noqa: F401
 from .smpl import SMPL  # noqa: F401
 from .iterative import Regressor  # noqa: F401
 from .evaluate import Evaluator  # noqa: F401
-from .ops import set_float32_matmul_precision, get_float32_matmul_precision  # noqa: F401
+from .ops import set_float32_matmul_precision, get_float32_matmul_precision, set_float32_backward_precision, get_float32_backward_precision  # noqa: F401

@@ -12,13 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAED_HIP_LIB") or os.path.join(HERE, "libmaed_hip.so")   # override: A/B builds of the same C-ABI
 
 F32, BF16 = 0, 1
-F32X3, F32X6 = 2, 3     # fp32 storage with an explicit matrix-product engine (split-bf16, 3 / 6 MFMAs per product): matrix-product entry points only
+F32X3, F32X6, F32X1 = 2, 3, 4     # (F32X1: one bf16 plane -- backward products of the mixed mode) fp32 storage with an explicit matrix-product engine (split-bf16, 3 / 6 MFMAs per product): matrix-product entry points only
 EPI_STORE, EPI_GELU, EPI_RESID_F32, EPI_MUL_DGELU, EPI_ATOMIC_F32, EPI_STORE_F32, EPI_TANH, EPI_ADD = range(8)
 IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
-IMPL_X3, IMPL_X6 = 7, 8  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
-OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS = range(5)   # maed_option (include/maed_hip.h)
+IMPL_X3, IMPL_X6, IMPL_X1 = 7, 8, 9  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
+OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS, OPT_F32_BWD_X1 = range(6)   # maed_option (include/maed_hip.h)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -171,6 +171,7 @@ _OPTIONS = {
     OPT_SIDE_STREAM: int(os.environ.get("MAED_WGRAD_SIDE_STREAM", "1") == "1"),
     OPT_TN_TARGET_WGS: int(os.environ.get("MAED_TN_TARGET_WGS", "0")),
     OPT_ABLATE: int(os.environ.get("MAED_GEMM_ABLATE", "0")),
+    OPT_F32_BWD_X1: int(os.environ.get("MAED_F32_BWD", "") == "bf16x1"),
     OPT_GN_BWD_ONEPASS: int(os.environ.get("MAED_GN_BWD_ONEPASS", "1")),      # A/B knob: 0 = the two-pass GroupNorm backward (2: 256-thread variant of the one-pass kernel)
 }
 

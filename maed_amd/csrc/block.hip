@@ -289,17 +289,19 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
 #define TO_SIDE() do { if (ss) ss->fence(main_s, ss->s); } while (0)   /* operands produced so far on the chain are visible to the side stream */
 #define FROM_SIDE() do { if (ss) ss->fence(ss->s, main_s); } while (0) /* the chain waits for the weight gradients issued so far */
 #define WGRAD(expr) do { ProfScope ps__(PROF_GEMM_WGRAD, wst); MAED_PROPAGATE(expr); } while (0)
+        // matrix-product engine of the backward products on fp32 tensors: the process-wide one, or one bf16 plane (MAED_OPT_F32_BWD_X1: "bf16x3 forward / bf16 backward")
+        const int dmm = (dt == MAED_F32 && maed_opt(MAED_OPT_F32_BWD_X1)) ? MAED_F32X1 : dt;
         // MLP: x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
         // ALIASING (the header lets dx_in alias dx_out): in f32 the fc2 weight gradient reads dx_out ITSELF on the side stream, and dx_in is written only by the
         // closing layernorm_bwd_ws.  What orders the two: ev[63] is recorded on the side stream behind the fc1 weight gradient (hence behind this one) and the
         // caller's stream waits for it before the attention backward -- long before the closing LayerNorm.  Keep that wait if the order below is ever changed.
         TO_SIDE();
-        WGRAD(maed_gemm_tn_wgrad(dyc, C, sv + L.hact, Hd, M, C, Hd, g->w_fc2, Hd, g->b_fc2, dt, wst));
-        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dt, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
+        WGRAD(maed_gemm_tn_wgrad(dyc, C, sv + L.hact, Hd, M, C, Hd, g->w_fc2, Hd, g->b_fc2, dmm, wst));
+        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dyc, C, p->wt_fc2, C, M, Hd, C, dmm, MAED_EPI_MUL_DGELU, nullptr, sc + S.bigA, Hd, nullptr, sv + L.hpre, Hd, 1, gi, stream));
         TO_SIDE();
-        WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dt, wst));
+        WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, Hd, sv + L.ln2, C, M, Hd, C, g->w_fc1, C, g->b_fc1, dmm, wst));
         if (ss) MAED_HIP(hipEventRecord(ss->ev[63], ss->s), "ste_block_bwd: event");                       // "fc1 weight gradient done" (named slot, outside the ring)
-        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
+        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, Hd, p->wt_fc1, Hd, M, C, Hd, dmm, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
         // LayerNorm dgamma/dbeta via partials in the (here unused) transpose slot instead of contended atomics (measured on MI355X,
         // profiles/r02_call2_steady_*.csv: 0.629 -> 0.503 + 0.080 ms per step)
         const size_t big_t_bytes = (size_t)(Hd > 3 * C ? Hd : 3 * C) * (size_t)Mp * dtype_size(dt);      // S.bigT: only the exact-f32 path transposes into it
@@ -308,20 +310,20 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
                                              dx_out, dxmid, dt == MAED_F32 ? nullptr : dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream));
         // attention: x_mid = x_in + proj(mix(x_s, x_t))
         TO_SIDE();
-        WGRAD(maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dt, wst));
-        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
+        WGRAD(maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dmm, wst));
+        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dmm, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
         MAED_PROPAGATE(maed_st_mix_bwd_reduce(sc + S.act, sv + L.xs, sv + L.xt, logits, sc + S.dlog, (float*)(sc + S.ws), d->F, d->P, C, dt, stream));
         TO_SIDE();
-        WGRAD(maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dt, wst));
-        MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
+        WGRAD(maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dmm, wst));
+        MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dmm, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
         MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
         if (ss) MAED_HIP(hipStreamWaitEvent(main_s, ss->ev[63], 0), "ste_block_bwd: stream wait");               // the attention backward overwrites bigA, which the fc1 weight gradient reads
         PROF(PROF_ATTN_TM_BWD, maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
         PROF(PROF_ATTN_SP_BWD, maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,
                                                      MAED_IMPL_AUTO, stream));
         TO_SIDE();
-        WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, 3 * C, sv + L.ln1, C, M, 3 * C, C, g->w_qkv, C, g->b_qkv, dt, wst));
-        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dt, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
+        WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, 3 * C, sv + L.ln1, C, M, 3 * C, C, g->w_qkv, C, g->b_qkv, dmm, wst));
+        PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dmm, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
         MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in,
                                              dx_in_twin, g->ln1_g, g->ln1_b, M, C, ln_part, stream));
         FROM_SIDE();                                                     // scratch and gradients: everything after this call sees the weight gradients

@@ -589,11 +589,11 @@ template <int EPI>
 static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype,
                     const EpiArgs& e, int splitk, int impl, hipStream_t s) {
     if (dtype == MAED_F32) {
-        MAED_CHECK_ARG(impl == MAED_IMPL_AUTO || impl == MAED_IMPL_VALU || impl == MAED_IMPL_X3 || impl == MAED_IMPL_X6, MAED_ERR_UNSUPPORTED,
+        MAED_CHECK_ARG(impl == MAED_IMPL_AUTO || impl == MAED_IMPL_VALU || impl == MAED_IMPL_X3 || impl == MAED_IMPL_X6 || impl == MAED_IMPL_X1, MAED_ERR_UNSUPPORTED,
                        "gemm_nt: f32 runs on the exact-f32 VALU kernel (MAED_IMPL_VALU) or the split-bf16 MFMA kernel (MAED_IMPL_X3 / _X6); impl=%d", impl);
         // split-bf16 MFMA kernel (gemm_x3.hip): explicitly, or when the process-wide fp32 matmul mode asks for it.  GEMMs with few output tiles
         // (ts_attn, the decoder head: M = frames) take the split-K route below -- a 128-row tile per workgroup would leave most of the chip idle.
-        const int np = impl == MAED_IMPL_X3 ? 2 : impl == MAED_IMPL_X6 ? 3 : impl == MAED_IMPL_AUTO ? maed_x3_planes() : 0;
+        const int np = impl == MAED_IMPL_X3 ? 2 : impl == MAED_IMPL_X6 ? 3 : impl == MAED_IMPL_X1 ? 1 : impl == MAED_IMPL_AUTO ? maed_x3_planes() : 0;
         if (np) {
             const bool ok = maed_x3_nt_shape_ok(A, lda, B, ldb, K);       // (otherwise: the exact kernel below -- never less accurate than asked for)
             const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
@@ -701,7 +701,7 @@ extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
     MAED_CHECK_ARG(A && B && out, MAED_ERR_ARG, "gemm_nt: null pointer");
     {   // MAED_F32X3 / MAED_F32X6: fp32 storage with an explicit engine = MAED_F32 + impl MAED_IMPL_X3 / _X6
         const int np_call = maed_x3_take_dtype(dtype);
-        if (np_call && impl == MAED_IMPL_AUTO) impl = np_call == 2 ? MAED_IMPL_X3 : MAED_IMPL_X6;
+        if (np_call && impl == MAED_IMPL_AUTO) impl = np_call == 2 ? MAED_IMPL_X3 : np_call == 1 ? MAED_IMPL_X1 : MAED_IMPL_X6;
     }
     MAED_CHECK_ARG(dtype == MAED_F32 || dtype == MAED_BF16, MAED_ERR_ARG, "gemm_nt: bad dtype %d", dtype);
     MAED_CHECK_ARG(M >= 0 && N > 0 && K > 0 && lda >= K && ldb >= K && ldo >= N, MAED_ERR_SHAPE, "gemm_nt: bad extents M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);

@@ -55,6 +55,7 @@ int maed_tn_splits(int tiles);          // gemm_tn.hip: M-split heuristic of the
 static inline int maed_x3_take_dtype(int& dtype) {
     if (dtype == MAED_F32X3) { dtype = MAED_F32; return 2; }
     if (dtype == MAED_F32X6) { dtype = MAED_F32; return 3; }
+    if (dtype == MAED_F32X1) { dtype = MAED_F32; return 1; }
     return 0;
 }
 

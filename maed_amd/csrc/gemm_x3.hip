@@ -370,6 +370,7 @@ static void launch_nt_np(int np, const float* A, int64_t lda, const float* B, in
                          hipStream_t s) {
     const X3ConvDims d{};
     if (np == 3) launch_nt<EPI, 3, false, false, false>(A, lda, B, ldb, M, N, K, d, e, splitk, s);
+    else if (np == 1) launch_nt<EPI, 1, false, false, false>(A, lda, B, ldb, M, N, K, d, e, splitk, s);     // "bf16x1": one plane, one MFMA (backward products of the mixed mode)
     else launch_nt<EPI, 2, false, false, false>(A, lda, B, ldb, M, N, K, d, e, splitk, s);
 }
 
@@ -414,7 +415,7 @@ int maed_conv3x3_x3_launch(int np, const void* x, const void* w, const X3ConvDim
     if (add) { if (narrow) X3_C3(MAED_EPI_ADD, NP_, true, false); else X3_C3(MAED_EPI_ADD, NP_, false, false); } \
     else if (gn) { if (narrow) X3_C3(MAED_EPI_STORE, NP_, true, true); else X3_C3(MAED_EPI_STORE, NP_, false, true); } \
     else { if (narrow) X3_C3(MAED_EPI_STORE, NP_, true, false); else X3_C3(MAED_EPI_STORE, NP_, false, false); }
-    if (np == 3) { X3_C3_NP(3) } else { X3_C3_NP(2) }
+    if (np == 3) { X3_C3_NP(3) } else if (np == 1 && !gn) { X3_C3_NP(1) } else { X3_C3_NP(2) }      // (np = 1 with statistics: no such caller -- two planes, never less accurate than asked)
 #undef X3_C3_NP
 #undef X3_C3
     return MAED_OK;
@@ -442,6 +443,7 @@ int maed_gemm_tn_x3_launch(int np, const void* Y, int64_t ldy, const void* X, in
 #define X3_TN(NP_, CONV_) hipLaunchKernelGGL((gemm_tn_x3_kernel<NP_, CONV_>), grid, dim3(256), 0, s, (const float*)Y, ldy, (const float*)X, ldx, M, N, K, dW, ldw, \
                                              dbias, tk, per, cv)
     if (np == 3) { if (conv) X3_TN(3, true); else X3_TN(3, false); }
+    else if (np == 1) { if (conv) X3_TN(1, true); else X3_TN(1, false); }
     else { if (conv) X3_TN(2, true); else X3_TN(2, false); }
 #undef X3_TN
     return MAED_OK;

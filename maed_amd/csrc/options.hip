@@ -12,6 +12,7 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {0},      // MAED_OPT_TN_TARGET_WGS: 0 = the built-in heuristic (gemm_tn.hip maed_tn_splits)
     {0},      // MAED_OPT_ABLATE
     {1},      // MAED_OPT_GN_BWD_ONEPASS
+    {0},      // MAED_OPT_F32_BWD_X1
 };
 
 extern "C" int maed_init(int device) {

@@ -63,7 +63,7 @@ def f32_split():
 def lib_matmul_dtype(dtype, prec=None):
     """dtypes whose matrix products have library kernels for every role (forward, input gradient, weight gradient straight from row-major operands);
     prec: a module's own fp32 engine ("bf16x3" / "bf16x6", see mm_code), which counts like the process-wide mode"""
-    return dtype == torch.bfloat16 or (dtype == torch.float32 and (f32_split() or prec in ("bf16x3", "bf16x6")))
+    return dtype == torch.bfloat16 or (dtype == torch.float32 and (f32_split() or prec in ("bf16x3", "bf16x6", "bf16x1")))
 
 
 def bwd_prec(prec):
@@ -72,14 +72,29 @@ def bwd_prec(prec):
     The backward products themselves are linear in dy; their ~2^-16 error is not amplified (a weight gradient is even a leaf).  Measured on the full-size model
     against fp64 (scripts/x3_probe.py, profiles/r03_x3_probe_*.txt): backbone gradients with forward bf16x6 + backward bf16x3 sit exactly where all-bf16x6 does
     (median 1.60e-2 / 1.38e-2 / 2.7e-3 per stage = the fp32 oracle's own distance), all-bf16x3 at 7.0e-2 / 5.8e-2 / 7.9e-3; the step 50.8 -> 48.7 ms."""
+    if L.get_option(L.OPT_F32_BWD_X1):
+        return "bf16x1"
     return "bf16x3" if prec == "bf16x6" else prec
 
 
+def set_float32_backward_precision(mode):
+    """engine of the BACKWARD matrix products on fp32 tensors: None / "same" = the forward's (bf16x6 -> bf16x3, see bwd_prec), "bf16x1" = ONE bf16 plane per operand,
+    one MFMA per product ("bf16x3 forward / bf16 backward", round 4): outputs keep the forward engine's accuracy (1e-3 on SMPL parameters and better), gradients are
+    what the bf16 mode computes -- bf16 products, fp32 accumulation -- but from fp32-stored activations.  Process-wide (MAED_OPT_F32_BWD_X1: the fused STE block
+    driver reads it); MAED_F32_BWD=bf16x1 in the environment sets the initial value."""
+    assert mode in (None, "same", "bf16x1"), mode
+    L.set_option(L.OPT_F32_BWD_X1, int(mode == "bf16x1"))
+
+
+def get_float32_backward_precision():
+    return "bf16x1" if L.get_option(L.OPT_F32_BWD_X1) else "same"
+
+
 def mm_code(dtype, prec=None):
-    """dtype code for the matrix-product entry points: fp32 tensors of a module with its own engine (ResNetV2.f32_matmul) go as MAED_F32X3 / MAED_F32X6,
-    everything else as dt_code (fp32 then follows the process-wide mode)"""
-    if dtype == torch.float32 and prec in ("bf16x3", "bf16x6"):
-        return L.F32X3 if prec == "bf16x3" else L.F32X6
+    """dtype code for the matrix-product entry points: fp32 tensors of a module with its own engine (ResNetV2.f32_matmul) go as MAED_F32X3 / MAED_F32X6
+    (backward products of the mixed mode: MAED_F32X1), everything else as dt_code (fp32 then follows the process-wide mode)"""
+    if dtype == torch.float32 and prec in ("bf16x3", "bf16x6", "bf16x1"):
+        return {"bf16x3": L.F32X3, "bf16x6": L.F32X6, "bf16x1": L.F32X1}[prec]
     return dt_code(dtype)
 
 

@@ -15,6 +15,7 @@ from oracle import maed_ref as R
 from _util import DEV, note, q, report, rnd
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def t(a):
@@ -558,6 +559,40 @@ def test_cfg2_full_size_forward_f32_vs_oracle():
     for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts"):
         scale = ref[k].abs().max().item()
         report(f"cfg2 full size f32 {k} vs oracle", out[k], ref[k], rtol=0, atol=1e-3 * scale)
+
+
+def test_cfg5_full_size_forward_vs_oracle_fixture():
+    """BASELINE.json configs[4] at FULL size against the CPU oracle: one 64-frame 256x256 clip, depth 12, dim 768, 12 heads, max_seqlen = 64, in the fp32-accurate
+    mode (fp32 storage, split-bf16 products).  The oracle's outputs are a committed fixture (oracle/make_golden_cfg5.py: minutes of CPU work, generated where the
+    oracle lives); parameters and clip are regenerated here from the same seeds -- the fixture carries checksums of pos_embed / temp_embed / clip so that a
+    generator mismatch fails as such and not as a parity error.  Bar: 1e-3 of the output's maximum (north_star), as cfg2's full-size test.  A wrong-but-finite
+    pos_embed / temp_embed slice at P = 257 / T = 64 -- invisible to the property-level train-step test above -- fails here."""
+    import maed_amd
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_cfg5", os.path.join(ROOT, "oracle", "make_golden_cfg5.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "g15_cfg5_full.npz"))
+    params, clip = mk.inputs()
+    c5 = mk.CFG5
+    chk = np.array([params["encoder.pos_embed"].double().sum().item(), params["encoder.temp_embed"].double().sum().item(), clip.double().sum().item()])
+    assert np.allclose(chk, G["checks"], rtol=0, atol=1e-9), "seeded inputs differ from the ones the fixture was generated with"
+    old = maed_amd.get_float32_matmul_precision()
+    maed_amd.set_float32_matmul_precision("bf16x3")
+    try:
+        m = maed_amd.MAED(num_blocks=c5["depth"], num_heads=c5["H"], embed_dim=c5["C"], hidden_dim=c5["hidden"], img_size=c5["img"], max_seqlen=c5["T"],
+                          compute_dtype=torch.float32)
+        missing, unexpected = m.load_state_dict(params, strict=False)
+        assert not unexpected and all(".smpl." in k for k in missing), (missing, unexpected)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            out = m(clip.to(DEV))
+            feat = m.encoder(clip.reshape(-1, *clip.shape[2:]).to(DEV), seqlen=c5["T"])
+    finally:
+        maed_amd.set_float32_matmul_precision(old)
+    out = dict(out, verts_sample=out["verts"][:, :, ::53], feature=feat)
+    for k in ("feature", "theta", "kp_3d", "kp_2d", "rotmat", "verts_sample"):
+        ref = torch.from_numpy(G[k])
+        report(f"cfg5 full size (T=64, 256^2, depth 12, dim 768) f32/bf16x3 {k} vs oracle fixture", out[k], ref, rtol=0, atol=1e-3 * ref.abs().max().item())
 
 
 def _rms_rel(a, ref):

@@ -196,6 +196,37 @@ def test_gemm_tn_x3_rejects_operands_past_4gb(x3_mode):
     assert dW.abs().max() == 0
 
 
+def test_bf16x1_backward_engine_one_plane_products(x3_mode):
+    """round 4, the mixed mode "bf16x3 forward / bf16 backward": MAED_F32X1 = fp32 operands, ONE bf16 plane, one MFMA per product -- the same kernels with NP = 1.
+    The error is what a bf16 product has (2^-8 of |a||b|), not the split product's 2^-16: checked from both sides, for the NT GEMM (input gradients, incl. the
+    masked-add epilogue), the TN weight gradient and the 3x3 input gradient -- and ops.bwd_prec routes the backward there when the option is set."""
+    A, B = rnd(200, 96, seed=21), rnd(136, 96, seed=22)
+    ref = A.double() @ B.double().t()
+    with patched():
+        o1 = ops.gemm_nt(A, B, prec="bf16x1")
+        o3 = ops.gemm_nt(A, B, prec="bf16x3")
+    bnd = A.abs().double() @ B.abs().double().t()
+    e1, e3 = ((o1.double() - ref).abs() / bnd).max().item(), ((o3.double() - ref).abs() / bnd).max().item()
+    assert e3 < 2.0 ** -14 < e1 < 2.0 ** -7, (e1, e3)
+    assert torch.allclose(o1.double(), A.bfloat16().double() @ B.bfloat16().double().t(), rtol=0, atol=1e-4 * ref.abs().max())     # = the product of the bf16-rounded operands
+    Y, X = rnd(200, 72, seed=23), rnd(200, 136, seed=24)
+    with patched():
+        dW = ops.gemm_tn_wgrad(Y, X, prec="bf16x1")
+    assert torch.allclose(dW.double(), Y.bfloat16().double().t() @ X.bfloat16().double(), rtol=0, atol=1e-4 * dW.abs().max().item())
+    x = rnd(1, 64, 7, 6, seed=25).contiguous(memory_format=torch.channels_last)
+    w = rnd(64, 3, 3, 64, seed=26, scale=0.05)
+    with patched():
+        y1 = ops.conv3x3(x, w, 1, prec="bf16x1")
+    yr = F.conv2d(x.bfloat16().double(), w.permute(0, 3, 1, 2).bfloat16().double(), padding=1)
+    assert torch.allclose(y1.double(), yr, rtol=0, atol=1e-4 * yr.abs().max().item())
+    assert ops.bwd_prec(None) is None and ops.bwd_prec("bf16x6") == "bf16x3"
+    ops.set_float32_backward_precision("bf16x1")
+    try:
+        assert ops.bwd_prec(None) == "bf16x1" and ops.bwd_prec("bf16x6") == "bf16x1" and ops.get_float32_backward_precision() == "bf16x1"
+    finally:
+        ops.set_float32_backward_precision(None)
+
+
 def test_f32_library_convolutions_need_the_split_mode():
     """in the exact mode the entry points without an exact fp32 kernel refuse fp32 (loudly: no silent precision change)"""
     assert ops.get_float32_matmul_precision() == "exact"
