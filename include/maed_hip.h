@@ -95,6 +95,7 @@ typedef enum {
     MAED_OPT_GN_BWD_ONEPASS = 4,/* 1 (default): maed_groupnorm_bwd with frame_sync reads x and dy once (register-resident slices + per-frame barrier); 0: two passes */
     MAED_OPT_F32_BWD_X1 = 5,    /* 1: the fused STE block's BACKWARD matrix products on fp32 tensors use one bf16 plane (MAED_F32X1) whatever the forward engine is;
                                  * 0 (default): the process-wide engine.  The host sets it together with its own per-call dtype codes (ops.set_float32_backward_precision) */
+    MAED_OPT_ST_FUSED = 6,      /* 1 (default): the fused STE block runs the attentive addition as ONE launch per direction (maed_st_fused_fwd/bwd) where supported */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's
@@ -169,6 +170,17 @@ int maed_st_mix_bwd_reduce(const void* dmix, const void* x_s, const void* x_t, c
 /* dx_s = dmix*a0 + dmeans[f][c]/P ; dx_t = dmix*a1 + dmeans[f][C+c]/P ; dmeans[T](F,2C) */
 int maed_st_mix_bwd_apply(const void* dmix, const float* logits, const void* dmeans, void* dx_s, void* dx_t,
                           int F, int P, int C, int dtype, void* stream);
+/* K5 in ONE launch per direction (bf16; vision_transformer.py:152-158,176): token means + ts_attn Linear + pair softmax + mix fused -- a workgroup owns 128 channels
+ * of one frame for all P tokens in registers, the C / 128 workgroups of a frame exchange their means (forward) / dlogits (backward) through `ex` and meet at
+ * `sync`.  Writes what the separate entry points write: means (F,2C) bf16, logits (F,2C) fp32, mix; backward: dlogits (F,2C) bf16 (operand of the ts_attn weight
+ * gradient, which stays a maed_gemm_tn_wgrad call), dx_s, dx_t.  w_ts (2C,2C) as nn.Linear stores it, wt_ts its transposed image.
+ * sync: F*16 uint32 (cleared by the call), ex: F*2C floats -- caller-owned scratch.  maed_st_fused_supported: bf16, C % 128 == 0, C <= 1024, P <= 288. */
+int maed_st_fused_supported(int P, int C, int dtype);
+int maed_st_fused_fwd(const void* x_s, const void* x_t, const void* w_ts, const float* b_ts, void* means, float* logits, void* mix,
+                      uint32_t* sync, float* ex, int F, int P, int C, int dtype, void* stream);
+int maed_st_fused_bwd(const void* dmix, const void* x_s, const void* x_t, const float* logits, const void* wt_ts, void* dlogits, void* dx_s,
+                      void* dx_t, uint32_t* sync, float* ex, int F, int P, int C, int dtype, void* stream);
+
 
 /* ---- K8: cls / pos / temporal embeddings (vision_transformer.py:392-399) ---------------------- */
 /* tokens[f32](F,P,C): row 0 = cls, rows 1.. = patch[T](F,P-1,C); + pos_embed[p] + temp_embed[f % T] */

@@ -18,7 +18,7 @@ IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
 IMPL_X3, IMPL_X6, IMPL_X1 = 7, 8, 9  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
-OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS, OPT_F32_BWD_X1 = range(6)   # maed_option (include/maed_hip.h)
+OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS, OPT_F32_BWD_X1, OPT_ST_FUSED = range(7)   # maed_option (include/maed_hip.h)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -75,6 +75,9 @@ SIGNATURES = {
     "maed_st_mix_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_st_mix_bwd_reduce": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_st_mix_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "maed_st_fused_supported": (i32, [i32, i32, i32]),
+    "maed_st_fused_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "maed_st_fused_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_embed_add_fwd": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_embed_add_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp]),
     "maed_ste_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
@@ -172,6 +175,7 @@ _OPTIONS = {
     OPT_TN_TARGET_WGS: int(os.environ.get("MAED_TN_TARGET_WGS", "0")),
     OPT_ABLATE: int(os.environ.get("MAED_GEMM_ABLATE", "0")),
     OPT_F32_BWD_X1: int(os.environ.get("MAED_F32_BWD", "") == "bf16x1"),
+    OPT_ST_FUSED: int(os.environ.get("MAED_ST_FUSED", "1") == "1"),              # A/B knob: 0 = the attentive addition as four launches per direction
     OPT_GN_BWD_ONEPASS: int(os.environ.get("MAED_GN_BWD_ONEPASS", "1")),      # A/B knob: 0 = the two-pass GroupNorm backward (2: 256-thread variant of the one-pass kernel)
 }
 

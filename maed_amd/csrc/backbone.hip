@@ -368,22 +368,6 @@ __device__ __forceinline__ void gn_chunk_put(GnChunk<bf16>& c, const float (&o)[
 __device__ __forceinline__ void gn_chunk_put(GnChunk<float>& c, const float (&o)[8]) {
     c.a = make_float4(o[0], o[1], o[2], o[3]); c.b = make_float4(o[4], o[5], o[6], o[7]);
 }
-// device-scope accesses of the frame barrier (the simulator never reaches the spin: see `phase`)
-#ifdef MAED_HOSTSIM
-__device__ __forceinline__ bool gn_frame_arrive_and_wait(uint32_t* ctr, uint32_t S) { atomicAdd(ctr, 1u); return *ctr >= S; }
-__device__ __forceinline__ float gn_coherent_read(float* p) { return *p; }
-#else
-__device__ __forceinline__ bool gn_frame_arrive_and_wait(uint32_t* ctr, uint32_t S) {      // ONE lane; every wave has drained its atomics (vmcnt 0 + barrier) before
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S; ) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 21)) return false;                  // seconds: a peer never arrived (dirty counter, lost launch) -- poison the result instead of hanging the GPU
-    }
-    return true;
-}
-__device__ __forceinline__ float gn_coherent_read(float* p) { return __hip_atomic_fetch_add(p, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#endif
-
 // GPC: groups an 8-channel chunk spans (C / 32 channels per group: 1 for C >= 256, 2 for C = 128, 4 for C = 64); CH: chunks a thread keeps per tensor.
 // What crosses the frame barrier is only what the apply step needs: 2 x 32 gamma-weighted GROUP sums per workgroup (64 atomics out, 64 returning atomics back),
 // in sync[n][16..79]; the per-channel partials ab[n] (dgamma / dbeta: read by the closing column-sum kernel, not here) are added while lane 0 waits at the counter.
@@ -476,7 +460,7 @@ __global__ __launch_bounds__(NT, 4) void gn_bwd_onepass_kernel(const T* __restri
         if (phase == 0 && S > 1) {
             MAED_WAIT_VMCNT0();                                    // the 64 group-sum atomics have been performed
             __syncthreads();
-            if (tid == 0 && !gn_frame_arrive_and_wait(sync + (int64_t)n * GN1_SYNC_WORDS, (uint32_t)S)) lfail = 1;
+            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)n * GN1_SYNC_WORDS, (uint32_t)S)) lfail = 1;
         }
         // per-channel partials for dgamma / dbeta (nobody in this kernel reads them): under lane 0's wait
         for (int i = tid; i < 2 * C; i += NT) {
@@ -487,7 +471,7 @@ __global__ __launch_bounds__(NT, 4) void gn_bwd_onepass_kernel(const T* __restri
         if (phase == 1) return;
         __syncthreads();
     }
-    if (tid < GN_G * 2 && (S > 1 || phase == 2)) lgrp[tid] = gn_coherent_read(gsum + tid);
+    if (tid < GN_G * 2 && (S > 1 || phase == 2)) lgrp[tid] = maed_coherent_read(gsum + tid);
     __syncthreads();
     if (tid < GN_G) {
         const float cnt = (float)((double)HW * cpg);

@@ -131,7 +131,7 @@ namespace {
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct SavedLayout {
-    size_t ln1, mean1, rstd1, qkv, xs, xt, lse_s, lse_t, means, logits, mix, xmid, mean2, rstd2, ln2, hpre, hact, total;
+    size_t ln1, mean1, rstd1, qkv, xs, xt, lse_s, lse_t, means, logits, mix, xmid, mean2, rstd2, ln2, hpre, hact, st_sync, st_ex, total;
 };
 struct ScratchLayout {
     size_t dyc, dyt, bigA, bigT, xT, act, dxs, dxt, dxmid, dlog, dmeans, dlogT, meansT, ws, total;
@@ -151,6 +151,7 @@ SavedLayout saved_layout(const maed_block_dims& d) {
     s.mix = take(M * C * es); s.xmid = take(M * C * 4);
     s.mean2 = take(M * 4); s.rstd2 = take(M * 4); s.ln2 = take(M * C * es);
     s.hpre = take(M * Hd * es); s.hact = take(M * Hd * es);
+    s.st_sync = take((size_t)d.F * 16 * 4); s.st_ex = take((size_t)d.F * 2 * C * 4);      // scratch of the fused attentive addition (maed_st_fused_fwd / _bwd)
     s.total = o;
     return s;
 }
@@ -191,6 +192,13 @@ int check_dims(const maed_block_dims* d, const char* who) {
     MAED_CHECK_ARG(d->F % d->T == 0, MAED_ERR_SHAPE, "%s: F=%d not a multiple of T=%d", who, d->F, d->T);
     MAED_CHECK_ARG(d->hidden % 64 == 0, MAED_ERR_SHAPE, "%s: hidden=%d must be a multiple of 64", who, d->hidden);
     return MAED_OK;
+}
+
+// the attentive addition as one launch per direction (bf16 MFMA mode; MAED_OPT_ST_FUSED = 0 keeps the four-launch sequence: A/B knob)
+bool st_fused(const maed_block_dims& d) {
+    // (P <= 224: the 7-chunk instantiations, two workgroups per CU; at cfg5's P = 257 / C = 768 the 9-chunk backward runs one workgroup per CU and measured 0.3 ms
+    //  per step SLOWER than the four-launch sequence -- profiles/r04_st_fused_bench_ab.txt)
+    return d.impl != MAED_IMPL_VALU && maed_opt(MAED_OPT_ST_FUSED) && d.P <= 224 && maed_st_fused_supported(d.P, d.C, d.dtype);
 }
 
 // split-K so that a weight-gradient GEMM (small output, huge K) still fills 256 CUs
@@ -238,9 +246,14 @@ static int block_fwd(const maed_block_dims* d, const maed_block_params* p, const
         PROF(PROF_ATTN_SP_FWD, maed_attn_spatial_fwd(sv + L.qkv, sv + L.xs, (float*)(sv + L.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
         if (ss) ss->fence(ss->s, (hipStream_t)stream);
     }
-    MAED_PROPAGATE(maed_st_colmean(sv + L.xs, sv + L.xt, sv + L.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
-    MAED_PROPAGATE(maed_gemm_nt(sv + L.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
-    MAED_PROPAGATE(maed_st_mix_fwd(sv + L.xs, sv + L.xt, logits, sv + L.mix, d->F, d->P, C, dt, stream));
+    if (st_fused(*d)) {       // token means + ts_attn Linear + pair softmax + mix: one launch, x_s / x_t read once (elementwise.hip)
+        PROF(PROF_ST_FWD, maed_st_fused_fwd(sv + L.xs, sv + L.xt, p->w_ts, p->b_ts, sv + L.means, logits, sv + L.mix, (uint32_t*)(sv + L.st_sync), (float*)(sv + L.st_ex),
+                                            d->F, d->P, C, dt, stream));
+    } else {
+        MAED_PROPAGATE(maed_st_colmean(sv + L.xs, sv + L.xt, sv + L.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
+        MAED_PROPAGATE(maed_gemm_nt(sv + L.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
+        MAED_PROPAGATE(maed_st_mix_fwd(sv + L.xs, sv + L.xt, logits, sv + L.mix, d->F, d->P, C, dt, stream));
+    }
     PROF(PROF_GEMM_PROJ, maed_gemm_nt(sv + L.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, sv + L.xmid, C, nullptr, x_in, C, 1, gi, stream));
     MAED_PROPAGATE(maed_layernorm_fwd((const float*)(sv + L.xmid), C, p->ln2_g, p->ln2_b, sv + L.ln2, dt, (float*)(sv + L.mean2), (float*)(sv + L.rstd2), M, C, d->eps, stream));
     PROF(PROF_GEMM_FC1, maed_gemm_nt(sv + L.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, sv + L.hact, Hd, for_backward ? sv + L.hpre : nullptr /* only GELU' reads it */, nullptr, 0, 1, gi, stream));
@@ -312,11 +325,18 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         TO_SIDE();
         WGRAD(maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dmm, wst));
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dmm, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
-        MAED_PROPAGATE(maed_st_mix_bwd_reduce(sc + S.act, sv + L.xs, sv + L.xt, logits, sc + S.dlog, (float*)(sc + S.ws), d->F, d->P, C, dt, stream));
-        TO_SIDE();
-        WGRAD(maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dmm, wst));
-        MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dmm, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
-        MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
+        if (st_fused(*d)) {   // dlogits + d(means) = dlogits . W_ts + dx_s / dx_t: one launch, dmix / x_s / x_t read once; the ts_attn weight gradient follows on the side stream
+            PROF(PROF_ST_BWD, maed_st_fused_bwd(sc + S.act, sv + L.xs, sv + L.xt, logits, p->wt_ts, sc + S.dlog, sc + S.dxs, sc + S.dxt, (uint32_t*)(sv + L.st_sync),
+                                                (float*)(sv + L.st_ex), d->F, d->P, C, dt, stream));
+            TO_SIDE();
+            WGRAD(maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dmm, wst));
+        } else {
+            MAED_PROPAGATE(maed_st_mix_bwd_reduce(sc + S.act, sv + L.xs, sv + L.xt, logits, sc + S.dlog, (float*)(sc + S.ws), d->F, d->P, C, dt, stream));
+            TO_SIDE();
+            WGRAD(maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dmm, wst));
+            MAED_PROPAGATE(maed_gemm_nt(sc + S.dlog, 2 * C, p->wt_ts, 2 * C, d->F, 2 * C, 2 * C, dmm, MAED_EPI_STORE, nullptr, sc + S.dmeans, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
+            MAED_PROPAGATE(maed_st_mix_bwd_apply(sc + S.act, logits, sc + S.dmeans, sc + S.dxs, sc + S.dxt, d->F, d->P, C, dt, stream));
+        }
         if (ss) MAED_HIP(hipStreamWaitEvent(main_s, ss->ev[63], 0), "ste_block_bwd: stream wait");               // the attention backward overwrites bigA, which the fc1 weight gradient reads
         PROF(PROF_ATTN_TM_BWD, maed_attn_temporal_bwd(sv + L.qkv, sv + L.xt, sc + S.dxt, (const float*)(sv + L.lse_t), sc + S.bigA, 0, d->F, d->P, d->H, d->T, scale, dt, stream));
         PROF(PROF_ATTN_SP_BWD, maed_attn_spatial_bwd(sv + L.qkv, sv + L.xs, sc + S.dxs, (const float*)(sv + L.lse_s), sc + S.bigA, 1, d->F, d->P, d->H, scale, dt,

@@ -171,6 +171,31 @@ __device__ __forceinline__ void colsum_add(const float* __restrict__ src, int ro
     if (rl == 0 && c < cols) atomicAdd(dst_of(c), (fold[0][threadIdx.x] + fold[1][threadIdx.x]) + (fold[2][threadIdx.x] + fold[3][threadIdx.x]));
 }
 
+// ---- hand-offs between workgroups INSIDE a launch (the one-pass GroupNorm backward, the fused attentive addition) ---------------------------------------
+// gfx950: eight XCDs with private L2s, a CU's vector L1 is never refreshed by another CU's stores.  The forms used here (MI355X_MICROARCH.md, "inter-workgroup
+// visibility"): payload as device-scope atomics (adds, or relaxed agent stores = write-through `sc1` stores) -> every storing wave drains (vmcnt 0) -> barrier ->
+// ONE lane adds to the arrival counter and polls it relaxed; consumers read the payload with device-scope loads / returning atomics.  No L2 write-back, no L1
+// invalidate.  The spin is bounded: a peer that never arrives (dirty counter, lost launch) turns into a poisoned result, not a hung GPU.
+// The host simulator runs workgroups one after another and never reaches the spin (the callers split such kernels into two launches there).
+#ifdef MAED_HOSTSIM
+__device__ __forceinline__ bool maed_frame_arrive_and_wait(uint32_t* ctr, uint32_t S) { atomicAdd(ctr, 1u); return *ctr >= S; }
+__device__ __forceinline__ float maed_coherent_read(float* p) { return *p; }
+__device__ __forceinline__ void maed_agent_store(float* p, float v) { *p = v; }
+__device__ __forceinline__ float maed_agent_load(const float* p) { return *p; }
+#else
+__device__ __forceinline__ bool maed_frame_arrive_and_wait(uint32_t* ctr, uint32_t S) {      // ONE lane; every wave has drained its payload (vmcnt 0 + barrier) before
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S; ) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 21)) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ float maed_coherent_read(float* p) { return __hip_atomic_fetch_add(p, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void maed_agent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float maed_agent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
 // ---- math ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_erf(float x) {

@@ -101,6 +101,245 @@ __global__ __launch_bounds__(256) void st_mix_bwd_apply_kernel(const T* __restri
     st4(dx_s + e, os); st4(dx_t + e, ot);
 }
 
+// ---- K5 in ONE launch per direction (round 4, bf16) ----------------------------------------------------------------------------------------------------
+// The attentive addition is small (x_s, x_t: 25 MB each at cfg3) but took four launches forward (token means, their cast, the F x 2C x 2C ts_attn GEMM, the mix)
+// and four backward, two of them token-axis reductions that run at 2 TB/s.  What forces the split is one dependency: a frame's 2C logits need the token means of
+// ALL its channels.  Here a frame is cut by CHANNELS: a workgroup owns 128 channels of one frame for all P tokens (2 x 50 KB of x_s / x_t at P = 197: 56 payload
+// VGPRs per thread), so its token means are complete inside the workgroup; the C / 128 workgroups of a frame publish their bf16-rounded means (device-scope
+// stores), meet at a per-frame counter, read the frame's 2C means back, compute THEIR 256 logits as a GEMV against the ts_attn weight (8 lanes per weight row:
+// coalesced 128-byte reads, L2-resident 2 MB), and mix straight from the registers.  x_s and x_t are read once, `means` / `logits` are still written (the
+// backward needs them).  Backward: the same cut -- dlogits of a channel pair are local to the workgroup, d(means) = dlogits . W_ts needs the frame's 2C dlogits.
+// The arithmetic is the separate kernels' (bf16-rounded means / dlogits / dmeans where those were stored as bf16, fp32 accumulation).
+// sync: F x 16 words, zero at launch (the launcher clears them); ex: F x 2C floats of exchange space.
+// phase 0: everything; 1 / 2: the halves before / after the frame barrier as two launches (host simulator: workgroups run one after another).
+#define ST1_NT 512
+__device__ __forceinline__ void st1_unpack(const uint4& v, float (&o)[8]) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u); o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u); o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+// this workgroup's 256 GEMV outputs: out[row] = sum_k W[row_of(row)][k] * vec[k], k < K2 (K2 % 64 == 0); 8 lanes per weight row, 64 rows per pass
+template <typename RowOf, typename Emit>
+__device__ __forceinline__ void st1_gemv256(const bf16* __restrict__ W, int K2, const float* vec, RowOf row_of, Emit emit) {
+    const int g = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 64 + g;
+        const bf16* wr = W + (int64_t)row_of(row) * K2;
+        float acc = 0.f;
+        for (int k8 = l8; k8 < K2 / 8; k8 += 8) {
+            float w[8];
+            ld8(wr + k8 * 8, w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(w[j], vec[k8 * 8 + j], acc);
+        }
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        if (l8 == 0) emit(row, acc);
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(ST1_NT, 4) void st_fused_fwd_kernel(const bf16* __restrict__ x_s, const bf16* __restrict__ x_t, const bf16* __restrict__ w_ts,
+                                                                 const float* __restrict__ b_ts, bf16* __restrict__ means, float* __restrict__ logits,
+                                                                 bf16* __restrict__ mix, uint32_t* sync, float* ex, int P, int C, int S, int phase) {
+    __shared__ float lpart[32 * 16 * 16];      // [row lane][chunk][x_s: 8 | x_t: 8] token-sum partials
+    __shared__ float lvec[2048];               // the frame's 2C means
+    __shared__ float llog[256];                // this slice's 128 logit pairs
+    __shared__ int lfail;
+    const int f = blockIdx.y, c0 = blockIdx.x * 128, tid = threadIdx.x, cb = tid & 15, rsub = tid >> 4;
+    const int64_t base = (int64_t)f * P * C + c0 + cb * 8;
+    uint4 xs[CH], xt[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int r = rsub + 32 * k;
+        if (r < P) { xs[k] = *reinterpret_cast<const uint4*>(x_s + base + (int64_t)r * C); xt[k] = *reinterpret_cast<const uint4*>(x_t + base + (int64_t)r * C); }
+        else { xs[k] = make_uint4(0u, 0u, 0u, 0u); xt[k] = xs[k]; }
+    }
+    if (tid == 0) lfail = 0;
+    if (phase != 2) {
+        float ss[8], st[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ss[j] = 0.f; st[j] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            float a[8], b[8];
+            st1_unpack(xs[k], a); st1_unpack(xt[k], b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ss[j] += a[j]; st[j] += b[j]; }
+        }
+        float* mine = lpart + (rsub * 16 + cb) * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mine[j] = ss[j]; mine[8 + j] = st[j]; }
+        __syncthreads();
+        if (tid < 256) {
+            const int which = tid >> 7, c = tid & 127;
+            float t = 0.f;
+            for (int r = 0; r < 32; ++r) t += lpart[(r * 16 + (c >> 3)) * 16 + which * 8 + (c & 7)];
+            const unsigned short mb = f2bf(t * (1.f / (float)P));            // the bf16 the ts_attn GEMM read (means are saved for its weight gradient)
+            means[(int64_t)f * 2 * C + which * C + c0 + c].v = mb;
+            maed_agent_store(ex + (int64_t)f * 2 * C + which * C + c0 + c, bf2f(mb));
+        }
+        if (phase == 1) return;
+        MAED_WAIT_VMCNT0();                                          // the published means have left this wave
+        __syncthreads();
+        if (S > 1) {
+            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, (uint32_t)S)) lfail = 1;
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < 2 * C; i += ST1_NT) lvec[i] = maed_agent_load(ex + (int64_t)f * 2 * C + i);
+    __syncthreads();
+    const float poison = lfail ? __uint_as_float(0x7fc00000u) : 0.f;
+    st1_gemv256(w_ts, 2 * C, lvec, [=](int row) { return 2 * c0 + row; },
+                [&](int row, float acc) { const float v = acc + b_ts[2 * c0 + row] + poison; logits[(int64_t)f * 2 * C + 2 * c0 + row] = v; llog[row] = v; });
+    __syncthreads();
+    float a0[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = 1.f / (1.f + __expf(llog[2 * (cb * 8 + j) + 1] - llog[2 * (cb * 8 + j)]));     // softmax over the pair, weight of x_s
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int r = rsub + 32 * k;
+        if (r >= P) continue;
+        float a[8], b[8], o[8];
+        st1_unpack(xs[k], a); st1_unpack(xt[k], b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = b[j] * (1.f - a0[j]) + a[j] * a0[j];
+        st8(mix + base + (int64_t)r * C, o);
+    }
+}
+
+template <int CH>
+// (P > 224: three tensors x 9 chunks do not fit 128 VGPRs -- one workgroup per CU there)
+__global__ __launch_bounds__(ST1_NT, (CH > 7 ? 2 : 4)) void st_fused_bwd_kernel(const bf16* __restrict__ dmix, const bf16* __restrict__ x_s, const bf16* __restrict__ x_t,
+                                                                 const float* __restrict__ logits, const bf16* __restrict__ wt_ts, bf16* __restrict__ dlogits,
+                                                                 bf16* __restrict__ dx_s, bf16* __restrict__ dx_t, uint32_t* sync, float* ex, int P, int C,
+                                                                 int S, int phase) {
+    __shared__ float lpart[32 * 16 * 16];      // [row lane][chunk][sum dmix x_s: 8 | sum dmix x_t: 8]
+    __shared__ float lvec[2048];               // the frame's 2C dlogits
+    __shared__ float ldm[256];                 // d(means) of this slice: x_s half, x_t half
+    __shared__ float la0[128];
+    __shared__ int lfail;
+    const int f = blockIdx.y, c0 = blockIdx.x * 128, tid = threadIdx.x, cb = tid & 15, rsub = tid >> 4;
+    const int64_t base = (int64_t)f * P * C + c0 + cb * 8;
+    uint4 dm[CH];
+    if (tid == 0) lfail = 0;
+    if (tid < 128) {
+        const float l0 = logits[(int64_t)f * 2 * C + 2 * (c0 + tid)], l1 = logits[(int64_t)f * 2 * C + 2 * (c0 + tid) + 1];
+        la0[tid] = 1.f / (1.f + __expf(l1 - l0));
+    }
+    {
+        uint4 xs[CH], xt[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int r = rsub + 32 * k;
+            if (r < P) {
+                dm[k] = *reinterpret_cast<const uint4*>(dmix + base + (int64_t)r * C);
+                if (phase != 2) { xs[k] = *reinterpret_cast<const uint4*>(x_s + base + (int64_t)r * C); xt[k] = *reinterpret_cast<const uint4*>(x_t + base + (int64_t)r * C); }
+            } else { dm[k] = make_uint4(0u, 0u, 0u, 0u); xs[k] = dm[k]; xt[k] = dm[k]; }
+        }
+        if (phase != 2) {
+            float s0[8], s1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (rsub + 32 * k >= P) continue;
+                float d[8], a[8], b[8];
+                st1_unpack(dm[k], d); st1_unpack(xs[k], a); st1_unpack(xt[k], b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s0[j] = fmaf(d[j], a[j], s0[j]); s1[j] = fmaf(d[j], b[j], s1[j]); }
+            }
+            float* mine = lpart + (rsub * 16 + cb) * 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mine[j] = s0[j]; mine[8 + j] = s1[j]; }
+        }
+    }
+    __syncthreads();
+    if (phase != 2) {
+        if (tid < 128) {
+            const int c = tid;
+            float d0 = 0.f, d1 = 0.f;
+            for (int r = 0; r < 32; ++r) { d0 += lpart[(r * 16 + (c >> 3)) * 16 + (c & 7)]; d1 += lpart[(r * 16 + (c >> 3)) * 16 + 8 + (c & 7)]; }
+            const float a0 = la0[c], a1 = 1.f - a0, dot = a0 * d0 + a1 * d1;
+            const unsigned short g0 = f2bf(a0 * (d0 - dot)), g1 = f2bf(a1 * (d1 - dot));           // dlogits as the ts_attn GEMMs read them (bf16)
+            const int64_t o = (int64_t)f * 2 * C + 2 * (c0 + c);
+            dlogits[o].v = g0; dlogits[o + 1].v = g1;
+            maed_agent_store(ex + o, bf2f(g0)); maed_agent_store(ex + o + 1, bf2f(g1));
+        }
+        if (phase == 1) return;
+        MAED_WAIT_VMCNT0();
+        __syncthreads();
+        if (S > 1) {
+            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, (uint32_t)S)) lfail = 1;
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < 2 * C; i += ST1_NT) lvec[i] = maed_agent_load(ex + (int64_t)f * 2 * C + i);
+    __syncthreads();
+    const float poison = lfail ? __uint_as_float(0x7fc00000u) : 0.f;
+    // d(means)[k] = sum_o dlogits[o] W_ts[o][k] = row k of the transposed weight image; rows 0..127: the x_s means of this slice, 128..255: the x_t means
+    st1_gemv256(wt_ts, 2 * C, lvec, [=](int row) { return row < 128 ? c0 + row : C + c0 + (row - 128); },
+                [&](int row, float acc) { ldm[row] = bf2f(f2bf(acc)) + poison; });                  // (bf16 like the stored d(means) of the separate path)
+    __syncthreads();
+    float a0[8], ms[8], mt[8];
+    const float invP = 1.f / (float)P;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a0[j] = la0[cb * 8 + j]; ms[j] = ldm[cb * 8 + j] * invP; mt[j] = ldm[128 + cb * 8 + j] * invP; }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int r = rsub + 32 * k;
+        if (r >= P) continue;
+        float d[8], os[8], ot[8];
+        st1_unpack(dm[k], d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { os[j] = d[j] * a0[j] + ms[j]; ot[j] = d[j] * (1.f - a0[j]) + mt[j]; }
+        st8(dx_s + base + (int64_t)r * C, os); st8(dx_t + base + (int64_t)r * C, ot);
+    }
+}
+
+extern "C" int maed_st_fused_supported(int P, int C, int dtype) { return dtype == MAED_BF16 && C % 128 == 0 && 2 * C <= 2048 && P > 0 && P <= 288; }
+
+#ifdef MAED_HOSTSIM
+#define ST1_LAUNCH(K_, ...) do { hipLaunchKernelGGL(K_, grid, dim3(ST1_NT), 0, s, __VA_ARGS__, 1); hipLaunchKernelGGL(K_, grid, dim3(ST1_NT), 0, s, __VA_ARGS__, 2); } while (0)
+#else
+#define ST1_LAUNCH(K_, ...) hipLaunchKernelGGL(K_, grid, dim3(ST1_NT), 0, s, __VA_ARGS__, 0)
+#endif
+
+extern "C" int maed_st_fused_fwd(const void* x_s, const void* x_t, const void* w_ts, const float* b_ts, void* means, float* logits, void* mix,
+                                 uint32_t* sync, float* ex, int F, int P, int C, int dtype, void* stream) {
+    MAED_CHECK_ARG(x_s && x_t && w_ts && b_ts && means && logits && mix && sync && ex, MAED_ERR_ARG, "st_fused_fwd: null pointer");
+    MAED_CHECK_ARG(maed_st_fused_supported(P, C, dtype), MAED_ERR_UNSUPPORTED, "st_fused_fwd: bf16, C %% 128 == 0, C <= 1024, P <= 288 (P=%d C=%d dtype=%d)", P, C, dtype);
+    MAED_CHECK_ARG(is_aligned(x_s, 16) && is_aligned(x_t, 16) && is_aligned(w_ts, 16) && is_aligned(mix, 16), MAED_ERR_ALIGN, "st_fused_fwd: 16-B alignment");
+    if (F <= 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MAED_HIP(hipMemsetAsync(sync, 0, (size_t)F * 16 * sizeof(uint32_t), s), "st_fused_fwd: memset");
+    const int S = C / 128;
+    const dim3 grid(S, F);
+    if (P <= 224) ST1_LAUNCH(st_fused_fwd_kernel<7>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S);
+    else ST1_LAUNCH(st_fused_fwd_kernel<9>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S);
+    MAED_CHECK_LAUNCH("st_fused_fwd");
+    return MAED_OK;
+}
+
+extern "C" int maed_st_fused_bwd(const void* dmix, const void* x_s, const void* x_t, const float* logits, const void* wt_ts, void* dlogits, void* dx_s,
+                                 void* dx_t, uint32_t* sync, float* ex, int F, int P, int C, int dtype, void* stream) {
+    MAED_CHECK_ARG(dmix && x_s && x_t && logits && wt_ts && dlogits && dx_s && dx_t && sync && ex, MAED_ERR_ARG, "st_fused_bwd: null pointer");
+    MAED_CHECK_ARG(maed_st_fused_supported(P, C, dtype), MAED_ERR_UNSUPPORTED, "st_fused_bwd: bf16, C %% 128 == 0, C <= 1024, P <= 288 (P=%d C=%d dtype=%d)", P, C, dtype);
+    MAED_CHECK_ARG(is_aligned(dmix, 16) && is_aligned(x_s, 16) && is_aligned(x_t, 16) && is_aligned(wt_ts, 16) && is_aligned(dx_s, 16) && is_aligned(dx_t, 16),
+                   MAED_ERR_ALIGN, "st_fused_bwd: 16-B alignment");
+    if (F <= 0) return MAED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MAED_HIP(hipMemsetAsync(sync, 0, (size_t)F * 16 * sizeof(uint32_t), s), "st_fused_bwd: memset");
+    const int S = C / 128;
+    const dim3 grid(S, F);
+    if (P <= 224) ST1_LAUNCH(st_fused_bwd_kernel<7>, (const bf16*)dmix, (const bf16*)x_s, (const bf16*)x_t, logits, (const bf16*)wt_ts, (bf16*)dlogits, (bf16*)dx_s,
+                             (bf16*)dx_t, sync, ex, P, C, S);
+    else ST1_LAUNCH(st_fused_bwd_kernel<9>, (const bf16*)dmix, (const bf16*)x_s, (const bf16*)x_t, logits, (const bf16*)wt_ts, (bf16*)dlogits, (bf16*)dx_s,
+                    (bf16*)dx_t, sync, ex, P, C, S);
+    MAED_CHECK_LAUNCH("st_fused_bwd");
+    return MAED_OK;
+}
+#undef ST1_LAUNCH
+
 // the token-axis reductions are split CM_SPLIT ways; partial sums meet in a caller-owned fp32 scratch `ws`
 extern "C" int maed_st_colmean(const void* x_s, const void* x_t, void* means, float* ws /* F*2C fp32 */, int F, int P, int C,
                                   int dtype, void* stream) {

@@ -13,6 +13,7 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {0},      // MAED_OPT_ABLATE
     {1},      // MAED_OPT_GN_BWD_ONEPASS
     {0},      // MAED_OPT_F32_BWD_X1
+    {1},      // MAED_OPT_ST_FUSED
 };
 
 extern "C" int maed_init(int device) {

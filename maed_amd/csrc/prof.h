@@ -6,7 +6,8 @@
 
 enum { PROF_ATTN_SP_FWD = 0, PROF_ATTN_TM_FWD, PROF_GEMM_QKV, PROF_GEMM_FC1, PROF_GEMM_FC2, PROF_ATTN_SP_BWD, PROF_ATTN_TM_BWD, PROF_GEMM_WGRAD,
        PROF_GEMM_PROJ, PROF_GEMM_DGRAD /* the four input-gradient GEMMs of a block */, PROF_LAYERNORM /* fwd + bwd */,
-       PROF_TN_ALL /* EVERY maed_gemm_tn_wgrad launch: STE and backbone 1x1 convolutions */, PROF_TN_CONV /* every maed_conv3x3_wgrad launch */, PROF_NTAGS };
+       PROF_TN_ALL /* EVERY maed_gemm_tn_wgrad launch: STE and backbone 1x1 convolutions */, PROF_TN_CONV /* every maed_conv3x3_wgrad launch */,
+       PROF_ST_FWD, PROF_ST_BWD /* the fused attentive addition (maed_st_fused_fwd / _bwd) */, PROF_NTAGS };
 
 bool maed_prof_on();
 void maed_prof_open(int tag, hipStream_t s, hipEvent_t* a);

@@ -1,6 +1,7 @@
 """STE element-wise kernels (maed_amd/csrc/elementwise.hip: attentive-addition mean / mix forward+backward, token embedding
 forward+backward, transpose-cast) on the host simulator against the CPU oracle -- the same comparisons tests/test_gpu_kernels.py
 runs on the real library, in fp32."""
+import pytest
 import torch
 
 from oracle import maed_ref as R
@@ -59,3 +60,44 @@ def test_transpose_cast_on_simulator():
         xt, xc = ops.transpose_cast(x, torch.float32, want_t=True, want_c=True, colsum=colsum, pad_to=64)
     assert xt.shape == (45, 128) and torch.equal(xt[:, :70], x.t()) and torch.equal(xt[:, 70:], torch.zeros(45, 58))
     assert torch.equal(xc, x) and torch.allclose(colsum, x.sum(0), atol=1e-5)
+
+
+@pytest.mark.parametrize("F_,P,C", [(3, 197, 256), (2, 257, 384), (2, 20, 128)])
+def test_attentive_addition_fused_one_launch_matches_the_four_launch_sequence(F_, P, C):
+    """round 4: maed_st_fused_fwd / _bwd (token means + ts_attn Linear + pair softmax + mix in one launch; backward likewise) against the separate entry points
+    they replace in the fused STE block -- same bf16 roundings (means, dlogits, d(means)), so the results agree to summation order: C / 128 = 2, 3 workgroups per
+    frame exchange through `ex` (the simulator runs the two halves of the kernel as two launches), P = 257 takes the 9-chunk instantiation."""
+    from maed_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    bf = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).bfloat16()
+    xs, xt, dmix = bf(F_, P, C), bf(F_, P, C), bf(F_, P, C)
+    w, b = bf(2 * C, 2 * C, sc=(2 * C) ** -0.5), torch.randn(2 * C, generator=g) * 0.1
+    wt = w.t().contiguous()
+    p = lambda t: ops._p(t)          # (resolved at call time: patched() swaps the pointer helper)
+    with patched() as lib:
+        assert lib.maed_st_fused_supported(P, C, L.BF16) == 1
+        # the four-launch sequence
+        means0 = ops.st_colmean(xs, xt)
+        logits0 = ops.gemm_nt(means0, w, L.EPI_STORE_F32, bias=b)
+        mix0 = ops.st_mix_fwd(xs, xt, logits0)
+        dmeans_fn = lambda dlog: ops.gemm_nt(dlog, wt, L.EPI_STORE)
+        dxs0, dxt0, dlog0 = ops.st_mix_bwd(dmix, xs, xt, logits0, dmeans_fn)
+        # one launch per direction
+        means1, logits1, mix1 = torch.empty(F_, 2 * C, dtype=torch.bfloat16), torch.empty(F_, 2 * C), torch.empty_like(xs)
+        sync, ex = torch.full((F_ * 16,), 7, dtype=torch.int32), torch.empty(F_ * 2 * C)
+        L.check(lib.maed_st_fused_fwd(p(xs), p(xt), p(w), p(b), p(means1), p(logits1), p(mix1), p(sync), p(ex), F_, P, C, L.BF16, None), "st_fused_fwd")
+        dlog1, dxs1, dxt1 = torch.empty(F_, 2 * C, dtype=torch.bfloat16), torch.empty_like(xs), torch.empty_like(xs)
+        L.check(lib.maed_st_fused_bwd(p(dmix), p(xs), p(xt), p(logits1), p(wt), p(dlog1), p(dxs1), p(dxt1), p(sync), p(ex), F_, P, C, L.BF16, None), "st_fused_bwd")
+    f = lambda t: t.float()
+    assert (f(means1) - f(means0)).abs().max() <= 2.0 ** -7 * f(means0).abs().max()            # at most one bf16 ulp (summation order before the rounding)
+    assert torch.allclose(logits1, logits0, rtol=0, atol=2e-3 * logits0.abs().max().item())
+    assert torch.allclose(f(mix1), f(mix0), rtol=0, atol=2e-2 * f(mix0).abs().max().item())
+    assert torch.allclose(f(dlog1), f(dlog0), rtol=0, atol=2e-2 * f(dlog0).abs().max().item())
+    assert torch.allclose(f(dxs1), f(dxs0), rtol=0, atol=2e-2 * f(dxs0).abs().max().item()) and torch.allclose(f(dxt1), f(dxt0), rtol=0, atol=2e-2 * f(dxt0).abs().max().item())
+    # and against fp64 on the same inputs
+    xs64, xt64 = xs.double(), xt.double()
+    m64 = torch.cat([xs64.mean(1), xt64.mean(1)], 1)
+    lg64 = m64 @ w.double().t() + b.double()
+    a0 = torch.softmax(lg64.view(F_, C, 2), -1)[..., 0][:, None, :]
+    mix64 = xs64 * a0 + xt64 * (1 - a0)
+    assert (f(mix1).double() - mix64).abs().max() <= 2e-2 * mix64.abs().max()
