@@ -446,6 +446,19 @@ int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* zero_page, v
 int maed_conv1x1_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int Cout, int Cin, void* y, int64_t ldy, int hw,
                      double* gn_sums, int dtype, void* stream);
 
+/* Input gradient of a STRIDE-2 3x3 SAME convolution (conv2 of the first block of stages 2 and 3, resnetv2.py:74-93,159-204) on the library's implicit-GEMM kernel:
+ * four launches, one per parity class of the input pixel (2 or 1 forward taps per axis and class; every pixel of dx is written exactly once: no zero-fill).
+ * dy (F,Ho,Wo,Cout), dx (F,H,W,Cin) channels_last bf16; wt_image (3,3,Cin,Cout): the transposed image of the standardised forward weight as maed_weight_std_fwd
+ * writes it; pad_top / pad_left: the forward's TF-SAME padding (0 or 1).  Cout % 64 == 0, Cin % 8 == 0. */
+int maed_conv3x3_s2_dgrad(const void* dy, const void* wt_image, const void* zero_page, void* dx, int F, int H, int W, int Cin, int Cout,
+                          int pad_top, int pad_left, int Ho, int Wo, int dtype, void* stream);
+/* Weight gradient of the same stride-2 convolution: dW (Cout,3,3,Cin) fp32 += over the output pixels of dy (F,Ho,Wo,Cout) x the input rows of x (F,H,W,Cin) they see --
+ * the TN weight-gradient kernel over gathered rows.  maed_conv3x3_s2_tables fills, once per feature-map geometry, the per-output-pixel tables it gathers through:
+ * tapmask (uint16, bit t = tap (t/3, t%3) inside the image) and rowtab (int32: x row of the top-left tap), both padded to a multiple of 64 entries.
+ * F*Ho*Wo % 64 == 0, Cin, Cout % 8 == 0, bf16. */
+int maed_conv3x3_s2_tables(void* tapmask, int* rowtab, int F, int H, int W, int pad_top, int pad_left, int Ho, int Wo, void* stream);
+int maed_conv3x3_s2_wgrad(const void* dy, const void* x, const void* tapmask, const int* rowtab, const void* zero_page, float* dW, int F, int H, int W,
+                          int Cin, int Cout, int Ho, int Wo, int dtype, void* stream);
 /* weight gradient of the stride-1 3x3 SAME convolution: dW (Cout, 9*Cin) fp32 += sum over pixels of dy (F,H,W,Cout) x shifted x (F,H,W,Cin)
  * (a TN GEMM over gathered rows on maed_gemm_tn_wgrad's kernel).  tapmask: F*H*W uint16 rounded up to a multiple of 64, filled once per
  * (F,H,W) by maed_conv3x3_tapmask; zero_page as for maed_conv3x3_fwd.  Needs F*H*W % 64 == 0, Cin % 8 == 0, Cout % 8 == 0. */

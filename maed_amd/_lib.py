@@ -121,6 +121,9 @@ SIGNATURES = {
     "maed_conv3x3_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp]),
     "maed_conv1x1_fwd": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, i32, vp, i32, vp]),
     "maed_conv3x3_tapmask": (i32, [vp, i32, i32, i32, vp]),
+    "maed_conv3x3_s2_dgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "maed_conv3x3_s2_tables": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "maed_conv3x3_s2_wgrad": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "maed_conv3x3_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "maed_eval_pose_errors": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "maed_similarity_transform": (i32, [vp, vp, i32, i32, vp, vp]),

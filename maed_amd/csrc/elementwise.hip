@@ -117,23 +117,39 @@ __device__ __forceinline__ void st1_unpack(const uint4& v, float (&o)[8]) {
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u); o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
     o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u); o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
 }
-// this workgroup's 256 GEMV outputs: out[row] = sum_k W[row_of(row)][k] * vec[k], k < K2 (K2 % 64 == 0); 8 lanes per weight row, 64 rows per pass
+// this workgroup's 256 GEMV outputs: out[row] = sum_k W[row_of(row)][k] * vec[k], k < K2 (K2 % 128 == 0).  8 lanes per weight row (coalesced 128-byte reads), the four
+// rows a lane group owns (row = 64 q + g) advance TOGETHER, two chunks each per step: 8 independent 16-byte loads in flight per lane and K2 / 128 dependent
+// steps -- the first version walked one row at a time with one load per step: 64 L2 round trips per lane, 30 us of a 47 us kernel.
 template <typename RowOf, typename Emit>
 __device__ __forceinline__ void st1_gemv256(const bf16* __restrict__ W, int K2, const float* vec, RowOf row_of, Emit emit) {
     const int g = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        const int row = pass * 64 + g;
-        const bf16* wr = W + (int64_t)row_of(row) * K2;
-        float acc = 0.f;
-        for (int k8 = l8; k8 < K2 / 8; k8 += 8) {
-            float w[8];
-            ld8(wr + k8 * 8, w);
+    const bf16* wr[4];
+    float acc[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(w[j], vec[k8 * 8 + j], acc);
+    for (int q = 0; q < 4; ++q) { wr[q] = W + (int64_t)row_of(q * 64 + g) * K2; acc[q] = 0.f; }
+    for (int k8 = l8; k8 < K2 / 8; k8 += 16) {
+        uint4 w[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w[q][0] = *reinterpret_cast<const uint4*>(wr[q] + k8 * 8); w[q][1] = *reinterpret_cast<const uint4*>(wr[q] + (k8 + 8) * 8); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = vec[(k8 + 8 * u) * 8 + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x[8];
+                st1_unpack(w[q][u], x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[q] = fmaf(x[j], v[j], acc[q]);
+            }
         }
-        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-        if (l8 == 0) emit(row, acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a = acc[q];
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+        if (l8 == 0) emit(q * 64 + g, a);
     }
 }
 

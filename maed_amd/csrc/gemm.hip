@@ -374,11 +374,21 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 4 : 2)) void gemm_nt_glds_bf16_ke
 // on MI355X (resnetv2.py; profiles/r02_call1_conv3x3_micro.txt).
 // ------------------------------------------------------------------------------------------------
 // B (weight) addressing: element (n, tap, c) of the GEMM's B operand lives at Wt[b_base + tap * b_tap + n * b_row + c]
-struct Conv3x3Dims { int F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left; int64_t b_row, b_tap, b_base; };
+struct Conv3x3Dims { int F, H, W, Cin, Ho, Wo, stride, pad_top, pad_left; int64_t b_row, b_tap, b_base;
+                     // CLS (one parity class of a stride-2 input gradient, maed_conv3x3_s2_dgrad): nty x ntx taps; loop tap (ty, tx) pairs with the FORWARD tap
+                     // (ky0 - 2 ty, kx0 - 2 tx); output pixel (f, a, b) of the class is row (f * o_h + 2 a + o_py) * o_w + 2 b + o_px of dX
+                     int nty = 3, ntx = 3, ky0 = 0, kx0 = 0, o_h = 0, o_w = 0, o_py = 0, o_px = 0; };
+
+// CLS: row m = (f, a, b) of a parity class -> its row of dX
+__device__ __forceinline__ int64_t cv_class_row(const Conv3x3Dims& d, int64_t m) {
+    const int b = (int)(m % d.Wo), a = (int)((m / d.Wo) % d.Ho);
+    const int64_t f = m / ((int64_t)d.Wo * d.Ho);
+    return (f * d.o_h + 2 * a + d.o_py) * (int64_t)d.o_w + 2 * b + d.o_px;
+}
 
 // NARROW: 128 x 64 output tile for Cout <= 64 (stage 1 of the R50: a 128-wide tile would spend half its MFMAs on duplicated weight rows):
 // the four waves take 32 pixel rows each and both 32-column halves; only 64 weight rows are staged.
-template <int EPI, bool NARROW, bool GN>
+template <int EPI, bool NARROW, bool GN, bool CLS = false>
 __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt, const bf16* __restrict__ zero_page,
                                                                    Conv3x3Dims d, int64_t M, int64_t N, int tiles_n, EpiArgs e) {
     constexpr int kTileElems = 2 * GM_BM * GM_BK, kStageElems = 4 * 32 * GL_ST * 2;
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
     const int wr = NARROW ? wave : wave >> 1, wc = NARROW ? 0 : wave & 1, l31 = lane & 31, hi = lane >> 5;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(id / tiles_n) * GM_BM, n0 = (int64_t)(id % tiles_n) * (NARROW ? 64 : GM_BN);
-    const int nkt = 9 * d.Cin / GM_BK;
+    const int nkt = (CLS ? d.nty * d.ntx : 9) * d.Cin / GM_BK;
     const int srow = wave * 8 + (lane >> 3);
     const int schunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
     // per staging round i: the output pixel of this lane's A row (top-left input tap, element offset of it) and its B row
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
     const int fsw = (l31 >> 1) & 7;
     int ty = 0, tx = 0, c0 = 0;                                     // K tile -> (tap, channel chunk), advanced incrementally (wave-uniform)
     for (int kt = 0; kt < nkt; ++kt) {
-        const int64_t k0 = (int64_t)(ty * 3 + tx) * d.b_tap + c0;     // B offset of this K tile
+        const int64_t k0 = (int64_t)(CLS ? (d.ky0 - 2 * ty) * 3 + (d.kx0 - 2 * tx) : ty * 3 + tx) * d.b_tap + c0;     // B offset of this K tile
         const int64_t toff = ((int64_t)ty * d.W + tx) * d.Cin + c0;
         CV_ISSUE1(0, ty, tx, toff, k0) CV_ISSUE1(1, ty, tx, toff, k0) CV_ISSUE1(2, ty, tx, toff, k0) CV_ISSUE1(3, ty, tx, toff, k0)
         MAED_WAIT_VMCNT0();
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
         }
         __syncthreads();
         c0 += GM_BK;
-        if (c0 == d.Cin) { c0 = 0; if (++tx == 3) { tx = 0; ++ty; } }
+        if (c0 == d.Cin) { c0 = 0; if (++tx == (CLS ? d.ntx : 3)) { tx = 0; ++ty; } }
     }
 #undef CV_PTRS
 #undef CV_ISSUE1
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
         const int64_t row = m0 + wr * (NARROW ? 32 : 64) + (i_) * 32 + lr, c0 = n0 + wc * 64 + cc;                     \
         float v8[8];                                                                                                   \
         ld8(stg + lr * GL_ST + cc, v8);                                                                                \
-        if (row < M && c0 < N) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);                                  \
+        if (row < M && c0 < N) epilogue_store8<EPI, bf16>(e, CLS ? cv_class_row(d, row) : row, c0, N, v8, vec_ok);     \
         if constexpr (GN) { if (row < M && c0 < N) gn_acc8(gnr, gnt, v8, row); }                                       \
     }
     CV_SHUFFLE_HALF(acc00, acc01, 0)
@@ -528,6 +538,48 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
     else { if (narrow) CV_LAUNCH(MAED_EPI_STORE, true, false); else CV_LAUNCH(MAED_EPI_STORE, false, false); }
 #undef CV_LAUNCH
     MAED_CHECK_LAUNCH("conv3x3_fwd");
+    return MAED_OK;
+}
+
+// Input gradient of a STRIDE-2 3x3 SAME convolution (resnetv2.py:74-93: conv2 of the first block of stages 2 and 3) as four implicit GEMMs, one per parity
+// class of the input pixel: dX[f, iy, ix, :] = sum over the forward taps (ky, kx) with (iy + pad_top - ky) and (ix + pad_left - kx) EVEN of
+// dY[f, (iy + pad_top - ky) / 2, (ix + pad_left - kx) / 2, :] W[:, ky, kx, :] -- a pixel of parity (py, px) sees 2 or 1 taps per axis (9/4 of the dense
+// kernel's multiply-adds in total), each class is a small stride-1 convolution over dY whose outputs land on every second row / column of dX.  Same kernel as the
+// forward (gathered LDS-DMA rows, zero page for taps outside dY), transposed forward-weight image read in place; the four launches cover dX: no zero-fill.
+// Replaces MIOpen's backward-data solver for these two layers together with the padded / sliced copies its symmetric-padding interface forced
+// (0.3 ms per cfg3 step, profiles/r03_rocprofv3_last_step_kernel_sequence.txt).
+extern "C" int maed_conv3x3_s2_dgrad(const void* dy, const void* wt_image, const void* zero_page, void* dx, int F, int H, int W, int Cin, int Cout,
+                                     int pad_top, int pad_left, int Ho, int Wo, int dtype, void* stream) {
+    // H, W, Cin: the forward convolution's INPUT (= dX) extents and channels; Ho, Wo, Cout: its output (= dY); wt_image (3,3,Cin,Cout) as maed_weight_std_fwd writes it
+    MAED_CHECK_ARG(dy && wt_image && zero_page && dx, MAED_ERR_ARG, "conv3x3_s2_dgrad: null pointer");
+    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_s2_dgrad: bf16 only (dtype=%d)", dtype);
+    MAED_CHECK_ARG(F >= 0 && H > 1 && W > 1 && Ho > 0 && Wo > 0 && pad_top >= 0 && pad_top <= 1 && pad_left >= 0 && pad_left <= 1, MAED_ERR_SHAPE, "conv3x3_s2_dgrad: bad extents");
+    MAED_CHECK_ARG(Cout % GM_BK == 0 && Cin % 8 == 0, MAED_ERR_SHAPE, "conv3x3_s2_dgrad: need Cout %% 64 == 0 and Cin %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(wt_image, 16) && is_aligned(zero_page, 16) && is_aligned(dx, 16), MAED_ERR_ALIGN, "conv3x3_s2_dgrad: 16-B alignment");
+    MAED_CHECK_ARG((uint64_t)F * H * W * Cin * 2 < (1ull << 32) && (uint64_t)F * Ho * Wo * Cout * 2 < (1ull << 32), MAED_ERR_SHAPE, "conv3x3_s2_dgrad: tensor larger than 4 GB");
+    if (F == 0) return MAED_OK;
+    const int64_t N = Cin;
+    const bool narrow = N <= 64;
+    const int tn = narrow ? 1 : (int)((N + GM_BN - 1) / GM_BN);
+    EpiArgs e{nullptr, dx, (int64_t)Cin, nullptr, nullptr, (int64_t)Cin};
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int Ha = (H - py + 1) / 2, Wb = (W - px + 1) / 2;                 // pixels of this class per frame
+            if (Ha <= 0 || Wb <= 0) continue;
+            const int ey = (py + pad_top) & 1, ex = (px + pad_left) & 1;            // parity the forward tap must have
+            const int nty = ey ? 1 : 2, ntx = ex ? 1 : 2;
+            // forward taps ky = ey + 2 jy read dY row a + (py + pad_top - ey) / 2 - jy; loop tap ty = nty - 1 - jy walks the rows upwards
+            const int base_y = (py + pad_top - ey) / 2 - (nty - 1), base_x = (px + pad_left - ex) / 2 - (ntx - 1);
+            Conv3x3Dims d{F, Ho, Wo, Cout, Ha, Wb, 1, -base_y, -base_x, (int64_t)Cout, (int64_t)Cin * Cout, 0};
+            d.nty = nty; d.ntx = ntx; d.ky0 = ey + 2 * (nty - 1); d.kx0 = ex + 2 * (ntx - 1); d.o_h = H; d.o_w = W; d.o_py = py; d.o_px = px;
+            const int64_t M = (int64_t)F * Ha * Wb;
+            const dim3 grid((unsigned)(((M + GM_BM - 1) / GM_BM) * tn));
+            if (narrow) hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<MAED_EPI_STORE, true, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dy,
+                                           (const bf16*)wt_image, (const bf16*)zero_page, d, M, N, tn, e);
+            else hipLaunchKernelGGL((conv3x3_glds_bf16_kernel<MAED_EPI_STORE, false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dy,
+                                    (const bf16*)wt_image, (const bf16*)zero_page, d, M, N, tn, e);
+        }
+    MAED_CHECK_LAUNCH("conv3x3_s2_dgrad");
     return MAED_OK;
 }
 

@@ -39,9 +39,13 @@ __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return __b
 // a thread's 8 K-columns lie in ONE tap (Cin % 8 == 0), so the tap's row shift is a constant folded into its loop-invariant lane
 // offsets; whether the shifted pixel is inside the image comes from a per-pixel 9-bit mask (maed_conv3x3_tapmask, computed once per
 // feature-map size), and a masked row loads a page of zeros instead.  Needs M % 64 == 0 (no ragged tile).  Opt-in path.
-struct TnConv { const uint16_t* tapmask; const bf16* zero_page; int Cin, Wimg; };
+struct TnConv { const uint16_t* tapmask; const bf16* zero_page; int Cin, Wimg;
+                const int* rowtab = nullptr; };   // S2 (stride-2 convolution): X row of the top-left tap of every output pixel (maed_conv3x3_s2_tables)
 
-template <bool CONV>
+// S2 = true (with CONV): the weight gradient of the STRIDE-2 3x3 convolution -- output pixel m = (f, oy, ox) pairs with the input rows
+// rowtab[m] + ky * Wimg + kx, no longer m + const: the 8 row bases of a thread's block come from the table (two 16-byte loads per M-tile), the tap's shift is still
+// a loop-invariant constant, the per-pixel 9-bit mask says which taps fall inside the image.
+template <bool CONV, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* __restrict__ Y, int64_t ldy, const bf16* __restrict__ X,
                                                                    int64_t ldx, int64_t M, int N, int K, float* __restrict__ dW,
                                                                    int64_t ldw, float* __restrict__ dbias, int tiles_k, int mtiles_per_split,
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
     int tap = 0, col_in = col_ok ? c0 : 0;                    // CONV, X side: K column -> (tap, channel); the tap's pixel shift in rows
     int shift = 0;
     if constexpr (CONV) {
-        if (side) { tap = col_in / cv.Cin; col_in -= tap * cv.Cin; shift = (tap / 3 - 1) * cv.Wimg + (tap % 3 - 1); }
+        if (side) { tap = col_in / cv.Cin; col_in -= tap * cv.Cin; shift = S2 ? (tap / 3) * cv.Wimg + (tap % 3) : (tap / 3 - 1) * cv.Wimg + (tap % 3 - 1); }
     }
     const int vo0 = (mg * 8 + shift) * ldi + col_in, vo1 = vo0 + ldi, vo2 = vo1 + ldi, vo3 = vo2 + ldi, vo4 = vo3 + ldi, vo5 = vo4 + ldi,
               vo6 = vo5 + ldi, vo7 = vo6 + ldi;               // fits 32 bits: the launcher checks ld < 2^24
@@ -124,11 +128,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16_kernel(const bf16* _
 #define TN_LD1(S, i, tb_) r##S##_##i = *reinterpret_cast<const uint4*>((tb_) + vo##i);
     // CONV, X side: row i of the 8-row group is taken from the image only if bit `tap` of its pixel's mask is set, else from the zero page
 #define TN_LD1M(S, i, tb_, mw_) r##S##_##i = *reinterpret_cast<const uint4*>(((((mw_) >> (((i) & 1) * 16 + tap)) & 1u) ? (tb_) + vo##i : cv.zero_page));
+    // S2: row i of the block comes from X row rt_ + shift (rt_: the table's entry for that output pixel)
+#define TN_LD1S(S, i, mw_, rt_) r##S##_##i = *reinterpret_cast<const uint4*>(((((mw_) >> (((i) & 1) * 16 + tap)) & 1u) ? src + ((int64_t)(rt_) + shift) * ldi + col_in : cv.zero_page));
 #define TN_LOAD(S, mt_) if (!(ablate & 2)) { int mtc__ = (mt_); if (mtc__ > mt_endf - 1) mtc__ = mt_endf - 1; \
         const bf16* tb__ = src + (int64_t)mtc__ * TN_BM * lds_src; \
         bool masked__ = false; \
         if constexpr (CONV) masked__ = side != 0; \
-        if (masked__) { \
+        if (masked__ && S2) { \
+            const uint4 mk__ = *reinterpret_cast<const uint4*>(cv.tapmask + (int64_t)mtc__ * TN_BM + mg * 8); \
+            const uint4 ra__ = *reinterpret_cast<const uint4*>(cv.rowtab + (int64_t)mtc__ * TN_BM + mg * 8), rb__ = *reinterpret_cast<const uint4*>(cv.rowtab + (int64_t)mtc__ * TN_BM + mg * 8 + 4); \
+            TN_LD1S(S, 0, mk__.x, (int)ra__.x) TN_LD1S(S, 1, mk__.x, (int)ra__.y) TN_LD1S(S, 2, mk__.y, (int)ra__.z) TN_LD1S(S, 3, mk__.y, (int)ra__.w) \
+            TN_LD1S(S, 4, mk__.z, (int)rb__.x) TN_LD1S(S, 5, mk__.z, (int)rb__.y) TN_LD1S(S, 6, mk__.w, (int)rb__.z) TN_LD1S(S, 7, mk__.w, (int)rb__.w) \
+        } else if (masked__) { \
             const uint4 mk__ = *reinterpret_cast<const uint4*>(cv.tapmask + (int64_t)mtc__ * TN_BM + mg * 8); \
             TN_LD1M(S, 0, tb__, mk__.x) TN_LD1M(S, 1, tb__, mk__.x) TN_LD1M(S, 2, tb__, mk__.y) TN_LD1M(S, 3, tb__, mk__.y) \
             TN_LD1M(S, 4, tb__, mk__.z) TN_LD1M(S, 5, tb__, mk__.z) TN_LD1M(S, 6, tb__, mk__.w) TN_LD1M(S, 7, tb__, mk__.w) \
@@ -281,6 +292,67 @@ extern "C" int maed_conv3x3_tapmask(void* mask, int F, int H, int W, void* strea
     const int64_t M = (int64_t)F * H * W, Mpad = (M + TN_BM - 1) / TN_BM * TN_BM;
     hipLaunchKernelGGL(conv_tapmask_kernel, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)mask, M, Mpad, H, W);
     MAED_CHECK_LAUNCH("conv3x3_tapmask");
+    return MAED_OK;
+}
+
+// stride-2 3x3 SAME convolution, per output pixel m = (f, oy, ox): rowtab[m] = X row of its top-left tap ((f H + 2 oy - pad_top) W + 2 ox - pad_left; may lie
+// outside the frame -- then the mask keeps it from being read), mask bit t = tap (t / 3, t % 3) inside the H x W image
+__global__ __launch_bounds__(256) void conv_s2_tables_kernel(uint16_t* __restrict__ mask, int* __restrict__ rowtab, int64_t M, int64_t Mpad, int H, int W, int Ho,
+                                                             int Wo, int pt, int pl) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= Mpad) return;
+    unsigned bits = 0;
+    int row = 0;
+    if (m < M) {
+        const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho);
+        const int64_t f = m / ((int64_t)Wo * Ho);
+        const int y0 = 2 * oy - pt, x0 = 2 * ox - pl;
+        row = (int)((f * H + y0) * W + x0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) bits |= ((unsigned)(y0 + t / 3) < (unsigned)H && (unsigned)(x0 + t % 3) < (unsigned)W ? 1u : 0u) << t;
+    }
+    mask[m] = (uint16_t)bits; rowtab[m] = row;
+}
+
+extern "C" int maed_conv3x3_s2_tables(void* mask, int* rowtab, int F, int H, int W, int pad_top, int pad_left, int Ho, int Wo, void* stream) {
+    MAED_CHECK_ARG(mask && rowtab, MAED_ERR_ARG, "conv3x3_s2_tables: null pointer");
+    MAED_CHECK_ARG(F > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (int64_t)F * H * W < (1ll << 31), MAED_ERR_SHAPE, "conv3x3_s2_tables: bad extents");
+    const int64_t M = (int64_t)F * Ho * Wo, Mpad = (M + TN_BM - 1) / TN_BM * TN_BM;
+    hipLaunchKernelGGL(conv_s2_tables_kernel, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t*)mask, rowtab, M, Mpad, H, W, Ho, Wo,
+                       pad_top, pad_left);
+    MAED_CHECK_LAUNCH("conv3x3_s2_tables");
+    return MAED_OK;
+}
+
+// dW (Cout, 3, 3, Cin) += weight gradient of the STRIDE-2 3x3 SAME convolution from dy (F,Ho,Wo,Cout) and x (F,H,W,Cin), channels_last bf16: the TN kernel over
+// rows gathered through the tables of maed_conv3x3_s2_tables (computed once per feature-map geometry).  F*Ho*Wo % 64 == 0.
+extern "C" int maed_conv3x3_s2_wgrad(const void* dy, const void* x, const void* tapmask, const int* rowtab, const void* zero_page, float* dW, int F, int H, int W,
+                                     int Cin, int Cout, int Ho, int Wo, int dtype, void* stream) {
+    MAED_CHECK_ARG(dy && x && tapmask && rowtab && zero_page && dW, MAED_ERR_ARG, "conv3x3_s2_wgrad: null pointer");
+    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_s2_wgrad: bf16 only (dtype=%d)", dtype);
+    const int64_t M = (int64_t)F * Ho * Wo;
+    const int N = Cout, K = 9 * Cin;
+    ProfScope prof__(PROF_TN_CONV, stream, 2.0 * (double)M * Cout * 9 * Cin, 2.0 * ((double)M * Cout + (double)F * H * W * Cin) + 36.0 * (double)Cout * Cin);
+    MAED_CHECK_ARG(M > 0 && M % TN_BM == 0, MAED_ERR_SHAPE, "conv3x3_s2_wgrad: F*Ho*Wo = %lld must be a multiple of 64", (long long)M);
+    MAED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && Cin < (1 << 20) && W + 1 < (1 << 10) && (int64_t)F * H * W < (1ll << 31), MAED_ERR_SHAPE,
+                   "conv3x3_s2_wgrad: need Cin, Cout multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
+    MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16) && is_aligned(tapmask, 16) && is_aligned(rowtab, 16) && is_aligned(zero_page, 16), MAED_ERR_ALIGN, "conv3x3_s2_wgrad: 16-B alignment");
+    const int tn = (N + 127) / 128, tk = (K + 127) / 128;
+    const int nmt = (int)(M / TN_BM);
+    int splits = maed_tn_splits(tn * tk);
+    if (splits > (nmt + 3) / 4) splits = (nmt + 3) / 4;
+    if (splits < 1) splits = 1;
+    const int per = (nmt + splits - 1) / splits;
+    const int z = (nmt + per - 1) / per;
+    TnConv cv{(const uint16_t*)tapmask, (const bf16*)zero_page, Cin, W};
+    cv.rowtab = rowtab;
+    hipLaunchKernelGGL((gemm_tn_mfma_bf16_kernel<true, true>), dim3(tn * tk, 1, z), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (int64_t)Cout,
+                       (const bf16*)x, (int64_t)Cin, M, N, K, dW, (int64_t)K, (float*)nullptr, tk, per, cv, tn_remap()
+#ifdef MAED_GEMM_ABLATE
+                       , 0
+#endif
+                       );
+    MAED_CHECK_LAUNCH("conv3x3_s2_wgrad");
     return MAED_OK;
 }
 

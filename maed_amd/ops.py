@@ -940,6 +940,18 @@ def conv3x3(x, w_taps, stride=1, add=None, w_layout=0, gn_sums=None, prec=None):
     return y
 
 
+def conv3x3_s2_dgrad(dy, wt, H, W, pad_top, pad_left):
+    """dX (N,I,H,W) of the stride-2 3x3 SAME convolution from channels_last bf16 dy (N,O,Ho,Wo) and the transposed image wt (3,3,I,O) of the standardised forward
+    weight (maed_conv3x3_s2_dgrad: one launch per parity class of the input pixel)"""
+    N, O, Ho, Wo = dy.shape
+    I = wt.numel() // (9 * O)
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    dx = torch.empty(N, I, H, W, dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    check(L.lib().maed_conv3x3_s2_dgrad(_p(dy), _p(wt), _p(_zero_page(dy.device)), _p(dx), N, H, W, I, O, pad_top, pad_left, Ho, Wo, dt_code(dy.dtype), _stream()),
+          "conv3x3_s2_dgrad")
+    return dx
+
+
 _TAPMASKS = {}
 
 
@@ -962,6 +974,27 @@ def conv3x3_wgrad(dy, x, out=None, prec=None):
     dW = torch.zeros(O, 3, 3, I, dtype=torch.float32, device=x.device) if out is None else out
     check(L.lib().maed_conv3x3_wgrad(_p(dy), _p(x), _p(_tapmask(N, H, W, x.device)), _p(_zero_page(x.device)), _p(dW), N, H, W, I, O,
                                      mm_code(x.dtype, prec), _stream()), "conv3x3_wgrad")
+    return dW
+
+
+_S2_TABLES = {}
+
+
+def conv3x3_s2_wgrad(dy, x, pad_top, pad_left, out=None):
+    """fp32 dW (O, 3, 3, I) of the stride-2 3x3 SAME convolution from channels_last bf16 dy (N,O,Ho,Wo) and x (N,I,H,W); accumulates into `out` when given.
+    The per-output-pixel gather tables depend only on the geometry: cached."""
+    N, I, H, W = x.shape
+    O, Ho, Wo = dy.shape[1:]
+    key = (N, H, W, Ho, Wo, pad_top, pad_left, str(x.device))
+    if key not in _S2_TABLES:
+        n = (N * Ho * Wo + 63) // 64 * 64
+        mask, rows = _aligned_bytes(2 * n, x.device), _aligned_bytes(4 * n, x.device)
+        check(L.lib().maed_conv3x3_s2_tables(_p(mask), _p(rows), N, H, W, pad_top, pad_left, Ho, Wo, _stream()), "conv3x3_s2_tables")
+        _S2_TABLES[key] = (mask, rows)
+    mask, rows = _S2_TABLES[key]
+    dW = torch.zeros(O, 3, 3, I, dtype=torch.float32, device=x.device) if out is None else out
+    check(L.lib().maed_conv3x3_s2_wgrad(_p(dy), _p(x), _p(mask), _p(rows), _p(_zero_page(x.device)), _p(dW), N, H, W, I, O, Ho, Wo, dt_code(x.dtype), _stream()),
+          "conv3x3_s2_wgrad")
     return dW
 
 
@@ -995,13 +1028,22 @@ class Conv3x3Fn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1] or dw_slice is not None
         dx = dw = None
         own_dx = need_x and s == 1 and O % 64 == 0               # (the gathered operand's channel count is O here)
-        if own_dx:
+        own_dx_s2 = need_x and s == 2 and wt is not None and O % 64 == 0 and I % 8 == 0 and dy.dtype == torch.bfloat16 and min(H, W) > 1
+        if own_dx_s2:                                            # one implicit GEMM per parity class of the input pixel, transposed image read in place
+            dx = conv3x3_s2_dgrad(dy, wt, H, W, ph // 2, pw // 2)
+            own_dx = True
+        elif own_dx:
             if wt is not None:                                   # in place from the transposed image: tap flip = negative tap stride
                 dx = conv3x3(dy, wt, 1, w_layout=1, prec=bwd_prec(prec))
             else:                                                # dX = conv3x3(dY, w'), w'[ci][ky][kx][co] = w[co][ci][2-ky][2-kx]
                 dx = conv3x3(dy, w.flip(2, 3).permute(1, 2, 3, 0).contiguous(), 1, prec=bwd_prec(prec))
         own_dw = need_w and s == 1 and ((N * H * W) % 64 == 0 or x.dtype == torch.float32) and I % 8 == 0 and O % 8 == 0      # (the bf16 kernel has no ragged tile)
-        if own_dw:                                               # TN GEMM over gathered rows; fp32, (O,3,3,I) like w's storage
+        own_dw_s2 = (need_w and s == 2 and dw_slice is not None and x.dtype == torch.bfloat16 and (N * Ho * Wo) % 64 == 0 and I % 8 == 0 and O % 8 == 0
+                     and N * H * W < 1 << 31)
+        if own_dw_s2:                                            # the TN kernel over rows gathered through per-output-pixel tables (stride 2)
+            side_stream_run(lambda: conv3x3_s2_wgrad(dy, x, ph // 2, pw // 2, out=dw_slice), dy, x, dw_slice)
+            need_w = False
+        elif own_dw:                                             # TN GEMM over gathered rows; fp32, (O,3,3,I) like w's storage
             if dw_slice is not None:
                 side_stream_run(lambda: conv3x3_wgrad(dy, x, out=dw_slice, prec=bwd_prec(prec)), dy, x, dw_slice)
             else:

@@ -302,7 +302,9 @@ class ResNetV2(nn.Module):
         if os.environ.get("MAED_GEMM_CONVS", "1") == "0":      # measurement knob: every convolution on MIOpen
             self._gemm_convs = []
         # MAED_CONV3X3=own: the stride-1 3x3 convolutions hand their weights / weight gradients over like the GEMM convolutions
-        self._own3x3 = [i for i, c in enumerate(self._convs) if _OWN_CONV3X3 and c.kernel_size == (3, 3) and c.stride == (1, 1)
+        # (round 4: the two stride-2 ones too -- their input gradient runs on maed_conv3x3_s2_dgrad, which reads the transposed image; MAED_CONV3X3_S2=0: as before)
+        s3 = ((1, 1), (2, 2)) if os.environ.get("MAED_CONV3X3_S2", "1") == "1" else ((1, 1),)
+        self._own3x3 = [i for i, c in enumerate(self._convs) if _OWN_CONV3X3 and c.kernel_size == (3, 3) and c.stride in s3
                         and c.in_channels % 64 == 0 and c.out_channels % 64 == 0]
         self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
         self._pending_backwards = 0

@@ -223,6 +223,30 @@ def conv3x3():
         check(tag + " forward vs fp32 conv", rel(y, ref), 1e-2)
         check(tag + " input gradient", rel(xs.grad, xr.grad), 1e-2)
         check(tag + " weight gradient", rel(ws.grad, wr.grad), 2e-2)
+    # round 4: the stride-2 convolutions' backward on the library (maed_conv3x3_s2_dgrad: one implicit GEMM per parity class of the input pixel;
+    # maed_conv3x3_s2_wgrad: the TN kernel through per-output-pixel gather tables) -- taken when WeightStdFn hands over the transposed image and the fp32 dW slice
+    for N, I, O, H, W in ([(4, 64, 128, 8, 8), (1, 128, 64, 7, 9)] if SIM else [(4, 64, 128, 16, 16), (1, 128, 128, 15, 17), (16, 256, 256, 28, 28), (4, 128, 128, 56, 56)]):
+        x = rnd(N, I, H, W, seed=H + 1).to(bf).float()
+        w = (rnd(O, I, 3, 3, seed=W + 1) * (1.0 / (3 * I ** 0.5))).to(bf).float()
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = F.conv2d(_same_pad(xr, 3, 2), wr, None, 2)
+        dy = rnd(*ref.shape, seed=4).to(bf).float()
+        ref.backward(dy)
+        xs = x.to(bf).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ws = w.to(bf).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        wt = w.to(bf).to(DEV).permute(2, 3, 1, 0).contiguous()                 # (3, 3, I, O): the transposed image maed_weight_std_fwd writes
+        dw = torch.zeros(O, 9 * I, device=DEV)
+        with patched():
+            y = ops.Conv3x3Fn.apply(xs, ws, 2, wt, dw)
+            y.backward(dy.to(bf).to(DEV).contiguous(memory_format=torch.channels_last))
+            if not SIM:
+                torch.cuda.synchronize()
+                ops.side_stream_join(xs.device)
+                torch.cuda.synchronize()
+        tag = f"conv3x3 N{N} I{I} O{O} {H}x{W} stride 2, library backward"
+        check(tag + " input gradient (parity classes)", rel(xs.grad, xr.grad), 1e-2)
+        check(tag + " weight gradient (gather tables)" + ("" if (N * ref.shape[-2] * ref.shape[-1]) % 64 == 0 else " [ragged: framework fallback]"),
+              rel(dw.view(O, 3, 3, I).permute(0, 3, 1, 2), wr.grad), 2e-2)
 
 
 if __name__ == "__main__":

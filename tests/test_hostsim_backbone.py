@@ -304,3 +304,49 @@ def test_conv1x1_stride2_on_packed_pixels_matches_aten(N, I, O, H, W):
     assert torch.allclose(xs.grad.double(), xr.grad, rtol=2e-2, atol=2e-2)
     assert (xs.grad[:, :, 1::2] == 0).all() and (xs.grad[:, :, :, 1::2] == 0).all()
     assert torch.allclose(dw.double(), wr.grad.reshape(O, I), rtol=1e-3, atol=1e-3 * wr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("N,I,O,H,W", [(2, 64, 64, 8, 8), (1, 128, 64, 7, 9), (1, 64, 128, 6, 5), (1, 64, 64, 14, 14)])
+def test_conv3x3_stride2_input_gradient_by_parity_classes(N, I, O, H, W):
+    """round 4: maed_conv3x3_s2_dgrad -- the input gradient of the stride-2 3x3 SAME convolution as four implicit GEMMs, one per parity class of the input
+    pixel (2 or 1 forward taps per axis), against autograd through F.conv2d on the TF-SAME padded input: even extents (pad 0 top / left, 1 bottom / right) and odd
+    ones (1 / 1), every pixel of dx written exactly once (the output starts as NaN)."""
+    import math
+    torch.manual_seed(7)
+    x = torch.randn(N, I, H, W).bfloat16()
+    w = (torch.randn(O, I, 3, 3) * (9 * I) ** -0.5).bfloat16()
+    Ho, Wo = math.ceil(H / 2), math.ceil(W / 2)
+    ph, pw = max((Ho - 1) * 2 + 3 - H, 0), max((Wo - 1) * 2 + 3 - W, 0)
+    xr = x.double().requires_grad_(True)
+    ref = F.conv2d(F.pad(xr, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]), w.double(), stride=2)
+    assert ref.shape[-2:] == (Ho, Wo)
+    dy = torch.randn(N, O, Ho, Wo).bfloat16()
+    ref.backward(dy.double())
+    wt = w.permute(2, 3, 1, 0).contiguous()            # (3, 3, I, O): the transposed image maed_weight_std_fwd writes
+    with patched():
+        dx = ops.conv3x3_s2_dgrad(cl(dy), wt, H, W, ph // 2, pw // 2)
+    assert dx.shape == (N, I, H, W) and torch.isfinite(dx.float()).all()
+    assert (dx.double() - xr.grad).abs().max() <= 1.5e-2 * xr.grad.abs().max()
+
+
+@pytest.mark.parametrize("N,I,O,H,W", [(4, 64, 64, 8, 8), (1, 64, 72, 16, 16), (4, 64, 64, 7, 7), (1, 128, 64, 15, 16), (2, 64, 136, 16, 8)])
+def test_conv3x3_stride2_weight_gradient_through_gather_tables(N, I, O, H, W):
+    """round 4: maed_conv3x3_s2_wgrad -- the TN weight-gradient kernel over input rows gathered through per-output-pixel tables (row of the top-left tap + 9-bit
+    'tap inside the image' mask), against autograd through F.conv2d on the TF-SAME padded input; accumulates into the given fp32 slice."""
+    import math
+    torch.manual_seed(8)
+    x = torch.randn(N, I, H, W).bfloat16()
+    w = (torch.randn(O, I, 3, 3) * (9 * I) ** -0.5).bfloat16()
+    Ho, Wo = math.ceil(H / 2), math.ceil(W / 2)
+    assert (N * Ho * Wo) % 64 == 0
+    ph, pw = max((Ho - 1) * 2 + 3 - H, 0), max((Wo - 1) * 2 + 3 - W, 0)
+    wr = w.double().requires_grad_(True)
+    ref = F.conv2d(F.pad(x.double(), [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]), wr, stride=2)
+    dy = torch.randn(N, O, Ho, Wo).bfloat16()
+    ref.backward(dy.double())
+    dW0 = torch.randn(O, 3, 3, I)
+    dW = dW0.clone()
+    with patched():
+        ops.conv3x3_s2_wgrad(cl(dy), cl(x), ph // 2, pw // 2, out=dW)
+    got = (dW - dW0).permute(0, 3, 1, 2).double()
+    assert (got - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max()
