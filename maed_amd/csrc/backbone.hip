@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NT, 4) void gn_bwd_onepass_kernel(const T* __restri
                                                                    const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float* ab /* [N][C][2], zero at launch */, T* __restrict__ dx, T* __restrict__ dres,
                                                                    uint32_t* sync /* [N][GN1_SYNC_WORDS], zero at launch */, int HW, int C, float eps, int S,
-                                                                   int rows_per_wg, int phase) {
+                                                                   int rows_per_wg, int phase, int skew) {
     MAED_DYN_SHARED(float, lpart);       // [NT / cbn][C][2] per-row-lane partials (32 KB)
     __shared__ float lmu[GN_G], lrs[GN_G], lgrp[GN_G * 2], lb[GN_G], lk[GN_G];
     __shared__ int lfail;
@@ -401,6 +401,13 @@ __global__ __launch_bounds__(NT, 4) void gn_bwd_onepass_kernel(const T* __restri
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
     const int64_t base = ((int64_t)n * HW) * C + cb * 8;
     float* const gsum = (float*)(sync + (int64_t)n * GN1_SYNC_WORDS + 16);
+#ifndef MAED_HOSTSIM
+    // phase skew (multi-round launches only): the workgroups of a frame move in lockstep by construction, and every frame of the first residency round starts at
+    // the same instant -- all of them stream, then all of them sit in their barrier, round after round (measured: the barrier's ~5 us stay fully exposed per
+    // round).  Odd frames of the FIRST round start `skew` sleep units late: from then on odd and even frames alternate between streaming and waiting.
+    if (skew > 0 && (n & 1) && (int)(blockIdx.y * gridDim.x + blockIdx.x) < 512)
+        for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(100);
+#endif
 
     // ---- all loads of the slice in flight at once ----
     GnChunk<T> xr[CH], dr[CH];
@@ -576,12 +583,17 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
 #define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
 #define GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, NT_) hipLaunchKernelGGL((gn_bwd_onepass_kernel<T, RELU_, YM_, GPC_, CH_, NT_>), dim3(S1, N), dim3(NT_), lds1, s, (const T*)x, relu_mask, \
-        (const T*)dy, sums, gamma, beta, ab_scratch, (T*)dx, (T*)dres, frame_sync, HW, C, eps, S1, rows1, PH_)
+        (const T*)dy, sums, gamma, beta, ab_scratch, (T*)dx, (T*)dres, frame_sync, HW, C, eps, (maed_opt(MAED_OPT_GN_BWD_ONEPASS) == 3 ? 1 : S1), rows1, PH_, skew1)
 #define GN_ONE3(RELU_, YM_, GPC_, CH_, PH_) do { if (nt1 == 256) GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, 256); else GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, GN1_NT); } while (0)
 #define GN_ONE2(RELU_, YM_, CH_, PH_) do { if (cpg >= 8) GN_ONE3(RELU_, YM_, 1, CH_, PH_); else if (cpg == 4) GN_ONE3(RELU_, YM_, 2, CH_, PH_); else GN_ONE3(RELU_, YM_, 4, CH_, PH_); } while (0)
 #define GN_ONE(PH_) do { constexpr int CH_ = sizeof(T) == 2 ? 8 : 4, CHM_ = sizeof(T) == 2 ? 7 : 4; \
         if (!relu) GN_ONE2(false, false, CH_, PH_); else if (ymask) GN_ONE2(true, true, CH_, PH_); else GN_ONE2(true, false, CHM_, PH_); } while (0)
     const size_t lds1 = (size_t)(nt1 / cbn1) * 2 * C * sizeof(float);
+    // phase skew of the odd frames of the first residency round (see the kernel), launches of three or more rounds: 2 x 100 sleep units ~ 5 us measured best
+    // (profiles/r04_gn_bwd_onepass_micro.txt: 56x56x256 171 -> 158 us, 28x28x512 98 -> 86; 4 units the same, 6 worse than none); MAED_OPT_GN_BWD_ONEPASS >= 10
+    // overrides with (value - 10) units (sweep knob)
+    const int opt1 = maed_opt(MAED_OPT_GN_BWD_ONEPASS);
+    const int skew1 = (int64_t)S1 * N >= 1536 ? (opt1 >= 10 ? opt1 - 10 : 2) : 0;
     MAED_DISPATCH_DTYPE(dtype, T, {
         if (onepass) {
 #ifdef MAED_HOSTSIM

@@ -19,7 +19,7 @@ SHAPES = [(112 * 112, 64, 1, 0, 1), (56 * 56, 64, 1, 0, 6), (56 * 56, 256, 1, 1,
 p = lambda t: None if t is None else t.data_ptr()
 lib = L.lib()
 st = torch.cuda.current_stream().cuda_stream
-MODES = (0, 1, 2)
+MODES = (0, 1, 3, 10, 14, 16)        # 3: DIAGNOSTIC -- the one-pass kernel without its frame barrier (wrong results: what the barrier + lockstep cost)
 tot = {m: 0.0 for m in MODES}
 for HW, C, relu, res, cnt in SHAPES:
     torch.manual_seed(0)
@@ -58,6 +58,6 @@ for HW, C, relu, res, cnt in SHAPES:
     L.set_option(L.OPT_GN_BWD_ONEPASS, 1)
     err = ((res_out[1] - res_out[0]).abs().max() / res_out[0].abs().max()).item()
     nbytes = N * HW * C * es * 3 + (N * HW * C // 8 if res else 0)
-    print(f"HW={HW:6d} C={C:5d} relu={relu} mask={res} x{cnt:2d}: two-pass {t[0]:7.1f} us   one-pass {t[1]:7.1f} us ({nbytes / t[1] / 1e6:5.2f} TB/s algorithmic)   256-thread {t[2]:7.1f} us   "
+    print(f"HW={HW:6d} C={C:5d} relu={relu} mask={res} x{cnt:2d}: two-pass {t[0]:7.1f} us   one-pass {t[1]:7.1f} us ({nbytes / t[1] / 1e6:5.2f} TB/s algorithmic)   no-barrier (diagnostic) {t[3]:7.1f} us   skew 0/4/6 {t[10]:6.1f} {t[14]:6.1f} {t[16]:6.1f} (default: 2 units)   "
           f"max|d dx| / max|dx| = {err:.2e}  finite={bool(torch.isfinite(res_out[1]).all())}", flush=True)
-print(f"backbone total per step (incl. the ab zero-fill and the dgamma/dbeta column sum of each call): two-pass {tot[0] / 1e3:.3f} ms   one-pass {tot[1] / 1e3:.3f} ms   256-thread {tot[2] / 1e3:.3f} ms")
+print(f"backbone total per step (incl. the ab zero-fill and the dgamma/dbeta column sum of each call): two-pass {tot[0] / 1e3:.3f} ms   one-pass {tot[1] / 1e3:.3f} ms   no-barrier {tot[3] / 1e3:.3f} ms")
