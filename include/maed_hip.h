@@ -186,9 +186,9 @@ int maed_st_fused_bwd(const void* dmix, const void* x_s, const void* x_t, const 
 /* tokens[f32](F,P,C): row 0 = cls, rows 1.. = patch[T](F,P-1,C); + pos_embed[p] + temp_embed[f % T] */
 int maed_embed_add_fwd(const void* patch, int dtype, const float* cls, const float* pos, const float* temp,
                        float* tokens, int F, int P, int C, int T, void* stream);
-/* dpatch[T](F,P-1,C) = dtokens rows 1.. ; dpos[f32](P,C) += sum_f ; frame_colsum[f32](F,C) = sum_p */
-int maed_embed_add_bwd(const float* dtokens, void* dpatch, int dtype, float* dpos, float* frame_colsum,
-                       int F, int P, int C, void* stream);
+/* dpatch[T](F,P-1,C) = dtokens rows 1.. ; dpos[f32](P,C) += sum_f dtokens[f] (row 0 of it is the cls token's gradient) ; dtemp[f32](T,C) += sum over the
+ * tokens of every frame f with f % T = t  (both accumulators zeroed by the caller: the reductions are split over workgroups and meet with atomics) */
+int maed_embed_add_bwd(const float* dtokens, void* dpatch, int dtype, float* dpos, float* dtemp, int F, int P, int C, int T, void* stream);
 
 /* ---- element-wise pieces of the training tail -------------------------------------------------- */
 /* nn.Dropout(p) in training (ktd.py:54,56): y[f32] = keep ? x / (1 - p) : 0 with keep = hash(seed, index) >= p; the same call with the
@@ -360,7 +360,10 @@ typedef struct {
     int32_t gout_f32;   /* backward: gout is fp32 (a maed_gemm_tn_wgrad result) instead of the compute dtype */
     int32_t pad_;
 } maed_ws_conv;
-int maed_weight_std_fwd(const void* conv_table, int n_convs, int n_filters, void* out, int dtype, float* stats, float eps, void* stream);
+int maed_weight_std_fwd(const void* conv_table, int n_convs, int n_filters, void* out, int dtype, float* stats, float eps, int transpose_tiles, void* stream);
+/* transpose_tiles > 0: the number of 64 x 64 tiles of all convolutions with dst_t_off >= 0 (sum of ceil(O / 64) * ceil(I * KHW / 64): the table is device memory, the
+ * caller counts) -- their transposed images are then written by a tile transpose of the forward image (128-byte runs) instead of element-wise strided stores;
+ * 0: the one-kernel form */
 int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int dtype, const float* stats, float eps, void* stream);
 /* GroupNorm(32 groups)(+ residual)(+ ReLU) on channels_last activations x (N, HW, C) (resnetv2.py:35-49,189-204):
  * y = act(GN(x) * gamma + beta [+ residual]).  sums: (N,32,2) doubles written by forward, read by backward.

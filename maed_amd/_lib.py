@@ -79,7 +79,7 @@ SIGNATURES = {
     "maed_st_fused_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_st_fused_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_embed_add_fwd": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "maed_embed_add_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp]),
+    "maed_embed_add_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "maed_ste_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_scratch_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
@@ -107,7 +107,7 @@ SIGNATURES = {
     "maed_ktd_pack": (i32, [C.POINTER(KtdPtrs), i32, vp, vp, vp, vp]),
     "maed_ktd_unpack_add": (i32, [C.POINTER(KtdPtrs), i32, vp, vp, vp, vp]),
     "maed_loss_fwd_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, i32, C.POINTER(LossWeights), vp, vp, vp, vp, vp, vp]),
-    "maed_weight_std_fwd": (i32, [vp, i32, i32, vp, i32, vp, f32, vp]),
+    "maed_weight_std_fwd": (i32, [vp, i32, i32, vp, i32, vp, f32, i32, vp]),
     "maed_weight_std_bwd": (i32, [vp, i32, i32, i32, vp, f32, vp]),
     "maed_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp]),
     "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp, vp, vp]),

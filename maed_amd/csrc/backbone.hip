@@ -32,7 +32,7 @@ __device__ __forceinline__ int ws_find_conv(const WsConv* __restrict__ tab, int 
 // one wave per filter
 template <typename T>
 __global__ __launch_bounds__(256) void ws_fwd_kernel(const WsConv* __restrict__ tab, int n_convs, int n_filters, T* __restrict__ out,
-                                                     float* __restrict__ stats /* [n_filters][2]: mean, 1/(std+eps) */, float eps) {
+                                                     float* __restrict__ stats /* [n_filters][2]: mean, 1/(std+eps) */, float eps, int skip_transposed) {
     const int fi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (fi >= n_filters) return;
     const WsConv d = tab[ws_find_conv(tab, n_convs, fi)];
@@ -46,12 +46,65 @@ __global__ __launch_bounds__(256) void ws_fwd_kernel(const WsConv* __restrict__ 
     const float inv = 1.f / (sqrtf(wave_sum(q) / (float)K) + eps);   // biased std, eps added to the std (resnetv2.py:87-88)
     if (lane == 0) { stats[2 * fi] = mean; stats[2 * fi + 1] = inv; }
     T* dst = out + d.dst_off + (int64_t)o * K;
-    T* dst_t = d.dst_t_off >= 0 ? out + d.dst_t_off + o : nullptr;
+    T* dst_t = (d.dst_t_off >= 0 && !skip_transposed) ? out + d.dst_t_off + o : nullptr;      // (skip: ws_transpose_kernel writes them)
     for (int i = lane; i < K; i += 64) {           // i = ci*KHW + r in the source; destination is (r, ci)
         const int ci = i / d.KHW, r = i % d.KHW;
         const float v = (src[i] - mean) * inv;
         stf(dst + (int64_t)r * d.I + ci, v);
         if (dst_t) stf(dst_t + ((int64_t)r * d.I + ci) * d.O, v);
+    }
+}
+
+// Round 4: the TRANSPOSED images by a tile transpose of the (O, K) image the kernel above has just written, instead of element-wise stores with a stride of O
+// between lanes (2-byte stores into 2-byte-wide columns: 11.9 M scattered stores per step at cfg3; the wave-per-filter kernel took 156 us for 94 MB of
+// weights).  One workgroup per 64 x 64 tile of one convolution (the tile -> convolution map is a scan over the <= 64-entry table), 128-byte runs both ways.
+// (A first version that also moved the statistics into 64-filter workgroups -- 16 filters per wave, one after the other -- was SLOWER than the original:
+// 21.49 vs 21.14 ms per step; the statistics are latency-bound and want the 26 K independent waves of the kernel above.)
+template <typename T>
+__global__ __launch_bounds__(256) void ws_transpose_kernel(const WsConv* __restrict__ tab, int n_convs, T* __restrict__ out) {
+    __shared__ T tile[64][66];
+    int t = blockIdx.x, c = 0, tk = 0;
+    for (; c < n_convs; ++c) {                       // block-uniform scan: which convolution owns tile t
+        const int K = tab[c].I * tab[c].KHW;
+        tk = (K + 63) / 64;
+        const int nt = tab[c].dst_t_off >= 0 ? ((tab[c].O + 63) / 64) * tk : 0;
+        if (t < nt) break;
+        t -= nt;
+    }
+    if (c >= n_convs) return;
+    const WsConv d = tab[c];
+    const int K = d.I * d.KHW, o0 = (t / tk) * 64, k0 = (t % tk) * 64;
+    const T* src = out + d.dst_off;                  // (O, K)
+    T* dst = out + d.dst_t_off;                      // (K, O)
+    const int r = threadIdx.x >> 2, q = (threadIdx.x & 3) * 16;
+    // whole 16-element runs as two 16-byte accesses (K and O are multiples of 8 for every convolution that has a transposed image, the arenas 16-byte aligned:
+    // checked per run, scalar otherwise)
+    constexpr int VE = 16 / (int)sizeof(T);          // elements per 16 bytes
+    if (o0 + r < d.O) {
+        const T* sp = src + (int64_t)(o0 + r) * K + k0 + q;
+        if (k0 + q + 16 <= K && ((uintptr_t)sp & 15) == 0) {
+#pragma unroll
+            for (int v = 0; v < 16 / VE; ++v) { const uint4 w = reinterpret_cast<const uint4*>(sp)[v]; T e[VE]; memcpy(e, &w, 16);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) tile[r][q + v * VE + j] = e[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (k0 + q + j < K) tile[r][q + j] = sp[j];
+        }
+    }
+    __syncthreads();
+    if (k0 + r < K) {
+        T* dp = dst + (int64_t)(k0 + r) * d.O + o0 + q;
+        if (o0 + q + 16 <= d.O && ((uintptr_t)dp & 15) == 0) {
+#pragma unroll
+            for (int v = 0; v < 16 / VE; ++v) { T e[VE];
+#pragma unroll
+                for (int j = 0; j < VE; ++j) e[j] = tile[q + v * VE + j][r];
+                uint4 w; memcpy(&w, e, 16); reinterpret_cast<uint4*>(dp)[v] = w; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (o0 + q + j < d.O) dp[j] = tile[q + j][r];
+        }
     }
 }
 
@@ -88,12 +141,18 @@ __global__ __launch_bounds__(256) void ws_bwd_kernel(const WsConv* __restrict__ 
 }
 
 extern "C" int maed_weight_std_fwd(const void* conv_table, int n_convs, int n_filters, void* out, int dtype, float* stats, float eps,
-                                   void* stream) {
+                                   int filters_aligned64, void* stream) {
     MAED_CHECK_ARG(conv_table && out && stats, MAED_ERR_ARG, "weight_std_fwd: null pointer");
     MAED_CHECK_ARG(n_convs > 0 && n_convs <= WS_MAX_CONVS, MAED_ERR_SHAPE, "weight_std_fwd: n_convs=%d out of range", n_convs);
     if (n_filters <= 0) return MAED_OK;
-    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ws_fwd_kernel<T>), dim3((n_filters + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                                                      (const WsConv*)conv_table, n_convs, n_filters, (T*)out, stats, eps));
+    // filters_aligned64 > 0: the transposed images by ws_transpose_kernel; its value is the number of 64 x 64 tiles of all convolutions that have one
+    // (the table lives in device memory: the caller counts)
+    const int t_tiles = filters_aligned64;
+    MAED_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL((ws_fwd_kernel<T>), dim3((n_filters + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const WsConv*)conv_table, n_convs, n_filters, (T*)out, stats, eps,
+                           t_tiles > 0 ? 1 : 0);
+        if (t_tiles > 0) hipLaunchKernelGGL((ws_transpose_kernel<T>), dim3(t_tiles), dim3(256), 0, (hipStream_t)stream, (const WsConv*)conv_table, n_convs, (T*)out);
+    });
     MAED_CHECK_LAUNCH("weight_std_fwd");
     return MAED_OK;
 }

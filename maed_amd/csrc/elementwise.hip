@@ -439,37 +439,41 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const T* __restrict__ pa
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restrict__ dtok, T* __restrict__ dpatch, float* __restrict__ dpos,
                                                             int F, int P, int C) {
+    // (round 4: the frames are split EMB_SPLIT ways over blockIdx.y and meet in dpos with atomics -- one thread per (p, 4 channels) walking all 128 frames was 99
+    //  workgroups with one dependent load each per step: 59 us for 77 MB)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n4 = (int64_t)P * C / 4;
     if (i >= n4) return;
     const int64_t e = i * 4;
     const int c = (int)(e % C); const int p = (int)(e / C);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int f = 0; f < F; ++f) {
+#pragma unroll 4
+    for (int f = blockIdx.y; f < F; f += gridDim.y) {
         float v[4];
         ld4(dtok + ((int64_t)f * P + p) * C + c, v);
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         if (p > 0 && dpatch) st4(dpatch + ((int64_t)f * (P - 1) + (p - 1)) * C + c, v);
     }
-    float o[4];
-    ld4(dpos + e, o);
-    o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3];
-    st4(dpos + e, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(dpos + e + j, s[j]);
 }
-// thread per (f, 4 channels): frame_colsum[f] = sum_p dtok[f][p]
-__global__ __launch_bounds__(256) void embed_bwd_frame_kernel(const float* __restrict__ dtok, float* __restrict__ fsum, int F, int P, int C) {
+// thread per (f, 4 channels): dtemp[f % T] += sum_p dtok[f][p]   (the temporal embedding is shared by the frames at the same position of every clip)
+__global__ __launch_bounds__(256) void embed_bwd_frame_kernel(const float* __restrict__ dtok, float* __restrict__ dtemp, int F, int P, int C, int T) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n4 = (int64_t)F * C / 4;
     if (i >= n4) return;
     const int64_t e = i * 4;
     const int c = (int)(e % C); const int64_t f = e / C;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int p = 0; p < P; ++p) {
+#pragma unroll 4
+    for (int p = blockIdx.y; p < P; p += gridDim.y) {          // (tokens split over blockIdx.y, see above)
         float v[4];
         ld4(dtok + (f * P + p) * C + c, v);
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
-    st4(fsum + e, s);
+    float* dst = dtemp + (f % T) * (int64_t)C + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(dst + j, s[j]);
 }
 
 extern "C" int maed_embed_add_fwd(const void* patch, int dtype, const float* cls, const float* pos, const float* temp, float* tokens,
@@ -484,16 +488,18 @@ extern "C" int maed_embed_add_fwd(const void* patch, int dtype, const float* cls
     return MAED_OK;
 }
 
-extern "C" int maed_embed_add_bwd(const float* dtokens, void* dpatch, int dtype, float* dpos, float* frame_colsum, int F, int P, int C,
+extern "C" int maed_embed_add_bwd(const float* dtokens, void* dpatch, int dtype, float* dpos, float* dtemp, int F, int P, int C, int T,
                                   void* stream) {
-    MAED_CHECK_ARG(dtokens && dpos && frame_colsum, MAED_ERR_ARG, "embed_add_bwd: null pointer");
-    MAED_CHECK_ARG(C % 4 == 0 && P > 1, MAED_ERR_SHAPE, "embed_add_bwd: bad extents");
+    MAED_CHECK_ARG(dtokens && dpos && dtemp, MAED_ERR_ARG, "embed_add_bwd: null pointer");
+    MAED_CHECK_ARG(C % 4 == 0 && P > 1 && T > 0, MAED_ERR_SHAPE, "embed_add_bwd: bad extents");
     if (F == 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n4 = (int64_t)P * C / 4, m4 = (int64_t)F * C / 4;
-    MAED_DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((embed_bwd_pos_kernel<TT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+#define EMB_SPLIT 8
+    MAED_DISPATCH_DTYPE(dtype, TT, hipLaunchKernelGGL((embed_bwd_pos_kernel<TT>), dim3((unsigned)((n4 + 255) / 256), F < EMB_SPLIT ? F : EMB_SPLIT), dim3(256), 0, s,
                                                        dtokens, (TT*)dpatch, dpos, F, P, C));
-    hipLaunchKernelGGL(embed_bwd_frame_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, s, dtokens, frame_colsum, F, P, C);
+    hipLaunchKernelGGL(embed_bwd_frame_kernel, dim3((unsigned)((m4 + 255) / 256), P < EMB_SPLIT ? P : EMB_SPLIT), dim3(256), 0, s, dtokens, dtemp, F, P, C, T);
+#undef EMB_SPLIT
     MAED_CHECK_LAUNCH("embed_add_bwd");
     return MAED_OK;
 }

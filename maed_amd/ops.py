@@ -513,11 +513,9 @@ class EmbedAddFn(torch.autograd.Function):
         F_, P, C_ = dtok.shape
         dpatch = torch.empty(F_, P - 1, C_, dtype=ctx.pdtype, device=dtok.device)
         dpos = torch.zeros(1, P, C_, dtype=torch.float32, device=dtok.device)
-        fsum = torch.empty(F_, C_, dtype=torch.float32, device=dtok.device)
-        check(L.lib().maed_embed_add_bwd(_p(dtok), _p(dpatch), dt_code(ctx.pdtype), _p(dpos), _p(fsum), F_, P, C_, _stream()), "embed_add_bwd")
-        dtemp = torch.zeros(ctx.temp_shape, dtype=torch.float32, device=dtok.device)
-        dtemp[0, :ctx.T, 0] = fsum.view(-1, ctx.T, C_).sum(0)
-        dcls = dtok[:, 0].sum(0).view(1, 1, C_)
+        dtemp = torch.zeros(ctx.temp_shape, dtype=torch.float32, device=dtok.device)       # (1, max_seqlen, 1, C): rows t < T are the first T * C floats
+        check(L.lib().maed_embed_add_bwd(_p(dtok), _p(dpatch), dt_code(ctx.pdtype), _p(dpos), _p(dtemp), F_, P, C_, ctx.T, _stream()), "embed_add_bwd")
+        dcls = dpos[:, :1].clone()                      # sum_f dtok[f][0]: the token-0 row of the positional sum (no second reduction over dtok)
         return dpatch, dcls, dpos, dtemp, None
 
 
@@ -656,7 +654,9 @@ class WeightStdFn(ReportingFn):
         out = torch.empty(total, dtype=dtype, device=dev)
         stats = torch.empty(nf * 2, dtype=torch.float32, device=dev)
         tab_dev = _upload_table(tab, dev)
-        check(L.lib().maed_weight_std_fwd(_p(tab_dev), len(weights), nf, _p(out), dt_code(dtype), _p(stats), eps, _stream()), "weight_std_fwd")
+        # transposed images by a tile transpose of the forward image (MAED_WS_TILED=0: element-wise strided stores from the statistics kernel, A/B knob)
+        t_tiles = sum(-(-weights[i].shape[0] // 64) * -(-(weights[i].numel() // weights[i].shape[0]) // 64) for i in t_offs) if os.environ.get("MAED_WS_TILED", "1") == "1" else 0
+        check(L.lib().maed_weight_std_fwd(_p(tab_dev), len(weights), nf, _p(out), dt_code(dtype), _p(stats), eps, t_tiles, _stream()), "weight_std_fwd")
         ctx.owner, ctx.dtype, ctx.eps, ctx.stats, ctx.nf = owner, dtype, eps, stats, nf
         ctx.weights = weights
         ctx.set_materialize_grads(False)     # the library convolutions hand their dW over in fp32 slices: no zero tensors in their place

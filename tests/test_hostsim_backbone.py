@@ -1,6 +1,8 @@
 """Backbone helper kernels (maed_amd/csrc/backbone.hip) on the host simulator against ATen on CPU: SAME max-pool forward /
 gather backward (incl. ATen's tie rule on ReLU zeros), fused GroupNorm(+residual)(+ReLU) forward/backward, batched weight
 standardisation forward/backward -- through the product's own autograd Functions (maed_amd/ops.py)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -350,3 +352,46 @@ def test_conv3x3_stride2_weight_gradient_through_gather_tables(N, I, O, H, W):
         ops.conv3x3_s2_wgrad(cl(dy), cl(x), ph // 2, pw // 2, out=dW)
     got = (dW - dW0).permute(0, 3, 1, 2).double()
     assert (got - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_weight_standardisation_tiled_kernel_64_filters_per_workgroup(dtype):
+    """round 4: the transposed weight images by a tile transpose of the forward image (ws_transpose_kernel: 64 x 64 tiles through LDS, 128-byte runs) instead of
+    element-wise strided stores.  Shapes: the stem's K = 147 (no transposed image), a 1x1 with two filter blocks, a 3x3 with a ragged filter block (O = 72) --
+    forward image and transposed image against ATen; the one-kernel form (MAED_WS_TILED=0) must give the same bits."""
+    torch.manual_seed(4)
+
+    class Owner:
+        _pending_backwards = 0
+        grads_ready = None
+        _gemm_convs = [1, 2]
+
+        def __init__(self, ws):
+            self._ws = ws
+            self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
+
+        def conv_weights(self):
+            return self._ws
+    shapes = [(64, 3, 7, 7), (128, 64, 1, 1), (72, 64, 3, 3)]
+    ws = [torch.randn(s) for s in shapes]
+    res = {}
+    for tiled in ("1", "0"):
+        owner = Owner(ws)
+        os.environ["MAED_WS_TILED"] = tiled
+        try:
+            with patched(), torch.no_grad():
+                outs = ops.WeightStdFn.apply(owner, dtype, 1e-5, *ws)
+                res[tiled] = ([o.clone() for o in outs], {i: t.clone() for i, t in owner._w_std_t.items()})       # (fp32 in the exact mode: no transposed images)
+        finally:
+            os.environ.pop("MAED_WS_TILED", None)
+    tol = dict(rtol=1e-2, atol=1e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    for i, w in enumerate(ws):
+        std, mean = torch.std_mean(w, dim=[1, 2, 3], keepdim=True, unbiased=False)
+        ref = (w - mean) / (std + 1e-5)
+        assert torch.allclose(res["1"][0][i].float(), ref, **tol), i
+        assert torch.equal(res["1"][0][i], res["0"][0][i]), i
+        if i in res["1"][1]:
+            O, I, kh, kw = shapes[i]
+            assert torch.allclose(res["1"][1][i].float(), ref.permute(2, 3, 1, 0).reshape(kh * kw * I, O), **tol), i
+            assert torch.equal(res["1"][1][i], res["0"][1][i]), i
+    assert (dtype == torch.bfloat16) == (sorted(res["1"][1]) == [1, 2])
