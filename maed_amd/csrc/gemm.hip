@@ -649,6 +649,20 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         if (np) {
             const bool ok = maed_x3_nt_shape_ok(A, lda, B, ldb, K);       // (otherwise: the exact kernel below -- never less accurate than asked for)
             const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+            if constexpr (EPI == MAED_EPI_STORE || EPI == MAED_EPI_STORE_F32) {
+                // an EXPLICIT split engine on a GEMM with few output tiles and a long K (the decoder head in the bf16 mode, round 4: 128 frames x 1024 x 512 is 8 tiles
+                // of 128 x 128): the split-K route of the exact kernel below, on the matrix cores -- bias fill, then K slices that meet with fp32 atomics
+                if (ok && impl != MAED_IMPL_AUTO && splitk == 1 && tiles128 < 48 && K >= 256 && e.ldo >= N) {
+                    int sk = (int)(256 / tiles128);
+                    if (sk > K / 32) sk = (int)(K / 32);
+                    if (sk > 1) {
+                        hipLaunchKernelGGL(bias_fill_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, (float*)e.out, e.ldo, e.bias, M, N);
+                        EpiArgs ea = e;
+                        ea.bias = nullptr;
+                        return maed_gemm_nt_x3_launch(MAED_EPI_ATOMIC_F32, np, A, lda, B, ldb, M, N, K, ea, sk, s);
+                    }
+                }
+            }
             if (ok && (impl != MAED_IMPL_AUTO || tiles128 >= 48 || EPI == MAED_EPI_ATOMIC_F32))
                 return maed_gemm_nt_x3_launch(EPI, np, A, lda, B, ldb, M, N, K, e, splitk, s);
         }

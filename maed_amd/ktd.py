@@ -50,6 +50,10 @@ class KTD(nn.Module):
         nn.init.xavier_uniform_(self.deccam.weight, gain=0.01)
         self._packed_key, self._packed = None, None
         self._fc_cache, self._fc_cache2 = ops.WeightCache(), ops.WeightCache()      # fp32 [out,in] master + transposed image of fc1 / fc2
+        # engine of the head's fp32 matrix products (fc1, fc2, the packed regressors and their gradients): None = the process-wide fp32 mode (exact VALU kernels by
+        # default); "bf16x3" = split-bf16 products on the matrix cores (error ~2^-16 of |a||b|: still 2^8 below a bf16 product) -- what MAED sets for a bf16-mode
+        # model, whose encoder output is bf16-accurate anyway; the fp32 model keeps the exact kernels
+        self.head_matmul = None
         self._pending_backwards = 0
         self.grads_ready = None  # callback(self) set by the data-parallel gradient bucketer
 
@@ -75,8 +79,9 @@ class KTD(nn.Module):
         """ktd.py:71-86 with the 26 small regressors as ONE packed GEMM + the chain kernel (differentiable)"""
         from . import ste_modes
         x = x.float()
-        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc1.weight, self.fc1.bias, self._fc_cache, True), self.drop1.p, self.drop1.training)
-        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc2.weight, self.fc2.bias, self._fc_cache2, True), self.drop2.p, self.drop2.training)
+        hm = self.head_matmul
+        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc1.weight, self.fc1.bias, self._fc_cache, True, hm), self.drop1.p, self.drop1.training)
+        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc2.weight, self.fc2.bias, self._fc_cache2, True, hm), self.drop2.p, self.drop2.training)
         return tail.KtdChainFn.apply(x, self, *self.fused_parameters())
 
     # ---- ATen composition for host tensors (the CPU suite's comparison arm; a library device takes _head_hip / _head_train) ----
@@ -104,9 +109,10 @@ class KTD(nn.Module):
     def _head_hip(self, x):
         w_feat, b_feat, w_anc = self._pack()
         x = x.float().contiguous()
-        h1 = ops.gemm_nt(x, self.fc1.weight.detach(), L.EPI_STORE, bias=self.fc1.bias)
-        h2 = ops.gemm_nt(h1, self.fc2.weight.detach(), L.EPI_STORE, bias=self.fc2.bias)
-        out = ops.gemm_nt(h2, w_feat, L.EPI_STORE, bias=b_feat)                      # (F, 144 + 10 + 3)
+        hm = self.head_matmul
+        h1 = ops.gemm_nt(x, self.fc1.weight.detach(), L.EPI_STORE, bias=self.fc1.bias, prec=hm)
+        h2 = ops.gemm_nt(h1, self.fc2.weight.detach(), L.EPI_STORE, bias=self.fc2.bias, prec=hm)
+        out = ops.gemm_nt(h2, w_feat, L.EPI_STORE, bias=b_feat, prec=hm)             # (F, 144 + 10 + 3)
         base = out[:, :144].contiguous()
         pose = torch.empty_like(base)
         ops.check(L.lib().maed_ktd_chain_fwd(ops._p(base), ops._p(w_anc), ops._p(pose), x.shape[0], ops._stream()), "ktd_chain_fwd")

@@ -33,6 +33,9 @@ class MAED(nn.Module):
         self.decoder_type = decoder
         if decoder.lower() == 'ktd':                 # maed.py:24-29
             self.decoder = KTD(feat_dim=self.encoder.num_features, hidden_dim=hidden_dim, smpl_arrays=smpl_arrays)
+            import os
+            if compute_dtype == torch.bfloat16 and os.environ.get("MAED_HEAD_X3", "1") == "1":        # (A/B knob: 0 = the head on the exact fp32 VALU kernels)
+                self.decoder.head_matmul = "bf16x3"
         elif decoder.lower() == 'iterative':
             from .iterative import Regressor
             self.decoder = Regressor(feat_dim=self.encoder.num_features, hidden_dim=hidden_dim, smpl_arrays=smpl_arrays,

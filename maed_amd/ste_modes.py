@@ -23,13 +23,13 @@ from . import _lib as L
 from . import ops
 
 
-def _wgrad(dy, x, need_bias):
-    """(dW fp32 [N,K], db fp32 [N] or None) for y = x W^T + b; dy (M,N), x (M,K) in the same compute dtype"""
+def _wgrad(dy, x, need_bias, prec=None):
+    """(dW fp32 [N,K], db fp32 [N] or None) for y = x W^T + b; dy (M,N), x (M,K) in the same compute dtype; prec: the caller's own fp32 engine (ops.mm_code)"""
     N, K = dy.shape[1], x.shape[1]
     db = torch.zeros(N, dtype=torch.float32, device=dy.device) if need_bias else None
-    if ops.lib_matmul_dtype(dy.dtype) and N % 8 == 0 and K % 8 == 0:
+    if ops.lib_matmul_dtype(dy.dtype, prec) and N % 8 == 0 and K % 8 == 0:
         dW = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
-        ops.gemm_tn_wgrad(dy, x, dW, db)
+        ops.gemm_tn_wgrad(dy, x, dW, db, prec=prec)
         return dW, db
     dyt, _ = ops.transpose_cast(dy, dy.dtype, colsum=db)
     xt, _ = ops.transpose_cast(x, x.dtype)
@@ -65,20 +65,21 @@ class LinearTokFn(torch.autograd.Function):
     """y = x W^T + b on (M,K) rows in the compute dtype; `out_f32` writes fp32 (the branch outputs that join the residual)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache, out_f32):
+    def forward(ctx, x, weight, bias, cache, out_f32, prec=None):
+        """prec: fp32 rows only -- the caller's own matrix-product engine ("bf16x3": the decoder head of a bf16-mode model, KTD.head_matmul)"""
         (wc, wt), = cache.get([weight], x.dtype)
         x = _as(x, x.dtype)
         ctx.save_for_backward(x)
-        ctx.wt, ctx.has_bias = wt, bias is not None
-        return ops.gemm_nt(x, wc, L.EPI_STORE_F32 if out_f32 else L.EPI_STORE, bias=bias)
+        ctx.wt, ctx.has_bias, ctx.prec = wt, bias is not None, prec
+        return ops.gemm_nt(x, wc, L.EPI_STORE_F32 if out_f32 else L.EPI_STORE, bias=bias, prec=prec)
 
     @staticmethod
     def backward(ctx, dy):
         x, = ctx.saved_tensors
         dy = _as(dy, x.dtype)
-        dW, db = _wgrad(dy, x, ctx.has_bias) if ctx.needs_input_grad[1] else (None, None)
-        dx = ops.gemm_nt(dy, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
-        return dx, dW, db, None, None
+        dW, db = _wgrad(dy, x, ctx.has_bias, ctx.prec) if ctx.needs_input_grad[1] else (None, None)
+        dx = ops.gemm_nt(dy, ctx.wt, L.EPI_STORE, prec=ctx.prec) if ctx.needs_input_grad[0] else None
+        return dx, dW, db, None, None, None
 
 
 class MlpFn(torch.autograd.Function):

@@ -44,12 +44,13 @@ class KtdChainFn(ops.ReportingFn):
         w_anc = torch.empty(L.KTD_W_ANC, dtype=torch.float32, device=dev)
         tbl = ktd._ptr_table(False)
         L.check(lib.maed_ktd_pack(C.byref(tbl), hidden, ops._p(w_feat), ops._p(b_feat), ops._p(w_anc), ops._stream()), "ktd_pack")
-        out = ops.gemm_nt(h2, w_feat, L.EPI_STORE, bias=b_feat)                      # (F, 144 + 10 + 3)
+        hm = getattr(ktd, "head_matmul", None)
+        out = ops.gemm_nt(h2, w_feat, L.EPI_STORE, bias=b_feat, prec=hm)             # (F, 144 + 10 + 3)
         base = out[:, :144].contiguous()
         pose = torch.empty_like(base)
         L.check(lib.maed_ktd_chain_fwd(ops._p(base), ops._p(w_anc), ops._p(pose), Fr, ops._stream()), "ktd_chain_fwd")
         ctx.save_for_backward(h2, pose, w_feat, w_anc)
-        ctx.ktd = ktd
+        ctx.ktd, ctx.hm = ktd, hm
         ctx.set_materialize_grads(False)
         if ops.ReportingFn.will_run_backward(ctx):
             ktd._pending_backwards += 1
@@ -75,9 +76,9 @@ class KtdChainFn(ops.ReportingFn):
         d_h2 = None
         if ctx.needs_input_grad[0]:
             w_feat_t, _ = ops.transpose_cast(w_feat, torch.float32, pad_to=1)       # (hidden, 157)
-            d_h2 = ops.gemm_nt(d_out, w_feat_t, L.EPI_STORE)
+            d_h2 = ops.gemm_nt(d_out, w_feat_t, L.EPI_STORE, prec=ctx.hm)           # (K = 157 is not a multiple of 32: the exact kernel either way)
         h2_t, _ = ops.transpose_cast(h2, torch.float32, pad_to=1)                   # (hidden, F)
-        d_w_feat = ops.gemm_nt(d_out_t, h2_t, L.EPI_STORE)                          # (157, hidden)
+        d_w_feat = ops.gemm_nt(d_out_t, h2_t, L.EPI_STORE, prec=ctx.hm)             # (157, hidden)
         tbl = ktd._ptr_table(True)
         L.check(lib.maed_ktd_unpack_add(C.byref(tbl), hidden, ops._p(d_w_feat), ops._p(d_b), ops._p(d_w_anc), ops._stream()), "ktd_unpack_add")
         ktd._pending_backwards -= 1

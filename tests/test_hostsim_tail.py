@@ -69,6 +69,23 @@ def test_tail_forward_backward_vs_aten(out_keys):
         assert rel(a, b) < 2e-4, (n, rel(a, b))
 
 
+def test_head_on_the_split_engine_for_bf16_mode_models():
+    """round 4: KTD.head_matmul = "bf16x3" (what MAED sets for a bf16-mode model) -- fc1, fc2, the packed regressor GEMM, their input and weight gradients on the
+    split-bf16 MFMA kernels (few output tiles + long K: bias fill + split-K atomics on the matrix cores; the ragged K = 157 input gradient stays exact).  Outputs
+    and gradients stay within the split engine's ~2^-16, four orders below what the bf16 encoder in front of the head delivers."""
+    ktd = make_ktd(feat=64, hidden=256)
+    ktd.head_matmul = "bf16x3"
+    x = torch.randn(5, 64, requires_grad=True)
+    out_ref, gref, out, gsim = run_both(ktd, x, ("kp_2d", "theta"))
+    for k in out_ref:
+        assert rel(out[k].detach(), out_ref[k].detach()) < 2e-4, (k, rel(out[k].detach(), out_ref[k].detach()))
+    names = ["x"] + [n for n, _ in ktd.named_parameters()]
+    for n, a, b in zip(names, gsim, gref):
+        if b is None:
+            continue
+        assert a is not None and rel(a, b) < 2e-3, (n, rel(a, b))
+
+
 def test_all_quaternion_branches_differentiated():
     """rotation_matrix_to_angle_axis takes one of four branches per joint (geometry.py:143-223); the dual-number backward
     must follow the same branch.  Random 6D poses hit all four; compare d(theta)/d(pose6d) joint by joint."""
