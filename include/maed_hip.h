@@ -393,6 +393,10 @@ int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, 
 int maed_maxpool3s2_same_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype, void* stream);
 int maed_maxpool3s2_same_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int dtype, void* stream);
 
+/* Input of the stem convolution in one pass: x fp32 (N,C,H,W) contiguous -> y (N, H + pad_top + pad_bottom, W + pad_left + pad_right, C) channels_last in the
+ * compute dtype, zero borders (the TF-SAME padding of resnetv2.py:51-59 materialised where the vendor convolution needs a symmetric one).  C <= 4. */
+int maed_stem_input(const float* x, void* y, int N, int C, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right, int dtype, void* stream);
+
 /* Pixel subsampling of the 1x1 stride-2 downsample convolutions (resnetv2.py:207-216; TF-SAME padding of a 1x1 kernel is always zero):
  * fwd: y (F,ceil(H/2),ceil(W/2),C) = x[:, ::2, ::2, :] on channels_last x (F,H,W,C), C % 8 == 0 -- the convolution is then
  * maed_conv1x1_fwd on the packed rows; bwd: dx (F,H,W,C) = the packed gradient g spread back, zeros elsewhere (one write pass). */

@@ -796,6 +796,34 @@ extern "C" int maed_maxpool3s2_same_bwd(const void* dy, const uint8_t* idx, void
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Input of the 7x7 stem convolution (resnetv2.py:51-59,74-93,282-285): the clip arrives fp32 NCHW; MIOpen's solver wants the compute dtype, channels_last, and
+// a SYMMETRIC padding -- TF-SAME for kernel 7 / stride 2 on 224 is 2 in front and 3 behind.  The framework did that in three passes (dtype cast, layout copy,
+// zero-filled padded copy: 35 + 31 + 8 us at cfg3).  One pass here: thread per padded pixel, three plane reads (coalesced along x), one 6- or 12-byte store.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_input_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t n, int C, int H, int W, int Hp, int Wp, int top, int left) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread: all C (<= 4) channels of one padded pixel
+    if (i >= n) return;
+    const int xp = (int)(i % Wp), yp = (int)((i / Wp) % Hp);
+    const int64_t f = i / ((int64_t)Wp * Hp);
+    const int xx = xp - left, yy = yp - top;
+    const bool in = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+    for (int c = 0; c < C; ++c) stf(y + i * C + c, in ? x[((f * C + c) * H + yy) * (int64_t)W + xx] : 0.f);
+}
+
+extern "C" int maed_stem_input(const float* x, void* y, int N, int C, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right, int dtype, void* stream) {
+    MAED_CHECK_ARG(x && y, MAED_ERR_ARG, "stem_input: null pointer");
+    MAED_CHECK_ARG(N >= 0 && C > 0 && C <= 4 && H > 0 && W > 0 && pad_top >= 0 && pad_bottom >= 0 && pad_left >= 0 && pad_right >= 0, MAED_ERR_SHAPE, "stem_input: bad extents (C <= 4)");
+    const int Hp = H + pad_top + pad_bottom, Wp = W + pad_left + pad_right;
+    const int64_t n = (int64_t)N * Hp * Wp;
+    if (n == 0) return MAED_OK;
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stem_input_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, n, C, H, W,
+                                                      Hp, Wp, pad_top, pad_left));
+    MAED_CHECK_LAUNCH("stem_input");
+    return MAED_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Pixel subsampling of a 1x1 stride-2 convolution (the downsample shortcut of stages 2 and 3, resnetv2.py:207-216: TF-SAME padding of a
 // 1x1 kernel is zero for every input size, so output pixel (oy, ox) reads input pixel (2 oy, 2 ox)).  Forward packs those pixels into a
 // dense (F, Ho, Wo, C) activation -- the convolution is then a plain GEMM on 1/4 of the rows, and the packed copy is also the weight

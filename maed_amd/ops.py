@@ -805,6 +805,17 @@ class GroupNormFn(torch.autograd.Function):
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+def stem_input(x, dtype, k, s):
+    """fp32 NCHW clip frames -> compute dtype, channels_last, TF-SAME padded for a kernel-k / stride-s convolution, in ONE pass (maed_stem_input); returns the
+    padded tensor as an (N, C, Hp, Wp) channels_last view: the convolution then runs with padding 0"""
+    N, C_, H, W = x.shape
+    ph = max((math.ceil(H / s) - 1) * s + k - H, 0)
+    pw = max((math.ceil(W / s) - 1) * s + k - W, 0)
+    y = torch.empty(N, H + ph, W + pw, C_, dtype=dtype, device=x.device)
+    check(L.lib().maed_stem_input(_p(x), _p(y), N, C_, H, W, ph // 2, ph - ph // 2, pw // 2, pw - pw // 2, dt_code(dtype), _stream()), "stem_input")
+    return y.permute(0, 3, 1, 2)
+
+
 class MaxPool3s2SameFn(torch.autograd.Function):
     """MaxPool2dSame(3, 2) on a channels_last tensor (maed_maxpool3s2_same_fwd/bwd): no -inf padded copy, gather backward"""
 

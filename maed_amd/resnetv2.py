@@ -111,6 +111,7 @@ class StdConv2dSame(nn.Conv2d):
     _w_t = None    # 1x1 stride-1 convolutions in bf16 mode: transposed standardised weight (I, O) -> the GEMM path
     _dw = None     # ... and the fp32 slice their weight gradient accumulates into
     _prec = None   # fp32 matrix-product engine of the owning backbone (ResNetV2.f32_matmul), None = the process-wide mode
+    _prepadded = False   # set by ResNetV2 for the stem when ops.stem_input already applied the TF-SAME padding
 
     @staticmethod
     def _gn_sums_for(gn, x_shape, out_channels, stride):
@@ -145,6 +146,8 @@ class StdConv2dSame(nn.Conv2d):
             w = self.get_weight().to(x.dtype)
             if ops.on_library_device(x):
                 w = w.contiguous(memory_format=torch.channels_last)
+        if self._prepadded:
+            return F.conv2d(x, w, None, self.stride, 0, self.dilation, self.groups)
         k, s = self.kernel_size[0], self.stride[0]
         ih, iw = x.shape[-2:]
         ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
@@ -333,7 +336,14 @@ class ResNetV2(nn.Module):
     def forward_features(self, x):
         if not ops.on_library_device(x):
             return self.stages(self.stem(x))
-        x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
+        stem = self.stem.conv
+        if (x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] <= 4 and not x.requires_grad and os.environ.get("MAED_STEM_INPUT", "1") == "1"
+                and stem.dilation == (1, 1) and stem.kernel_size[0] == stem.kernel_size[1]):
+            # cast + channels_last + the stem's TF-SAME padding in one pass (the framework: three); the stem convolution below sees an already padded image
+            x = ops.stem_input(x, self.compute_dtype, stem.kernel_size[0], stem.stride[0])
+            _slots(stem, _prepadded=True)
+        else:
+            x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
         ws = None if _ws_per_stage() else ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
         # GroupNorm scratch for all layers of this pass: ONE zero-fill each instead of a memset per layer and direction
         N = x.shape[0]
@@ -370,6 +380,7 @@ class ResNetV2(nn.Module):
                 g._ws_on_side = bool(runs) and g is not runs[0] and g in runs
             return x
         finally:
+            _slots(self.stem.conv, _prepadded=False)
             for c in self._convs:
                 _slots(c, _w_std=None, _w_t=None, _dw=None, _prec=None)
             for m in self._norms:
