@@ -291,6 +291,7 @@ def main():
     from maed_amd import _lib as L
     from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
     from maed_amd.loss import LossVideo
+    from maed_amd.resnetv2 import _ws_per_stage
     lib = L.lib()  # raises if libmaed_hip.so is missing: no fallback
     if args.f32_matmul:
         import maed_amd
@@ -503,7 +504,7 @@ def main():
             roofline_wgrad = dict(kernel="gemm_tn_mfma_bf16_kernel (weight gradients dW += Y^T X of the STE, five per block)", bound="mfma", achieved=k["tflops"],
                                   peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=k["frac_mfma_peak"], traffic=traffic_db.get("gemm_tn_ste_shapes", traffic_db.get("gemm_tn")), avg_us=k["avg_us"],
                                   note="flops averaged over the five shapes; in-situ hipEvent timing")
-        # THE roofline object: the kernel with the most time in the step's rocprofv3 summary -- the TN weight-gradient GEMM (gemm_tn_mfma_bf16_kernel<false>:
+        # THE roofline object: the kernel with the most time in the step's rocprofv3 summary -- the TN weight-gradient GEMM (gemm_tn_mfma_bf16_kernel<false, false>:
         # STE Linear layers AND the backbone's 1x1 convolutions) -- over EVERY launch of it (tag 11: maed_gemm_tn_wgrad brackets itself and declares 2*M*N*K)
         if ntags > TN_ALL and cnt[TN_ALL] > 0:
             us = 1e3 * ms[TN_ALL] / cnt[TN_ALL]
@@ -524,7 +525,7 @@ def main():
                         for (fl, by), e in sorted(shapes.items(), key=lambda kv: -kv[1][1])]
             launch_bound = dict(frac=round(tb_sum / dur_sum, 4) if dur_sum else None, hbm_bound_launches_per_step=round(n_hbm / nprof, 1),
                                 mfma_bound_launches_per_step=round((len(tn_recs) - n_hbm) / nprof, 1), mfma_ops_per_product=mult, by_shape=by_shape[:12])
-            roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_mfma_bf16_kernel<false>") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
+            roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_mfma_bf16_kernel<false, false>") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
                                    "5 per STE block + the backbone's 1x1 convolutions)", bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                             frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=traffic_db.get("gemm_tn"), avg_us=round(us, 2), launches=cnt[TN_ALL] // nprof,
                             ms_per_step=round(ms[TN_ALL] / nprof, 3), algorithmic_bytes=(int(sum(r[2] for r in tn_recs) / len(tn_recs)) if tn_recs else None),
@@ -583,13 +584,19 @@ def main():
             "ddp": (None if args.forward_only else dict(transport="maed_comm (own RCCL communicator)" if comm is not None else ("torch.distributed/" + (dist.get_backend() if dist.is_initialized() else "none")),
                                                      rccl_ranks=world, collectives=bool(bucketer.collectives), gradient_dtype="f32",
                                                      buckets=[dict(mbytes=round(4 * (e - s) / 2 ** 20, 2), params=n) for s, e, n in bucketer.buckets],
-                                                     bucket_launch_order=list(bucketer.launch_order), per_stage_weight_std=bool(bucketer.world > 1))),
+                                                     bucket_launch_order=list(bucketer.launch_order), per_stage_weight_std=bool(_ws_per_stage()))),
             "roofline": roofline, "roofline_nt": roofline_nt, "roofline_attention": roofline_attention, "roofline_wgrad": roofline_wgrad, "kernels": kernels,
             "kernel_groups": groups,
             "cpu_baseline": cpu,
             "parity_err_bf16": (cpu or {}).get("parity_probe", {}).get("rel_err", {}).get("bf16") if cpu and (cpu.get("parity_probe") or {}).get("rel_err") else None,
             "parity_mode": (cpu or {}).pop("parity_mode", None) if cpu else None,
         }
+        # first-class beside `value`: the same train step in the fastest mode whose OUTPUTS meet north_star's 1e-3 on SMPL parameters at full module
+        # size -- `value` itself is the bf16 mode's number, at bf16 accuracy
+        pm = out.get("parity_mode") or {}
+        fw = pm.get("fastest_within_1e3")
+        out["value_at_1e3"] = (dict(value=fw["clips_per_sec"], unit="video-clips/sec", ms_per_step=fw["ms_per_step"], theta_rel_err=fw["theta_rel_err"], mode=fw["name"],
+                                    note="fp32 storage, split-bf16 matrix products; see parity_mode.variants") if fw else None)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

@@ -3,8 +3,8 @@
     python scripts/group_rooflines.py steady_state_kernels.csv [traffic.json]
 With a traffic.json the result is stored under "__groups__" (bench.py then reports it as kernel_groups for the same source hash).
 GroupNorm bytes per step at cfg3 (128 frames, bf16), from the layer list of the hybrid R50: forward apply reads x (+ residual) and writes y (+ 1 bit per element
-when a residual precedes the ReLU); the three layers behind MIOpen convolutions also read x once for the statistics; backward reduce reads x, dy (+ bits);
-backward apply reads x, dy (+ bits) and writes dx (+ the masked residual gradient in the four downsample blocks)."""
+when a residual precedes the ReLU); the layer behind the MIOpen stem convolution also reads x once for the statistics; backward (round 4: one pass, gn_bwd_onepass_kernel)
+reads x, dy (+ bits) once and writes dx (+ the masked residual gradient in the four downsample blocks) -- the round-3 figure counted x and dy twice (reduce + apply)."""
 import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -27,8 +27,7 @@ def groupnorm_bytes(frames=128, E=2):
         t = frames * h * h * C * E
         bits = t // (8 * E) if res else 0
         fwd += t * (2 + (1 if res else 0)) + bits + (t if stats_pass else 0)
-        bwd += t * 2 + bits                                              # reduce
-        bwd += t * (3 + (1 if res is True else 0)) + bits                # apply
+        bwd += t * (3 + (1 if res is True else 0)) + bits                # round 4: ONE pass -- x, dy read once, dx written (+ the masked residual gradient in the downsample blocks)
     return len(layers), fwd, bwd
 
 
