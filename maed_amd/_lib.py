@@ -179,7 +179,7 @@ _OPTIONS = {
     OPT_TN_TARGET_WGS: int(os.environ.get("MAED_TN_TARGET_WGS", "0")),
     OPT_ABLATE: int(os.environ.get("MAED_GEMM_ABLATE", "0")),
     OPT_F32_BWD_X1: int(os.environ.get("MAED_F32_BWD", "") == "bf16x1"),
-    OPT_ST_FUSED: int(os.environ.get("MAED_ST_FUSED", "1") == "1"),              # A/B knob: 0 = the attentive addition as four launches per direction
+    OPT_ST_FUSED: int(os.environ.get("MAED_ST_FUSED", "1")),              # A/B knob: 0 = the attentive addition as four launches per direction
     OPT_GN_BWD_ONEPASS: int(os.environ.get("MAED_GN_BWD_ONEPASS", "1")),      # A/B knob: 0 = the two-pass GroupNorm backward (2: 256-thread variant of the one-pass kernel)
 }
 

@@ -181,7 +181,14 @@ ScratchLayout scratch_layout(const maed_block_dims& d) {
 size_t maed_layernorm_bwd_partials_bytes(int64_t rows, int C);
 int maed_layernorm_bwd_ws(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma, const float* mean, const float* rstd,
                           const float* dres_in, float* dx_out, void* dx_twin, float* dgamma, float* dbeta, int64_t rows, int C, float* partials,
-                          void* stream);
+                          void* stream, bool finish = true, uint32_t* clear = nullptr, int clear_words = 0);
+int maed_layernorm_affine_finish(const float* partials, int64_t rows, int C, float* dgamma, float* dbeta, void* stream);
+int maed_layernorm_fwd_ws(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y, int dtype, float* mean, float* rstd, int64_t rows,
+                          int C, float eps, uint32_t* clear, int clear_words, void* stream);
+int maed_st_fused_fwd_ws(const void* x_s, const void* x_t, const void* w_ts, const float* b_ts, void* means, float* logits, void* mix,
+                         uint32_t* sync, float* ex, int F, int P, int C, int dtype, bool clear_sync, uint32_t arrive_base, void* stream);
+int maed_st_fused_bwd_ws(const void* dmix, const void* x_s, const void* x_t, const float* logits, const void* wt_ts, void* dlogits, void* dx_s,
+                         void* dx_t, uint32_t* sync, float* ex, int F, int P, int C, int dtype, bool clear_sync, uint32_t arrive_base, void* stream);
 namespace {
 
 int check_dims(const maed_block_dims* d, const char* who) {
@@ -236,7 +243,11 @@ static int block_fwd(const maed_block_dims* d, const maed_block_params* p, const
     const float scale = 1.0f / sqrtf((float)HEAD_DIM);
     float* logits = (float*)(sv + L.logits);
 
-    MAED_PROPAGATE(maed_layernorm_fwd(x_in, C, p->ln1_g, p->ln1_b, sv + L.ln1, dt, (float*)(sv + L.mean1), (float*)(sv + L.rstd1), M, C, d->eps, stream));
+    // (the LayerNorm kernel also zeroes the per-frame arrival counters of the fused attentive addition further down: no memset launch of their own)
+    const bool stf = st_fused(*d);
+    const bool piggy = stf && maed_opt(MAED_OPT_ST_FUSED) != 2 && (int64_t)d->F * 16 <= 256 * ((M + 31) / 32);       // (the backward LayerNorm's grid is the smaller one; otherwise the fused call clears itself; option value 2: A/B knob -- memset nodes, LayerNorm column sums on the caller's stream)
+    MAED_PROPAGATE(maed_layernorm_fwd_ws(x_in, C, p->ln1_g, p->ln1_b, sv + L.ln1, dt, (float*)(sv + L.mean1), (float*)(sv + L.rstd1), M, C, d->eps,
+                                         piggy ? (uint32_t*)(sv + L.st_sync) : nullptr, piggy ? d->F * 16 : 0, stream));
     PROF(PROF_GEMM_QKV, maed_gemm_nt(sv + L.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, sv + L.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
     {   // the two attention branches read the same qkv and write disjoint outputs: temporal on the side stream beside spatial
         SideStream* ss = (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || maed_x3_planes())) ? side_stream() : nullptr;
@@ -246,9 +257,9 @@ static int block_fwd(const maed_block_dims* d, const maed_block_params* p, const
         PROF(PROF_ATTN_SP_FWD, maed_attn_spatial_fwd(sv + L.qkv, sv + L.xs, (float*)(sv + L.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
         if (ss) ss->fence(ss->s, (hipStream_t)stream);
     }
-    if (st_fused(*d)) {       // token means + ts_attn Linear + pair softmax + mix: one launch, x_s / x_t read once (elementwise.hip)
-        PROF(PROF_ST_FWD, maed_st_fused_fwd(sv + L.xs, sv + L.xt, p->w_ts, p->b_ts, sv + L.means, logits, sv + L.mix, (uint32_t*)(sv + L.st_sync), (float*)(sv + L.st_ex),
-                                            d->F, d->P, C, dt, stream));
+    if (stf) {       // token means + ts_attn Linear + pair softmax + mix: one launch, x_s / x_t read once (elementwise.hip)
+        PROF(PROF_ST_FWD, maed_st_fused_fwd_ws(sv + L.xs, sv + L.xt, p->w_ts, p->b_ts, sv + L.means, logits, sv + L.mix, (uint32_t*)(sv + L.st_sync), (float*)(sv + L.st_ex),
+                                               d->F, d->P, C, dt, !piggy, 0u, stream));
     } else {
         MAED_PROPAGATE(maed_st_colmean(sv + L.xs, sv + L.xt, sv + L.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
         MAED_PROPAGATE(maed_gemm_nt(sv + L.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
@@ -318,16 +329,27 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         // LayerNorm dgamma/dbeta via partials in the (here unused) transpose slot instead of contended atomics (measured on MI355X,
         // profiles/r02_call2_steady_*.csv: 0.629 -> 0.503 + 0.080 ms per step)
         const size_t big_t_bytes = (size_t)(Hd > 3 * C ? Hd : 3 * C) * (size_t)Mp * dtype_size(dt);      // S.bigT: only the exact-f32 path transposes into it
-        float* ln_part = maed_layernorm_bwd_partials_bytes(M, C) <= big_t_bytes ? (float*)(sc + S.bigT) : nullptr;
+        // round 4 experiment (MAED_OPT_ST_FUSED = 4): the closing column sums (12 launches of ~7 us per step) on the side stream -- nothing reads the LayerNorm
+        // gradients before the end of the block (FROM_SIDE); LN2 and LN1 get their own partial regions, LN1's kernel would otherwise overwrite what the side stream
+        // still sums.  Measured same-box: 21.07 / 21.20 ms against 21.04 / 21.10 with the sums on the caller's stream -- the two fences cost what the launches
+        // did; not the default.
+        const size_t ln_pb = (maed_layernorm_bwd_partials_bytes(M, C) + 255) & ~(size_t)255;
+        float* ln_part = 2 * ln_pb <= big_t_bytes ? (float*)(sc + S.bigT) : nullptr;
+        float* ln_part1 = ln_part ? (float*)(sc + S.bigT + ln_pb) : nullptr;
+        const bool ln_side = ss != nullptr && ln_part != nullptr && maed_opt(MAED_OPT_ST_FUSED) == 4;
+        const bool piggy = st_fused(*d) && maed_opt(MAED_OPT_ST_FUSED) != 2 && (int64_t)d->F * 16 <= 256 * ((M + 31) / 32);
         MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, (const float*)(sv + L.xmid), C, p->ln2_g, (const float*)(sv + L.mean2), (const float*)(sv + L.rstd2),
-                                             dx_out, dxmid, dt == MAED_F32 ? nullptr : dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream));
+                                             dx_out, dxmid, dt == MAED_F32 ? nullptr : dxmid_tw, g->ln2_g, g->ln2_b, M, C, ln_part, stream, !ln_side,
+                                             piggy ? (uint32_t*)(sv + L.st_sync) : nullptr, piggy ? d->F * 16 : 0));      // (+ clears the counters st_fused_bwd polls)
+        if (ln_side) { TO_SIDE(); MAED_PROPAGATE(maed_layernorm_affine_finish(ln_part, M, C, g->ln2_g, g->ln2_b, wst)); }
         // attention: x_mid = x_in + proj(mix(x_s, x_t))
         TO_SIDE();
         WGRAD(maed_gemm_tn_wgrad(dxmid_tw, C, sv + L.mix, C, M, C, C, g->w_proj, C, g->b_proj, dmm, wst));
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(dxmid_tw, C, p->wt_proj, C, M, C, C, dmm, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));  // dmix
         if (st_fused(*d)) {   // dlogits + d(means) = dlogits . W_ts + dx_s / dx_t: one launch, dmix / x_s / x_t read once; the ts_attn weight gradient follows on the side stream
-            PROF(PROF_ST_BWD, maed_st_fused_bwd(sc + S.act, sv + L.xs, sv + L.xt, logits, p->wt_ts, sc + S.dlog, sc + S.dxs, sc + S.dxt, (uint32_t*)(sv + L.st_sync),
-                                                (float*)(sv + L.st_ex), d->F, d->P, C, dt, stream));
+            // (the frames' arrival counters were cleared by the LayerNorm-2 backward kernel above)
+            PROF(PROF_ST_BWD, maed_st_fused_bwd_ws(sc + S.act, sv + L.xs, sv + L.xt, logits, p->wt_ts, sc + S.dlog, sc + S.dxs, sc + S.dxt, (uint32_t*)(sv + L.st_sync),
+                                                   (float*)(sv + L.st_ex), d->F, d->P, C, dt, !piggy, 0u, stream));
             TO_SIDE();
             WGRAD(maed_gemm_tn_wgrad(sc + S.dlog, 2 * C, sv + L.means, 2 * C, d->F, 2 * C, 2 * C, g->w_ts, 2 * C, g->b_ts, dmm, wst));
         } else {
@@ -345,7 +367,8 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
         WGRAD(maed_gemm_tn_wgrad(sc + S.bigA, 3 * C, sv + L.ln1, C, M, 3 * C, C, g->w_qkv, C, g->b_qkv, dmm, wst));
         PROF(PROF_GEMM_DGRAD, maed_gemm_nt(sc + S.bigA, 3 * C, p->wt_qkv, 3 * C, M, C, 3 * C, dmm, MAED_EPI_STORE, nullptr, sc + S.act, C, nullptr, nullptr, 0, 1, gi, stream));
         MAED_PROPAGATE(maed_layernorm_bwd_ws(sc + S.act, dt, x_in, C, p->ln1_g, (const float*)(sv + L.mean1), (const float*)(sv + L.rstd1), dxmid, dx_in,
-                                             dx_in_twin, g->ln1_g, g->ln1_b, M, C, ln_part, stream));
+                                             dx_in_twin, g->ln1_g, g->ln1_b, M, C, ln_part1, stream, !ln_side));
+        if (ln_side) { TO_SIDE(); MAED_PROPAGATE(maed_layernorm_affine_finish(ln_part1, M, C, g->ln1_g, g->ln1_b, wst)); }
         FROM_SIDE();                                                     // scratch and gradients: everything after this call sees the weight gradients
 #undef TO_SIDE
 #undef FROM_SIDE

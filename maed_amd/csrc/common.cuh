@@ -185,7 +185,9 @@ __device__ __forceinline__ float maed_agent_load(const float* p) { return *p; }
 #else
 __device__ __forceinline__ bool maed_frame_arrive_and_wait(uint32_t* ctr, uint32_t S) {      // ONE lane; every wave has drained its payload (vmcnt 0 + barrier) before
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S; ) {
+    // (!= and not <: exactly S workgroups arrive at a counter that was zero at launch -- a counter that was NOT cleared can then never release the barrier early
+    //  with stale data behind it; it runs into the spin bound and poisons the result: loud instead of subtly wrong)
+    for (uint32_t spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S; ) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 21)) return false;
     }

@@ -156,7 +156,7 @@ __device__ __forceinline__ void st1_gemv256(const bf16* __restrict__ W, int K2, 
 template <int CH>
 __global__ __launch_bounds__(ST1_NT, 4) void st_fused_fwd_kernel(const bf16* __restrict__ x_s, const bf16* __restrict__ x_t, const bf16* __restrict__ w_ts,
                                                                  const float* __restrict__ b_ts, bf16* __restrict__ means, float* __restrict__ logits,
-                                                                 bf16* __restrict__ mix, uint32_t* sync, float* ex, int P, int C, int S, int phase) {
+                                                                 bf16* __restrict__ mix, uint32_t* sync, float* ex, int P, int C, int S, uint32_t target, int phase) {
     __shared__ float lpart[32 * 16 * 16];      // [row lane][chunk][x_s: 8 | x_t: 8] token-sum partials
     __shared__ float lvec[2048];               // the frame's 2C means
     __shared__ float llog[256];                // this slice's 128 logit pairs
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(ST1_NT, 4) void st_fused_fwd_kernel(const bf16* __r
         MAED_WAIT_VMCNT0();                                          // the published means have left this wave
         __syncthreads();
         if (S > 1) {
-            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, (uint32_t)S)) lfail = 1;
+            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, target)) lfail = 1;
             __syncthreads();
         }
     }
@@ -228,7 +228,7 @@ template <int CH>
 __global__ __launch_bounds__(ST1_NT, (CH > 7 ? 2 : 4)) void st_fused_bwd_kernel(const bf16* __restrict__ dmix, const bf16* __restrict__ x_s, const bf16* __restrict__ x_t,
                                                                  const float* __restrict__ logits, const bf16* __restrict__ wt_ts, bf16* __restrict__ dlogits,
                                                                  bf16* __restrict__ dx_s, bf16* __restrict__ dx_t, uint32_t* sync, float* ex, int P, int C,
-                                                                 int S, int phase) {
+                                                                 int S, uint32_t target, int phase) {
     __shared__ float lpart[32 * 16 * 16];      // [row lane][chunk][sum dmix x_s: 8 | sum dmix x_t: 8]
     __shared__ float lvec[2048];               // the frame's 2C dlogits
     __shared__ float ldm[256];                 // d(means) of this slice: x_s half, x_t half
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(ST1_NT, (CH > 7 ? 2 : 4)) void st_fused_bwd_kernel(
         MAED_WAIT_VMCNT0();
         __syncthreads();
         if (S > 1) {
-            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, (uint32_t)S)) lfail = 1;
+            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, target)) lfail = 1;
             __syncthreads();
         }
     }
@@ -320,37 +320,53 @@ extern "C" int maed_st_fused_supported(int P, int C, int dtype) { return dtype =
 #define ST1_LAUNCH(K_, ...) hipLaunchKernelGGL(K_, grid, dim3(ST1_NT), 0, s, __VA_ARGS__, 0)
 #endif
 
+// arrive_base: value of the frames' arrival counters at launch -- 0 after a clear; the block driver's backward continues from the forward's C / 128 instead of
+// clearing again (one counter, monotonic over the two launches of a block); clear_sync: memset the counters first (stand-alone calls)
+int maed_st_fused_fwd_ws(const void* x_s, const void* x_t, const void* w_ts, const float* b_ts, void* means, float* logits, void* mix,
+                         uint32_t* sync, float* ex, int F, int P, int C, int dtype, bool clear_sync, uint32_t arrive_base, void* stream);
+int maed_st_fused_bwd_ws(const void* dmix, const void* x_s, const void* x_t, const float* logits, const void* wt_ts, void* dlogits, void* dx_s,
+                         void* dx_t, uint32_t* sync, float* ex, int F, int P, int C, int dtype, bool clear_sync, uint32_t arrive_base, void* stream);
 extern "C" int maed_st_fused_fwd(const void* x_s, const void* x_t, const void* w_ts, const float* b_ts, void* means, float* logits, void* mix,
                                  uint32_t* sync, float* ex, int F, int P, int C, int dtype, void* stream) {
+    return maed_st_fused_fwd_ws(x_s, x_t, w_ts, b_ts, means, logits, mix, sync, ex, F, P, C, dtype, true, 0u, stream);
+}
+extern "C" int maed_st_fused_bwd(const void* dmix, const void* x_s, const void* x_t, const float* logits, const void* wt_ts, void* dlogits, void* dx_s,
+                                 void* dx_t, uint32_t* sync, float* ex, int F, int P, int C, int dtype, void* stream) {
+    return maed_st_fused_bwd_ws(dmix, x_s, x_t, logits, wt_ts, dlogits, dx_s, dx_t, sync, ex, F, P, C, dtype, true, 0u, stream);
+}
+int maed_st_fused_fwd_ws(const void* x_s, const void* x_t, const void* w_ts, const float* b_ts, void* means, float* logits, void* mix,
+                         uint32_t* sync, float* ex, int F, int P, int C, int dtype, bool clear_sync, uint32_t arrive_base, void* stream) {
     MAED_CHECK_ARG(x_s && x_t && w_ts && b_ts && means && logits && mix && sync && ex, MAED_ERR_ARG, "st_fused_fwd: null pointer");
     MAED_CHECK_ARG(maed_st_fused_supported(P, C, dtype), MAED_ERR_UNSUPPORTED, "st_fused_fwd: bf16, C %% 128 == 0, C <= 1024, P <= 288 (P=%d C=%d dtype=%d)", P, C, dtype);
     MAED_CHECK_ARG(is_aligned(x_s, 16) && is_aligned(x_t, 16) && is_aligned(w_ts, 16) && is_aligned(mix, 16), MAED_ERR_ALIGN, "st_fused_fwd: 16-B alignment");
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
-    MAED_HIP(hipMemsetAsync(sync, 0, (size_t)F * 16 * sizeof(uint32_t), s), "st_fused_fwd: memset");
+    if (clear_sync) MAED_HIP(hipMemsetAsync(sync, 0, (size_t)F * 16 * sizeof(uint32_t), s), "st_fused_fwd: memset");
     const int S = C / 128;
+    const uint32_t target = arrive_base + (uint32_t)S;
     const dim3 grid(S, F);
-    if (P <= 224) ST1_LAUNCH(st_fused_fwd_kernel<7>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S);
-    else ST1_LAUNCH(st_fused_fwd_kernel<9>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S);
+    if (P <= 224) ST1_LAUNCH(st_fused_fwd_kernel<7>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S, target);
+    else ST1_LAUNCH(st_fused_fwd_kernel<9>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S, target);
     MAED_CHECK_LAUNCH("st_fused_fwd");
     return MAED_OK;
 }
 
-extern "C" int maed_st_fused_bwd(const void* dmix, const void* x_s, const void* x_t, const float* logits, const void* wt_ts, void* dlogits, void* dx_s,
-                                 void* dx_t, uint32_t* sync, float* ex, int F, int P, int C, int dtype, void* stream) {
+int maed_st_fused_bwd_ws(const void* dmix, const void* x_s, const void* x_t, const float* logits, const void* wt_ts, void* dlogits, void* dx_s,
+                         void* dx_t, uint32_t* sync, float* ex, int F, int P, int C, int dtype, bool clear_sync, uint32_t arrive_base, void* stream) {
     MAED_CHECK_ARG(dmix && x_s && x_t && logits && wt_ts && dlogits && dx_s && dx_t && sync && ex, MAED_ERR_ARG, "st_fused_bwd: null pointer");
     MAED_CHECK_ARG(maed_st_fused_supported(P, C, dtype), MAED_ERR_UNSUPPORTED, "st_fused_bwd: bf16, C %% 128 == 0, C <= 1024, P <= 288 (P=%d C=%d dtype=%d)", P, C, dtype);
     MAED_CHECK_ARG(is_aligned(dmix, 16) && is_aligned(x_s, 16) && is_aligned(x_t, 16) && is_aligned(wt_ts, 16) && is_aligned(dx_s, 16) && is_aligned(dx_t, 16),
                    MAED_ERR_ALIGN, "st_fused_bwd: 16-B alignment");
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
-    MAED_HIP(hipMemsetAsync(sync, 0, (size_t)F * 16 * sizeof(uint32_t), s), "st_fused_bwd: memset");
+    if (clear_sync) MAED_HIP(hipMemsetAsync(sync, 0, (size_t)F * 16 * sizeof(uint32_t), s), "st_fused_bwd: memset");
     const int S = C / 128;
+    const uint32_t target = arrive_base + (uint32_t)S;
     const dim3 grid(S, F);
     if (P <= 224) ST1_LAUNCH(st_fused_bwd_kernel<7>, (const bf16*)dmix, (const bf16*)x_s, (const bf16*)x_t, logits, (const bf16*)wt_ts, (bf16*)dlogits, (bf16*)dx_s,
-                             (bf16*)dx_t, sync, ex, P, C, S);
+                             (bf16*)dx_t, sync, ex, P, C, S, target);
     else ST1_LAUNCH(st_fused_bwd_kernel<9>, (const bf16*)dmix, (const bf16*)x_s, (const bf16*)x_t, logits, (const bf16*)wt_ts, (bf16*)dlogits, (bf16*)dx_s,
-                    (bf16*)dx_t, sync, ex, P, C, S);
+                    (bf16*)dx_t, sync, ex, P, C, S, target);
     MAED_CHECK_LAUNCH("st_fused_bwd");
     return MAED_OK;
 }

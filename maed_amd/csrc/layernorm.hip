@@ -10,7 +10,10 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ g, const float* __restrict__ b,
                                                      T* __restrict__ y, float* __restrict__ mean_o,
-                                                     float* __restrict__ rstd_o, int64_t rows, int C, float eps) {
+                                                     float* __restrict__ rstd_o, int64_t rows, int C, float eps, uint32_t* __restrict__ clear, int clear_words) {
+    // (piggy-backed scratch clear of the fused STE block: the arrival counters its attentive-addition kernel polls later in the same call -- a memset node of
+    //  its own was a launch per block and direction on the dependent chain)
+    if (clear) { const int64_t ci = (int64_t)blockIdx.x * 256 + threadIdx.x; if (ci < clear_words) clear[ci] = 0u; }
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -61,8 +64,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ g, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ dres,
                                                      float* __restrict__ dx, T* __restrict__ dx_twin, float* __restrict__ dg,
-                                                     float* __restrict__ db, int64_t rows, int C) {
+                                                     float* __restrict__ db, int64_t rows, int C, uint32_t* __restrict__ clear, int clear_words) {
     MAED_DYN_SHARED(float, lds);  // [2][4 waves][C]
+    if (clear) { const int64_t ci = (int64_t)blockIdx.x * 256 + threadIdx.x; if (ci < clear_words) clear[ci] = 0u; }       // (piggy-backed scratch clear, as in ln_fwd_kernel)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C / 4;
     float gg[NV][4], pg[NV][4], pb[NV][4];
@@ -139,15 +143,23 @@ __global__ __launch_bounds__(256) void ln_affine_finish_kernel(const float* __re
     colsum_add(partials, nwg, 2 * C, [=](int i) { return i < C ? dg + i : db + (i - C); });       // rows = [dgamma (C) | dbeta (C)]
 }
 
+// internal (block.hip): the forward that also zeroes `clear_words` 4-byte words at `clear` (clear_words <= 256 * ceil(rows / 4))
+int maed_layernorm_fwd_ws(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y, int dtype, float* mean, float* rstd, int64_t rows,
+                          int C, float eps, uint32_t* clear, int clear_words, void* stream);
 extern "C" int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
                                   void* y, int dtype, float* mean, float* rstd, int64_t rows, int C, float eps,
                                   void* stream) {
+    return maed_layernorm_fwd_ws(x, x_row_stride, gamma, beta, y, dtype, mean, rstd, rows, C, eps, nullptr, 0, stream);
+}
+int maed_layernorm_fwd_ws(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y, int dtype, float* mean, float* rstd, int64_t rows,
+                          int C, float eps, uint32_t* clear, int clear_words, void* stream) {
     MAED_CHECK_ARG(x && gamma && beta && y, MAED_ERR_ARG, "layernorm_fwd: null pointer");
     MAED_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXV, MAED_ERR_SHAPE, "layernorm_fwd: C=%d must be a multiple of 4, <= %d", C, 64 * 4 * LN_MAXV);
     MAED_CHECK_ARG(x_row_stride % 4 == 0 && is_aligned(x, 16) && is_aligned(y, 8), MAED_ERR_ALIGN, "layernorm_fwd: x/y/stride alignment");
     if (rows == 0) return MAED_OK;
     dim3 grid((unsigned)((rows + 3) / 4));
-#define LN_FWD(NV_) hipLaunchKernelGGL((ln_fwd_kernel<T, NV_>), grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, gamma, beta, (T*)y, mean, rstd, rows, C, eps)
+    MAED_CHECK_ARG(!clear || (int64_t)clear_words <= (int64_t)grid.x * 256, MAED_ERR_SHAPE, "layernorm_fwd: %d words to clear exceed the grid", clear_words);
+#define LN_FWD(NV_) hipLaunchKernelGGL((ln_fwd_kernel<T, NV_>), grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, gamma, beta, (T*)y, mean, rstd, rows, C, eps, clear, clear_words)
     MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_FWD(2); else if (C <= 768) LN_FWD(3); else if (C <= 1024) LN_FWD(4); else LN_FWD(8); });
 #undef LN_FWD
     MAED_CHECK_LAUNCH("layernorm_fwd");
@@ -161,7 +173,15 @@ size_t maed_layernorm_bwd_partials_bytes(int64_t rows, int C) {
 // internal (block.hip): `partials` (maed_layernorm_bwd_partials_bytes, or null) selects the store-then-sum form of dgamma/dbeta
 int maed_layernorm_bwd_ws(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma,
                           const float* mean, const float* rstd, const float* dres_in, float* dx_out, void* dx_twin,
-                          float* dgamma, float* dbeta, int64_t rows, int C, float* partials, void* stream);
+                          float* dgamma, float* dbeta, int64_t rows, int C, float* partials, void* stream, bool finish = true, uint32_t* clear = nullptr,
+                          int clear_words = 0);
+// the closing column sum of the store-then-sum form on its own (block.hip runs it on the side stream: finish = false above, then this)
+int maed_layernorm_affine_finish(const float* partials, int64_t rows, int C, float* dgamma, float* dbeta, void* stream) {
+    const int nwg = (int)((rows + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG);
+    hipLaunchKernelGGL(ln_affine_finish_kernel, dim3((2 * C + 63) / 64, (nwg + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, nwg, C, dgamma, dbeta);
+    MAED_CHECK_LAUNCH("layernorm_affine_finish");
+    return MAED_OK;
+}
 
 extern "C" int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma,
                                   const float* mean, const float* rstd, const float* dres_in, float* dx_out, void* dx_twin,
@@ -171,21 +191,22 @@ extern "C" int maed_layernorm_bwd(const void* dy, int dtype, const float* x, int
 
 int maed_layernorm_bwd_ws(const void* dy, int dtype, const float* x, int64_t x_row_stride, const float* gamma,
                           const float* mean, const float* rstd, const float* dres_in, float* dx_out, void* dx_twin,
-                          float* dgamma, float* dbeta, int64_t rows, int C, float* partials, void* stream) {
+                          float* dgamma, float* dbeta, int64_t rows, int C, float* partials, void* stream, bool finish, uint32_t* clear, int clear_words) {
     MAED_CHECK_ARG(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta, MAED_ERR_ARG, "layernorm_bwd: null pointer");
     MAED_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXV, MAED_ERR_SHAPE, "layernorm_bwd: C=%d unsupported", C);
     MAED_CHECK_ARG(x_row_stride % 4 == 0 && is_aligned(x, 16) && is_aligned(dy, 8) && is_aligned(dx_out, 16), MAED_ERR_ALIGN, "layernorm_bwd: alignment");
     if (rows == 0) return MAED_OK;
     dim3 grid((unsigned)((rows + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG));
+    MAED_CHECK_ARG(!clear || (int64_t)clear_words <= (int64_t)grid.x * 256, MAED_ERR_SHAPE, "layernorm_bwd: %d words to clear exceed the grid", clear_words);
     const size_t lds = (size_t)8 * C * sizeof(float);
 #define LN_BWD(NV_) hipLaunchKernelGGL((ln_bwd_kernel<T, NV_>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)dy, x, x_row_stride, gamma, mean, \
-                                      rstd, dres_in, dx_out, (T*)dx_twin, dgamma, dbeta, rows, C)
+                                      rstd, dres_in, dx_out, (T*)dx_twin, dgamma, dbeta, rows, C, clear, clear_words)
 #define LN_BWD_P(NV_) hipLaunchKernelGGL((ln_bwd_kernel<T, NV_, true>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)dy, x, x_row_stride, gamma, \
-                                        mean, rstd, dres_in, dx_out, (T*)dx_twin, partials, (float*)nullptr, rows, C)
+                                        mean, rstd, dres_in, dx_out, (T*)dx_twin, partials, (float*)nullptr, rows, C, clear, clear_words)
     if (partials) {
         MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_BWD_P(2); else if (C <= 768) LN_BWD_P(3); else if (C <= 1024) LN_BWD_P(4); else LN_BWD_P(8); });
-        hipLaunchKernelGGL(ln_affine_finish_kernel, dim3((2 * C + 63) / 64, (grid.x + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, (int)grid.x, C,
-                           dgamma, dbeta);
+        if (finish) hipLaunchKernelGGL(ln_affine_finish_kernel, dim3((2 * C + 63) / 64, (grid.x + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, (int)grid.x, C,
+                                       dgamma, dbeta);
     } else {
         MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_BWD(2); else if (C <= 768) LN_BWD(3); else if (C <= 1024) LN_BWD(4); else LN_BWD(8); });
     }
