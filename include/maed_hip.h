@@ -393,9 +393,24 @@ int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, 
 int maed_maxpool3s2_same_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype, void* stream);
 int maed_maxpool3s2_same_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int dtype, void* stream);
 
-/* Input of the stem convolution in one pass: x fp32 (N,C,H,W) contiguous -> y (N, H + pad_top + pad_bottom, W + pad_left + pad_right, C) channels_last in the
- * compute dtype, zero borders (the TF-SAME padding of resnetv2.py:51-59 materialised where the vendor convolution needs a symmetric one).  C <= 4. */
-int maed_stem_input(const float* x, void* y, int N, int C, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right, int dtype, void* stream);
+/* Input of the stem convolution in one pass: x fp32 (N,C,H,W) contiguous -> y (N, H + pad_top + pad_bottom, W + pad_left + pad_right, c_stride) channels_last in
+ * the compute dtype, zero borders (the TF-SAME padding of resnetv2.py:51-59 materialised), channel slots C .. c_stride-1 zero.  C <= c_stride <= 4
+ * (c_stride 4: 8-byte pixels for maed_stem7x7s2_*; y 16-B aligned). */
+int maed_stem_input(const float* x, void* y, int N, int C, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right, int c_stride, int dtype,
+                    void* stream);
+
+/* The stem convolution itself -- StdConv2dSame(3 -> 64, kernel 7, stride 2), resnetv2.py:74-93 as instantiated by :330-333 -- on the library (csrc/stem.hip;
+ * replaces the vendor convolution F.conv2d dispatches to).  bf16 only; even H, W with (H/2)*(W/2) % 128 == 0 and (W/2) % 16 == 0 (maed_stem7x7s2_supported).
+ *   xp   (F, H+5, W+6, 4)  maed_stem_input(pad_top 2, pad_bottom 3, pad_left 2, pad_right 4, c_stride 4): TF-SAME padding plus one zero column (even width)
+ *   w    (64, 7, 7, 3)     the standardised weight, channels_last (O, kh, kw, I) memory order
+ *   wimg 28672 bytes of scratch (the fragment-major weight image the forward builds for itself), 16-B aligned
+ *   y    (F, H/2, W/2, 64) channels_last;  gn_sums (optional): (F, 32, 2) fp64 sum / sum of squares of the rounded outputs per 2-channel group, ACCUMULATED
+ *        (the statistics of the GroupNorm behind the stem, as maed_conv3x3_fwd / maed_conv1x1_fwd produce them)
+ *   dW   (64, 7, 7, 3) fp32, ACCUMULATED with atomics (zero it once per step)
+ * Non-finite pixels: the zero-weight slots (kx = 7, c = 3) are multiplied like any other, so an Inf/NaN pixel also reaches the one output column to its left. */
+int maed_stem7x7s2_supported(int H, int W);
+int maed_stem7x7s2_fwd(const void* xp, const void* w, void* wimg, void* y, double* gn_sums, int F, int H, int W, int dtype, void* stream);
+int maed_stem7x7s2_wgrad(const void* dy, const void* xp, float* dW, int F, int H, int W, int dtype, void* stream);
 
 /* Pixel subsampling of the 1x1 stride-2 downsample convolutions (resnetv2.py:207-216; TF-SAME padding of a 1x1 kernel is always zero):
  * fwd: y (F,ceil(H/2),ceil(W/2),C) = x[:, ::2, ::2, :] on channels_last x (F,H,W,C), C % 8 == 0 -- the convolution is then

@@ -801,24 +801,34 @@ extern "C" int maed_maxpool3s2_same_bwd(const void* dy, const uint8_t* idx, void
 // zero-filled padded copy: 35 + 31 + 8 us at cfg3).  One pass here: thread per padded pixel, three plane reads (coalesced along x), one 6- or 12-byte store.
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void stem_input_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t n, int C, int H, int W, int Hp, int Wp, int top, int left) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread: all C (<= 4) channels of one padded pixel
+__global__ __launch_bounds__(256) void stem_input_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t n, int C, int CS, int H, int W, int Hp, int Wp, int top, int left) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread: all CS (<= 4) channel slots of one padded pixel (slots >= C: zero)
     if (i >= n) return;
     const int xp = (int)(i % Wp), yp = (int)((i / Wp) % Hp);
     const int64_t f = i / ((int64_t)Wp * Hp);
     const int xx = xp - left, yy = yp - top;
     const bool in = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
-    for (int c = 0; c < C; ++c) stf(y + i * C + c, in ? x[((f * C + c) * H + yy) * (int64_t)W + xx] : 0.f);
+    if (CS == 4) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (in && c < C) ? x[((f * C + c) * H + yy) * (int64_t)W + xx] : 0.f;
+        st4(y + i * 4, v);
+        return;
+    }
+    for (int c = 0; c < CS; ++c) stf(y + i * CS + c, (in && c < C) ? x[((f * C + c) * H + yy) * (int64_t)W + xx] : 0.f);
 }
 
-extern "C" int maed_stem_input(const float* x, void* y, int N, int C, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right, int dtype, void* stream) {
+extern "C" int maed_stem_input(const float* x, void* y, int N, int C, int H, int W, int pad_top, int pad_bottom, int pad_left, int pad_right, int c_stride, int dtype,
+                               void* stream) {
     MAED_CHECK_ARG(x && y, MAED_ERR_ARG, "stem_input: null pointer");
-    MAED_CHECK_ARG(N >= 0 && C > 0 && C <= 4 && H > 0 && W > 0 && pad_top >= 0 && pad_bottom >= 0 && pad_left >= 0 && pad_right >= 0, MAED_ERR_SHAPE, "stem_input: bad extents (C <= 4)");
+    MAED_CHECK_ARG(N >= 0 && C > 0 && C <= c_stride && c_stride <= 4 && H > 0 && W > 0 && pad_top >= 0 && pad_bottom >= 0 && pad_left >= 0 && pad_right >= 0, MAED_ERR_SHAPE,
+                   "stem_input: bad extents (C <= c_stride <= 4)");
+    MAED_CHECK_ARG(c_stride != 4 || is_aligned(y, 16), MAED_ERR_ALIGN, "stem_input: y must be 16-B aligned");
     const int Hp = H + pad_top + pad_bottom, Wp = W + pad_left + pad_right;
     const int64_t n = (int64_t)N * Hp * Wp;
     if (n == 0) return MAED_OK;
-    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stem_input_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, n, C, H, W,
-                                                      Hp, Wp, pad_top, pad_left));
+    MAED_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stem_input_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, n, C, c_stride, H,
+                                                      W, Hp, Wp, pad_top, pad_left));
     MAED_CHECK_LAUNCH("stem_input");
     return MAED_OK;
 }

@@ -18,7 +18,11 @@
 typedef void maed_lds_void_t;
 typedef const void maed_glb_void_t;
 #define MAED_DS_READ_TR16(p_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((hostsim_v4i16*)(p_))
+#define MAED_WAVE_LDS_SYNC() hostsim_wave_lds_sync()
 #else
+// between LDS writes of one wave and reads of the same data by OTHER lanes of that wave: the hardware executes a wave's LDS operations in order, so only the
+// compiler has to keep them in program order (the host simulator runs lanes as threads and needs a real wave barrier here)
+#define MAED_WAVE_LDS_SYNC() __builtin_amdgcn_wave_barrier()
 #define MAED_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define MAED_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")      // counted: the n most recent VMEM operations stay in flight
 #define MAED_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -100,6 +104,17 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     const bf16x2_hw_t v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
+
+// c + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (v_dot2c_f32_bf16): sums / sums of squares of ROUNDED outputs without unpacking them
+#ifdef MAED_HOSTSIM
+static inline float maed_dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return c + (bf2f((unsigned short)(a & 0xffffu)) * bf2f((unsigned short)(b & 0xffffu)) + bf2f((unsigned short)(a >> 16)) * bf2f((unsigned short)(b >> 16)));
+}
+#else
+__device__ __forceinline__ float maed_dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw_t, a), __builtin_bit_cast(bf16x2_hw_t, b), c, false);
+}
+#endif
 
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return bf2f(p->v); }

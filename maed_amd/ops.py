@@ -805,15 +805,53 @@ class GroupNormFn(torch.autograd.Function):
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def stem_input(x, dtype, k, s):
+def stem_input(x, dtype, k, s, own=False):
     """fp32 NCHW clip frames -> compute dtype, channels_last, TF-SAME padded for a kernel-k / stride-s convolution, in ONE pass (maed_stem_input); returns the
-    padded tensor as an (N, C, Hp, Wp) channels_last view: the convolution then runs with padding 0"""
+    padded tensor as an (N, C, Hp, Wp) channels_last view: the convolution then runs with padding 0.
+    own=True: the layout of maed_stem7x7s2_* instead -- 4 channel slots per pixel (the 4th zero) and one more zero column on the right (even width)"""
     N, C_, H, W = x.shape
     ph = max((math.ceil(H / s) - 1) * s + k - H, 0)
     pw = max((math.ceil(W / s) - 1) * s + k - W, 0)
-    y = torch.empty(N, H + ph, W + pw, C_, dtype=dtype, device=x.device)
-    check(L.lib().maed_stem_input(_p(x), _p(y), N, C_, H, W, ph // 2, ph - ph // 2, pw // 2, pw - pw // 2, dt_code(dtype), _stream()), "stem_input")
+    cs, extra = (4, 1) if own else (C_, 0)
+    y = torch.empty(N, H + ph, W + pw + extra, cs, dtype=dtype, device=x.device)
+    check(L.lib().maed_stem_input(_p(x), _p(y), N, C_, H, W, ph // 2, ph - ph // 2, pw // 2, pw - pw // 2 + extra, cs, dt_code(dtype), _stream()), "stem_input")
     return y.permute(0, 3, 1, 2)
+
+
+def stem7x7s2_supported(H, W):
+    return bool(L.lib().maed_stem7x7s2_supported(int(H), int(W)))
+
+
+class StemConvFn(torch.autograd.Function):
+    """The stem convolution StdConv2dSame(3 -> 64, 7, stride 2) (resnetv2.py:74-93, :330-333) on maed_stem7x7s2_fwd / _wgrad.
+    xp: the padded 4-slot image of stem_input(own=True) as an (F, 4, H+5, W+6) channels_last view; w: the standardised weight (64, I, 7, 7) channels_last view of
+    WeightStdFn's arena; dw: its fp32 gradient slice (64, 147) (accumulated with atomics: WeightStdFn zeroes the arena once per step); sums: the (F, 32, 2) fp64
+    statistics slice of the GroupNorm behind, or None.  The frames get no gradient."""
+
+    @staticmethod
+    def forward(ctx, xp, w, dw, sums, hw):
+        H, W = hw
+        F_ = xp.shape[0]
+        assert xp.shape[1] == 4 and xp.shape[2] == H + 5 and xp.shape[3] == W + 6 and xp.dtype == torch.bfloat16 and w.shape[0] == 64 and w.shape[2:] == (7, 7), (xp.shape, w.shape)
+        wc = w.permute(0, 2, 3, 1)
+        assert wc.is_contiguous() and wc.shape[3] == 3, "stem: the standardised weight must be the channels_last (64, 7, 7, 3) image"
+        y = torch.empty((F_, 64, H // 2, W // 2), dtype=xp.dtype, device=xp.device, memory_format=torch.channels_last)
+        wimg = torch.empty(64 * 224, dtype=xp.dtype, device=xp.device)
+        check(L.lib().maed_stem7x7s2_fwd(_p(xp), _p(wc), _p(wimg), _p(y), _p(sums), F_, H, W, dt_code(xp.dtype), _stream()), "stem7x7s2_fwd")
+        ctx.save_for_backward(xp)
+        ctx.dw, ctx.hw = dw, hw
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xp,) = ctx.saved_tensors
+        H, W = ctx.hw
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        assert ctx.dw is not None, "stem: no fp32 weight-gradient slice (WeightStdFn hands it out when the backward will run)"
+        dw = ctx.dw
+        side_stream_run(lambda: check(L.lib().maed_stem7x7s2_wgrad(_p(dy), _p(xp), _p(dw), xp.shape[0], H, W, dt_code(dy.dtype), _stream()), "stem7x7s2_wgrad"),
+                        dy, xp, dw)
+        return None, None, None, None, None
 
 
 class MaxPool3s2SameFn(torch.autograd.Function):

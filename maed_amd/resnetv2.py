@@ -111,7 +111,9 @@ class StdConv2dSame(nn.Conv2d):
     _w_t = None    # 1x1 stride-1 convolutions in bf16 mode: transposed standardised weight (I, O) -> the GEMM path
     _dw = None     # ... and the fp32 slice their weight gradient accumulates into
     _prec = None   # fp32 matrix-product engine of the owning backbone (ResNetV2.f32_matmul), None = the process-wide mode
-    _prepadded = False   # set by ResNetV2 for the stem when ops.stem_input already applied the TF-SAME padding
+    _prepadded = False   # set by ResNetV2 for the stem when ops.stem_input already applied the TF-SAME padding ("own": ... in the layout of maed_stem7x7s2_*)
+    _gn_behind = None    # stem only: (GroupNormAct,) it feeds -- a tuple, so that the norm is not registered a second time as a submodule
+    _stem_hw = None      # stem, "own" route: (H, W) of the unpadded frames
 
     @staticmethod
     def _gn_sums_for(gn, x_shape, out_channels, stride):
@@ -146,6 +148,13 @@ class StdConv2dSame(nn.Conv2d):
             w = self.get_weight().to(x.dtype)
             if ops.on_library_device(x):
                 w = w.contiguous(memory_format=torch.channels_last)
+        if self._prepadded == "own":
+            # the stem on the library (ops.StemConvFn): x is the 4-channel padded image of ops.stem_input(own=True); statistics of the norm behind from the epilogue
+            gn = self._gn_behind[0] if self._gn_behind else None
+            sums = None
+            if gn is not None and _FUSE_GN_STATS and gn._sums_buf is not None and gn.num_groups == 32 and self.out_channels == 64:
+                gn._stats_ready, sums = True, gn._sums_buf
+            return ops.StemConvFn.apply(x, w, self._dw, sums, self._stem_hw)
         if self._prepadded:
             return F.conv2d(x, w, None, self.stride, 0, self.dilation, self.groups)
         k, s = self.kernel_size[0], self.stride[0]
@@ -309,6 +318,9 @@ class ResNetV2(nn.Module):
         s3 = ((1, 1), (2, 2)) if os.environ.get("MAED_CONV3X3_S2", "1") == "1" else ((1, 1),)
         self._own3x3 = [i for i, c in enumerate(self._convs) if _OWN_CONV3X3 and c.kernel_size == (3, 3) and c.stride in s3
                         and c.in_channels % 64 == 0 and c.out_channels % 64 == 0]
+        # the stem (7x7 stride 2, 3 -> 64) on maed_stem7x7s2_* in bf16 mode when the frame geometry allows (decided per forward); MAED_STEM_OWN=0: vendor convolution
+        self.stem.conv._gn_behind = (self.stem.norm,)
+        self._own_stem_now = []
         self._w_std_t, self._dw_slices, self._dw_arena = {}, {}, None
         self._pending_backwards = 0
         self._grad_forward_seen = False     # a grad-enabled forward ran since the bucketer last looked (ddp.GradBucketer.finish)
@@ -326,7 +338,7 @@ class ResNetV2(nn.Module):
     def _direct_convs(self):
         """convolutions on the library's own kernels (transposed weight image + fp32 dW slice from WeightStdFn); computed on access so that
         switching `_gemm_convs` off at run time (tests/test_gpu_model.py's all-MIOpen variant) keeps its meaning"""
-        return list(self._gemm_convs) + list(self._own3x3)
+        return list(self._gemm_convs) + list(self._own3x3) + list(self._own_stem_now)
 
     def fused_parameters(self):
         """parameters whose gradients the HIP kernels write directly into .grad: conv weights (batched
@@ -340,8 +352,11 @@ class ResNetV2(nn.Module):
         if (x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] <= 4 and not x.requires_grad and os.environ.get("MAED_STEM_INPUT", "1") == "1"
                 and stem.dilation == (1, 1) and stem.kernel_size[0] == stem.kernel_size[1]):
             # cast + channels_last + the stem's TF-SAME padding in one pass (the framework: three); the stem convolution below sees an already padded image
-            x = ops.stem_input(x, self.compute_dtype, stem.kernel_size[0], stem.stride[0])
-            _slots(stem, _prepadded=True)
+            own = (self.compute_dtype == torch.bfloat16 and os.environ.get("MAED_STEM_OWN", "1") == "1" and stem.kernel_size == (7, 7) and stem.stride == (2, 2)
+                   and stem.in_channels <= 3 and stem.out_channels == 64 and stem.groups == 1 and ops.stem7x7s2_supported(x.shape[2], x.shape[3]))
+            self._own_stem_now = [0] if own else []
+            _slots(stem, _prepadded="own" if own else True, _stem_hw=(x.shape[2], x.shape[3]))
+            x = ops.stem_input(x, self.compute_dtype, stem.kernel_size[0], stem.stride[0], own=own)
         else:
             x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
         ws = None if _ws_per_stage() else ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
@@ -380,7 +395,8 @@ class ResNetV2(nn.Module):
                 g._ws_on_side = bool(runs) and g is not runs[0] and g in runs
             return x
         finally:
-            _slots(self.stem.conv, _prepadded=False)
+            _slots(self.stem.conv, _prepadded=False, _stem_hw=None)
+            self._own_stem_now = []
             for c in self._convs:
                 _slots(c, _w_std=None, _w_t=None, _dw=None, _prec=None)
             for m in self._norms:

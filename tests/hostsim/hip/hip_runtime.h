@@ -124,6 +124,10 @@ void launch(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, Args..
 
 static inline void __syncthreads() { hostsim::t_block->bar.arrive_and_wait(); }
 
+// lanes of one wave exchanging data through LDS without a block barrier (hardware: the wave's LDS operations execute in order): here the lanes are host
+// threads, so the hand-over needs the wave's barrier
+static inline void hostsim_wave_lds_sync() { hostsim::t_block->waves[hostsim::t_tid / 64]->bar.arrive_and_wait(); }
+
 static inline float __shfl_xor(float v, int mask, int /*width*/ = 64) {
     hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
     const int lane = hostsim::t_tid % 64;
@@ -213,6 +217,24 @@ static inline void __builtin_amdgcn_global_load_lds(const void* gptr, void* lds_
     if (lane == 0) w.u64[p][1] = (uint64_t)(uintptr_t)lds_ptr;
     w.bar.arrive_and_wait();
     memcpy((char*)(uintptr_t)w.u64[p][1] + (size_t)lane * size + offset, (const char*)gptr + offset, size);   // visible to readers after the kernel's own barrier
+}
+// v_mfma_f32_16x16x32_bf16: A[i][k] = lane (k/8)*16 + i, element k%8;  B[k][j] = lane (k/8)*16 + j, element k%8;  D[4*(lane>>4) + r][lane & 15] in reg r
+typedef float hostsim_f32x4 __attribute__((ext_vector_type(4)));
+static inline hostsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hostsim_bf16x8 a, hostsim_bf16x8 b, hostsim_f32x4 acc, int, int, int) {
+    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
+    const int lane = hostsim::t_tid % 64;
+    const unsigned p = hostsim::t_wop++ & 1u;
+    for (int e = 0; e < 8; ++e) { w.ha[p][lane][e] = (float)a[e]; w.hb[p][lane][e] = (float)b[e]; }
+    w.bar.arrive_and_wait();
+    const int j = lane & 15, q = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * q + r;
+        float s = acc[r];
+        for (int kg = 0; kg < 4; ++kg)
+            for (int e = 0; e < 8; ++e) s = fmaf(w.ha[p][kg * 16 + i][e], w.hb[p][kg * 16 + j][e], s);
+        acc[r] = s;
+    }
+    return acc;
 }
 // v_perm_b32: byte select from the 8-byte pool {src0 (bytes 7..4), src1 (bytes 3..0)}; selector values 0..7 only (what the kernels use)
 static inline uint32_t __builtin_amdgcn_perm(uint32_t src0, uint32_t src1, uint32_t sel) {

@@ -563,6 +563,38 @@ def test_conv1x1_stride2_on_packed_pixels(N, I, O, H, W):
     report(f"conv1x1s2 dw{tag}", dw - 1.0, wd.grad.reshape(O, I), rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("N,H,W", [(16, 224, 224), (2, 256, 256), (3, 32, 64)])
+def test_stem7x7s2_forward_statistics_and_weight_gradient(N, H, W):
+    """round 4: the stem convolution on the library (csrc/stem.hip) at the cfg3 / cfg5 frame sizes and a small one: forward from the padded 4-slot image vs fp64
+    conv2d on the TF-SAME padded frames, the GroupNorm statistics of the rounded outputs from the epilogue, the weight gradient (LDS-DMA rows, transposing reads,
+    512 workgroups walking 3-4 output rows each at cfg3) accumulated into a non-zero fp32 slice; bit-identical between the two forward variants and repeatable."""
+    ops, _ = _ops()
+    x = rnd(N, 3, H, W, seed=1)
+    w = q(rnd(64, 3, 7, 7, seed=2, scale=147 ** -0.5), torch.bfloat16)
+    wd = w.double().requires_grad_(True)
+    ref = F.conv2d(F.pad(q(x, torch.bfloat16).double(), [2, 3, 2, 3]), wd, stride=2)
+    dy = q(rnd(*ref.shape, seed=3), torch.bfloat16)
+    ref.backward(dy.double())
+    assert ops.stem7x7s2_supported(H, W)
+    xp = ops.stem_input(x.to(DEV), torch.bfloat16, 7, 2, own=True)
+    wg = w.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sums = torch.zeros(N, 32, 2, dtype=torch.float64, device=DEV)
+    dw = torch.ones(64, 147, dtype=torch.float32, device=DEV)
+    y = ops.StemConvFn.apply(xp, wg, dw, sums, (H, W))
+    y0 = ops.StemConvFn.apply(xp, wg, dw, None, (H, W))
+    assert torch.equal(y, y0)
+    tag = f"[{N}x{H}x{W}]"
+    report(f"stem7x7s2 fwd{tag}", y.float(), ref, **tol(torch.bfloat16, 2))
+    yg = y.permute(0, 2, 3, 1).reshape(N, -1, 32, 2).double()
+    want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
+    report(f"stem7x7s2 gn statistics{tag}", sums, want, rtol=2e-5, atol=2e-5 * want.abs().max().item())
+    y.backward(dy.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last))
+    ops.side_stream_join(torch.device(DEV))
+    torch.cuda.synchronize()
+    got = (dw - 1.0).view(64, 7, 7, 3).permute(0, 3, 1, 2)
+    report(f"stem7x7s2 dw{tag}", got, wd.grad, rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())
+
+
 def test_stream_fence_orders_two_streams():
     """maed_stream_fence(from, to): everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on (the fence the host uses for
     side-stream launches instead of framework events).  A long fill on stream A, the fence, a read on stream B: B must see the fill -- 20 rounds, fresh values."""

@@ -395,3 +395,77 @@ def test_weight_standardisation_tiled_kernel_64_filters_per_workgroup(dtype):
             assert torch.allclose(res["1"][1][i].float(), ref.permute(2, 3, 1, 0).reshape(kh * kw * I, O), **tol), i
             assert torch.equal(res["1"][1][i], res["0"][1][i]), i
     assert (dtype == torch.bfloat16) == (sorted(res["1"][1]) == [1, 2])
+
+
+def _stem_reference(x, w, dy=None):
+    """fp64 F.conv2d on the TF-SAME padded frames (resnetv2.py:51-59, :74-93): 2 rows / columns before, 3 after for even extents"""
+    wr = w.double().requires_grad_(True)
+    ref = F.conv2d(F.pad(x.double(), [2, 3, 2, 3]), wr, stride=2)
+    if dy is not None:
+        ref.backward(dy.double())
+    return ref.detach(), wr.grad
+
+
+@pytest.mark.parametrize("N,H,W,stats", [(2, 32, 32, True), (1, 32, 64, False), (1, 48, 96, True)])
+def test_stem7x7s2_forward_from_padded_4slot_image(N, H, W, stats):
+    """round 4: maed_stem_input(c_stride 4) + maed_stem7x7s2_fwd -- the stem convolution with the pixel operand loaded from global memory straight into the MFMA
+    fragment layout (16 bytes = 2 pixels x 4 slots = the stride-2 step), against F.conv2d on the padded frames; the GroupNorm statistics of the rounded outputs
+    (32 groups of 2 channels) from the epilogue.  2 / 4 / 3 tiles per wave."""
+    torch.manual_seed(11)
+    x = torch.randn(N, 3, H, W)
+    w = (torch.randn(64, 3, 7, 7) * 147 ** -0.5).bfloat16()
+    ref, _ = _stem_reference(x.bfloat16(), w)
+    sums = torch.zeros(N, 32, 2, dtype=torch.float64) if stats else None
+    with patched():
+        assert ops.stem7x7s2_supported(H, W) and not ops.stem7x7s2_supported(H + 1, W) and not ops.stem7x7s2_supported(20, 20)
+        xp = ops.stem_input(x, torch.bfloat16, 7, 2, own=True)
+        assert xp.shape == (N, 4, H + 5, W + 6) and (xp[:, 3] == 0).all() and (xp[:, :, :, -1] == 0).all() and torch.equal(xp[:, :3, 2:H + 2, 2:W + 2], x.bfloat16())
+        y = ops.StemConvFn.apply(xp, cl(w), None, sums, (H, W))
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert (y.double() - ref).abs().max() <= 1e-2 * ref.abs().max()
+    if stats:
+        yg = y.float().permute(0, 2, 3, 1).reshape(N, (H // 2) * (W // 2), 32, 2).double()
+        want = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
+        assert torch.allclose(sums, want, rtol=1e-5, atol=1e-3), (sums - want).abs().max()
+
+
+@pytest.mark.parametrize("N,H,W,wgs", [(2, 32, 32, None), (1, 32, 64, None), (3, 48, 96, 5), (2, 32, 32, 3)])
+def test_stem7x7s2_weight_gradient_by_lds_dma_and_transposing_reads(N, H, W, wgs, monkeypatch):
+    """round 4: maed_stem7x7s2_wgrad -- one output row of dy and its seven input rows per work item, copied into LDS unchanged (LDS-DMA, swizzled dy chunks) and
+    contracted over pixels through ds_read_b64_tr_b16 fragments; accumulates into the given fp32 slice.  One row per workgroup by default at these sizes; with
+    MAED_STEM_WGS = 5 / 3 the double-buffered walk over 15 (14 for the last workgroup... 72 = 4 * 15 + 12) resp. 11 / 11 / 10 rows."""
+    if wgs:
+        monkeypatch.setenv("MAED_STEM_WGS", str(wgs))
+    torch.manual_seed(12)
+    x = torch.randn(N, 3, H, W)
+    w = (torch.randn(64, 3, 7, 7) * 147 ** -0.5).bfloat16()
+    dy = torch.randn(N, 64, H // 2, W // 2).bfloat16()
+    _, gw = _stem_reference(x.bfloat16(), w, dy)
+    dW0 = torch.randn(64, 147)
+    dW = dW0.clone()
+    with patched() as lib:
+        xp = ops.stem_input(x, torch.bfloat16, 7, 2, own=True)
+        dyc = cl(dy)
+        rc = lib.maed_stem7x7s2_wgrad(dyc.data_ptr(), xp.data_ptr(), dW.data_ptr(), N, H, W, L.BF16, None)
+        assert rc == 0, lib.maed_last_error()
+    got = (dW - dW0).view(64, 7, 7, 3).permute(0, 3, 1, 2).double()
+    assert (got - gw).abs().max() <= 2e-3 * gw.abs().max(), (got - gw).abs().max() / gw.abs().max()
+
+
+def test_stem7x7s2_autograd_node_fills_the_fp32_slice_and_rejects_other_geometries():
+    torch.manual_seed(13)
+    x = torch.randn(2, 3, 32, 32)
+    w = (torch.randn(64, 3, 7, 7) * 147 ** -0.5).bfloat16()
+    dy = torch.randn(2, 64, 16, 16).bfloat16()
+    _, gw = _stem_reference(x.bfloat16(), w, dy)
+    dw = torch.zeros(64, 147)
+    with patched() as lib:
+        xp = ops.stem_input(x, torch.bfloat16, 7, 2, own=True)
+        ws = cl(w).requires_grad_(True)          # (autograd must see a differentiable input for the node's backward to run)
+        y = ops.StemConvFn.apply(xp, ws, dw, None, (32, 32))
+        y.backward(cl(dy))
+        assert ws.grad is None                   # the gradient travels in the fp32 slice, not through autograd
+        bad = torch.zeros(1, 20 + 5, 20 + 6, 4, dtype=torch.bfloat16)
+        assert lib.maed_stem7x7s2_wgrad(dy.data_ptr(), bad.data_ptr(), dw.data_ptr(), 1, 20, 20, L.BF16, None) != 0
+    got = dw.view(64, 7, 7, 3).permute(0, 3, 1, 2).double()
+    assert (got - gw).abs().max() <= 2e-3 * gw.abs().max()

@@ -269,3 +269,36 @@ def test_backbone_f32_split_mode_runs_on_library_convolutions(mode, tol_y, tol_g
     print(f"{mode}: output rel-to-max {rel(ys, yr.detach()):.2e}, worst parameter gradient rel-to-max {worst:.2e}")
     for (n, p), q in zip(sim.named_parameters(), ref.parameters()):
         assert p.grad is not None and rel(p.grad, q.grad) <= tol_g, (n, rel(p.grad, q.grad))
+
+
+@pytest.mark.parametrize("own", [True, False])
+def test_stem_convolution_on_the_library_when_the_frame_geometry_allows(own, monkeypatch):
+    """round 4: 32 x 32 frames (16 x 16 = 256 output pixels, 16 per row) take ops.StemConvFn -- padded 4-slot image, statistics of the stem norm from the
+    epilogue, weight gradient into the fp32 slice WeightStdFn hands out; MAED_STEM_OWN=0 (and geometries the kernels do not cover: every other test of this
+    file with 16 x 16 / 48 x 48 frames) stay on the framework convolution.  Forward and every parameter gradient against the fp32 ATen composition."""
+    from maed_amd import ops
+    monkeypatch.setenv("MAED_STEM_OWN", "1" if own else "0")
+    torch.manual_seed(3)
+    ref = ResNetV2(layers=(1,), channels=(256,), in_chans=3, compute_dtype=torch.float32)
+    for m in ref._norms:
+        torch.nn.init.normal_(m.weight, 1.0, 0.2); torch.nn.init.normal_(m.bias, 0.0, 0.2)
+    sim = copy.deepcopy(ref)
+    sim.compute_dtype = torch.bfloat16
+    x = torch.randn(2, 3, 32, 32)
+    yr = ref(x)
+    gout = torch.randn_like(yr)
+    (yr * gout).sum().backward()
+    calls = []
+    real = ops.StemConvFn.forward
+    with patched():
+        ops.StemConvFn.forward = staticmethod(lambda ctx, *a: (calls.append((tuple(a[0].shape), a[2] is not None, a[3] is not None)), real(ctx, *a))[1])
+        try:
+            ys = sim(x)
+            (ys.float() * gout).sum().backward()
+        finally:
+            ops.StemConvFn.forward = real
+    assert calls == ([((2, 4, 37, 38), True, True)] if own else []), calls
+    assert sim._own_stem_now == [] and sim.stem.conv._prepadded is False
+    assert cos(ys.float(), yr.detach()) > 0.999
+    for (n, p), q in zip(sim.named_parameters(), ref.parameters()):
+        assert p.grad is not None and cos(p.grad, q.grad) > 0.97, (n, cos(p.grad, q.grad))
