@@ -406,11 +406,20 @@ int maed_stem_input(const float* x, void* y, int N, int C, int H, int W, int pad
  *   wimg 28672 bytes of scratch (the fragment-major weight image the forward builds for itself), 16-B aligned
  *   y    (F, H/2, W/2, 64) channels_last;  gn_sums (optional): (F, 32, 2) fp64 sum / sum of squares of the rounded outputs per 2-channel group, ACCUMULATED
  *        (the statistics of the GroupNorm behind the stem, as maed_conv3x3_fwd / maed_conv1x1_fwd produce them)
- *   dW   (64, 7, 7, 3) fp32, ACCUMULATED with atomics (zero it once per step)
+ *   dW   (64, 7, 7, 3) fp32, ACCUMULATED (zero it once per step); scratch (optional): maed_stem7x7s2_wgrad_scratch_floats(F, H, W) fp32 elements for the
+ *        per-workgroup partial results (plain stores + one reduction pass); NULL: the workgroups add into dW with atomics (slower: one 37 KB hot spot)
  * Non-finite pixels: the zero-weight slots (kx = 7, c = 3) are multiplied like any other, so an Inf/NaN pixel also reaches the one output column to its left. */
+/* Weight gradient of the stride-1 3x3 SAME convolution at 64 -> 64 channels (the conv2 of the stage-1 bottlenecks, resnetv2.py:218-233) one image row per work item
+ * (csrc/conv3x3_rows.hip); maed_conv3x3_wgrad takes the same kernel for this shape with atomics.  dy, x (F, H, W, 64) channels_last bf16; W % 8 == 0, 8 <= W <= 64.
+ * dW (64, 3, 3, 64) fp32, ACCUMULATED.  scratch: maed_conv3x3_wgrad_rows64_scratch_floats(...) fp32 elements (0 = shape not covered) for per-workgroup partial results --
+ * NULL: the workgroups add into dW with atomics (slower: every workgroup adds onto the same 147 KB). */
+int maed_conv3x3_wgrad_rows64_scratch_floats(int F, int H, int W, int Cin, int Cout);
+int maed_conv3x3_wgrad_rows64(const void* dy, const void* x, float* dW, void* scratch, int F, int H, int W, int dtype, void* stream);
+
 int maed_stem7x7s2_supported(int H, int W);
 int maed_stem7x7s2_fwd(const void* xp, const void* w, void* wimg, void* y, double* gn_sums, int F, int H, int W, int dtype, void* stream);
-int maed_stem7x7s2_wgrad(const void* dy, const void* xp, float* dW, int F, int H, int W, int dtype, void* stream);
+int maed_stem7x7s2_wgrad_scratch_floats(int F, int H, int W);
+int maed_stem7x7s2_wgrad(const void* dy, const void* xp, float* dW, void* scratch, int F, int H, int W, int dtype, void* stream);
 
 /* Pixel subsampling of the 1x1 stride-2 downsample convolutions (resnetv2.py:207-216; TF-SAME padding of a 1x1 kernel is always zero):
  * fwd: y (F,ceil(H/2),ceil(W/2),C) = x[:, ::2, ::2, :] on channels_last x (F,H,W,C), C % 8 == 0 -- the convolution is then

@@ -132,9 +132,12 @@ SIGNATURES = {
     "maed_maxpool3s2_same_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "maed_maxpool3s2_same_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "maed_stem_input": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "maed_conv3x3_wgrad_rows64_scratch_floats": (i32, [i32, i32, i32, i32, i32]),
+    "maed_conv3x3_wgrad_rows64": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_stem7x7s2_supported": (i32, [i32, i32]),
     "maed_stem7x7s2_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "maed_stem7x7s2_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "maed_stem7x7s2_wgrad_scratch_floats": (i32, [i32, i32, i32]),
+    "maed_stem7x7s2_wgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_subsample2_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "maed_subsample2_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "maed_weight_refresh": (i32, [vp, i32, i32, i32, vp]),

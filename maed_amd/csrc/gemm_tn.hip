@@ -28,6 +28,9 @@ int maed_tn_splits(int tiles) {
 }
 static int tn_remap() { return 1; }     // XCD-aware (split, tile) order: -6...8 % and 292 -> 189 MB of HBM traffic per launch (profiles/r02_pmc)
 
+bool maed_conv3x3_wgrad_rows64_ok(int F, int H, int W, int Cin, int Cout);                                            // conv3x3_rows.hip
+int maed_conv3x3_wgrad_rows64_launch(const void* dy, const void* x, float* dW, void* scratch, int F, int H, int W, hipStream_t stream);
+
 #define TN_BM 64      // reduction rows per LDS tile
 #define TN_LD 72      // LDS row stride (elements): 144 B
 
@@ -374,6 +377,10 @@ extern "C" int maed_conv3x3_wgrad(const void* dy, const void* x, const void* tap
         MAED_PROPAGATE(maed_gemm_tn_x3_launch(np, dy, (int64_t)Cout, x, (int64_t)Cin, M, N, K, dW, (int64_t)K, nullptr, &cv, 0, (hipStream_t)stream));
         MAED_CHECK_LAUNCH("conv3x3_wgrad(x3)");
         return MAED_OK;
+    }
+    if (maed_conv3x3_wgrad_rows64_ok(F, H, W, Cin, Cout)) {      // 64 -> 64 channels (stage 1): one image row per work item, all nine taps from LDS (conv3x3_rows.hip)
+        MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16), MAED_ERR_ALIGN, "conv3x3_wgrad: 16-B alignment");
+        return maed_conv3x3_wgrad_rows64_launch(dy, x, dW, nullptr, F, H, W, (hipStream_t)stream);
     }
     MAED_CHECK_ARG(M > 0 && M % TN_BM == 0, MAED_ERR_SHAPE, "conv3x3_wgrad: F*H*W = %lld must be a multiple of 64", (long long)M);
     MAED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && Cin < (1 << 20) && W + 1 < (1 << 10), MAED_ERR_SHAPE, "conv3x3_wgrad: need Cin, Cout multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);

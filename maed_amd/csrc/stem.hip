@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void stem7x7s2_fwd_kernel(const bf16* __res
 // 64 x 147 partial gradient with fp32 atomics.
 #define STEM_WG_THREADS 448
 __global__ __launch_bounds__(STEM_WG_THREADS, 2) void stem7x7s2_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ dW,
-                                                                              int Hp, int Wp, int Ho, int Wo, int n_items, int items_per_wg) {
+                                                                              float* __restrict__ partial, int Hp, int Wp, int Ho, int Wo, int n_items, int items_per_wg) {
     MAED_DYN_SHARED(unsigned short, smem);
     const int tid = threadIdx.x, lane = tid & 63, ky = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5, i16 = lane & 15;
     const int dy_chunks = Wo * 8, x_chunks = 7 * (Wp / 2);
@@ -203,13 +203,29 @@ __global__ __launch_bounds__(STEM_WG_THREADS, 2) void stem7x7s2_wgrad_kernel(con
 #undef STEM_ISSUE
     // D[channel][e]: column e = l31 of kernel row ky, rows (r & 3) + 8 (r >> 2) + 4 hi
     const int e = l31, kx = e >> 2, c = e & 3;
+    // with `partial`: plain stores into the workgroup's own 64 x 147 slot, summed by wgrad_slots_reduce_kernel (conv3x3_rows.hip) -- 512 workgroups adding onto the
+    // same 37 KB with atomics is a hot spot
     if (kx < 7 && c < 3) {
-        float* d = dW + (ky * 7 + kx) * 3 + c;
+        float* d = (partial ? partial + (size_t)blockIdx.x * (64 * 147) : dW) + (ky * 7 + kx) * 3 + c;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(d + (32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi) * 147, acc[a][r]);
+            for (int r = 0; r < 16; ++r) {
+                float* e2 = d + (32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi) * 147;
+                if (partial) *e2 = acc[a][r]; else atomicAdd(e2, acc[a][r]);
+            }
     }
+}
+
+void maed_wgrad_slots_reduce(const float* partial, float* dW, int n_slots, int n_elems, hipStream_t stream);      // conv3x3_rows.hip
+
+static int stem_wgrad_wgs(int n_items, int* per_out) {
+    int wgs = 512;                                        // two workgroups per CU, each a contiguous range of output rows
+    if (const char* ev = getenv("MAED_STEM_WGS")) { const int v = atoi(ev); if (v > 0) wgs = v; }       // (sweep knob; the tests use it to force multi-row walks)
+    if (wgs > n_items) wgs = n_items;
+    const int per = (n_items + wgs - 1) / wgs;
+    *per_out = per;
+    return (n_items + per - 1) / per;
 }
 
 static int stem_tpw(int hw) {                  // tiles of 32 pixels per wave: the largest count <= 8 with hw % (128 * tpw) == 0
@@ -245,25 +261,30 @@ extern "C" int maed_stem7x7s2_fwd(const void* xp, const void* w, void* wimg, voi
     return MAED_OK;
 }
 
-// dW (64, 7, 7, 3) fp32 += weight gradient from dy (F, H/2, W/2, 64) and xp (F, H+5, W+6, 4), channels_last bf16
-extern "C" int maed_stem7x7s2_wgrad(const void* dy, const void* xp, float* dW, int F, int H, int W, int dtype, void* stream) {
+// fp32 elements of scratch maed_stem7x7s2_wgrad wants for its per-workgroup partial results (0: geometry not covered)
+extern "C" int maed_stem7x7s2_wgrad_scratch_floats(int F, int H, int W) {
+    if (F <= 0 || !maed_stem7x7s2_supported(H, W)) return 0;
+    int per = 0;
+    return stem_wgrad_wgs(F * (H / 2), &per) * 64 * 147;
+}
+
+// dW (64, 7, 7, 3) fp32 += weight gradient from dy (F, H/2, W/2, 64) and xp (F, H+5, W+6, 4), channels_last bf16; scratch (optional): see above -- NULL: atomics
+extern "C" int maed_stem7x7s2_wgrad(const void* dy, const void* xp, float* dW, void* scratch, int F, int H, int W, int dtype, void* stream) {
     MAED_CHECK_ARG(dy && xp && dW, MAED_ERR_ARG, "stem7x7s2_wgrad: null pointer");
     MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "stem7x7s2_wgrad: bf16 only (dtype=%d)", dtype);
     STEM_CHECK_GEOM("stem7x7s2_wgrad");
-    MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(xp, 16), MAED_ERR_ALIGN, "stem7x7s2_wgrad: 16-B alignment");
+    MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(xp, 16) && is_aligned(scratch, 16), MAED_ERR_ALIGN, "stem7x7s2_wgrad: 16-B alignment");
     const int dy_rounds = (Wo * 8 + STEM_WG_THREADS - 1) / STEM_WG_THREADS, x_rounds = (7 * (Wp / 2) + STEM_WG_THREADS - 1) / STEM_WG_THREADS;
     const size_t lds = (size_t)2 * (dy_rounds + x_rounds) * STEM_WG_THREADS * 16;
     MAED_CHECK_ARG(lds <= 160 * 1024, MAED_ERR_SHAPE, "stem7x7s2_wgrad: image too wide for the LDS row buffers (W=%d)", W);
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)stem7x7s2_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     const int n_items = F * Ho;
-    int wgs = 512;                                        // two workgroups per CU, each a contiguous range of output rows
-    if (const char* ev = getenv("MAED_STEM_WGS")) { const int v = atoi(ev); if (v > 0) wgs = v; }       // (sweep knob; the tests use it to force multi-row walks)
-    if (wgs > n_items) wgs = n_items;
-    const int per = (n_items + wgs - 1) / wgs;
-    wgs = (n_items + per - 1) / per;
-    hipLaunchKernelGGL(stem7x7s2_wgrad_kernel, dim3(wgs), dim3(STEM_WG_THREADS), lds, (hipStream_t)stream, (const bf16*)dy, (const bf16*)xp, dW, Hp, Wp, Ho, Wo,
-                       n_items, per);
+    int per = 0;
+    const int wgs = stem_wgrad_wgs(n_items, &per);
+    hipLaunchKernelGGL(stem7x7s2_wgrad_kernel, dim3(wgs), dim3(STEM_WG_THREADS), lds, (hipStream_t)stream, (const bf16*)dy, (const bf16*)xp, dW, (float*)scratch, Hp, Wp,
+                       Ho, Wo, n_items, per);
+    if (scratch) maed_wgrad_slots_reduce((const float*)scratch, dW, wgs, 64 * 147, (hipStream_t)stream);
     MAED_CHECK_LAUNCH("stem7x7s2_wgrad");
     return MAED_OK;
 }

@@ -198,6 +198,13 @@ def _keep_until_join(device, st, tensors):
 _KEEP = {}
 
 
+def _keep_alive_on_stream(t):
+    """scratch a wrapper allocates for a launch that may be running on the side stream (side_stream_run's thread-local override): referenced until the join, like
+    the operands (_keep_until_join); on the caller's own stream the caching allocator's stream order already covers it"""
+    if getattr(_TLS, "stream", None) is not None:
+        _KEEP.setdefault(t.device, []).append(t)
+
+
 def side_stream_join(device):
     st = _SIDE.get(device)
     if st is not None and st[1]:
@@ -849,8 +856,9 @@ class StemConvFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         assert ctx.dw is not None, "stem: no fp32 weight-gradient slice (WeightStdFn hands it out when the backward will run)"
         dw = ctx.dw
-        side_stream_run(lambda: check(L.lib().maed_stem7x7s2_wgrad(_p(dy), _p(xp), _p(dw), xp.shape[0], H, W, dt_code(dy.dtype), _stream()), "stem7x7s2_wgrad"),
-                        dy, xp, dw)
+        scratch = torch.empty(L.lib().maed_stem7x7s2_wgrad_scratch_floats(xp.shape[0], H, W), dtype=torch.float32, device=dy.device)
+        side_stream_run(lambda: check(L.lib().maed_stem7x7s2_wgrad(_p(dy), _p(xp), _p(dw), _p(scratch), xp.shape[0], H, W, dt_code(dy.dtype), _stream()), "stem7x7s2_wgrad"),
+                        dy, xp, dw, scratch)
         return None, None, None, None, None
 
 
@@ -1021,6 +1029,13 @@ def conv3x3_wgrad(dy, x, out=None, prec=None):
     N, I, H, W = x.shape
     O = dy.shape[1]
     dW = torch.zeros(O, 3, 3, I, dtype=torch.float32, device=x.device) if out is None else out
+    if x.dtype == torch.bfloat16:
+        nb = L.lib().maed_conv3x3_wgrad_rows64_scratch_floats(N, H, W, I, O)
+        if nb > 0:      # 64 -> 64 channels: one image row per work item, per-workgroup partial results in scratch (no atomics on a 147 KB hot spot)
+            scratch = torch.empty(nb, dtype=torch.float32, device=x.device)
+            check(L.lib().maed_conv3x3_wgrad_rows64(_p(dy), _p(x), _p(dW), _p(scratch), N, H, W, dt_code(x.dtype), _stream()), "conv3x3_wgrad_rows64")
+            _keep_alive_on_stream(scratch)
+            return dW
     check(L.lib().maed_conv3x3_wgrad(_p(dy), _p(x), _p(_tapmask(N, H, W, x.device)), _p(_zero_page(x.device)), _p(dW), N, H, W, I, O,
                                      mm_code(x.dtype, prec), _stream()), "conv3x3_wgrad")
     return dW

@@ -595,6 +595,23 @@ def test_stem7x7s2_forward_statistics_and_weight_gradient(N, H, W):
     report(f"stem7x7s2 dw{tag}", got, wd.grad, rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("N,H,W", [(16, 56, 56), (3, 64, 64), (2, 5, 8)])
+def test_conv3x3_weight_gradient_row_items_64_channels(N, H, W):
+    """round 4: maed_conv3x3_wgrad at 64 -> 64 channels takes the row-item kernel (conv3x3_rows.hip: LDS-DMA rows in a ring, wave = tap, transposing reads) --
+    the stage-1 shape of cfg3 (56 x 56) and cfg5 (64 x 64), and a tiny ragged one (5 x 8: 80 pixels, not a multiple of 64 -- the general kernel would refuse);
+    accumulation into a non-zero slice, vs fp64 autograd through conv2d"""
+    ops, _ = _ops()
+    x = q(rnd(N, 64, H, W, seed=1), torch.bfloat16)
+    dy = q(rnd(N, 64, H, W, seed=2), torch.bfloat16)
+    wd = rnd(64, 64, 3, 3, seed=3, scale=576 ** -0.5).double().requires_grad_(True)
+    F.conv2d(x.double(), wd, padding=1).backward(dy.double())
+    dW = torch.ones(64, 3, 3, 64, dtype=torch.float32, device=DEV)
+    cl = lambda t: t.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    ops.conv3x3_wgrad(cl(dy), cl(x), out=dW)
+    torch.cuda.synchronize()
+    report(f"conv3x3 wgrad rows[{N}x64x{H}x{W}]", (dW - 1.0).permute(0, 3, 1, 2), wd.grad, rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())
+
+
 def test_stream_fence_orders_two_streams():
     """maed_stream_fence(from, to): everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on (the fence the host uses for
     side-stream launches instead of framework events).  A long fill on stream A, the fence, a read on stream B: B must see the fill -- 20 rounds, fresh values."""

@@ -429,11 +429,12 @@ def test_stem7x7s2_forward_from_padded_4slot_image(N, H, W, stats):
         assert torch.allclose(sums, want, rtol=1e-5, atol=1e-3), (sums - want).abs().max()
 
 
-@pytest.mark.parametrize("N,H,W,wgs", [(2, 32, 32, None), (1, 32, 64, None), (3, 48, 96, 5), (2, 32, 32, 3)])
-def test_stem7x7s2_weight_gradient_by_lds_dma_and_transposing_reads(N, H, W, wgs, monkeypatch):
+@pytest.mark.parametrize("N,H,W,wgs,slots", [(2, 32, 32, None, True), (1, 32, 64, None, False), (3, 48, 96, 5, True), (2, 32, 32, 3, False), (2, 32, 32, 3, True)])
+def test_stem7x7s2_weight_gradient_by_lds_dma_and_transposing_reads(N, H, W, wgs, slots, monkeypatch):
     """round 4: maed_stem7x7s2_wgrad -- one output row of dy and its seven input rows per work item, copied into LDS unchanged (LDS-DMA, swizzled dy chunks) and
     contracted over pixels through ds_read_b64_tr_b16 fragments; accumulates into the given fp32 slice.  One row per workgroup by default at these sizes; with
-    MAED_STEM_WGS = 5 / 3 the double-buffered walk over 15 (14 for the last workgroup... 72 = 4 * 15 + 12) resp. 11 / 11 / 10 rows."""
+    MAED_STEM_WGS = 5 / 3 the double-buffered walk over 15 (14 for the last workgroup... 72 = 4 * 15 + 12) resp. 11 / 11 / 10 rows.  slots: per-workgroup partial
+    results in scratch + the reduction pass (the product path) / atomics straight into the slice."""
     if wgs:
         monkeypatch.setenv("MAED_STEM_WGS", str(wgs))
     torch.manual_seed(12)
@@ -446,7 +447,9 @@ def test_stem7x7s2_weight_gradient_by_lds_dma_and_transposing_reads(N, H, W, wgs
     with patched() as lib:
         xp = ops.stem_input(x, torch.bfloat16, 7, 2, own=True)
         dyc = cl(dy)
-        rc = lib.maed_stem7x7s2_wgrad(dyc.data_ptr(), xp.data_ptr(), dW.data_ptr(), N, H, W, L.BF16, None)
+        sc = torch.full((lib.maed_stem7x7s2_wgrad_scratch_floats(N, H, W),), float("nan")) if slots else None
+        assert sc is None or sc.numel() % (64 * 147) == 0 and sc.numel() > 0
+        rc = lib.maed_stem7x7s2_wgrad(dyc.data_ptr(), xp.data_ptr(), dW.data_ptr(), sc.data_ptr() if sc is not None else None, N, H, W, L.BF16, None)
         assert rc == 0, lib.maed_last_error()
     got = (dW - dW0).view(64, 7, 7, 3).permute(0, 3, 1, 2).double()
     assert (got - gw).abs().max() <= 2e-3 * gw.abs().max(), (got - gw).abs().max() / gw.abs().max()
@@ -466,6 +469,27 @@ def test_stem7x7s2_autograd_node_fills_the_fp32_slice_and_rejects_other_geometri
         y.backward(cl(dy))
         assert ws.grad is None                   # the gradient travels in the fp32 slice, not through autograd
         bad = torch.zeros(1, 20 + 5, 20 + 6, 4, dtype=torch.bfloat16)
-        assert lib.maed_stem7x7s2_wgrad(dy.data_ptr(), bad.data_ptr(), dw.data_ptr(), 1, 20, 20, L.BF16, None) != 0
+        assert lib.maed_stem7x7s2_wgrad(dy.data_ptr(), bad.data_ptr(), dw.data_ptr(), None, 1, 20, 20, L.BF16, None) != 0
     got = dw.view(64, 7, 7, 3).permute(0, 3, 1, 2).double()
     assert (got - gw).abs().max() <= 2e-3 * gw.abs().max()
+
+
+@pytest.mark.parametrize("N,H,W,wgs", [(2, 5, 8, None), (1, 3, 16, None), (3, 4, 24, 2), (2, 6, 56, 5), (1, 2, 64, 1)])
+def test_conv3x3_weight_gradient_row_items_64_channels(N, H, W, wgs, monkeypatch):
+    """round 4: the 64 -> 64 channel weight gradient one image row at a time (conv3x3_rows.hip, taken by maed_conv3x3_wgrad for the stage-1 shape): rows in a
+    ring of four LDS slots framed by zero pixels, wave = tap, transposing reads.  Image heights / widths that exercise the borders (H = 2, 3), k-steps with a zero
+    tail (W = 8, 24, 56), the full 64-pixel row, workgroups that walk rows across frame boundaries (MAED_CONV3X3_ROWS_WGS), and accumulation into a non-zero
+    slice; against autograd through F.conv2d.  MAED_CONV3X3_WGRAD_ROWS=0 (the general TN kernel) gives the same numbers where it applies."""
+    if wgs:
+        monkeypatch.setenv("MAED_CONV3X3_ROWS_WGS", str(wgs))
+    torch.manual_seed(21)
+    x = torch.randn(N, 64, H, W).bfloat16()
+    dy = torch.randn(N, 64, H, W).bfloat16()
+    wr = (torch.randn(64, 64, 3, 3) * 576 ** -0.5).double().requires_grad_(True)
+    F.conv2d(x.double(), wr, padding=1).backward(dy.double())
+    dW0 = torch.randn(64, 3, 3, 64)
+    dW = dW0.clone()
+    with patched():
+        ops.conv3x3_wgrad(cl(dy), cl(x), out=dW)
+    got = (dW - dW0).permute(0, 3, 1, 2).double()
+    assert (got - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max(), ((got - wr.grad).abs().max() / wr.grad.abs().max())
