@@ -416,12 +416,6 @@ int maed_stem_input(const float* x, void* y, int N, int C, int H, int W, int pad
 int maed_conv3x3_wgrad_rows64_scratch_floats(int F, int H, int W, int Cin, int Cout);
 int maed_conv3x3_wgrad_rows64(const void* dy, const void* x, float* dW, void* scratch, int F, int H, int W, int dtype, void* stream);
 
-/* ... and at the other channel counts (multiples of 64; stage 2 / 3: 128 / 256 channels, rows of 28 / 14 pixels): strips of image rows, one 64 x 64 channel block
- * per workgroup (same file).  W in 8 .. 64.  scratch (required): maed_conv3x3_wgrad_strips_scratch_floats(...) fp32 elements (0 = shape not covered: use
- * maed_conv3x3_wgrad).  dW (Cout, 3, 3, Cin) fp32, ACCUMULATED. */
-int maed_conv3x3_wgrad_strips_scratch_floats(int F, int H, int W, int Cin, int Cout);
-int maed_conv3x3_wgrad_strips(const void* dy, const void* x, float* dW, void* scratch, int F, int H, int W, int Cin, int Cout, int dtype, void* stream);
-
 int maed_stem7x7s2_supported(int H, int W);
 int maed_stem7x7s2_fwd(const void* xp, const void* w, void* wimg, void* y, double* gn_sums, int F, int H, int W, int dtype, void* stream);
 int maed_stem7x7s2_wgrad_scratch_floats(int F, int H, int W);

@@ -134,8 +134,6 @@ SIGNATURES = {
     "maed_stem_input": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "maed_conv3x3_wgrad_rows64_scratch_floats": (i32, [i32, i32, i32, i32, i32]),
     "maed_conv3x3_wgrad_rows64": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "maed_conv3x3_wgrad_strips_scratch_floats": (i32, [i32, i32, i32, i32, i32]),
-    "maed_conv3x3_wgrad_strips": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "maed_stem7x7s2_supported": (i32, [i32, i32]),
     "maed_stem7x7s2_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "maed_stem7x7s2_wgrad_scratch_floats": (i32, [i32, i32, i32]),

@@ -15,7 +15,6 @@
 #define MAED_WAIT_VMCNT(n) do { } while (0)
 #define MAED_WAIT_LGKMCNT0() do { } while (0)
 #define MAED_LDS_DMA16(base_, voff_, lds_ptr_) __builtin_amdgcn_global_load_lds((const char*)(base_) + (voff_), (void*)(lds_ptr_), 16, 0, 0)
-#define MAED_LDS_DMA16_IF(active_, base_, voff_, lds_ptr_) hostsim_global_load_lds_masked((active_), (const char*)(base_) + (voff_), (void*)(lds_ptr_), 16)
 typedef void maed_lds_void_t;
 typedef const void maed_glb_void_t;
 #define MAED_DS_READ_TR16(p_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((hostsim_v4i16*)(p_))
@@ -34,24 +33,11 @@ typedef const void maed_glb_void_t;
 #define MAED_LDS_DMA16(base_, voff_, lds_ptr_)                                                                                   \
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"                                                 \
                  :: "v"((uint32_t)(voff_)), "s"((uint32_t)(uintptr_t)(lds_ptr_)), "s"((const char*)(base_)) : "memory")
-// ... for the active lanes only (EXEC): inactive lanes leave their 16 bytes of the destination untouched
-#define MAED_LDS_DMA16_IF(active_, base_, voff_, lds_ptr_) do { if (active_) MAED_LDS_DMA16(base_, voff_, lds_ptr_); } while (0)
 typedef __attribute__((address_space(3))) void maed_lds_void_t;
 typedef const __attribute__((address_space(1))) void maed_glb_void_t;
 // ds_read_b64_tr_b16: every lane reads 8 bytes at its own LDS address; inside each 16-lane group the 16 x 4 elements come back transposed
 typedef short maed_v4i16_t __attribute__((ext_vector_type(4)));
 #define MAED_DS_READ_TR16(p_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) maed_v4i16_t*)(p_))
-#endif
-
-// a wave-uniform pointer the compiler could not prove uniform (it came through VALU arithmetic, e.g. an integer division): back into SGPRs
-#ifdef MAED_HOSTSIM
-template <typename P> static inline P* maed_uniform_ptr(P* p) { return p; }
-#else
-template <typename P> __device__ __forceinline__ P* maed_uniform_ptr(P* p) {
-    const uint64_t v = (uint64_t)(uintptr_t)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (P*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-}
 #endif
 
 // ---- buffer loads: 16 bytes per lane at (wave-uniform 128-bit resource: base + extent) + 32-bit lane byte offset + wave-uniform byte offset.  No 64-bit lane

@@ -116,149 +116,6 @@ bool maed_conv3x3_wgrad_rows64_ok(int F, int H, int W, int Cin, int Cout) {
     return on && Cin == 64 && Cout == 64 && W % 8 == 0 && W >= 8 && W <= 64 && H >= 1 && (int64_t)F * H * W * 128 < (1ll << 31);
 }
 
-// ---- the other stages: strips of image rows, 64 x 64 channel blocks -----------------------------------------------------------------------------------
-// C > 64 and short rows (stage 2: 128 channels, 28 x 28; stage 3: 256 channels, 14 x 14): a work item is a STRIP of R image rows of one frame (R = 7 / 14: fourteen
-// 16-pixel k-steps, 56 MFMAs per wave and item), a workgroup owns one (64 output x 64 input channels) block and walks a range of strips; nine waves = nine taps as
-// above.  The strip's dy rows (the block's 128-byte channel slice of every pixel) and its R + 2 input rows are LDS-DMA'd row by row into zero-framed row slots (the
-// last instruction of a row under a lane mask), double-buffered.  Every workgroup ends with its 64 x 576 partial block in its own scratch slot; the reduction pass
-// adds the slots of a block into the (Cout, 9, Cin) gradient.
-struct StripDims { int H, W, Cin, Cout, R, ks, xs, dys, n_strips, strips_per_wg, wpb; };     // ks: k-steps per row; xs / dys: pixel slots per LDS row
-
-__global__ __launch_bounds__(R3_THREADS, 1) void conv3x3_wgrad_strips_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ partial, StripDims d) {
-    MAED_DYN_SHARED(unsigned short, smem);
-    const int tid = threadIdx.x, lane = tid & 63, tap = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5, i16 = lane & 15;
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    // (integer division runs on the VALU: results that feed SGPR operands of the DMA go through readfirstlane)
-    const int blk = __builtin_amdgcn_readfirstlane((int)blockIdx.x / d.wpb), sg = (int)blockIdx.x - blk * d.wpb;
-    const int nib = d.Cin >> 6, cb = __builtin_amdgcn_readfirstlane(blk / nib), ib = blk - cb * nib;
-    const int x_elems = (d.R + 2) * d.xs * 64, dy_elems = d.R * d.dys * 64, buf_elems = x_elems + dy_elems;
-    for (int i = tid; i < buf_elems / 4; i += R3_THREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);      // both buffers (2 * buf_elems * 2 B)
-    __syncthreads();
-    const int s0 = sg * d.strips_per_wg;
-    int s1 = s0 + d.strips_per_wg;
-    if (s1 > d.n_strips) s1 = d.n_strips;
-    const int spf = __builtin_amdgcn_readfirstlane(d.H / d.R);          // strips per frame
-    const int row_chunks = d.W * 8, nin = (row_chunks + 63) >> 6;       // wave-instructions per row
-    const int n_instr = (2 * d.R + 2) * nin;
-    // this lane's chunk of a row for instruction part q: pixel (q * 64 + lane) >> 3, chunk (..) & 7
-#define S3_ISSUE(strip_, b_) { const int st__ = __builtin_amdgcn_readfirstlane(strip_); const int f__ = __builtin_amdgcn_readfirstlane(st__ / spf), y0__ = (st__ - f__ * spf) * d.R; \
-        unsigned short* xb__ = smem + (size_t)__builtin_amdgcn_readfirstlane(b_) * buf_elems; unsigned short* db__ = xb__ + x_elems; \
-        for (int j = tap; j < n_instr; j += 9) { const int row = __builtin_amdgcn_readfirstlane(j / nin), part = j - row * nin; const int p = part * 64 + lane, px = p >> 3, c = p & 7; \
-            const bool act = p < row_chunks; \
-            if (row < d.R + 2) { const int yy = y0__ + row - 1;           /* input row (wave-uniform); outside the image: nothing to copy, the MFMAs skip it */ \
-                if (yy >= 0 && yy < d.H) MAED_LDS_DMA16_IF(act, maed_uniform_ptr((const char*)(x + ((int64_t)(f__ * d.H + yy) * d.W) * d.Cin + ib * 64)), \
-                                                          (uint32_t)(px * d.Cin * 2 + ((c ^ ((((px + 1) >> 1) & 1) << 2)) << 4)), maed_uniform_ptr(xb__ + (row * d.xs + 1) * 64 + part * 512)); \
-            } else { const int r = row - (d.R + 2); \
-                MAED_LDS_DMA16_IF(act, maed_uniform_ptr((const char*)(dy + ((int64_t)(f__ * d.H + y0__ + r) * d.W) * d.Cout + cb * 64)), \
-                                  (uint32_t)(px * d.Cout * 2 + ((c ^ (((px >> 1) & 1) << 2)) << 4)), maed_uniform_ptr(db__ + (r * d.dys) * 64 + part * 512)); } } }
-
-    f32x16_t acc[2][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f; }
-    const int prow = 4 * hi + (i16 >> 2), pcol = (lane & 16) + 4 * (i16 & 3);
-    const int swa = ((prow >> 1) & 1) << 2, swb = (((prow + kx) >> 1) & 1) << 2;
-    const int a_off0 = prow * 64 + ((((pcol >> 3) ^ swa) << 3) | (pcol & 7)), a_off1 = prow * 64 + (((((pcol + 32) >> 3) ^ swa) << 3) | (pcol & 7));
-    const int b_off0 = (prow + kx) * 64 + ((((pcol >> 3) ^ swb) << 3) | (pcol & 7)), b_off1 = (prow + kx) * 64 + (((((pcol + 32) >> 3) ^ swb) << 3) | (pcol & 7));
-
-    if (s0 < s1) S3_ISSUE(s0, 0);
-    for (int st = s0; st < s1; ++st) {
-        const int b = (st - s0) & 1;
-        MAED_WAIT_VMCNT0();
-        __syncthreads();
-        if (st + 1 < s1) S3_ISSUE(st + 1, b ^ 1);
-        const int y0 = (st % spf) * d.R;
-        const unsigned short* xb = smem + (size_t)b * buf_elems;
-        const unsigned short* da = xb + x_elems;
-        for (int r = 0; r < d.R; ++r) {
-            const int yy = y0 + r + ky - 1;
-            if (yy < 0 || yy >= d.H) continue;                           // wave-uniform: this tap's input row lies outside the image (its slot may hold an older strip's row)
-            const unsigned short* ar = da + r * d.dys * 64;
-            const unsigned short* br = xb + (r + ky) * d.xs * 64;
-            for (int s = 0; s < d.ks; ++s) {
-                union { bf16x8_t v; uint2 u[2]; } a0, a1, b0, b1;
-#define S3_FRAG(dst_, base_, off_) { auto lo__ = MAED_DS_READ_TR16((base_) + s * 1024 + (off_)); auto hi__ = MAED_DS_READ_TR16((base_) + s * 1024 + 512 + (off_)); \
-                __builtin_memcpy(&dst_.u[0], &lo__, 8); __builtin_memcpy(&dst_.u[1], &hi__, 8); }
-                S3_FRAG(a0, ar, a_off0) S3_FRAG(a1, ar, a_off1) S3_FRAG(b0, br, b_off0) S3_FRAG(b1, br, b_off1)
-#undef S3_FRAG
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, b0.v, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, b1.v, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b0.v, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, acc[1][1], 0, 0, 0);
-            }
-        }
-    }
-#undef S3_ISSUE
-    float* const base = partial + (size_t)blockIdx.x * (64 * 576) + tap * 64 + l31;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int bt = 0; bt < 2; ++bt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) base[(32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi) * 576 + 32 * bt] = acc[a][bt][r];
-}
-
-// dW (Cout, 9, Cin) += the wpb slots of every 64 x 64 channel block: grid (144, blocks), one block element per thread (the only writer of its dW element)
-__global__ __launch_bounds__(256) void wgrad_block_slots_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int wpb, int Cin) {
-    const int e = blockIdx.x * 256 + threadIdx.x, blk = blockIdx.y;
-    const int nib = Cin >> 6, cb = blk / nib, ib = blk - cb * nib;
-    const float* p = partial + (size_t)blk * wpb * (64 * 576) + e;
-    float t0 = 0.f, t1 = 0.f;
-    int w = 0;
-    for (; w + 1 < wpb; w += 2) { t0 += p[(size_t)w * (64 * 576)]; t1 += p[(size_t)(w + 1) * (64 * 576)]; }
-    if (w < wpb) t0 += p[(size_t)w * (64 * 576)];
-    const int co = e / 576, tc = e - co * 576, tap = tc >> 6, ci = tc & 63;
-    dW[((size_t)(cb * 64 + co) * 9 + tap) * Cin + ib * 64 + ci] += t0 + t1;
-}
-
-// geometry of a strips launch; false: shape not covered (the general TN kernel takes it)
-static bool strips_dims(int F, int H, int W, int Cin, int Cout, StripDims* out) {
-    static const bool on = !(getenv("MAED_CONV3X3_WGRAD_STRIPS") && atoi(getenv("MAED_CONV3X3_WGRAD_STRIPS")) == 0);      // (A/B knob: 0 = the general TN kernel)
-    if (!on || F <= 0 || H <= 0 || W < 8 || W > 64 || Cin % 64 || Cout % 64 || Cin <= 0 || Cout <= 0 || (Cin == 64 && Cout == 64)) return false;
-    if ((int64_t)F * H * W * (Cin > Cout ? Cin : Cout) * 2 >= (1ll << 31)) return false;
-    StripDims d{};
-    d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout;
-    d.ks = (W + 15) >> 4; d.xs = 16 * d.ks + 2; d.dys = 16 * d.ks;
-    d.R = 0;
-    for (int R = H; R >= 1; --R)                     // the largest divisor of H whose two buffers fit in 150 KB of LDS, at most 16 k-steps per item
-        if (H % R == 0 && R * d.ks <= 16 && (size_t)2 * ((R + 2) * d.xs + R * d.dys) * 128 <= 150 * 1024) { d.R = R; break; }
-    if (!d.R) return false;
-    d.n_strips = F * (H / d.R);
-    const int nblk = (Cin >> 6) * (Cout >> 6);
-    int wpb = 256 / nblk;
-    if (const char* ev = getenv("MAED_CONV3X3_STRIPS_WPB")) { const int v = atoi(ev); if (v > 0) wpb = v; }      // (sweep knob)
-    if (wpb < 1) wpb = 1;
-    if (wpb > d.n_strips) wpb = d.n_strips;
-    d.strips_per_wg = (d.n_strips + wpb - 1) / wpb;
-    d.wpb = (d.n_strips + d.strips_per_wg - 1) / d.strips_per_wg;
-    *out = d;
-    return true;
-}
-
-extern "C" int maed_conv3x3_wgrad_strips_scratch_floats(int F, int H, int W, int Cin, int Cout) {
-    StripDims d;
-    if (!strips_dims(F, H, W, Cin, Cout, &d)) return 0;
-    const int64_t n = (int64_t)d.wpb * (Cin >> 6) * (Cout >> 6) * 64 * 576;
-    return n < (1ll << 31) ? (int)n : 0;
-}
-
-// dW (Cout, 3, 3, Cin) fp32 += weight gradient of the stride-1 3x3 SAME convolution from dy (F,H,W,Cout), x (F,H,W,Cin), channels_last bf16, Cin / Cout multiples of 64
-extern "C" int maed_conv3x3_wgrad_strips(const void* dy, const void* x, float* dW, void* scratch, int F, int H, int W, int Cin, int Cout, int dtype, void* stream) {
-    MAED_CHECK_ARG(dy && x && dW && scratch, MAED_ERR_ARG, "conv3x3_wgrad_strips: null pointer");
-    MAED_CHECK_ARG(dtype == MAED_BF16, MAED_ERR_UNSUPPORTED, "conv3x3_wgrad_strips: bf16 only (dtype=%d)", dtype);
-    StripDims d;
-    MAED_CHECK_ARG(strips_dims(F, H, W, Cin, Cout, &d), MAED_ERR_SHAPE, "conv3x3_wgrad_strips: shape not covered (F=%d H=%d W=%d Cin=%d Cout=%d)", F, H, W, Cin, Cout);
-    MAED_CHECK_ARG(is_aligned(dy, 16) && is_aligned(x, 16) && is_aligned(scratch, 16), MAED_ERR_ALIGN, "conv3x3_wgrad_strips: 16-B alignment");
-    ProfScope prof__(PROF_TN_CONV, stream, 2.0 * (double)F * H * W * Cout * 9 * Cin, 2.0 * (double)F * H * W * ((double)Cout + Cin) + 36.0 * (double)Cout * Cin);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_strips_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    const int nblk = (Cin >> 6) * (Cout >> 6);
-    const size_t lds = (size_t)2 * ((d.R + 2) * d.xs + d.R * d.dys) * 128;
-    hipLaunchKernelGGL(conv3x3_wgrad_strips_kernel, dim3(nblk * d.wpb), dim3(R3_THREADS), lds, (hipStream_t)stream, (const bf16*)dy, (const bf16*)x, (float*)scratch, d);
-    hipLaunchKernelGGL(wgrad_block_slots_reduce_kernel, dim3(64 * 576 / 256, nblk), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, dW, d.wpb, Cin);
-    MAED_CHECK_LAUNCH("conv3x3_wgrad_strips");
-    return MAED_OK;
-}
-
 void maed_wgrad_slots_reduce(const float* partial, float* dW, int n_slots, int n_elems, hipStream_t stream) {
     hipLaunchKernelGGL(wgrad_slots_reduce_kernel, dim3((n_elems + 255) / 256, (n_slots + 31) / 32), dim3(256), 0, stream, partial, dW, n_slots, n_elems);
 }

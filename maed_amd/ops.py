@@ -1036,12 +1036,6 @@ def conv3x3_wgrad(dy, x, out=None, prec=None):
             check(L.lib().maed_conv3x3_wgrad_rows64(_p(dy), _p(x), _p(dW), _p(scratch), N, H, W, dt_code(x.dtype), _stream()), "conv3x3_wgrad_rows64")
             _keep_alive_on_stream(scratch)
             return dW
-        nb = L.lib().maed_conv3x3_wgrad_strips_scratch_floats(N, H, W, I, O)
-        if nb > 0:      # other multiples of 64 channels: strips of rows, one 64 x 64 channel block per workgroup
-            scratch = torch.empty(nb, dtype=torch.float32, device=x.device)
-            check(L.lib().maed_conv3x3_wgrad_strips(_p(dy), _p(x), _p(dW), _p(scratch), N, H, W, I, O, dt_code(x.dtype), _stream()), "conv3x3_wgrad_strips")
-            _keep_alive_on_stream(scratch)
-            return dW
     check(L.lib().maed_conv3x3_wgrad(_p(dy), _p(x), _p(_tapmask(N, H, W, x.device)), _p(_zero_page(x.device)), _p(dW), N, H, W, I, O,
                                      mm_code(x.dtype, prec), _stream()), "conv3x3_wgrad")
     return dW

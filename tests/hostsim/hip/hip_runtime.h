@@ -218,15 +218,6 @@ static inline void __builtin_amdgcn_global_load_lds(const void* gptr, void* lds_
     w.bar.arrive_and_wait();
     memcpy((char*)(uintptr_t)w.u64[p][1] + (size_t)lane * size + offset, (const char*)gptr + offset, size);   // visible to readers after the kernel's own barrier
 }
-// the same under a lane mask (hardware: EXEC): every lane of the wave takes part in the exchange, only active ones copy
-static inline void hostsim_global_load_lds_masked(bool active, const void* gptr, void* lds_ptr, unsigned size) {
-    hostsim::WaveCtx& w = *hostsim::t_block->waves[hostsim::t_tid / 64];
-    const int lane = hostsim::t_tid % 64;
-    const unsigned p = hostsim::t_wop++ & 1u;
-    if (lane == 0) w.u64[p][1] = (uint64_t)(uintptr_t)lds_ptr;
-    w.bar.arrive_and_wait();
-    if (active) memcpy((char*)(uintptr_t)w.u64[p][1] + (size_t)lane * size, (const char*)gptr, size);
-}
 // v_mfma_f32_16x16x32_bf16: A[i][k] = lane (k/8)*16 + i, element k%8;  B[k][j] = lane (k/8)*16 + j, element k%8;  D[4*(lane>>4) + r][lane & 15] in reg r
 typedef float hostsim_f32x4 __attribute__((ext_vector_type(4)));
 static inline hostsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hostsim_bf16x8 a, hostsim_bf16x8 b, hostsim_f32x4 acc, int, int, int) {

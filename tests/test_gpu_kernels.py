@@ -612,25 +612,6 @@ def test_conv3x3_weight_gradient_row_items_64_channels(N, H, W):
     report(f"conv3x3 wgrad rows[{N}x64x{H}x{W}]", (dW - 1.0).permute(0, 3, 1, 2), wd.grad, rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("N,I,O,H,W", [(16, 128, 128, 28, 28), (16, 256, 256, 14, 14), (3, 128, 64, 16, 16), (2, 64, 192, 5, 30)])
-def test_conv3x3_weight_gradient_strips_of_rows_per_channel_block(N, I, O, H, W):
-    """round 4: maed_conv3x3_wgrad_strips (the stage-2 / stage-3 shapes of cfg3, the 16 x 16 rows of cfg5's stage 3, unequal channel counts with a ragged row
-    width): strips of image rows, one 64 x 64 channel block per workgroup, per-workgroup slots + block reduction; accumulation into a non-zero slice, vs fp64
-    autograd through conv2d"""
-    ops, _ = _ops()
-    x = q(rnd(N, I, H, W, seed=1), torch.bfloat16)
-    dy = q(rnd(N, O, H, W, seed=2), torch.bfloat16)
-    wd = rnd(O, I, 3, 3, seed=3, scale=(9 * I) ** -0.5).double().requires_grad_(True)
-    F.conv2d(x.double(), wd, padding=1).backward(dy.double())
-    from maed_amd import _lib as L
-    assert L.lib().maed_conv3x3_wgrad_strips_scratch_floats(N, H, W, I, O) > 0
-    dW = torch.ones(O, 3, 3, I, dtype=torch.float32, device=DEV)
-    cl = lambda t: t.to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
-    ops.conv3x3_wgrad(cl(dy), cl(x), out=dW)
-    torch.cuda.synchronize()
-    report(f"conv3x3 wgrad strips[{N}x{I}->{O},{H}x{W}]", (dW - 1.0).permute(0, 3, 1, 2), wd.grad, rtol=2e-3, atol=2e-3 * wd.grad.abs().max().item())
-
-
 def test_stream_fence_orders_two_streams():
     """maed_stream_fence(from, to): everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on (the fence the host uses for
     side-stream launches instead of framework events).  A long fill on stream A, the fence, a read on stream B: B must see the fill -- 20 rounds, fresh values."""

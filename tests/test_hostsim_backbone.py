@@ -493,25 +493,3 @@ def test_conv3x3_weight_gradient_row_items_64_channels(N, H, W, wgs, monkeypatch
         ops.conv3x3_wgrad(cl(dy), cl(x), out=dW)
     got = (dW - dW0).permute(0, 3, 1, 2).double()
     assert (got - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max(), ((got - wr.grad).abs().max() / wr.grad.abs().max())
-
-
-@pytest.mark.parametrize("N,I,O,H,W,wpb", [(2, 128, 128, 6, 8, None), (1, 64, 128, 4, 14, None), (3, 128, 64, 14, 14, 2), (2, 128, 128, 28, 28, 1), (1, 192, 64, 2, 16, None)])
-def test_conv3x3_weight_gradient_strips_of_rows_per_channel_block(N, I, O, H, W, wpb, monkeypatch):
-    """round 4: the 3x3 weight gradient for the other multiples of 64 channels (stage 2 / 3) as strips of image rows (conv3x3_rows.hip): one 64 x 64 channel block
-    per workgroup, the block's channel slices of the strip's dy and input rows LDS-DMA'd row by row (last instruction of a row under a lane mask: W = 14, 28),
-    per-workgroup slots + the block reduction into (O, 9, I).  Whole-frame strips (14 x 14), several strips per frame (28 x 28: R = 7), workgroups that walk
-    strips across frames (MAED_CONV3X3_STRIPS_WPB), unequal channel counts; accumulation into a non-zero slice; against autograd through F.conv2d."""
-    if wpb:
-        monkeypatch.setenv("MAED_CONV3X3_STRIPS_WPB", str(wpb))
-    torch.manual_seed(22)
-    x = torch.randn(N, I, H, W).bfloat16()
-    dy = torch.randn(N, O, H, W).bfloat16()
-    wr = (torch.randn(O, I, 3, 3) * (9 * I) ** -0.5).double().requires_grad_(True)
-    F.conv2d(x.double(), wr, padding=1).backward(dy.double())
-    dW0 = torch.randn(O, 3, 3, I)
-    dW = dW0.clone()
-    with patched() as lib:
-        assert lib.maed_conv3x3_wgrad_strips_scratch_floats(N, H, W, I, O) > 0 and lib.maed_conv3x3_wgrad_strips_scratch_floats(N, H, W, 64, 64) == 0
-        ops.conv3x3_wgrad(cl(dy), cl(x), out=dW)
-    got = (dW - dW0).permute(0, 3, 1, 2).double()
-    assert (got - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max(), ((got - wr.grad).abs().max() / wr.grad.abs().max())
