@@ -3,15 +3,16 @@
     python scripts/group_rooflines.py steady_state_kernels.csv [traffic.json]
 With a traffic.json the result is stored under "__groups__" (bench.py then reports it as kernel_groups for the same source hash).
 GroupNorm bytes per step at cfg3 (128 frames, bf16), from the layer list of the hybrid R50: forward apply reads x (+ residual) and writes y (+ 1 bit per element
-when a residual precedes the ReLU); the layer behind the MIOpen stem convolution also reads x once for the statistics; backward (round 4: one pass, gn_bwd_onepass_kernel)
+when a residual precedes the ReLU); every layer's statistics come from the epilogue of the convolution in front (since round 4 the stem's too: csrc/stem.hip); backward (round 4: one pass, gn_bwd_onepass_kernel)
 reads x, dy (+ bits) once and writes dx (+ the masked residual gradient in the four downsample blocks) -- the round-3 figure counted x and dy twice (reduce + apply)."""
 import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def groupnorm_bytes(frames=128, E=2):
-    # (channels, H) of every GroupNorm in forward order; residual = norm3 of each bottleneck; stats_pass = behind a MIOpen convolution
-    layers = [(64, 112, False, True)]                                   # stem norm (7x7 MIOpen conv in front)
+    # (channels, H) of every GroupNorm in forward order; residual = norm3 of each bottleneck; stats_pass = a separate statistics read of x (none since the stem runs
+    # on the library: MAED_STEM_OWN=0 brings the gn_stats_kernel pass back)
+    layers = [(64, 112, False, os.environ.get("MAED_STEM_OWN", "1") == "0")]     # stem norm
     chans, depth, H = (256, 512, 1024), (3, 4, 9), (56, 28, 14)
     for s in range(3):
         for b in range(depth[s]):
@@ -39,7 +40,7 @@ def main():
         if "igemm" in n or n.startswith("ck::") or "SubTensor" in n or "Cijk" in n: return "miopen_rocblas"
         if n.startswith("gemm_tn"): return "gemm_tn"
         if n.startswith("gemm_nt_glds") or n.startswith("gemm_nt_256") or n.startswith("gemm_nt_mfma"): return "gemm_nt"
-        if n.startswith("conv3x3"): return "conv3x3"
+        if n.startswith("conv3x3") or n.startswith("stem7x7s2") or n.startswith("stem_wimg") or n.startswith("wgrad_slots_reduce"): return "conv3x3"   # (+ the stem: 3 launches)
         if n.startswith("attn_"): return "attention"
         if n.startswith("ln_"): return "layernorm"
         if n.startswith("at::") or "elementwise" in n or "rocclr" in n or "reduce_kernel<" in n or "CatArray" in n: return "aten_runtime"

@@ -132,6 +132,13 @@ def test_weight_cache_batched_refresh_on_simulator():
             (b3c, b3t), = cb.get([w3], torch.bfloat16)
             assert len(calls) == n + 1, "the second cache was refreshed by the same launch"
             assert torch.equal(a1c, w1.bfloat16()) and torch.equal(b3t, w3.bfloat16().t().contiguous())
+            # full 64 x 64 tiles of matrices with 4-element-aligned extents take the vectorised path (several tiles; full and ragged tiles in one matrix)
+            cv = ops.WeightCache()
+            w4, w5 = torch.randn(128, 192), torch.randn(68, 132)
+            for dt in (torch.bfloat16, torch.float32):
+                (v4c, v4t), (v5c, v5t) = cv.get([w4, w5], dt)
+                for w, c, t in ((w4, v4c, v4t), (w5, v5c, v5t)):
+                    assert torch.equal(c, w.to(dt)) and torch.equal(t, w.to(dt).t().contiguous())
             # parity mode: the [out,in] image is the fp32 master itself, only the transposed copy is built
             cf = ops.WeightCache()
             (f1, f1t), = cf.get([w2], torch.float32)
