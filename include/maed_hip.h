@@ -306,6 +306,12 @@ int maed_smpl_joints_project_bwd(const float* kp3d, const float* cam, const int6
 int maed_smpl_skin_bwd(const maed_smpl_params* sp, const float* A, const float* v_posed, const float* d_verts,
                        const float* d_extra21, const int64_t* extra_vertex_ids, const float* d_extra9, const float* Jextra,
                        float* d_vposed, float* dA, int F, void* stream);
+/* ... for the case d_verts == NULL (the training objective reads key points only): d_v is non-zero only on the vertices the extra joints read -- `active`
+ * (n_active sorted vertex ids: the non-zero columns of Jextra and extra_vertex_ids; the host derives the list once per model).  Writes the COMPACT
+ * d_vposed_active (F, n_active, 3); the pose-corrective GEMM then runs on the matching columns of [posedirs; shapedirs^T].  dA as above. */
+int maed_smpl_skin_bwd_sparse(const maed_smpl_params* sp, const float* A, const float* v_posed, const int32_t* active, int n_active,
+                              const float* d_extra21, const int64_t* extra_vertex_ids, const float* d_extra9, const float* Jextra,
+                              float* d_vposed_active, float* dA, int F, void* stream);
 /* K12 backward, kinematic chain.  dpf_dbeta (F,217): columns 0..206 = d pose_feature (posedirs . d_vposed), 207..216 =
  * shapedirs^T d_vposed (both from the caller's GEMM).  d_rotmat_in (F,24,9) / d_betas_in (row stride given) optional
  * upstream gradients.  Outputs d_rotmat (F,24,9), d_betas (F,10).                                                    */

@@ -101,6 +101,7 @@ SIGNATURES = {
     "maed_smpl_joints_project_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
     "maed_smpl_joints_project_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, vp]),
     "maed_smpl_skin_bwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "maed_smpl_skin_bwd_sparse": (i32, [C.POINTER(SmplParams), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "maed_smpl_chain_bwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp]),
     "maed_rot6d_pose_bwd": (i32, [vp, vp, vp, i64, vp, i64, vp]),
     "maed_ktd_chain_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp]),

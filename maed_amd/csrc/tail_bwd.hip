@@ -142,6 +142,85 @@ extern "C" int maed_smpl_skin_bwd(const maed_smpl_params* sp, const float* A, co
     return MAED_OK;
 }
 
+// ---- K12 backward, vertex part, ACTIVE vertices only ---------------------------------------------------------------------------
+// Without a gradient on the vertices themselves (the training objective of lib/core/loss.py reads key points only) d_v is non-zero exactly on the vertices the
+// 9 regressed + 21 selected extra joints read: the non-zero columns of J_regressor_extra and extra_vertex_ids -- ~290 of 6890.  The dense kernel above spends
+// 24 x 12 FMAs per (vertex, frame) on transforms that then multiply zeros, and the pose-corrective GEMM behind it contracts 20670 columns of which ~870 are
+// non-zero.  Here: thread per (active vertex, frame), compact d_vposed (F, na, 3); the GEMM runs on the matching columns of [posedirs; shapedirs^T]
+// (SMPL.pose_shape_dirs_active).  Same arithmetic per active vertex, same LDS reduction of dA.
+#define SKS_VB 64
+__global__ __launch_bounds__(256) void smpl_skin_bwd_sparse_kernel(maed_smpl_params sp, const float* __restrict__ A, const float* __restrict__ v_posed,
+                                                                   const int* __restrict__ active, int na, const float* __restrict__ d_e21,
+                                                                   const int64_t* __restrict__ extra_ids, const float* __restrict__ d_e9,
+                                                                   const float* __restrict__ Jextra, float* __restrict__ d_vposed_a, float* __restrict__ dA, int F) {
+    __shared__ float s_A[SK_FB][NJ * 12];
+    __shared__ float s_dA[SK_FB][NJ * 12];
+    __shared__ float s_de9[SK_FB][27];
+    __shared__ float s_de21[SK_FB][63];
+    __shared__ int s_ids[21];
+    const int f0 = blockIdx.y * SK_FB;
+    for (int i = threadIdx.x; i < SK_FB * NJ * 12; i += 256) {
+        const int fb = i / (NJ * 12), k = i % (NJ * 12);
+        s_A[fb][k] = A[(int64_t)min(f0 + fb, F - 1) * NJ * 12 + k];
+        s_dA[fb][k] = 0.f;
+    }
+    for (int i = threadIdx.x; i < SK_FB * 27; i += 256) s_de9[i / 27][i % 27] = d_e9[(int64_t)min(f0 + i / 27, F - 1) * 27 + i % 27];
+    for (int i = threadIdx.x; i < SK_FB * 63; i += 256) s_de21[i / 63][i % 63] = d_e21[(int64_t)min(f0 + i / 63, F - 1) * 63 + i % 63];
+    if (threadIdx.x < 21) s_ids[threadIdx.x] = (int)extra_ids[threadIdx.x];
+    __syncthreads();
+    const int a = blockIdx.x * SKS_VB + (threadIdx.x & (SKS_VB - 1)), fb = threadIdx.x / SKS_VB, f = f0 + fb;
+    if (a < na && f < F) {
+        const int v = active[a];
+        float dv[3] = {0.f, 0.f, 0.f};
+        for (int r = 0; r < 9; ++r) {
+            const float jx = Jextra[(int64_t)r * NV + v];
+            for (int c = 0; c < 3; ++c) dv[c] = fmaf(jx, s_de9[fb][r * 3 + c], dv[c]);
+        }
+        for (int k = 0; k < 21; ++k)
+            if (s_ids[k] == v) { dv[0] += s_de21[fb][k * 3]; dv[1] += s_de21[fb][k * 3 + 1]; dv[2] += s_de21[fb][k * 3 + 2]; }
+        float T[12];
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            const float w = sp.lbs_weights[v * NJ + j];
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(w, s_A[fb][j * 12 + e], T[e]);
+        }
+        float* q = d_vposed_a + ((int64_t)f * na + a) * 3;
+        q[0] = T[0] * dv[0] + T[4] * dv[1] + T[8] * dv[2];
+        q[1] = T[1] * dv[0] + T[5] * dv[1] + T[9] * dv[2];
+        q[2] = T[2] * dv[0] + T[6] * dv[1] + T[10] * dv[2];
+        if (dv[0] != 0.f || dv[1] != 0.f || dv[2] != 0.f) {
+            const int64_t o = ((int64_t)f * NV + v) * 3;
+            const float vh[4] = {v_posed[o], v_posed[o + 1], v_posed[o + 2], 1.0f};
+            for (int j = 0; j < NJ; ++j) {
+                const float w = sp.lbs_weights[v * NJ + j];
+                if (w == 0.f) continue;
+                for (int r = 0; r < 3; ++r)
+                    for (int e = 0; e < 4; ++e) atomicAdd(&s_dA[fb][j * 12 + r * 4 + e], w * dv[r] * vh[e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SK_FB * NJ * 12; i += 256) {
+        const int fb2 = i / (NJ * 12), k = i % (NJ * 12);
+        const float x = s_dA[fb2][k];
+        if (f0 + fb2 < F && x != 0.f) atomicAdd(dA + (int64_t)(f0 + fb2) * NJ * 12 + k, x);
+    }
+}
+
+extern "C" int maed_smpl_skin_bwd_sparse(const maed_smpl_params* sp, const float* A, const float* v_posed, const int32_t* active, int n_active,
+                                         const float* d_extra21, const int64_t* extra_vertex_ids, const float* d_extra9, const float* Jextra,
+                                         float* d_vposed_active, float* dA, int F, void* stream) {
+    MAED_CHECK_ARG(sp && A && v_posed && active && d_extra21 && extra_vertex_ids && d_extra9 && Jextra && d_vposed_active && dA, MAED_ERR_ARG, "smpl_skin_bwd_sparse: null pointer");
+    MAED_CHECK_ARG(sp->lbs_weights, MAED_ERR_ARG, "smpl_skin_bwd_sparse: null SMPL parameter");
+    MAED_CHECK_ARG(n_active > 0 && n_active <= NV, MAED_ERR_SHAPE, "smpl_skin_bwd_sparse: n_active=%d out of range", n_active);
+    static_assert(SKS_VB * SK_FB == 256, "one thread per (active vertex, frame) of the block");
+    if (F <= 0) return MAED_OK;
+    hipLaunchKernelGGL(smpl_skin_bwd_sparse_kernel, dim3((n_active + SKS_VB - 1) / SKS_VB, (F + SK_FB - 1) / SK_FB), dim3(256), 0, (hipStream_t)stream, *sp, A, v_posed,
+                       (const int*)active, n_active, d_extra21, extra_vertex_ids, d_extra9, Jextra, d_vposed_active, dA, F);
+    MAED_CHECK_LAUNCH("smpl_skin_bwd_sparse");
+    return MAED_OK;
+}
+
 // ---- K12 backward, kinematic chain -----------------------------------------------------------------------------------------
 // recompute J, Rw, tw, then walk the tree from the leaves.
 //   forward:  Rw_j = Rw_p R_j,  tw_j = Rw_p (J_j - J_p) + tw_p,  A_j = [Rw_j | tw_j - Rw_j J_j],  joints24_j = tw_j

@@ -141,6 +141,27 @@ class SMPL(nn.Module):
             self._ps_t = torch.cat([self.posedirs, self.shapedirs.reshape(-1, 10).t()], dim=0).contiguous()
         return self._ps_t
 
+    def active_vertices(self):
+        """sorted int32 ids of the vertices the 9 regressed + 21 selected extra joints read (non-zero columns of J_regressor_extra, extra_vertex_ids): where the
+        vertex gradient of the training objective can be non-zero (tail.SmplTailFn backward without d_verts).  Derived once per regressor state (one host sync)."""
+        key = (self.J_regressor_extra.data_ptr(), self.J_regressor_extra._version, str(self.J_regressor_extra.device))
+        if getattr(self, "_active_key", None) != key:
+            with torch.no_grad():
+                cols = (self.J_regressor_extra != 0).any(dim=0)
+                cols[self.extra_vertex_ids.to(cols.device)] = True
+                self._active = torch.nonzero(cols).flatten().to(torch.int32).contiguous()
+            self._active_key, self._ps_active = key, None
+        return self._active
+
+    def pose_shape_dirs_active(self):
+        """(207+10, 3 * n_active): the columns of pose_shape_dirs() that belong to active_vertices()"""
+        act = self.active_vertices()
+        full = self.pose_shape_dirs()
+        if getattr(self, "_ps_active", None) is None or self._ps_active_src is not full:
+            cols = (act.long()[:, None] * 3 + torch.arange(3, device=act.device)[None, :]).flatten()
+            self._ps_active, self._ps_active_src = full[:, cols].contiguous(), full
+        return self._ps_active
+
     def pose_shape_dirs_t(self):
         """(20670, 207+10) view of pose_shape_dirs()"""
         return self.pose_shape_dirs().t()

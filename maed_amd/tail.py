@@ -14,6 +14,7 @@ Every GEMM of the two Functions -- the packed (157 x hidden) projection and its 
 pose-/shape-direction product of the LBS backward -- runs on maed_gemm_nt (exact-fp32 kernel, split-K where the output is tiny).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -128,17 +129,32 @@ class SmplTailFn(torch.autograd.Function):
                 "smpl_joints_project_bwd")
         sp = smpl._c_params()
         dA = torch.zeros(Fr, 24, 12, dtype=torch.float32, device=dev)
-        d_vposed = new(Fr, N_VERTS * 3)
-        L.check(lib.maed_smpl_skin_bwd(C.byref(sp), ops._p(A), ops._p(v_posed), ops._p(d_verts), ops._p(d_e21), ops._p(smpl.extra_vertex_ids),
-                                       ops._p(d_e9), ops._p(smpl.J_regressor_extra), ops._p(d_vposed), ops._p(dA), Fr, st), "smpl_skin_bwd")
-        # (F, 20670) x (20670, 207 + 10): tiny output, K = 20670 -> split-K with the fp32 atomic epilogue (8 output tiles x 32 K slices)
-        dpf = ops.gemm_nt(d_vposed, smpl.pose_shape_dirs(), L.EPI_ATOMIC_F32, splitk=32)
+        dpf = _smpl_vertex_backward(lib, smpl, sp, A, v_posed, d_verts, d_e21, d_e9, dA, Fr, st)
         d_rot, d_betas = new(Fr, 24, 9), new(Fr, 10)
         L.check(lib.maed_smpl_chain_bwd(C.byref(sp), ops._p(shape), ops._p(rotmat), ops._p(dA), ops._p(d_j24), ops._p(dpf), ops._p(d_rotmat),
                                         _off(d_theta, 75), 85, ops._p(d_rot), ops._p(d_betas), Fr, st), "smpl_chain_bwd")
         d_pose6d = new(Fr, 144)
         L.check(lib.maed_rot6d_pose_bwd(ops._p(pose6d), ops._p(d_rot), _off(d_theta, 3), 85, ops._p(d_pose6d), Fr * 24, st), "rot6d_pose_bwd")
         return d_pose6d, d_betas, d_cam, None
+
+
+def _smpl_vertex_backward(lib, smpl, sp, A, v_posed, d_verts, d_e21, d_e9, dA, Fr, st):
+    """vertex part of the LBS backward: dA (accumulated) and dpf (F, 207 + 10) = d_vposed [posedirs; shapedirs^T]^T.
+    With a gradient on the vertices: every vertex (maed_smpl_skin_bwd) and the (F, 20670) x (20670, 217) product -- tiny output, split-K with the fp32 atomic
+    epilogue.  Without (the training objective reads key points only): the ~290 vertices the extra joints read (maed_smpl_skin_bwd_sparse) and their ~870 columns
+    (MAED_SMPL_SPARSE_BWD=0: the dense form either way, A/B knob)."""
+    dev = A.device
+    if d_verts is None and os.environ.get("MAED_SMPL_SPARSE_BWD", "1") == "1":
+        act = smpl.active_vertices()
+        na = act.numel()
+        d_vp = torch.empty(Fr, na * 3, dtype=torch.float32, device=dev)
+        L.check(lib.maed_smpl_skin_bwd_sparse(C.byref(sp), ops._p(A), ops._p(v_posed), ops._p(act), na, ops._p(d_e21), ops._p(smpl.extra_vertex_ids),
+                                              ops._p(d_e9), ops._p(smpl.J_regressor_extra), ops._p(d_vp), ops._p(dA), Fr, st), "smpl_skin_bwd_sparse")
+        return ops.gemm_nt(d_vp, smpl.pose_shape_dirs_active(), L.EPI_ATOMIC_F32, splitk=4)
+    d_vposed = torch.empty(Fr, N_VERTS * 3, dtype=torch.float32, device=dev)
+    L.check(lib.maed_smpl_skin_bwd(C.byref(sp), ops._p(A), ops._p(v_posed), ops._p(d_verts), ops._p(d_e21), ops._p(smpl.extra_vertex_ids),
+                                   ops._p(d_e9), ops._p(smpl.J_regressor_extra), ops._p(d_vposed), ops._p(dA), Fr, st), "smpl_skin_bwd")
+    return ops.gemm_nt(d_vposed, smpl.pose_shape_dirs(), L.EPI_ATOMIC_F32, splitk=32)
 
 
 class SmplLbsFn(torch.autograd.Function):
@@ -183,10 +199,7 @@ class SmplLbsFn(torch.autograd.Function):
                                                  ops._p(d_e21), ops._p(d_e9), ops._p(d_cam), Fr, st), "smpl_joints_project_bwd")
         sp = smpl._c_params()
         dA = torch.zeros(Fr, 24, 12, dtype=torch.float32, device=dev)
-        d_vposed = new(Fr, N_VERTS * 3)
-        L.check(lib.maed_smpl_skin_bwd(C.byref(sp), ops._p(A), ops._p(v_posed), ops._p(d_verts), ops._p(d_e21), ops._p(smpl.extra_vertex_ids),
-                                       ops._p(d_e9), ops._p(smpl.J_regressor_extra), ops._p(d_vposed), ops._p(dA), Fr, st), "smpl_skin_bwd")
-        dpf = ops.gemm_nt(d_vposed, smpl.pose_shape_dirs(), L.EPI_ATOMIC_F32, splitk=32)
+        dpf = _smpl_vertex_backward(lib, smpl, sp, A, v_posed, d_verts, d_e21, d_e9, dA, Fr, st)
         d_rot, d_betas = new(Fr, 24, 9), new(Fr, 10)
         L.check(lib.maed_smpl_chain_bwd(C.byref(sp), ops._p(betas), ops._p(rotmat), ops._p(dA), ops._p(d_j24), ops._p(dpf), None, None, 0,
                                         ops._p(d_rot), ops._p(d_betas), Fr, st), "smpl_chain_bwd")

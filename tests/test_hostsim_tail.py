@@ -159,3 +159,34 @@ def test_forward_without_backward_does_not_block_the_readiness_report():
         assert ktd._pending_backwards == 1
         (pose.sum() + shape.sum() + cam.sum()).backward()
     assert fired == [ktd] and ktd._pending_backwards == 0
+
+
+def test_vertex_backward_on_the_active_vertices_only_matches_the_dense_form(monkeypatch):
+    """round 4: without a gradient on the vertices the LBS backward visits only the vertices the extra joints read (maed_smpl_skin_bwd_sparse, ~290 of 6890) and
+    contracts only their columns of [posedirs; shapedirs^T]: same parameter / input gradients as the dense kernels (MAED_SMPL_SPARSE_BWD=0), and the dense kernels
+    stay in charge when the vertices carry a gradient."""
+    ktd = make_ktd()
+    act = ktd.smpl.active_vertices()
+    assert act.dtype == torch.int32 and 21 <= act.numel() <= 9 * 30 + 21 and bool((act[1:] > act[:-1]).all())
+    assert ktd.smpl.pose_shape_dirs_active().shape == (217, 3 * act.numel())
+    assert torch.equal(ktd.smpl.pose_shape_dirs_active()[:, 3:6], ktd.smpl.pose_shape_dirs()[:, 3 * int(act[1]):3 * int(act[1]) + 3])
+    calls = []
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MAED_SMPL_SPARSE_BWD", mode)
+        x = torch.randn(3, 48, generator=torch.Generator().manual_seed(5)).requires_grad_(True)
+        for p in ktd.parameters():
+            p.grad = None
+        with patched() as lib:
+            real = lib.maed_smpl_skin_bwd_sparse
+            lib.maed_smpl_skin_bwd_sparse = lambda *a: (calls.append(mode), real(*a))[1]
+            try:
+                pose, shape, cam = ktd._head_train(x)
+                theta, verts, kp2d, kp3d, rotmat = tail.SmplTailFn.apply(pose, shape, cam, ktd.smpl)
+                ((kp2d * kp2d).sum() + kp3d.sum()).backward()
+            finally:
+                lib.maed_smpl_skin_bwd_sparse = real
+        grads[mode] = [x.grad.clone()] + [p.grad.clone() for p in ktd.parameters() if p.grad is not None]
+    assert calls == ["1"]
+    for a, b in zip(grads["1"], grads["0"]):
+        assert rel(a, b) < 1e-5, rel(a, b)
