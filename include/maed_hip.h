@@ -283,6 +283,8 @@ int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas, const floa
                       float* verts, float* joints24, float* scratch_A, float* v_posed, int F, void* stream);
 /* out[f][j][:] = sum_v Jreg[j][v] verts[f][v][:]  (J <= 32 rows; MFMA f32 32x32x2) */
 int maed_joint_regress_fwd(const float* Jreg, int J, const float* verts, float* out, int F, void* stream);
+/* ... through the regressor's non-zeros (CSR: rowptr (J+1), cols / vals (nnz), vertex ids ascending per row; J <= 64): SMPL's joint regressors are sparse */
+int maed_joint_regress_csr_fwd(const int32_t* rowptr, const int32_t* cols, const float* vals, int J, const float* verts, float* out, int F, void* stream);
 /* joints49 = gather(cat(joints24, verts[extra_vertex_ids(21)], extra9), joint_map(49 int64)) -- the
  * integer index work is bit-exact (smpl.py:98-99); kp2d = projection(joints, cam) (spin.py:113-157).
  * If joints_override (F,Jo,3) is non-NULL it replaces the 49 joints before projection (ktd.py:108-112). */

@@ -98,6 +98,7 @@ SIGNATURES = {
     "maed_rot6d_pose_fwd": (i32, [vp, vp, vp, i64, vp]),
     "maed_smpl_lbs_fwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, vp, i32, vp]),
     "maed_joint_regress_fwd": (i32, [vp, i32, vp, vp, i32, vp]),
+    "maed_joint_regress_csr_fwd": (i32, [vp, vp, vp, i32, vp, vp, i32, vp]),
     "maed_smpl_joints_project_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
     "maed_smpl_joints_project_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, vp]),
     "maed_smpl_skin_bwd": (i32, [C.POINTER(SmplParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),

@@ -148,14 +148,13 @@ __global__ __launch_bounds__(64) void lbs_chain_par_kernel(maed_smpl_params sp, 
 }
 
 // kernel B: thread per vertex, LBS_FB frames per workgroup so posedirs (17 MB) is streamed once per LBS_FB frames
-// (measured at 128 frames, scripts/lbs_micro.py: 1 / 2 / 4 / 8 frames per workgroup = 319 / 279 / 164 / 194 us)
-#ifndef LBS_FB
-#define LBS_FB 4
-#endif
+// (measured at 128 frames, scripts/lbs_micro.py: 1 / 2 / 4 / 8 frames per workgroup = 319 / 279 / 164 / 194 us with the pose feature as [frame][k])
+template <int LBS_FB>
 __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
                                                        const float* __restrict__ A, float* __restrict__ verts,
                                                        float* __restrict__ v_posed, int F) {
-    __shared__ float s_pf[LBS_FB][208];
+    // pose feature as [k][frame]: the LBS_FB weights of one k are ONE 16- / 32-byte LDS read (broadcast) instead of LBS_FB four-byte ones
+    __shared__ __attribute__((aligned(16))) float s_pf[208][LBS_FB];
     __shared__ float s_A[LBS_FB][NJ * 12];
     __shared__ float s_b[LBS_FB][10];
     const int f0 = blockIdx.y * LBS_FB;
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, cons
         const int fb = i / 207, k = i % 207;
         const int f = min(f0 + fb, F - 1);
         const int j = 1 + k / 9, rc = k % 9;
-        s_pf[fb][k] = rotmat[((int64_t)f * NJ + j) * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.f : 0.f);
+        s_pf[k][fb] = rotmat[((int64_t)f * NJ + j) * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.f : 0.f);
     }
     for (int i = threadIdx.x; i < LBS_FB * NJ * 12; i += 256) {
         const int fb = i / (NJ * 12), k = i % (NJ * 12);
@@ -188,12 +187,19 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, cons
     float po[LBS_FB][3];
 #pragma unroll
     for (int fb = 0; fb < LBS_FB; ++fb) { po[fb][0] = 0.f; po[fb][1] = 0.f; po[fb][2] = 0.f; }
+    // (`#pragma unroll 9` here -- nine rows of posedirs in flight per lane -- measured 285 us at 4 frames per workgroup against 157 rolled)
     for (int k = 0; k < 207; ++k) {
         const float* pd = sp.posedirs + (int64_t)k * (NV * 3) + v * 3;
         const float p0 = pd[0], p1 = pd[1], p2 = pd[2];
+        float wk[LBS_FB];
+#pragma unroll
+        for (int q = 0; q < LBS_FB / 4; ++q) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&s_pf[k][4 * q]);
+            wk[4 * q] = w4.x; wk[4 * q + 1] = w4.y; wk[4 * q + 2] = w4.z; wk[4 * q + 3] = w4.w;
+        }
 #pragma unroll
         for (int fb = 0; fb < LBS_FB; ++fb) {
-            const float w = s_pf[fb][k];
+            const float w = wk[fb];
             po[fb][0] = fmaf(w, p0, po[fb][0]); po[fb][1] = fmaf(w, p1, po[fb][1]); po[fb][2] = fmaf(w, p2, po[fb][2]);
         }
     }
@@ -226,7 +232,10 @@ extern "C" int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas,
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lbs_chain_par_kernel, dim3((F + LC_FPB - 1) / LC_FPB), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
-    hipLaunchKernelGGL(lbs_skin_kernel, dim3((NV + 255) / 256, (F + LBS_FB - 1) / LBS_FB), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
+    static const int fb = getenv("MAED_LBS_FB") ? atoi(getenv("MAED_LBS_FB")) : 16;     // frames per workgroup (sweep knob: 4 / 8 / 16 = 157 / 183 / 138 us per forward at 128 frames)
+    if (fb == 8) hipLaunchKernelGGL(lbs_skin_kernel<8>, dim3((NV + 255) / 256, (F + 7) / 8), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
+    else if (fb == 4 || F <= 32) hipLaunchKernelGGL(lbs_skin_kernel<4>, dim3((NV + 255) / 256, (F + 3) / 4), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
+    else hipLaunchKernelGGL(lbs_skin_kernel<16>, dim3((NV + 255) / 256, (F + 15) / 16), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
     MAED_CHECK_LAUNCH("smpl_lbs_fwd");
     return MAED_OK;
 }
@@ -272,6 +281,29 @@ __global__ __launch_bounds__(64) void joint_regress_kernel(const float* __restri
             if (j < J) atomicAdd(out + ((int64_t)(f0 + fl) * J + j) * 3 + c, acc[r]);
         }
     }
+}
+
+// The same regression through the regressor's NON-ZEROS: SMPL's joint regressors are sparse (J_regressor_extra: 9 rows, a few dozen vertices each -- the dense
+// product above spends 67 us per step on 6890 columns of which ~270 are non-zero).  CSR built once per regressor by the host (SMPL.regressor_csr); thread per
+// (frame, joint, coordinate), the row's non-zeros in ascending vertex order (the dense fma chain without its zero terms).
+__global__ __launch_bounds__(256) void joint_regress_csr_kernel(const int* __restrict__ rowptr, const int* __restrict__ cols, const float* __restrict__ vals, int J,
+                                                                const float* __restrict__ verts, float* __restrict__ out, int F) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F * J * 3) return;
+    const int c = i % 3, j = (i / 3) % J, f = i / (3 * J);
+    const float* v = verts + (int64_t)f * NV * 3 + c;
+    float s = 0.f;
+    for (int k = rowptr[j]; k < rowptr[j + 1]; ++k) s = fmaf(vals[k], v[cols[k] * 3], s);
+    out[i] = s;
+}
+
+extern "C" int maed_joint_regress_csr_fwd(const int32_t* rowptr, const int32_t* cols, const float* vals, int J, const float* verts, float* out, int F, void* stream) {
+    MAED_CHECK_ARG(rowptr && cols && vals && verts && out, MAED_ERR_ARG, "joint_regress_csr_fwd: null pointer");
+    MAED_CHECK_ARG(J > 0 && J <= 64, MAED_ERR_SHAPE, "joint_regress_csr_fwd: J=%d must be in 1..64", J);
+    if (F <= 0) return MAED_OK;
+    hipLaunchKernelGGL(joint_regress_csr_kernel, dim3((F * J * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const int*)rowptr, (const int*)cols, vals, J, verts, out, F);
+    MAED_CHECK_LAUNCH("joint_regress_csr_fwd");
+    return MAED_OK;
 }
 
 extern "C" int maed_joint_regress_fwd(const float* Jreg, int J, const float* verts, float* out, int F, void* stream) {

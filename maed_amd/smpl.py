@@ -229,9 +229,33 @@ class SMPL(nn.Module):
                                             ops._p(j24), ops._p(A), None, Fr, ops._stream()), 'smpl_lbs_fwd')
         return verts, j24
 
+    def regressor_csr(self, Jreg):
+        """(rowptr, cols, vals) int32 / int32 / fp32 device tensors of a (J, 6890) joint regressor, or None when it is not sparse enough to bother (> 10 % non-zero)
+        or has more than 64 rows.  Built once per regressor state (one host sync), cached by storage pointer / version."""
+        cache = self.__dict__.setdefault("_csr_cache", {})
+        key = (Jreg.data_ptr(), Jreg._version, tuple(Jreg.shape), str(Jreg.device))
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            with torch.no_grad():
+                nz = Jreg != 0
+                if Jreg.dim() != 2 or Jreg.shape[0] > 64 or Jreg.shape[1] != N_VERTS or float(nz.float().mean()) > 0.10 or os.environ.get("MAED_JREG_CSR", "1") == "0":
+                    cache[key] = None
+                else:
+                    idx = torch.nonzero(nz)                  # row-major: ascending vertex id inside a row
+                    counts = torch.bincount(idx[:, 0], minlength=Jreg.shape[0])
+                    rowptr = torch.zeros(Jreg.shape[0] + 1, dtype=torch.int32, device=Jreg.device)
+                    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+                    cache[key] = (rowptr, idx[:, 1].to(torch.int32).contiguous(), Jreg[nz].float().contiguous())
+        return cache[key]
+
     def joint_regress_hip(self, Jreg, verts):
         Fr, J = verts.shape[0], Jreg.shape[0]
         out = torch.empty(Fr, J, 3, dtype=torch.float32, device=verts.device)
+        csr = self.regressor_csr(Jreg)
+        if csr is not None:
+            ops.check(L.lib().maed_joint_regress_csr_fwd(ops._p(csr[0]), ops._p(csr[1]), ops._p(csr[2]), J, ops._p(verts), ops._p(out), Fr, ops._stream()), 'joint_regress_csr_fwd')
+            return out
         ops.check(L.lib().maed_joint_regress_fwd(ops._p(Jreg.contiguous()), J, ops._p(verts), ops._p(out), Fr, ops._stream()), 'joint_regress_fwd')
         return out
 

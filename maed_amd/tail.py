@@ -102,8 +102,7 @@ class SmplTailFn(torch.autograd.Function):
         sp = smpl._c_params()
         L.check(lib.maed_smpl_lbs_fwd(C.byref(sp), ops._p(shape), ops._p(rotmat), ops._p(verts), ops._p(j24), ops._p(A), ops._p(v_posed), Fr,
                                       ops._stream()), "smpl_lbs_fwd")
-        extra9 = new(Fr, 9, 3)
-        L.check(lib.maed_joint_regress_fwd(ops._p(smpl.J_regressor_extra), 9, ops._p(verts), ops._p(extra9), Fr, ops._stream()), "joint_regress_fwd")
+        extra9 = smpl.joint_regress_hip(smpl.J_regressor_extra, verts)
         kp3d, kp2d = new(Fr, 49, 3), new(Fr, 49, 2)
         L.check(lib.maed_smpl_joints_project_fwd(ops._p(j24), ops._p(verts), ops._p(smpl.extra_vertex_ids), ops._p(extra9), ops._p(smpl.joint_map),
                                                  ops._p(cam), None, 0, ops._p(kp3d), ops._p(kp2d), Fr, ops._stream()), "smpl_joints_project_fwd")
@@ -172,8 +171,7 @@ class SmplLbsFn(torch.autograd.Function):
         sp = smpl._c_params()
         L.check(lib.maed_smpl_lbs_fwd(C.byref(sp), ops._p(betas), ops._p(rotmat), ops._p(verts), ops._p(j24), ops._p(A), ops._p(v_posed), Fr,
                                       ops._stream()), "smpl_lbs_fwd")
-        extra9 = new(Fr, 9, 3)
-        L.check(lib.maed_joint_regress_fwd(ops._p(smpl.J_regressor_extra), 9, ops._p(verts), ops._p(extra9), Fr, ops._stream()), "joint_regress_fwd")
+        extra9 = smpl.joint_regress_hip(smpl.J_regressor_extra, verts)
         cam = torch.zeros(Fr, 3, dtype=torch.float32, device=dev)
         cam[:, 0] = 1.0
         joints, kp2d = new(Fr, 49, 3), new(Fr, 49, 2)

@@ -354,6 +354,11 @@ def test_smpl_lbs_and_joint_gather_bit_exact():
     report("joint_regress[J=9, f32 MFMA]", extra, torch.einsum("bik,ji->bjk", verts.cpu().double(), sp["J_regressor_extra"].double()), rtol=1e-4, atol=1e-5)
     h36m = smpl.joint_regress_hip(sp["J_regressor_h36m"].to(DEV), verts)
     report("joint_regress[J=17, f32 MFMA]", h36m, torch.einsum("bik,ji->bjk", verts.cpu().double(), sp["J_regressor_h36m"].double()), rtol=1e-4, atol=1e-5)
+    # (both regressors are sparse: the calls above took the CSR kernel; the dense f32-MFMA kernel on a regressor that is not)
+    assert smpl.regressor_csr(smpl.J_regressor_extra) is not None
+    dense = (torch.rand(9, 6890, generator=torch.Generator().manual_seed(3)) / 6890).to(DEV)
+    assert smpl.regressor_csr(dense) is None
+    report("joint_regress[J=9, dense, f32 MFMA]", smpl.joint_regress_hip(dense, verts), torch.einsum("bik,ji->bjk", verts.cpu().double(), dense.cpu().double()), rtol=1e-4, atol=1e-5)
     cam = torch.tensor([[0.9, 0.1, -0.2]]).repeat(Fr, 1).to(DEV)
     kp3d = torch.empty(Fr, 49, 3, device=DEV)
     kp2d = torch.empty(Fr, 49, 2, device=DEV)

@@ -190,3 +190,24 @@ def test_vertex_backward_on_the_active_vertices_only_matches_the_dense_form(monk
     assert calls == ["1"]
     for a, b in zip(grads["1"], grads["0"]):
         assert rel(a, b) < 1e-5, rel(a, b)
+
+
+def test_joint_regression_through_the_regressors_nonzeros():
+    """round 4: maed_joint_regress_csr_fwd -- SMPL's joint regressors are sparse (9 x 30 / 17 x 50 of 6890 columns in the stand-in, like the real ones): CSR built
+    once per regressor state, the dense f32-MFMA kernel kept for regressors that are not sparse; both against the einsum"""
+    from maed_amd.smpl import SMPL, synthetic_smpl_arrays
+    arrays = synthetic_smpl_arrays(0)
+    smpl = SMPL(arrays)
+    verts = torch.randn(3, 6890, 3, generator=torch.Generator().manual_seed(1))
+    with patched() as lib:
+        csr = smpl.regressor_csr(smpl.J_regressor_extra)
+        assert csr is not None and csr[0].tolist()[0] == 0 and csr[0].tolist()[-1] == csr[1].numel() == csr[2].numel() == int((smpl.J_regressor_extra != 0).sum())
+        assert smpl.regressor_csr(smpl.J_regressor_extra) is csr, "cached"
+        got = smpl.joint_regress_hip(smpl.J_regressor_extra, verts)
+        h36 = smpl.joint_regress_hip(arrays["J_regressor_h36m"], verts)
+        dense = torch.rand(5, 6890, generator=torch.Generator().manual_seed(2)) / 6890
+        assert smpl.regressor_csr(dense) is None
+        gd = smpl.joint_regress_hip(dense, verts)
+    for g, R in ((got, smpl.J_regressor_extra), (h36, arrays["J_regressor_h36m"]), (gd, dense)):
+        want = torch.einsum("bik,ji->bjk", verts.double(), R.double())
+        assert float((g.double() - want).abs().max()) < 1e-5
