@@ -96,6 +96,10 @@ typedef enum {
     MAED_OPT_F32_BWD_X1 = 5,    /* 1: the fused STE block's BACKWARD matrix products on fp32 tensors use one bf16 plane (MAED_F32X1) whatever the forward engine is;
                                  * 0 (default): the process-wide engine.  The host sets it together with its own per-call dtype codes (ops.set_float32_backward_precision) */
     MAED_OPT_ST_FUSED = 6,      /* 1 (default): the fused STE block runs the attentive addition as ONE launch per direction (maed_st_fused_fwd/bwd) where supported */
+    MAED_OPT_CONV3X3_ROWS_WGS = 7, /* row-item 3x3 weight gradient at 64 -> 64 channels (maed_conv3x3_wgrad_rows64): workgroups per launch (default 256); 0: the shape
+                                   * goes to the general TN kernel instead (A/B knob) */
+    MAED_OPT_STEM_WGRAD_WGS = 8,   /* workgroups of maed_stem7x7s2_wgrad (default 512) */
+    MAED_OPT_LBS_FRAMES = 9,       /* frames per workgroup of the LBS skinning kernel: 0 (default) = 16 for more than 32 frames, else 4; or 4 / 8 / 16 */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's

@@ -18,7 +18,8 @@ IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
 IMPL_X3, IMPL_X6, IMPL_X1 = 7, 8, 9  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
-OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS, OPT_F32_BWD_X1, OPT_ST_FUSED = range(7)   # maed_option (include/maed_hip.h)
+(OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS, OPT_F32_BWD_X1, OPT_ST_FUSED, OPT_CONV3X3_ROWS_WGS, OPT_STEM_WGRAD_WGS,
+ OPT_LBS_FRAMES) = range(10)   # maed_option (include/maed_hip.h)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -189,6 +190,10 @@ _OPTIONS = {
     OPT_F32_BWD_X1: int(os.environ.get("MAED_F32_BWD", "") == "bf16x1"),
     OPT_ST_FUSED: int(os.environ.get("MAED_ST_FUSED", "1")),              # A/B knob: 0 = the attentive addition as four launches per direction
     OPT_GN_BWD_ONEPASS: int(os.environ.get("MAED_GN_BWD_ONEPASS", "1")),      # A/B knob: 0 = the two-pass GroupNorm backward (2: 256-thread variant of the one-pass kernel)
+    # row-item 3x3 weight gradient (64 -> 64 channels): MAED_CONV3X3_WGRAD_ROWS=0 sends the shape to the general TN kernel; ..._ROWS_WGS: workgroups per launch
+    OPT_CONV3X3_ROWS_WGS: 0 if os.environ.get("MAED_CONV3X3_WGRAD_ROWS", "1") == "0" else int(os.environ.get("MAED_CONV3X3_ROWS_WGS", "256")),
+    OPT_STEM_WGRAD_WGS: int(os.environ.get("MAED_STEM_WGS", "512")),
+    OPT_LBS_FRAMES: int(os.environ.get("MAED_LBS_FB", "0")),
 }
 
 

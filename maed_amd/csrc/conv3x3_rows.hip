@@ -112,8 +112,7 @@ __global__ __launch_bounds__(256) void wgrad_slots_reduce_kernel(const float* __
 }
 
 bool maed_conv3x3_wgrad_rows64_ok(int F, int H, int W, int Cin, int Cout) {
-    static const bool on = !(getenv("MAED_CONV3X3_WGRAD_ROWS") && atoi(getenv("MAED_CONV3X3_WGRAD_ROWS")) == 0);      // (A/B knob: 0 = the general TN kernel)
-    return on && Cin == 64 && Cout == 64 && W % 8 == 0 && W >= 8 && W <= 64 && H >= 1 && (int64_t)F * H * W * 128 < (1ll << 31);
+    return maed_opt(MAED_OPT_CONV3X3_ROWS_WGS) > 0 && Cin == 64 && Cout == 64 && W % 8 == 0 && W >= 8 && W <= 64 && H >= 1 && (int64_t)F * H * W * 128 < (1ll << 31);
 }
 
 void maed_wgrad_slots_reduce(const float* partial, float* dW, int n_slots, int n_elems, hipStream_t stream) {
@@ -122,8 +121,7 @@ void maed_wgrad_slots_reduce(const float* partial, float* dW, int n_slots, int n
 
 // workgroups (= partial-sum slots) of a launch over n_rows image rows
 static int rows64_wgs(int n_rows, int* per_out) {
-    int wgs = 256;                                   // one per CU: every workgroup ends with a 147 KB partial result
-    if (const char* ev = getenv("MAED_CONV3X3_ROWS_WGS")) { const int v = atoi(ev); if (v > 0) wgs = v; }      // (sweep knob)
+    int wgs = maed_opt(MAED_OPT_CONV3X3_ROWS_WGS);   // default 256, one per CU: every workgroup ends with a 147 KB partial result
     if (wgs > n_rows) wgs = n_rows;
     const int per = (n_rows + wgs - 1) / wgs;
     *per_out = per;

@@ -14,6 +14,9 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {1},      // MAED_OPT_GN_BWD_ONEPASS
     {0},      // MAED_OPT_F32_BWD_X1
     {1},      // MAED_OPT_ST_FUSED
+    {256},    // MAED_OPT_CONV3X3_ROWS_WGS
+    {512},    // MAED_OPT_STEM_WGRAD_WGS
+    {0},      // MAED_OPT_LBS_FRAMES: auto
 };
 
 extern "C" int maed_init(int device) {
@@ -34,6 +37,8 @@ extern "C" int maed_set_option(int key, int value) {
     MAED_CHECK_ARG(key >= 0 && key < MAED_OPT_COUNT, MAED_ERR_ARG, "set_option: unknown option %d", key);
     if (key == MAED_OPT_F32_MATMUL) MAED_CHECK_ARG(value >= 0 && value <= 2, MAED_ERR_ARG, "set_option: MAED_OPT_F32_MATMUL takes 0 (exact), 1 (bf16x3) or 2 (bf16x6)");
     if (key == MAED_OPT_TN_TARGET_WGS) MAED_CHECK_ARG(value == 0 || value >= 64, MAED_ERR_ARG, "set_option: MAED_OPT_TN_TARGET_WGS must be 0 (heuristic) or >= 64");
+    if (key == MAED_OPT_CONV3X3_ROWS_WGS || key == MAED_OPT_STEM_WGRAD_WGS) MAED_CHECK_ARG(value >= 0 && value <= 65535, MAED_ERR_ARG, "set_option: workgroup count out of range");
+    if (key == MAED_OPT_LBS_FRAMES) MAED_CHECK_ARG(value == 0 || value == 4 || value == 8 || value == 16, MAED_ERR_ARG, "set_option: MAED_OPT_LBS_FRAMES takes 0 (auto), 4, 8 or 16");
     g_opt[key].store(value, std::memory_order_relaxed);
     return MAED_OK;
 }

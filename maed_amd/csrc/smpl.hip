@@ -232,7 +232,7 @@ extern "C" int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas,
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lbs_chain_par_kernel, dim3((F + LC_FPB - 1) / LC_FPB), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
-    const int fb = getenv("MAED_LBS_FB") ? atoi(getenv("MAED_LBS_FB")) : (F > 32 ? 16 : 4);     // frames per workgroup (knob: 4 / 8 / 16 = 157 / 183 / 138 us per forward at 128 frames)
+    const int fb = maed_opt(MAED_OPT_LBS_FRAMES) ? maed_opt(MAED_OPT_LBS_FRAMES) : (F > 32 ? 16 : 4);     // frames per workgroup (4 / 8 / 16 = 157 / 183 / 138 us per forward at 128 frames)
     if (fb == 8) hipLaunchKernelGGL(lbs_skin_kernel<8>, dim3((NV + 255) / 256, (F + 7) / 8), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
     else if (fb == 4) hipLaunchKernelGGL(lbs_skin_kernel<4>, dim3((NV + 255) / 256, (F + 3) / 4), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
     else hipLaunchKernelGGL(lbs_skin_kernel<16>, dim3((NV + 255) / 256, (F + 15) / 16), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);

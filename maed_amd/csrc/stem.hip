@@ -220,8 +220,8 @@ __global__ __launch_bounds__(STEM_WG_THREADS, 2) void stem7x7s2_wgrad_kernel(con
 void maed_wgrad_slots_reduce(const float* partial, float* dW, int n_slots, int n_elems, hipStream_t stream);      // conv3x3_rows.hip
 
 static int stem_wgrad_wgs(int n_items, int* per_out) {
-    int wgs = 512;                                        // two workgroups per CU, each a contiguous range of output rows
-    if (const char* ev = getenv("MAED_STEM_WGS")) { const int v = atoi(ev); if (v > 0) wgs = v; }       // (sweep knob; the tests use it to force multi-row walks)
+    int wgs = maed_opt(MAED_OPT_STEM_WGRAD_WGS);          // default 512: two workgroups per CU, each a contiguous range of output rows (the tests lower it to force multi-row walks)
+    if (wgs < 1) wgs = 1;
     if (wgs > n_items) wgs = n_items;
     const int per = (n_items + wgs - 1) / wgs;
     *per_out = per;

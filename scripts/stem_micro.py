@@ -54,11 +54,11 @@ t = timeit(lambda: F.conv2d(xv, w, None, 2, 0))
 print(f"vendor fwd (F.conv2d on the padded 3-channel image): {t:7.1f} us")
 yv = F.conv2d(xv, w, None, 2, 0)
 for wgs, use_sc in ((256, 1), (384, 1), (512, 1), (512, 0), (768, 1), (1024, 1)):
-    os.environ["MAED_STEM_WGS"] = str(wgs)
+    L.set_option(L.OPT_STEM_WGRAD_WGS, wgs)
     sc = torch.empty(lib.maed_stem7x7s2_wgrad_scratch_floats(N, H, W), device=dev) if use_sc else None
     t = timeit(lambda: ops.check(lib.maed_stem7x7s2_wgrad(dy.data_ptr(), xp.data_ptr(), dw.data_ptr(), sc.data_ptr() if sc is not None else None, N, H, W, L.BF16, torch.cuda.current_stream().cuda_stream), "wgrad"))
     print(f"own wgrad {wgs:5d} workgroups, {'partial slots + reduce' if use_sc else 'atomics'}: {t:7.1f} us")
-os.environ.pop("MAED_STEM_WGS")
+L.set_option(L.OPT_STEM_WGRAD_WGS, 512)
 sc = torch.empty(lib.maed_stem7x7s2_wgrad_scratch_floats(N, H, W), device=dev)
 t = timeit(lambda: torch.ops.aten.convolution_backward(dy, xv, w, None, (2, 2), (0, 0), (1, 1), False, (0, 0), 1, (False, True, False)))
 print(f"vendor wgrad (aten.convolution_backward, weight only):  {t:7.1f} us")

@@ -39,3 +39,14 @@ def patched(module_paths=True):
         yield L._lib
     finally:
         L._lib, ops._p, ops._stream, ops.SIM_MODULE_PATHS = saved
+
+
+@contextlib.contextmanager
+def option(lib, key, value):
+    """one library option (maed_set_option) for the duration of a block; the simulator handle is shared between tests, so the old value is put back"""
+    old = lib.maed_get_option(key)
+    assert lib.maed_set_option(key, value) == 0, lib.maed_last_error()
+    try:
+        yield
+    finally:
+        lib.maed_set_option(key, old)

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from maed_amd import _lib as L
 from maed_amd import ops
 
-from _hostsim import patched
+from _hostsim import option, patched
 
 
 def cl(t):
@@ -430,13 +430,11 @@ def test_stem7x7s2_forward_from_padded_4slot_image(N, H, W, stats):
 
 
 @pytest.mark.parametrize("N,H,W,wgs,slots", [(2, 32, 32, None, True), (1, 32, 64, None, False), (3, 48, 96, 5, True), (2, 32, 32, 3, False), (2, 32, 32, 3, True)])
-def test_stem7x7s2_weight_gradient_by_lds_dma_and_transposing_reads(N, H, W, wgs, slots, monkeypatch):
+def test_stem7x7s2_weight_gradient_by_lds_dma_and_transposing_reads(N, H, W, wgs, slots):
     """round 4: maed_stem7x7s2_wgrad -- one output row of dy and its seven input rows per work item, copied into LDS unchanged (LDS-DMA, swizzled dy chunks) and
     contracted over pixels through ds_read_b64_tr_b16 fragments; accumulates into the given fp32 slice.  One row per workgroup by default at these sizes; with
-    MAED_STEM_WGS = 5 / 3 the double-buffered walk over 15 (14 for the last workgroup... 72 = 4 * 15 + 12) resp. 11 / 11 / 10 rows.  slots: per-workgroup partial
+    MAED_OPT_STEM_WGRAD_WGS = 5 / 3 the double-buffered walk over 15 (14 for the last workgroup... 72 = 4 * 15 + 12) resp. 11 / 11 / 10 rows.  slots: per-workgroup partial
     results in scratch + the reduction pass (the product path) / atomics straight into the slice."""
-    if wgs:
-        monkeypatch.setenv("MAED_STEM_WGS", str(wgs))
     torch.manual_seed(12)
     x = torch.randn(N, 3, H, W)
     w = (torch.randn(64, 3, 7, 7) * 147 ** -0.5).bfloat16()
@@ -444,7 +442,7 @@ def test_stem7x7s2_weight_gradient_by_lds_dma_and_transposing_reads(N, H, W, wgs
     _, gw = _stem_reference(x.bfloat16(), w, dy)
     dW0 = torch.randn(64, 147)
     dW = dW0.clone()
-    with patched() as lib:
+    with patched() as lib, option(lib, L.OPT_STEM_WGRAD_WGS, wgs or 512):
         xp = ops.stem_input(x, torch.bfloat16, 7, 2, own=True)
         dyc = cl(dy)
         sc = torch.full((lib.maed_stem7x7s2_wgrad_scratch_floats(N, H, W),), float("nan")) if slots else None
@@ -475,13 +473,11 @@ def test_stem7x7s2_autograd_node_fills_the_fp32_slice_and_rejects_other_geometri
 
 
 @pytest.mark.parametrize("N,H,W,wgs", [(2, 5, 8, None), (1, 3, 16, None), (3, 4, 24, 2), (2, 6, 56, 5), (1, 2, 64, 1)])
-def test_conv3x3_weight_gradient_row_items_64_channels(N, H, W, wgs, monkeypatch):
+def test_conv3x3_weight_gradient_row_items_64_channels(N, H, W, wgs):
     """round 4: the 64 -> 64 channel weight gradient one image row at a time (conv3x3_rows.hip, taken by maed_conv3x3_wgrad for the stage-1 shape): rows in a
     ring of four LDS slots framed by zero pixels, wave = tap, transposing reads.  Image heights / widths that exercise the borders (H = 2, 3), k-steps with a zero
-    tail (W = 8, 24, 56), the full 64-pixel row, workgroups that walk rows across frame boundaries (MAED_CONV3X3_ROWS_WGS), and accumulation into a non-zero
-    slice; against autograd through F.conv2d.  MAED_CONV3X3_WGRAD_ROWS=0 (the general TN kernel) gives the same numbers where it applies."""
-    if wgs:
-        monkeypatch.setenv("MAED_CONV3X3_ROWS_WGS", str(wgs))
+    tail (W = 8, 24, 56), the full 64-pixel row, workgroups that walk rows across frame boundaries (MAED_OPT_CONV3X3_ROWS_WGS), and accumulation into a non-zero
+    slice; against autograd through F.conv2d.  MAED_OPT_CONV3X3_ROWS_WGS = 0 (the general TN kernel) gives the same numbers where it applies."""
     torch.manual_seed(21)
     x = torch.randn(N, 64, H, W).bfloat16()
     dy = torch.randn(N, 64, H, W).bfloat16()
@@ -489,7 +485,7 @@ def test_conv3x3_weight_gradient_row_items_64_channels(N, H, W, wgs, monkeypatch
     F.conv2d(x.double(), wr, padding=1).backward(dy.double())
     dW0 = torch.randn(64, 3, 3, 64)
     dW = dW0.clone()
-    with patched():
+    with patched() as lib, option(lib, L.OPT_CONV3X3_ROWS_WGS, wgs or 256):
         ops.conv3x3_wgrad(cl(dy), cl(x), out=dW)
     got = (dW - dW0).permute(0, 3, 1, 2).double()
     assert (got - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max(), ((got - wr.grad).abs().max() / wr.grad.abs().max())

@@ -13,7 +13,8 @@ from maed_amd import tail
 from maed_amd.geometry import rot6d_to_rotmat
 from maed_amd.ktd import KTD
 
-from _hostsim import patched
+from _hostsim import option, patched
+from maed_amd import _lib as L
 
 
 def make_ktd(seed=0, feat=48, hidden=32):
@@ -54,12 +55,12 @@ _SLOW = pytest.mark.skipif(os.environ.get("MAED_SLOW_TESTS") != "1", reason="28 
 
 @pytest.mark.parametrize("out_keys", [("theta", "verts", "kp_2d", "kp_3d", "rotmat"), pytest.param(("kp_2d", "kp_3d", "theta"), marks=_SLOW), ("kp_2d",),
                                       pytest.param(("rotmat",), marks=_SLOW)])
-def test_tail_forward_backward_vs_aten(out_keys, monkeypatch):
-    if out_keys == ("kp_2d",):
-        monkeypatch.setenv("MAED_LBS_FB", "16")        # the skinning kernel's 16-frames-per-workgroup instance (what 128-frame clips take), here with a ragged frame group
+def test_tail_forward_backward_vs_aten(out_keys):
     ktd = make_ktd()
     x = torch.randn(3, 48, requires_grad=True)
-    out_ref, gref, out, gsim = run_both(ktd, x, out_keys)
+    # ("kp_2d",): the skinning kernel's 16-frames-per-workgroup instance (what 128-frame clips take), here with a ragged frame group
+    with patched() as lib, option(lib, L.OPT_LBS_FRAMES, 16 if out_keys == ("kp_2d",) else 0):
+        out_ref, gref, out, gsim = run_both(ktd, x, out_keys)
     for k in out_ref:
         assert rel(out[k].detach(), out_ref[k].detach()) < 5e-6, k
     names = ["x"] + [n for n, _ in ktd.named_parameters()]
