@@ -628,6 +628,7 @@ extern "C" int maed_attn_spatial_bwd(const void* qkv, const void* o, const void*
     // the tiled two-pass backward is the default for every length since its round-2 rework (delta from staged chunks, transposing LDS reads, trimmed
     // score arithmetic): P = 197 108.5 vs 147.7 us for the whole-head kernels, P = 257 (third row tile holds ONE row) 252.6 vs 314.1 us
     // (profiles/r02_attn_long_micro_v2.txt); the whole-head kernels stay reachable with impl = MAED_IMPL_MFMA
+    // (round 4: a one-kernel backward per (frame, head) for P <= 224 measured 120 us against 106 for the tiled kernels: profiles/r04_attn_bwd_fused_rejected.txt)
     if (dtype == MAED_BF16 && impl != MAED_IMPL_VALU &&
         (impl == MAED_IMPL_MFMA_LONG || impl == MAED_IMPL_AUTO ||
          (!mfma_fits && (impl == MAED_IMPL_MFMA || valu_lds_bytes(P, true) > 160 * 1024))))
