@@ -151,17 +151,14 @@ __global__ __launch_bounds__(256, 4) void attn_long_fwd_mfma(const bf16* __restr
         }
     }
     l += __shfl_xor(l, 32, 64);
-    if (active && q < L) {
+    __syncthreads();                                // the K / V tiles are retired: their LDS carries the waves' output patches (full-line stores, attn_mfma.cuh)
+    if (active) {
         const float inv = 1.f / l;
-        bf16* orow = o + ((int64_t)f * L + q) * C + h * D;
 #pragma unroll
-        for (int et = 0; et < 2; ++et)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint2 w = make_uint2(pack_bf2(oacc[et][4 * g] * inv, oacc[et][4 * g + 1] * inv),
-                                           pack_bf2(oacc[et][4 * g + 2] * inv, oacc[et][4 * g + 3] * inv));
-                *reinterpret_cast<uint2*>(orow + et * 32 + 8 * g + 4 * hi) = w;
-            }
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= inv; oacc[1][r] *= inv; }
+        store_tile_lines((wave < 2 ? Ks : Vs) + (wave & 1) * 2048, o + ((int64_t)f * L + q0) * C + h * D, C, L - q0, oacc, lane, 0);
+    }
+    if (active && q < L) {
         if (hi == 0) lse[((int64_t)f * H + h) * L + q] = (m + log2f(l)) * 0.69314718055994530942f;
     }
 }
@@ -245,7 +242,8 @@ __global__ __launch_bounds__(256, 3) void attn_long_bwd_dq_mfma(const bf16* __re
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
-    if (active && q < L) store_rowT(dqkv + ((int64_t)f * L + q) * ld + h * D, dq, hi, accumulate);
+    __syncthreads();                                // (as in the forward: result tiles leave through the retired tile buffers)
+    if (active) store_tile_lines((wave < 2 ? Ks : Vs) + (wave & 1) * 2048, dqkv + ((int64_t)f * L + q0) * ld + h * D, ld, L - q0, dq, lane, accumulate);
 }
 
 __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __restrict__ qkv, const bf16* __restrict__ o, const bf16* __restrict__ d_o,
@@ -357,10 +355,12 @@ __global__ __launch_bounds__(256, 2) void attn_long_bwd_dkv_mfma(const bf16* __r
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] *= scale; dk[1][r] *= scale; }
-    if (active && k < L) {
-        bf16* drow = dqkv + ((int64_t)f * L + k) * ld + h * D;
-        store_rowT(drow + C, dk, hi, accumulate);
-        store_rowT(drow + 2 * C, dv, hi, accumulate);
+    __syncthreads();
+    if (active) {
+        unsigned short* patch = (wave < 2 ? Qs : dOs) + (wave & 1) * 2048;
+        bf16* drow0 = dqkv + ((int64_t)f * L + k0w) * ld + h * D;
+        store_tile_lines(patch, drow0 + C, ld, L - k0w, dk, lane, accumulate);
+        store_tile_lines(patch, drow0 + 2 * C, ld, L - k0w, dv, lane, accumulate);
     }
 }
 

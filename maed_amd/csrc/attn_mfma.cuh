@@ -42,3 +42,43 @@ __device__ __forceinline__ void store_rowT(bf16* row, const f32x16_t (&acc)[2], 
         }
 }
 
+
+// The same result tile (32 rows of this wave x 64 head channels, acc in the D layout above) written as FULL 128-byte lines: through a 4 KB LDS patch of the wave
+// (16-byte chunk c of row r at slot c ^ (r & 7): conflict-free ds_write_b64 / ds_read_b128), then four 16-byte stores per lane, eight lanes per row.  store_rowT
+// writes 8-byte pieces, 32 different lines per instruction -- partial-line writes are what bounded the stem's first forward (26 of 91 us) and cost the one-kernel
+// attention backward experiment 20 of 119 us.
+// The patch must not be in use by anybody else (callers put a block barrier behind the last tile); the wave's LDS operations execute in order.
+// row_ptr(r): element 0 of the destination of tile row r (0 .. 31), or nullptr for a row that is not written.
+template <typename RowPtr>
+__device__ __forceinline__ void store_tile_lines_at(unsigned short* patch, RowPtr row_ptr, const f32x16_t (&acc)[2], int lane, int accumulate) {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint2*>(patch + l31 * 64 + (((4 * et + g) ^ (l31 & 7)) << 3) + 4 * hi) =
+                make_uint2(pack_bf2(acc[et][4 * g], acc[et][4 * g + 1]), pack_bf2(acc[et][4 * g + 2], acc[et][4 * g + 3]));
+    MAED_WAVE_LDS_SYNC();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = r * 64 + lane, row = n >> 3, c = n & 7;
+        bf16* const rp = row_ptr(row);
+        if (rp) {
+            bf16* dst = rp + c * 8;
+            uint4 v = *reinterpret_cast<const uint4*>(patch + row * 64 + ((c ^ (row & 7)) << 3));
+            if (accumulate) {
+                float a[8], b[8];
+                ld8(dst, a);
+                ld8(reinterpret_cast<const bf16*>(&v), b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += b[j];
+                st8(dst, a);
+            } else *reinterpret_cast<uint4*>(dst) = v;
+        }
+    }
+    MAED_WAVE_LDS_SYNC();
+}
+// rows at a constant stride: row0_ptr = element 0 of the tile's first row, rows >= n_valid are not written
+__device__ __forceinline__ void store_tile_lines(unsigned short* patch, bf16* row0_ptr, int64_t row_stride, int n_valid, const f32x16_t (&acc)[2], int lane, int accumulate) {
+    store_tile_lines_at(patch, [=](int row) -> bf16* { return row < n_valid ? row0_ptr + row * row_stride : nullptr; }, acc, lane, accumulate);
+}

@@ -460,7 +460,13 @@ __global__ __launch_bounds__(1024) void attn_tm_fwd_mfma(const bf16* __restrict_
         (void)any;
     }
     l += __shfl_xor(l, 32, 64);
-    if (q_ok) {
+    if (Lk == 32) {      // one-wave workgroup (cfg3: T = 16): the output tile leaves as full 128-byte lines through the K image, whose last reader was this wave's S product
+        const float inv = q_ok ? 1.f / l : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] *= inv; oacc[1][r] *= inv; }
+        store_tile_lines_at(Ks, [&](int r) -> bf16* { return TM_ROW_OK(r) ? o + (((int64_t)n * Tn + r % Tn) * P + p0 + r / Tn) * C + h * D : nullptr; }, oacc, lane, 0);
+        if (q_ok && hi == 0) lse[(((int64_t)n * Tn + q % Tn) * H + h) * P + p0 + qg] = (m + log2f(l)) * 0.69314718055994530942f;
+    } else if (q_ok) {
         const float inv = 1.f / l;
         const int t = q % Tn, p = p0 + qg;
         const int64_t f = (int64_t)n * Tn + t;
@@ -749,7 +755,8 @@ __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __rest
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
-        if (row_ok) store_rowT(drow, dq, hi, accumulate);
+        // full 128-byte lines through the K image (its last reader was the dQ product above; one-wave workgroup): attn_mfma.cuh store_tile_lines_at
+        store_tile_lines_at(Ks, [&](int r) -> bf16* { return TM_ROW_OK(r) ? dqkv + TM_TOK(r) * ld + h * D : nullptr; }, dq, lane, accumulate);
     }
     {   // ---- pass B: lane = key;  S = Q K^T, dP = dO V^T (rows = queries = the wave's own rows) ----
         f32x16_t sb, dp, dk[2], dv[2];
@@ -779,10 +786,8 @@ __global__ __launch_bounds__(64, 3) void attn_tm_bwd_mfma_l32(const bf16* __rest
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[0][r] *= scale; dk[1][r] *= scale; }
-        if (row_ok) {
-            store_rowT(drow + C, dk, hi, accumulate);
-            store_rowT(drow + 2 * C, dv, hi, accumulate);
-        }
+        store_tile_lines_at(Ks, [&](int r) -> bf16* { return TM_ROW_OK(r) ? dqkv + TM_TOK(r) * ld + h * D + C : nullptr; }, dk, lane, accumulate);
+        store_tile_lines_at(Ks, [&](int r) -> bf16* { return TM_ROW_OK(r) ? dqkv + TM_TOK(r) * ld + h * D + 2 * C : nullptr; }, dv, lane, accumulate);
     }
 #undef TM_ROW_OK
 #undef TM_TOK
