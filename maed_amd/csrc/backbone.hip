@@ -47,11 +47,16 @@ __global__ __launch_bounds__(256) void ws_fwd_kernel(const WsConv* __restrict__ 
     if (lane == 0) { stats[2 * fi] = mean; stats[2 * fi + 1] = inv; }
     T* dst = out + d.dst_off + (int64_t)o * K;
     T* dst_t = (d.dst_t_off >= 0 && !skip_transposed) ? out + d.dst_t_off + o : nullptr;      // (skip: ws_transpose_kernel writes them)
-    for (int i = lane; i < K; i += 64) {           // i = ci*KHW + r in the source; destination is (r, ci)
-        const int ci = i / d.KHW, r = i % d.KHW;
-        const float v = (src[i] - mean) * inv;
-        stf(dst + (int64_t)r * d.I + ci, v);
-        if (dst_t) stf(dst_t + ((int64_t)r * d.I + ci) * d.O, v);
+    // source (ci, r), destination (r, ci): lane = input channel, taps in the inner loop -- the stores of one tap are consecutive elements (whole lines for the 3x3
+    // filters, 63 % of the weights; with lane = source index they were 2-byte pieces nine rows apart, and every element paid an integer division by KHW)
+    const int KHW = d.KHW, I = d.I;
+    for (int ci = lane; ci < I; ci += 64) {
+        const float* sp = src + (int64_t)ci * KHW;
+        for (int r = 0; r < KHW; ++r) {
+            const float v = (sp[r] - mean) * inv;
+            stf(dst + (int64_t)r * I + ci, v);
+            if (dst_t) stf(dst_t + ((int64_t)r * I + ci) * d.O, v);
+        }
     }
 }
 
@@ -122,10 +127,15 @@ __global__ __launch_bounds__(256) void ws_bwd_kernel(const WsConv* __restrict__ 
     const float* g32 = (const float*)d.gout + (int64_t)o * K;
     const bool f32 = d.gout_f32 != 0;               // wave-uniform
     const float mean = stats[2 * fi], inv = stats[2 * fi + 1];
+    // lane = SOURCE index here (unlike ws_fwd_kernel): the read-modify-write of the fp32 gradient is the side that has to be whole lines -- with lane = input channel it
+    // became 4-byte pieces nine elements apart and the kernel went from 87 to 119 us; the gather of the (r, ci)-ordered incoming gradient is absorbed by the caches.
+    // ci = i / KHW by a float reciprocal (exact for these sizes: i < 2^20, KHW in {1, 9, 49}) instead of an integer division per element.
+    const int KHW = d.KHW, I = d.I;
+    const float rk = 1.0f / (float)KHW;
     float sg = 0.f, sgw = 0.f;
     for (int i = lane; i < K; i += 64) {
-        const int ci = i / d.KHW, r = i % d.KHW;
-        const float gi = f32 ? g32[(int64_t)r * d.I + ci] : ldf(g + (int64_t)r * d.I + ci);
+        const int ci = KHW == 1 ? i : (int)(((float)i + 0.5f) * rk), r = i - ci * KHW;
+        const float gi = f32 ? g32[(int64_t)r * I + ci] : ldf(g + (int64_t)r * I + ci);
         sg += gi; sgw += gi * (src[i] - mean);
     }
     sg = wave_sum(sg); sgw = wave_sum(sgw);
@@ -134,8 +144,8 @@ __global__ __launch_bounds__(256) void ws_bwd_kernel(const WsConv* __restrict__ 
     const float gm = sg / (float)K;
     float* dst = d.gw + (int64_t)o * K;
     for (int i = lane; i < K; i += 64) {
-        const int ci = i / d.KHW, r = i % d.KHW;
-        const float gi = f32 ? g32[(int64_t)r * d.I + ci] : ldf(g + (int64_t)r * d.I + ci);
+        const int ci = KHW == 1 ? i : (int)(((float)i + 0.5f) * rk), r = i - ci * KHW;
+        const float gi = f32 ? g32[(int64_t)r * I + ci] : ldf(g + (int64_t)r * I + ci);
         dst[i] += inv * (gi - gm) - (src[i] - mean) * c2;
     }
 }
