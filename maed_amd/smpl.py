@@ -13,6 +13,7 @@ joint_map, smpl.py:97-99).
 import ctypes as C
 import os
 import warnings
+import weakref
 from collections import namedtuple
 
 import torch
@@ -231,23 +232,25 @@ class SMPL(nn.Module):
 
     def regressor_csr(self, Jreg):
         """(rowptr, cols, vals) int32 / int32 / fp32 device tensors of a (J, 6890) joint regressor, or None when it is not sparse enough to bother (> 10 % non-zero)
-        or has more than 64 rows.  Built once per regressor state (one host sync), cached by storage pointer / version."""
-        cache = self.__dict__.setdefault("_csr_cache", {})
-        key = (Jreg.data_ptr(), Jreg._version, tuple(Jreg.shape), str(Jreg.device))
-        if key not in cache:
-            if len(cache) > 8:
-                cache.clear()
-            with torch.no_grad():
-                nz = Jreg != 0
-                if Jreg.dim() != 2 or Jreg.shape[0] > 64 or Jreg.shape[1] != N_VERTS or float(nz.float().mean()) > 0.10 or os.environ.get("MAED_JREG_CSR", "1") == "0":
-                    cache[key] = None
-                else:
-                    idx = torch.nonzero(nz)                  # row-major: ascending vertex id inside a row
-                    counts = torch.bincount(idx[:, 0], minlength=Jreg.shape[0])
-                    rowptr = torch.zeros(Jreg.shape[0] + 1, dtype=torch.int32, device=Jreg.device)
-                    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-                    cache[key] = (rowptr, idx[:, 1].to(torch.int32).contiguous(), Jreg[nz].float().contiguous())
-        return cache[key]
+        or has more than 64 rows.  Built once per regressor tensor and version (one host sync)."""
+        # keyed by the tensor OBJECT (weak reference) + its version: a storage address alone can be handed to a different regressor after the first one is freed
+        cache = self.__dict__.setdefault("_csr_cache", [])
+        cache[:] = [e for e in cache if e[0]() is not None][-8:]
+        for ref, version, csr in cache:
+            if ref() is Jreg and version == Jreg._version:
+                return csr
+        with torch.no_grad():
+            nz = Jreg != 0
+            if Jreg.dim() != 2 or Jreg.shape[0] > 64 or Jreg.shape[1] != N_VERTS or float(nz.float().mean()) > 0.10 or os.environ.get("MAED_JREG_CSR", "1") == "0":
+                csr = None
+            else:
+                idx = torch.nonzero(nz)                  # row-major: ascending vertex id inside a row
+                counts = torch.bincount(idx[:, 0], minlength=Jreg.shape[0])
+                rowptr = torch.zeros(Jreg.shape[0] + 1, dtype=torch.int32, device=Jreg.device)
+                rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+                csr = (rowptr, idx[:, 1].to(torch.int32).contiguous(), Jreg[nz].float().contiguous())
+        cache.append((weakref.ref(Jreg), Jreg._version, csr))
+        return csr
 
     def joint_regress_hip(self, Jreg, verts):
         Fr, J = verts.shape[0], Jreg.shape[0]

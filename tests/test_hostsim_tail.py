@@ -214,3 +214,21 @@ def test_joint_regression_through_the_regressors_nonzeros():
     for g, R in ((got, smpl.J_regressor_extra), (h36, arrays["J_regressor_h36m"]), (gd, dense)):
         want = torch.einsum("bik,ji->bjk", verts.double(), R.double())
         assert float((g.double() - want).abs().max()) < 1e-5
+
+
+def test_regressor_csr_cache_follows_the_tensor_not_its_address():
+    """the CSR of a joint regressor is cached per tensor object and version: an in-place edit or a different tensor (even one that reuses a freed tensor's storage
+    address) gets its own"""
+    from maed_amd.smpl import SMPL, synthetic_smpl_arrays
+    smpl = SMPL(synthetic_smpl_arrays(0))
+    a = torch.zeros(2, 6890); a[0, 5] = 1.0; a[1, 7] = 2.0
+    c1 = smpl.regressor_csr(a)
+    assert c1[1].tolist() == [5, 7] and smpl.regressor_csr(a) is c1
+    a[1, 9] = 3.0                                    # in-place edit: version bump
+    c2 = smpl.regressor_csr(a)
+    assert c2 is not c1 and c2[1].tolist() == [5, 7, 9]
+    ptr = a.data_ptr()
+    del a
+    b = torch.zeros(2, 6890); b[0, 1] = 1.0          # (often lands on the freed storage)
+    c3 = smpl.regressor_csr(b)
+    assert c3[1].tolist() == [1], (ptr == b.data_ptr(), c3[1].tolist())
