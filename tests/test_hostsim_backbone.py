@@ -406,7 +406,7 @@ def _stem_reference(x, w, dy=None):
     return ref.detach(), wr.grad
 
 
-@pytest.mark.parametrize("N,H,W,stats", [(2, 32, 32, True), (1, 32, 64, False), (1, 48, 96, True)])
+@pytest.mark.parametrize("N,H,W,stats", [(2, 32, 32, True), (1, 32, 64, False), (1, 48, 96, True), (1, 16, 256, True)])
 def test_stem7x7s2_forward_from_padded_4slot_image(N, H, W, stats):
     """round 4: maed_stem_input(c_stride 4) + maed_stem7x7s2_fwd -- the stem convolution with the pixel operand loaded from global memory straight into the MFMA
     fragment layout (16 bytes = 2 pixels x 4 slots = the stride-2 step), against F.conv2d on the padded frames; the GroupNorm statistics of the rounded outputs
@@ -429,7 +429,8 @@ def test_stem7x7s2_forward_from_padded_4slot_image(N, H, W, stats):
         assert torch.allclose(sums, want, rtol=1e-5, atol=1e-3), (sums - want).abs().max()
 
 
-@pytest.mark.parametrize("N,H,W,wgs,slots", [(2, 32, 32, None, True), (1, 32, 64, None, False), (3, 48, 96, 5, True), (2, 32, 32, 3, False), (2, 32, 32, 3, True)])
+@pytest.mark.parametrize("N,H,W,wgs,slots", [(2, 32, 32, None, True), (1, 32, 64, None, False), (3, 48, 96, 5, True), (2, 32, 32, 3, False), (2, 32, 32, 3, True),
+                                              (1, 16, 256, 3, True)])      # (last: cfg5's row width -- three DMA rounds per image, 86 KB of LDS)
 def test_stem7x7s2_weight_gradient_by_lds_dma_and_transposing_reads(N, H, W, wgs, slots):
     """round 4: maed_stem7x7s2_wgrad -- one output row of dy and its seven input rows per work item, copied into LDS unchanged (LDS-DMA, swizzled dy chunks) and
     contracted over pixels through ds_read_b64_tr_b16 fragments; accumulates into the given fp32 slice.  One row per workgroup by default at these sizes; with
