@@ -323,16 +323,14 @@ def main():
         want_direct = os.environ.get("MAED_COMM", "direct") == "direct" and not sim and dist.is_available() and dist.is_initialized() and (world > 1 or force_coll)
         if want_direct:
             from maed_amd.ddp import RcclComm
-            try:
-                comm = RcclComm()
-            except Exception as e:  # noqa: BLE001
-                log(f"MAED_COMM=direct: own RCCL communicator unavailable ({e}); falling back to torch.distributed")
-                comm = None
-            ok = torch.tensor([1.0 if comm is not None else 0.0], device=dev)          # every rank takes the same transport
+            # agree on feasibility with a NON-collective step first (load + symbol check on every rank, then one all-reduce of the verdict): creating the communicator
+            # is itself collective, so a rank that cannot must say so before anybody enters the constructor -- otherwise its peers hang in ncclCommInitRank
+            ok_here, why = RcclComm.available()
+            if not ok_here:
+                log(f"MAED_COMM=direct: own RCCL communicator unavailable on rank {rank} ({why}); every rank falls back to torch.distributed")
+            ok = torch.tensor([1.0 if ok_here else 0.0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() == 0.0 and comm is not None:
-                comm.destroy()
-                comm = None
+            comm = RcclComm() if ok.item() == 1.0 else None     # (a failure inside the collective constructor now raises on this rank: loud, not a silent fallback)
         bucketer = GradBucketer(arena, model, comm=comm, force_collectives=force_coll, **(dict(bucket_bytes=16 << 10) if sim else {}))
         bucketer.broadcast_parameters(0)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=bucketer)  # configs/config_stage2.yaml:63-66

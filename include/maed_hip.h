@@ -106,6 +106,14 @@ typedef enum {
  * architecture in maed_last_error() -- the host calls it once after loading the library, so that a wrong device fails here and not as an "invalid device
  * function" at the first launch.  The library keeps no per-device state. */
 int maed_init(int device);
+/* Frame-barrier timeouts since the process started (or since maed_device_faults_clear).  The one-pass GroupNorm backward (MAED_OPT_GN_BWD_ONEPASS) and the fused
+ * attentive addition (MAED_OPT_ST_FUSED) synchronise the workgroups of one frame INSIDE a launch; that needs them co-resident, which holds on a GPU this process has
+ * to itself.  When a peer does not arrive within the spin bound (GPU shared with another process, preemption, a debugger), the affected call's result is poisoned with
+ * NaN (loud, never subtly wrong), the kernel raises this counter (pinned host memory, system-scope atomic: no synchronisation needed to read it), and from the next
+ * call on both operations run as their multi-launch forms for the rest of the process; maed_last_error() carries the explanation.  Hosts that share GPUs should set
+ * MAED_OPT_GN_BWD_ONEPASS = 0 and MAED_OPT_ST_FUSED = 0 up front (environment: MAED_GN_BWD_ONEPASS=0 MAED_ST_FUSED=0).  No reference counterpart (scheduling only). */
+int maed_device_faults(void);
+int maed_device_faults_clear(void);
 int maed_set_option(int key, int value);   /* MAED_OK or MAED_ERR_ARG */
 int maed_get_option(int key);              /* the value, or MAED_ERR_ARG (negative) for an unknown key */
 

@@ -11,3 +11,4 @@ from .smpl import SMPL  # noqa: F401
 from .iterative import Regressor  # noqa: F401
 from .evaluate import Evaluator  # noqa: F401
 from .ops import set_float32_matmul_precision, get_float32_matmul_precision, set_float32_backward_precision, get_float32_backward_precision  # noqa: F401
+from ._lib import device_faults  # noqa: F401,E402

@@ -61,6 +61,8 @@ SIGNATURES = {
     "maed_last_error": (C.c_char_p, []),
     "maed_version": (i32, []),
     "maed_init": (i32, [i32]),
+    "maed_device_faults": (i32, []),
+    "maed_device_faults_clear": (i32, []),
     "maed_set_option": (i32, [i32, i32]),
     "maed_get_option": (i32, [i32]),
     "maed_layernorm_fwd": (i32, [vp, i64, vp, vp, vp, i32, vp, vp, i64, i32, f32, vp]),
@@ -218,6 +220,12 @@ def check(rc, what=""):
     if rc != 0:
         msg = lib().maed_last_error().decode("utf-8", "replace")
         raise MaedHipError(f"{what or 'libmaed_hip'} failed with status {rc}: {msg}")
+
+
+def device_faults():
+    """frame-barrier timeouts the kernels reported since the process started (include/maed_hip.h maed_device_faults): 0 on a GPU this process has to itself.
+    Non-zero: the affected step's result was NaN-poisoned and the library switched to its multi-launch forms; maed_last_error() says so."""
+    return 0 if _lib is None else int(_lib.maed_device_faults())
 
 
 def loaded_path():

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(NT, 4) void gn_bwd_onepass_kernel(const T* __restri
                                                                    const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float* ab /* [N][C][2], zero at launch */, T* __restrict__ dx, T* __restrict__ dres,
                                                                    uint32_t* sync /* [N][GN1_SYNC_WORDS], zero at launch */, int HW, int C, float eps, int S,
-                                                                   int rows_per_wg, int phase, int skew) {
+                                                                   int rows_per_wg, int phase, int skew, uint32_t* fault /* maed_fault_word() */) {
     MAED_DYN_SHARED(float, lpart);       // [NT / cbn][C][2] per-row-lane partials (32 KB)
     __shared__ float lmu[GN_G], lrs[GN_G], lgrp[GN_G * 2], lb[GN_G], lk[GN_G];
     __shared__ int lfail;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(NT, 4) void gn_bwd_onepass_kernel(const T* __restri
         if (phase == 0 && S > 1) {
             MAED_WAIT_VMCNT0();                                    // the 64 group-sum atomics have been performed
             __syncthreads();
-            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)n * GN1_SYNC_WORDS, (uint32_t)S)) lfail = 1;
+            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)n * GN1_SYNC_WORDS, (uint32_t)S)) { lfail = 1; maed_report_fault(fault); }
         }
         // per-channel partials for dgamma / dbeta (nobody in this kernel reads them): under lane 0's wait
         for (int i = tid; i < 2 * C; i += NT) {
@@ -640,7 +640,10 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
     const int cpg = C / GN_G, cbn1 = C / 8, ch1 = dtype == MAED_BF16 ? ((relu && !ymask) ? 7 : 8) : 4;
     int S1 = 0, rows1 = 0;
     const int nt1 = maed_opt(MAED_OPT_GN_BWD_ONEPASS) == 2 ? 256 : GN1_NT;      // (2: experiment -- 256-thread workgroups, four per CU)
-    bool onepass = frame_sync && maed_opt(MAED_OPT_GN_BWD_ONEPASS) && cpg >= 2 && cbn1 <= nt1;
+    // a frame barrier that timed out earlier in this process (shared GPU, preemption: the peers of a frame were not co-resident) poisoned that call's result with NaN
+    // and raised the fault word: from then on the two-pass kernels run (maed_device_faults() / maed_last_error() tell the host)
+    uint32_t* const fault1 = maed_fault_word();
+    bool onepass = frame_sync && maed_opt(MAED_OPT_GN_BWD_ONEPASS) && cpg >= 2 && cbn1 <= nt1 && !maed_fault_seen("groupnorm_bwd");
     if (onepass) {
         const int rstep = nt1 / cbn1, cap = ch1 * rstep;
         S1 = (HW + cap - 1) / cap;
@@ -652,7 +655,7 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
 #define GN_APP(RES_, RELU_) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, RES_, RELU_>), grid, dim3(256), 0, s, (const T*)x, relu_mask, (const T*)dy, \
         sums, ab_scratch, gamma, beta, (T*)dx, (T*)dres, HW, C, eps, rows)
 #define GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, NT_) hipLaunchKernelGGL((gn_bwd_onepass_kernel<T, RELU_, YM_, GPC_, CH_, NT_>), dim3(S1, N), dim3(NT_), lds1, s, (const T*)x, relu_mask, \
-        (const T*)dy, sums, gamma, beta, ab_scratch, (T*)dx, (T*)dres, frame_sync, HW, C, eps, (maed_opt(MAED_OPT_GN_BWD_ONEPASS) == 3 ? 1 : S1), rows1, PH_, skew1)
+        (const T*)dy, sums, gamma, beta, ab_scratch, (T*)dx, (T*)dres, frame_sync, HW, C, eps, (maed_opt(MAED_OPT_GN_BWD_ONEPASS) == 3 ? 1 : S1), rows1, PH_, skew1, fault1)
 #define GN_ONE3(RELU_, YM_, GPC_, CH_, PH_) do { if (nt1 == 256) GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, 256); else GN_ONE4(RELU_, YM_, GPC_, CH_, PH_, GN1_NT); } while (0)
 #define GN_ONE2(RELU_, YM_, CH_, PH_) do { if (cpg >= 8) GN_ONE3(RELU_, YM_, 1, CH_, PH_); else if (cpg == 4) GN_ONE3(RELU_, YM_, 2, CH_, PH_); else GN_ONE3(RELU_, YM_, 4, CH_, PH_); } while (0)
 #define GN_ONE(PH_) do { constexpr int CH_ = sizeof(T) == 2 ? 8 : 4, CHM_ = sizeof(T) == 2 ? 7 : 4; \

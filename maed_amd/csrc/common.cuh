@@ -213,6 +213,20 @@ __device__ __forceinline__ void maed_agent_store(float* p, float v) { __hip_atom
 __device__ __forceinline__ float maed_agent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
+// A bounded spin that expired (the workgroups of a frame were not co-resident: GPU shared with another process, preemption, a debugger) poisons THAT call's result
+// with NaN -- and tells the host: one system-scope add to the library's fault word (pinned host memory, options.hip).  The launchers of the kernels that use the
+// barrier look at the word before every launch: once it is non-zero they take their two-pass forms for the rest of the process, maed_device_faults() returns the
+// count and maed_last_error() says what happened.
+uint32_t* maed_fault_word(void);
+bool maed_fault_seen(const char* who);
+__device__ __forceinline__ void maed_report_fault(uint32_t* w) {
+#ifdef MAED_HOSTSIM
+    if (w) ++*w;
+#else
+    if (w) __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+
 // ---- math ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_erf(float x) {

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void wgrad_slots_reduce_kernel(const float* __
 }
 
 bool maed_conv3x3_wgrad_rows64_ok(int F, int H, int W, int Cin, int Cout) {
-    return maed_opt(MAED_OPT_CONV3X3_ROWS_WGS) > 0 && Cin == 64 && Cout == 64 && W % 8 == 0 && W >= 8 && W <= 64 && H >= 1 && (int64_t)F * H * W * 128 < (1ll << 31);
+    // (F >= 1: an empty batch has no rows to split over workgroups -- callers get "not applicable" and take the general route, which returns early on M == 0)
+    return maed_opt(MAED_OPT_CONV3X3_ROWS_WGS) > 0 && F >= 1 && Cin == 64 && Cout == 64 && W % 8 == 0 && W >= 8 && W <= 64 && H >= 1 && (int64_t)F * H * W * 128 < (1ll << 31);
 }
 
 void maed_wgrad_slots_reduce(const float* partial, float* dW, int n_slots, int n_elems, hipStream_t stream) {
@@ -122,6 +123,7 @@ void maed_wgrad_slots_reduce(const float* partial, float* dW, int n_slots, int n
 // workgroups (= partial-sum slots) of a launch over n_rows image rows
 static int rows64_wgs(int n_rows, int* per_out) {
     int wgs = maed_opt(MAED_OPT_CONV3X3_ROWS_WGS);   // default 256, one per CU: every workgroup ends with a 147 KB partial result
+    if (n_rows < 1 || wgs < 1) { *per_out = 0; return 0; }
     if (wgs > n_rows) wgs = n_rows;
     const int per = (n_rows + wgs - 1) / wgs;
     *per_out = per;
@@ -134,6 +136,7 @@ int maed_conv3x3_wgrad_rows64_launch(const void* dy, const void* x, float* dW, v
     const int n_rows = F * H;
     int per = 0;
     const int wgs = rows64_wgs(n_rows, &per);
+    if (wgs == 0) return MAED_OK;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_rows64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     hipLaunchKernelGGL(conv3x3_wgrad_rows64_kernel, dim3(wgs), dim3(R3_THREADS), R3_LDS_BYTES, stream, (const bf16*)dy, (const bf16*)x, dW, (float*)scratch, H, W, n_rows, per);

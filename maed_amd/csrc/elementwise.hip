@@ -156,7 +156,7 @@ __device__ __forceinline__ void st1_gemv256(const bf16* __restrict__ W, int K2, 
 template <int CH>
 __global__ __launch_bounds__(ST1_NT, 4) void st_fused_fwd_kernel(const bf16* __restrict__ x_s, const bf16* __restrict__ x_t, const bf16* __restrict__ w_ts,
                                                                  const float* __restrict__ b_ts, bf16* __restrict__ means, float* __restrict__ logits,
-                                                                 bf16* __restrict__ mix, uint32_t* sync, float* ex, int P, int C, int S, uint32_t target, int phase) {
+                                                                 bf16* __restrict__ mix, uint32_t* sync, float* ex, int P, int C, int S, uint32_t target, uint32_t* fault, int phase) {
     __shared__ float lpart[32 * 16 * 16];      // [row lane][chunk][x_s: 8 | x_t: 8] token-sum partials
     __shared__ float lvec[2048];               // the frame's 2C means
     __shared__ float llog[256];                // this slice's 128 logit pairs
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(ST1_NT, 4) void st_fused_fwd_kernel(const bf16* __r
         MAED_WAIT_VMCNT0();                                          // the published means have left this wave
         __syncthreads();
         if (S > 1) {
-            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, target)) lfail = 1;
+            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, target)) { lfail = 1; maed_report_fault(fault); }
             __syncthreads();
         }
     }
@@ -228,7 +228,7 @@ template <int CH>
 __global__ __launch_bounds__(ST1_NT, (CH > 7 ? 2 : 4)) void st_fused_bwd_kernel(const bf16* __restrict__ dmix, const bf16* __restrict__ x_s, const bf16* __restrict__ x_t,
                                                                  const float* __restrict__ logits, const bf16* __restrict__ wt_ts, bf16* __restrict__ dlogits,
                                                                  bf16* __restrict__ dx_s, bf16* __restrict__ dx_t, uint32_t* sync, float* ex, int P, int C,
-                                                                 int S, uint32_t target, int phase) {
+                                                                 int S, uint32_t target, uint32_t* fault, int phase) {
     __shared__ float lpart[32 * 16 * 16];      // [row lane][chunk][sum dmix x_s: 8 | sum dmix x_t: 8]
     __shared__ float lvec[2048];               // the frame's 2C dlogits
     __shared__ float ldm[256];                 // d(means) of this slice: x_s half, x_t half
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(ST1_NT, (CH > 7 ? 2 : 4)) void st_fused_bwd_kernel(
         MAED_WAIT_VMCNT0();
         __syncthreads();
         if (S > 1) {
-            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, target)) lfail = 1;
+            if (tid == 0 && !maed_frame_arrive_and_wait(sync + (int64_t)f * 16, target)) { lfail = 1; maed_report_fault(fault); }
             __syncthreads();
         }
     }
@@ -312,7 +312,10 @@ __global__ __launch_bounds__(ST1_NT, (CH > 7 ? 2 : 4)) void st_fused_bwd_kernel(
     }
 }
 
-extern "C" int maed_st_fused_supported(int P, int C, int dtype) { return dtype == MAED_BF16 && C % 128 == 0 && 2 * C <= 2048 && P > 0 && P <= 288; }
+// (after a frame-barrier timeout in this process -- maed_device_faults() -- the answer is no: callers fall back to the four-launch sequence)
+extern "C" int maed_st_fused_supported(int P, int C, int dtype) {
+    return dtype == MAED_BF16 && C % 128 == 0 && 2 * C <= 2048 && P > 0 && P <= 288 && !maed_fault_seen("st_fused");
+}
 
 #ifdef MAED_HOSTSIM
 #define ST1_LAUNCH(K_, ...) do { hipLaunchKernelGGL(K_, grid, dim3(ST1_NT), 0, s, __VA_ARGS__, 1); hipLaunchKernelGGL(K_, grid, dim3(ST1_NT), 0, s, __VA_ARGS__, 2); } while (0)
@@ -345,8 +348,8 @@ int maed_st_fused_fwd_ws(const void* x_s, const void* x_t, const void* w_ts, con
     const int S = C / 128;
     const uint32_t target = arrive_base + (uint32_t)S;
     const dim3 grid(S, F);
-    if (P <= 224) ST1_LAUNCH(st_fused_fwd_kernel<7>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S, target);
-    else ST1_LAUNCH(st_fused_fwd_kernel<9>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S, target);
+    if (P <= 224) ST1_LAUNCH(st_fused_fwd_kernel<7>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S, target, maed_fault_word());
+    else ST1_LAUNCH(st_fused_fwd_kernel<9>, (const bf16*)x_s, (const bf16*)x_t, (const bf16*)w_ts, b_ts, (bf16*)means, logits, (bf16*)mix, sync, ex, P, C, S, target, maed_fault_word());
     MAED_CHECK_LAUNCH("st_fused_fwd");
     return MAED_OK;
 }
@@ -364,9 +367,9 @@ int maed_st_fused_bwd_ws(const void* dmix, const void* x_s, const void* x_t, con
     const uint32_t target = arrive_base + (uint32_t)S;
     const dim3 grid(S, F);
     if (P <= 224) ST1_LAUNCH(st_fused_bwd_kernel<7>, (const bf16*)dmix, (const bf16*)x_s, (const bf16*)x_t, logits, (const bf16*)wt_ts, (bf16*)dlogits, (bf16*)dx_s,
-                             (bf16*)dx_t, sync, ex, P, C, S, target);
+                             (bf16*)dx_t, sync, ex, P, C, S, target, maed_fault_word());
     else ST1_LAUNCH(st_fused_bwd_kernel<9>, (const bf16*)dmix, (const bf16*)x_s, (const bf16*)x_t, logits, (const bf16*)wt_ts, (bf16*)dlogits, (bf16*)dx_s,
-                    (bf16*)dx_t, sync, ex, P, C, S, target);
+                    (bf16*)dx_t, sync, ex, P, C, S, target, maed_fault_word());
     MAED_CHECK_LAUNCH("st_fused_bwd");
     return MAED_OK;
 }

@@ -30,8 +30,45 @@ extern "C" int maed_init(int device) {
 #else
     (void)device;
 #endif
+    (void)maed_fault_word();
     return MAED_OK;
 }
+
+// ---- device-fault word (common.cuh maed_report_fault): one uint32 in pinned, device-mapped host memory -- the kernels add to it with system scope, the host reads
+// it without a synchronisation.  Allocated by maed_init (or on first use); never freed.
+static std::atomic<uint32_t*> g_fault{nullptr};
+static std::atomic<int> g_fault_told{0};
+uint32_t* maed_fault_word(void) {
+    uint32_t* w = g_fault.load(std::memory_order_acquire);
+    if (w) return w;
+#ifdef MAED_HOSTSIM
+    uint32_t* n = (uint32_t*)calloc(16, sizeof(uint32_t));
+#else
+    uint32_t* n = nullptr;
+    if (hipHostMalloc((void**)&n, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !n) { (void)hipGetLastError(); return nullptr; }
+    memset(n, 0, 64);
+#endif
+    uint32_t* expected = nullptr;
+    if (!g_fault.compare_exchange_strong(expected, n, std::memory_order_acq_rel)) {
+#ifdef MAED_HOSTSIM
+        free(n);
+#else
+        (void)hipHostFree(n);
+#endif
+        return expected;
+    }
+    return n;
+}
+bool maed_fault_seen(const char* who) {
+    uint32_t* w = g_fault.load(std::memory_order_acquire);
+    if (!w || *(volatile uint32_t*)w == 0) return false;
+    if (!g_fault_told.exchange(1))
+        maed_set_error("%s: %u frame-barrier timeout(s) on this device (workgroups of a frame were not co-resident: shared GPU / preemption); the affected results were "
+                       "NaN-poisoned, the one-pass GroupNorm backward and the fused attentive addition now run as their multi-launch forms", who, *(volatile uint32_t*)w);
+    return true;
+}
+extern "C" int maed_device_faults(void) { uint32_t* w = g_fault.load(std::memory_order_acquire); return w ? (int)*(volatile uint32_t*)w : 0; }
+extern "C" int maed_device_faults_clear(void) { uint32_t* w = g_fault.load(std::memory_order_acquire); if (w) *(volatile uint32_t*)w = 0; g_fault_told.store(0); return MAED_OK; }
 
 extern "C" int maed_set_option(int key, int value) {
     MAED_CHECK_ARG(key >= 0 && key < MAED_OPT_COUNT, MAED_ERR_ARG, "set_option: unknown option %d", key);

@@ -221,6 +221,7 @@ void maed_wgrad_slots_reduce(const float* partial, float* dW, int n_slots, int n
 
 static int stem_wgrad_wgs(int n_items, int* per_out) {
     int wgs = maed_opt(MAED_OPT_STEM_WGRAD_WGS);          // default 512: two workgroups per CU, each a contiguous range of output rows (the tests lower it to force multi-row walks)
+    if (n_items < 1) { *per_out = 0; return 0; }
     if (wgs < 1) wgs = 1;
     if (wgs > n_items) wgs = n_items;
     const int per = (n_items + wgs - 1) / wgs;

@@ -80,6 +80,23 @@ class RcclComm:
     fences) instead of torch.distributed's ProcessGroupNCCL.  The 128-byte unique id travels from rank 0 through the
     already-initialised torch.distributed group (any backend) -- or no exchange at all for world == 1."""
 
+    @staticmethod
+    def _lib_path(lib_path=None):
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return lib_path or os.environ.get("MAED_RCCL_LIB") or (bundled if os.path.exists(bundled) else None)
+
+    @staticmethod
+    def available(lib_path=None):
+        """NON-collective feasibility check (every rank may call it independently): the NCCL-API library loads and exports what maed_comm_* binds.  Returns (ok, why).
+        Creating the communicator itself is collective (unique-id broadcast + ncclCommInitRank): ranks must agree on feasibility FIRST -- a rank that failed here while
+        its peers sat inside the constructor would hang the job instead of falling back."""
+        try:
+            path = RcclComm._lib_path(lib_path)
+            L.check(L.lib().maed_comm_load(path.encode() if path else None), "comm_load")
+            return True, ""
+        except Exception as e:  # noqa: BLE001
+            return False, str(e)
+
     def __init__(self, rank=None, world=None, lib_path=None):
         """lib_path: the NCCL-API library to bind (default: $MAED_RCCL_LIB, else the librccl.so PyTorch-ROCm ships -- one RCCL per process -- else the loader's
         librccl.so.1).  tests/test_comm_world2.py names a shared-memory stand-in here to run two ranks on a box without GPUs."""
@@ -87,8 +104,7 @@ class RcclComm:
         have_pg = dist.is_available() and dist.is_initialized()
         self.rank = rank if rank is not None else (dist.get_rank() if have_pg else 0)
         self.world = world if world is not None else (dist.get_world_size() if have_pg else 1)
-        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        path = lib_path or os.environ.get("MAED_RCCL_LIB") or (bundled if os.path.exists(bundled) else None)
+        path = RcclComm._lib_path(lib_path)
         L.check(lib.maed_comm_load(path.encode() if path else None), "comm_load")
         uid = ctypes.create_string_buffer(128)
         if self.rank == 0:

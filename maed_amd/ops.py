@@ -825,8 +825,13 @@ def stem_input(x, dtype, k, s, own=False):
     return y.permute(0, 3, 1, 2)
 
 
-def stem7x7s2_supported(H, W):
-    return bool(L.lib().maed_stem7x7s2_supported(int(H), int(W)))
+def stem7x7s2_supported(H, W, F_=1):
+    """geometry AND clip size: the stem kernels address with 32-bit byte offsets (csrc/stem.hip STEM_CHECK_GEOM) -- a clip past those limits (about 2 675 frames of
+    224 x 224) takes the vendor convolution instead of failing with MAED_ERR_SHAPE"""
+    H, W, F_ = int(H), int(W), int(F_)
+    if F_ < 1 or F_ * (H + 5) * (W + 6) * 8 >= 1 << 31 or F_ * (H // 2) * (W // 2) * 128 >= 1 << 32:
+        return False
+    return bool(L.lib().maed_stem7x7s2_supported(H, W))
 
 
 class StemConvFn(torch.autograd.Function):

@@ -348,12 +348,25 @@ class ResNetV2(nn.Module):
     def forward_features(self, x):
         if not ops.on_library_device(x):
             return self.stages(self.stem(x))
+        # every per-pass hand-over slot (pre-padded stem input, standardised weights, GroupNorm scratch) is set INSIDE the try: an exception anywhere -- alignment,
+        # out of memory, an unsupported size -- must not leave the stem marked "pre-padded" (the next forward would convolve an unpadded image: silently wrong)
+        try:
+            return self._forward_features_library(x)
+        finally:
+            _slots(self.stem.conv, _prepadded=False, _stem_hw=None)
+            self._own_stem_now = []
+            for c in self._convs:
+                _slots(c, _w_std=None, _w_t=None, _dw=None, _prec=None)
+            for m in self._norms:
+                _slots(m, _sums_buf=None, _ab_buf=None, _sync_buf=None)
+
+    def _forward_features_library(self, x):
         stem = self.stem.conv
         if (x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] <= 4 and not x.requires_grad and os.environ.get("MAED_STEM_INPUT", "1") == "1"
                 and stem.dilation == (1, 1) and stem.kernel_size[0] == stem.kernel_size[1]):
             # cast + channels_last + the stem's TF-SAME padding in one pass (the framework: three); the stem convolution below sees an already padded image
             own = (self.compute_dtype == torch.bfloat16 and os.environ.get("MAED_STEM_OWN", "1") == "1" and stem.kernel_size == (7, 7) and stem.stride == (2, 2)
-                   and stem.in_channels <= 3 and stem.out_channels == 64 and stem.groups == 1 and ops.stem7x7s2_supported(x.shape[2], x.shape[3]))
+                   and stem.in_channels <= 3 and stem.out_channels == 64 and stem.groups == 1 and ops.stem7x7s2_supported(x.shape[2], x.shape[3], x.shape[0]))
             self._own_stem_now = [0] if own else []
             _slots(stem, _prepadded="own" if own else True, _stem_hw=(x.shape[2], x.shape[3]))
             x = ops.stem_input(x, self.compute_dtype, stem.kernel_size[0], stem.stride[0], own=own)
@@ -370,37 +383,29 @@ class ResNetV2(nn.Module):
             # (+ N * GN_SYNC_WORDS zero words per layer behind the partial sums: per-frame arrival counter + group sums of the one-pass GroupNorm backward --
             #  same fill, single use)
             ab = torch.zeros(N * 2 * sum(m.num_channels for m in self._norms) + N * ops.GN_SYNC_WORDS * len(self._norms), dtype=torch.float32, device=x.device)
-        try:
-            if ws is not None:
-                for i, (c, w) in enumerate(zip(self._convs, ws)):
-                    _slots(c, _w_std=w, _w_t=self._w_std_t.get(i), _dw=self._dw_slices.get(i), _prec=self.f32_matmul)
-            off = 0
-            for i, m in enumerate(self._norms):
-                _slots(m, _sums_buf=sums[i])
-                if ab is not None:
-                    n = N * 2 * m.num_channels
-                    _slots(m, _ab_buf=ab[off:off + n].view(N, m.num_channels, 2), _sync_buf=ab[off + n:off + n + N * ops.GN_SYNC_WORDS])
-                    off += n + N * ops.GN_SYNC_WORDS
-            if ws is not None:
-                return self.stages(self.stem(x))
-            for gi, g in enumerate(self._ws_groups):       # standardise a stage's weights right before it runs: its autograd node
-                wg = ops.WeightStdFn.apply(g, self.compute_dtype, self._convs[0].eps, *g.conv_weights())   # then fires right after its backward
-                for k, (ci, w) in enumerate(zip(g.conv_idx, wg)):
-                    c = self._convs[ci]
-                    _slots(c, _w_std=w, _w_t=g._w_std_t.get(k), _dw=g._dw_slices.get(k), _prec=self.f32_matmul)
-                x = self.stages[0](self.stem(x)) if gi == 0 else self.stages[gi](x)
-            # backward order is last stage first: every group but the one that runs last may finish on the side stream (ops.WeightStdFn.backward)
-            runs = [g for g in self._ws_groups if g._pending_backwards > 0]
-            for k, g in enumerate(self._ws_groups):
-                g._ws_on_side = bool(runs) and g is not runs[0] and g in runs
-            return x
-        finally:
-            _slots(self.stem.conv, _prepadded=False, _stem_hw=None)
-            self._own_stem_now = []
-            for c in self._convs:
-                _slots(c, _w_std=None, _w_t=None, _dw=None, _prec=None)
-            for m in self._norms:
-                _slots(m, _sums_buf=None, _ab_buf=None, _sync_buf=None)
+        if ws is not None:
+            for i, (c, w) in enumerate(zip(self._convs, ws)):
+                _slots(c, _w_std=w, _w_t=self._w_std_t.get(i), _dw=self._dw_slices.get(i), _prec=self.f32_matmul)
+        off = 0
+        for i, m in enumerate(self._norms):
+            _slots(m, _sums_buf=sums[i])
+            if ab is not None:
+                n = N * 2 * m.num_channels
+                _slots(m, _ab_buf=ab[off:off + n].view(N, m.num_channels, 2), _sync_buf=ab[off + n:off + n + N * ops.GN_SYNC_WORDS])
+                off += n + N * ops.GN_SYNC_WORDS
+        if ws is not None:
+            return self.stages(self.stem(x))
+        for gi, g in enumerate(self._ws_groups):       # standardise a stage's weights right before it runs: its autograd node
+            wg = ops.WeightStdFn.apply(g, self.compute_dtype, self._convs[0].eps, *g.conv_weights())   # then fires right after its backward
+            for k, (ci, w) in enumerate(zip(g.conv_idx, wg)):
+                c = self._convs[ci]
+                _slots(c, _w_std=w, _w_t=g._w_std_t.get(k), _dw=g._dw_slices.get(k), _prec=self.f32_matmul)
+            x = self.stages[0](self.stem(x)) if gi == 0 else self.stages[gi](x)
+        # backward order is last stage first: every group but the one that runs last may finish on the side stream (ops.WeightStdFn.backward)
+        runs = [g for g in self._ws_groups if g._pending_backwards > 0]
+        for k, g in enumerate(self._ws_groups):
+            g._ws_on_side = bool(runs) and g is not runs[0] and g in runs
+        return x
 
     def forward(self, x, seqlen=8):
         return self.forward_features(x)
