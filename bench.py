@@ -183,9 +183,10 @@ def parity_mode_line(dev, steps=5):
         with torch.no_grad():
             ref = R.maed_forward(one, params, R.make_synthetic_smpl(0), depth=CFG["depth"], H=CFG["heads"])
         variants = {}
-        for name, bb in (("bf16x3", None), ("bf16x3_backbone_bf16x6", "bf16x6"), ("bf16x3_fwd_bf16_bwd", None)):
+        for name, bb in (("bf16x3", None), ("bf16x3_backbone_bf16x6", "bf16x6"), ("bf16x3_fwd_bf16_bwd", None), ("bf16x3_fwd_bf16_twin_bwd", None)):
             # third variant (round 4): the same forward, the backward's matrix products with ONE bf16 plane (MAED_F32X1): outputs as accurate as bf16x3, gradients bf16-level
-            maed_amd.set_float32_backward_precision("bf16x1" if name == "bf16x3_fwd_bf16_bwd" else None)
+            # fourth (round 5): the same forward on fp32 operands, bf16 TWINS of what the backward reads, the bf16 mode's backward on them
+            maed_amd.set_float32_backward_precision({"bf16x3_fwd_bf16_bwd": "bf16x1", "bf16x3_fwd_bf16_twin_bwd": "bf16"}.get(name))
             model = build_model(torch.float32, dev, bb).train()
             arena = ParamArena(model)
             opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=GradBucketer(arena, model))
@@ -248,7 +249,7 @@ def main():
                     help="TEST ONLY (tests/test_bench_world2.py): the whole driver -- process group, broadcast, bucketed all-reduce overlapped with backward, "
                          "extra profiling steps, barriers, JSON -- on CPU tensors with the kernels on the host simulator and the gloo backend, tiny workload; "
                          "the number it prints is meaningless")
-    ap.add_argument("--f32-backward", default=None, choices=["same", "bf16x1"],
+    ap.add_argument("--f32-backward", default=None, choices=["same", "bf16x1", "bf16"],
                     help="--dtype f32 only: engine of the backward matrix products (maed_amd.set_float32_backward_precision): bf16x1 = one bf16 plane per operand")
     ap.add_argument("--backbone-f32-matmul", default=None, choices=["bf16x3", "bf16x6"],
                     help="--dtype f32 only: the backbone's own engine (MAED(backbone_f32_matmul=...)); default: the process-wide mode")

@@ -239,6 +239,13 @@ size_t maed_ste_block_scratch_bytes(const maed_block_dims* d);
  * handed unchanged to maed_ste_block_bwd.  x_out may alias x_in only if no backward is wanted. */
 int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in,
                        float* x_out, void* saved, void* stream);
+/* "bf16x3 forward / bf16 backward from bf16 twins" (round 5).  d->dtype = MAED_F32 describes the FORWARD: fp32 activations, products on the process-wide fp32
+ * engine (MAED_OPT_F32_MATMUL; p->w_* = the fp32 master weights, wt_* unused), written to the transient `work_f32` (maed_ste_block_twin_work_bytes).  What the
+ * backward reads is saved to `saved_bf16` in the layout of a MAED_BF16 block (maed_ste_block_saved_bytes of the same dims with dtype MAED_BF16): bf16 twins of the
+ * activations, the fp32 statistics as they are.  The backward is then maed_ste_block_bwd with dtype MAED_BF16 and bf16 weight images on that arena -- the throughput
+ * mode's backward behind the accurate mode's forward.  Same reference lines as maed_ste_block_fwd. */
+size_t maed_ste_block_twin_work_bytes(const maed_block_dims* d);
+int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved_bf16, void* work_f32, void* stream);
 /* the same forward when no backward will follow (inference): `work` = maed_ste_block_saved_bytes of scratch; what only the backward would read
  * (fc1's pre-activation: 103 MB per block at cfg3) is not written.  x_out may alias x_in. */
 int maed_ste_block_infer(const maed_block_dims* d, const maed_block_params* p, const float* x_in,

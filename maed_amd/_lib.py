@@ -85,6 +85,8 @@ SIGNATURES = {
     "maed_embed_add_bwd": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "maed_ste_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_scratch_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
+    "maed_ste_block_twin_work_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
+    "maed_ste_block_fwd_twin": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp, vp]),
     "maed_ste_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
     "maed_ste_block_infer": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
     "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -231,44 +231,106 @@ int wgrad(const void* Yt, const void* Xt, int64_t No, int64_t Ko, int64_t Mp, fl
 extern "C" size_t maed_ste_block_saved_bytes(const maed_block_dims* d) { return d ? saved_layout(*d).total : 0; }
 extern "C" size_t maed_ste_block_scratch_bytes(const maed_block_dims* d) { return d ? scratch_layout(*d).total : 0; }
 
+// where the forward writes what it saves: one pointer per field of SavedLayout.  Plain forward: every field inside `saved`.  Twin forward (maed_ste_block_fwd_twin):
+// the fields in the compute dtype go to an fp32 work buffer (they are the forward chain's operands), the fp32 fields straight into the bf16-layout arena the
+// backward will read.
+struct FwdBufs { char *ln1, *mean1, *rstd1, *qkv, *xs, *xt, *lse_s, *lse_t, *means, *logits, *mix, *xmid, *mean2, *rstd2, *ln2, *hpre, *hact, *st_sync, *st_ex; };
+static FwdBufs fwd_bufs(char* act_base, const SavedLayout& A, char* f32_base, const SavedLayout& Fl) {
+    FwdBufs b;
+    b.ln1 = act_base + A.ln1; b.qkv = act_base + A.qkv; b.xs = act_base + A.xs; b.xt = act_base + A.xt; b.means = act_base + A.means; b.mix = act_base + A.mix;
+    b.ln2 = act_base + A.ln2; b.hpre = act_base + A.hpre; b.hact = act_base + A.hact;
+    b.mean1 = f32_base + Fl.mean1; b.rstd1 = f32_base + Fl.rstd1; b.lse_s = f32_base + Fl.lse_s; b.lse_t = f32_base + Fl.lse_t; b.logits = f32_base + Fl.logits;
+    b.xmid = f32_base + Fl.xmid; b.mean2 = f32_base + Fl.mean2; b.rstd2 = f32_base + Fl.rstd2; b.st_sync = f32_base + Fl.st_sync; b.st_ex = f32_base + Fl.st_ex;
+    return b;
+}
+
+static int block_fwd_bufs(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, const FwdBufs& B, bool for_backward, void* stream) {
+    const int64_t M = (int64_t)d->F * d->P;
+    const int C = d->C, Hd = d->hidden, dt = d->dtype;
+    const int gi = d->impl == MAED_IMPL_VALU ? MAED_IMPL_VALU : MAED_IMPL_AUTO;
+    const float scale = 1.0f / sqrtf((float)HEAD_DIM);
+    float* logits = (float*)B.logits;
+
+    // (the LayerNorm kernel also zeroes the per-frame arrival counters of the fused attentive addition further down: no memset launch of their own)
+    const bool stf = st_fused(*d);
+    const bool piggy = stf && maed_opt(MAED_OPT_ST_FUSED) != 2 && (int64_t)d->F * 16 <= 256 * ((M + 31) / 32);       // (the backward LayerNorm's grid is the smaller one; otherwise the fused call clears itself; option value 2: A/B knob -- memset nodes, LayerNorm column sums on the caller's stream)
+    MAED_PROPAGATE(maed_layernorm_fwd_ws(x_in, C, p->ln1_g, p->ln1_b, B.ln1, dt, (float*)(B.mean1), (float*)(B.rstd1), M, C, d->eps,
+                                         piggy ? (uint32_t*)(B.st_sync) : nullptr, piggy ? d->F * 16 : 0, stream));
+    PROF(PROF_GEMM_QKV, maed_gemm_nt(B.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, B.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
+    {   // the two attention branches read the same qkv and write disjoint outputs: temporal on the side stream beside spatial
+        SideStream* ss = (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || maed_x3_planes())) ? side_stream() : nullptr;
+        void* tst = ss ? (void*)ss->s : stream;
+        if (ss) ss->fence((hipStream_t)stream, ss->s);
+        { ProfScope ps__(PROF_ATTN_TM_FWD, tst); MAED_PROPAGATE(maed_attn_temporal_fwd(B.qkv, B.xt, (float*)(B.lse_t), d->F, d->P, d->H, d->T, scale, dt, tst)); }
+        PROF(PROF_ATTN_SP_FWD, maed_attn_spatial_fwd(B.qkv, B.xs, (float*)(B.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
+        if (ss) ss->fence(ss->s, (hipStream_t)stream);
+    }
+    if (stf) {       // token means + ts_attn Linear + pair softmax + mix: one launch, x_s / x_t read once (elementwise.hip)
+        PROF(PROF_ST_FWD, maed_st_fused_fwd_ws(B.xs, B.xt, p->w_ts, p->b_ts, B.means, logits, B.mix, (uint32_t*)(B.st_sync), (float*)(B.st_ex),
+                                               d->F, d->P, C, dt, !piggy, 0u, stream));
+    } else {
+        MAED_PROPAGATE(maed_st_colmean(B.xs, B.xt, B.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
+        MAED_PROPAGATE(maed_gemm_nt(B.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
+        MAED_PROPAGATE(maed_st_mix_fwd(B.xs, B.xt, logits, B.mix, d->F, d->P, C, dt, stream));
+    }
+    PROF(PROF_GEMM_PROJ, maed_gemm_nt(B.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, B.xmid, C, nullptr, x_in, C, 1, gi, stream));
+    MAED_PROPAGATE(maed_layernorm_fwd((const float*)(B.xmid), C, p->ln2_g, p->ln2_b, B.ln2, dt, (float*)(B.mean2), (float*)(B.rstd2), M, C, d->eps, stream));
+    PROF(PROF_GEMM_FC1, maed_gemm_nt(B.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, B.hact, Hd, for_backward ? B.hpre : nullptr /* only GELU' reads it */, nullptr, 0, 1, gi, stream));
+    PROF(PROF_GEMM_FC2, maed_gemm_nt(B.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, B.xmid, C, 1, gi, stream));
+    return MAED_OK;
+}
+
 static int block_fwd(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved, bool for_backward, void* stream) {
     MAED_PROPAGATE(check_dims(d, "ste_block_fwd"));
     MAED_CHECK_ARG(p && x_in && x_out && saved, MAED_ERR_ARG, "ste_block_fwd: null pointer");
     MAED_CHECK_ARG(is_aligned(saved, 256), MAED_ERR_ALIGN, "ste_block_fwd: saved buffer must be 256-B aligned");
     const SavedLayout L = saved_layout(*d);
-    char* sv = (char*)saved;
-    const int64_t M = (int64_t)d->F * d->P;
-    const int C = d->C, Hd = d->hidden, dt = d->dtype;
-    const int gi = d->impl == MAED_IMPL_VALU ? MAED_IMPL_VALU : MAED_IMPL_AUTO;
-    const float scale = 1.0f / sqrtf((float)HEAD_DIM);
-    float* logits = (float*)(sv + L.logits);
+    return block_fwd_bufs(d, p, x_in, x_out, fwd_bufs((char*)saved, L, (char*)saved, L), for_backward, stream);
+}
 
-    // (the LayerNorm kernel also zeroes the per-frame arrival counters of the fused attentive addition further down: no memset launch of their own)
-    const bool stf = st_fused(*d);
-    const bool piggy = stf && maed_opt(MAED_OPT_ST_FUSED) != 2 && (int64_t)d->F * 16 <= 256 * ((M + 31) / 32);       // (the backward LayerNorm's grid is the smaller one; otherwise the fused call clears itself; option value 2: A/B knob -- memset nodes, LayerNorm column sums on the caller's stream)
-    MAED_PROPAGATE(maed_layernorm_fwd_ws(x_in, C, p->ln1_g, p->ln1_b, sv + L.ln1, dt, (float*)(sv + L.mean1), (float*)(sv + L.rstd1), M, C, d->eps,
-                                         piggy ? (uint32_t*)(sv + L.st_sync) : nullptr, piggy ? d->F * 16 : 0, stream));
-    PROF(PROF_GEMM_QKV, maed_gemm_nt(sv + L.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, sv + L.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
-    {   // the two attention branches read the same qkv and write disjoint outputs: temporal on the side stream beside spatial
-        SideStream* ss = (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || maed_x3_planes())) ? side_stream() : nullptr;
-        void* tst = ss ? (void*)ss->s : stream;
-        if (ss) ss->fence((hipStream_t)stream, ss->s);
-        { ProfScope ps__(PROF_ATTN_TM_FWD, tst); MAED_PROPAGATE(maed_attn_temporal_fwd(sv + L.qkv, sv + L.xt, (float*)(sv + L.lse_t), d->F, d->P, d->H, d->T, scale, dt, tst)); }
-        PROF(PROF_ATTN_SP_FWD, maed_attn_spatial_fwd(sv + L.qkv, sv + L.xs, (float*)(sv + L.lse_s), d->F, d->P, d->H, scale, dt, d->impl, stream));
-        if (ss) ss->fence(ss->s, (hipStream_t)stream);
+// ---- "bf16x3 forward / bf16 backward from bf16 twins" (round 5) -----------------------------------------------------------------------------------------
+// The accurate mode's forward needs fp32 operands (split-bf16 products: north_star's 1e-3 on the outputs); its backward does not -- gradients of the bf16 mode's
+// quality are what the bf16 headline trains with.  So the forward runs on fp32 tensors in a transient work buffer, and what the backward will read is saved as bf16
+// TWINS in the bf16 mode's arena layout: the backward IS the bf16 mode's (maed_ste_block_bwd with dtype MAED_BF16 and bf16 weight images), at its speed, instead of
+// one-plane products on fp32-stored operands (MAED_F32X1: bound by fp32 operand traffic and conversion, 9.2 vs 4.8 ms per step at cfg3).
+struct CastTab { const float* src[12]; bf16* dst[12]; long long n8[12]; };
+__global__ __launch_bounds__(256) void cast_table_kernel(CastTab t) {
+    const float* __restrict__ src = t.src[blockIdx.y];
+    bf16* __restrict__ dst = t.dst[blockIdx.y];
+    const long long n8 = t.n8[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        float v[8];
+        ld8(src + i * 8, v);
+        st8(dst + i * 8, v);
     }
-    if (stf) {       // token means + ts_attn Linear + pair softmax + mix: one launch, x_s / x_t read once (elementwise.hip)
-        PROF(PROF_ST_FWD, maed_st_fused_fwd_ws(sv + L.xs, sv + L.xt, p->w_ts, p->b_ts, sv + L.means, logits, sv + L.mix, (uint32_t*)(sv + L.st_sync), (float*)(sv + L.st_ex),
-                                               d->F, d->P, C, dt, !piggy, 0u, stream));
-    } else {
-        MAED_PROPAGATE(maed_st_colmean(sv + L.xs, sv + L.xt, sv + L.means, logits /* scratch, overwritten below */, d->F, d->P, C, dt, stream));
-        MAED_PROPAGATE(maed_gemm_nt(sv + L.means, 2 * C, p->w_ts, 2 * C, d->F, 2 * C, 2 * C, dt, MAED_EPI_STORE_F32, p->b_ts, logits, 2 * C, nullptr, nullptr, 0, 1, gi, stream));
-        MAED_PROPAGATE(maed_st_mix_fwd(sv + L.xs, sv + L.xt, logits, sv + L.mix, d->F, d->P, C, dt, stream));
-    }
-    PROF(PROF_GEMM_PROJ, maed_gemm_nt(sv + L.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, sv + L.xmid, C, nullptr, x_in, C, 1, gi, stream));
-    MAED_PROPAGATE(maed_layernorm_fwd((const float*)(sv + L.xmid), C, p->ln2_g, p->ln2_b, sv + L.ln2, dt, (float*)(sv + L.mean2), (float*)(sv + L.rstd2), M, C, d->eps, stream));
-    PROF(PROF_GEMM_FC1, maed_gemm_nt(sv + L.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, sv + L.hact, Hd, for_backward ? sv + L.hpre : nullptr /* only GELU' reads it */, nullptr, 0, 1, gi, stream));
-    PROF(PROF_GEMM_FC2, maed_gemm_nt(sv + L.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, sv + L.xmid, C, 1, gi, stream));
+}
+
+extern "C" size_t maed_ste_block_twin_work_bytes(const maed_block_dims* d) {
+    if (!d) return 0;
+    maed_block_dims d32 = *d; d32.dtype = MAED_F32;
+    return saved_layout(d32).total;
+}
+
+extern "C" int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved_bf16, void* work_f32,
+                                       void* stream) {
+    MAED_PROPAGATE(check_dims(d, "ste_block_fwd_twin"));
+    MAED_CHECK_ARG(d->dtype == MAED_F32, MAED_ERR_ARG, "ste_block_fwd_twin: dims describe the FORWARD (dtype MAED_F32); the arena is laid out for MAED_BF16");
+    MAED_CHECK_ARG(p && x_in && x_out && saved_bf16 && work_f32, MAED_ERR_ARG, "ste_block_fwd_twin: null pointer");
+    MAED_CHECK_ARG(is_aligned(saved_bf16, 256) && is_aligned(work_f32, 256), MAED_ERR_ALIGN, "ste_block_fwd_twin: buffers must be 256-B aligned");
+    MAED_CHECK_ARG(d->C % 8 == 0 && d->hidden % 8 == 0, MAED_ERR_SHAPE, "ste_block_fwd_twin: C and hidden must be multiples of 8");
+    maed_block_dims d16 = *d; d16.dtype = MAED_BF16;
+    const SavedLayout L32 = saved_layout(*d), L16 = saved_layout(d16);
+    char* w = (char*)work_f32; char* sv = (char*)saved_bf16;
+    MAED_PROPAGATE(block_fwd_bufs(d, p, x_in, x_out, fwd_bufs(w, L32, sv, L16), true, stream));
+    const long long M = (long long)d->F * d->P, C = d->C, Hd = d->hidden;
+    CastTab t{};
+    int k = 0;
+    auto add = [&](size_t o32, size_t o16, long long n) { t.src[k] = (const float*)(w + o32); t.dst[k] = (bf16*)(sv + o16); t.n8[k] = n / 8; ++k; };
+    add(L32.ln1, L16.ln1, M * C); add(L32.qkv, L16.qkv, M * 3 * C); add(L32.xs, L16.xs, M * C); add(L32.xt, L16.xt, M * C);
+    add(L32.means, L16.means, (long long)d->F * 2 * C); add(L32.mix, L16.mix, M * C); add(L32.ln2, L16.ln2, M * C);
+    add(L32.hpre, L16.hpre, M * Hd); add(L32.hact, L16.hact, M * Hd);
+    hipLaunchKernelGGL(cast_table_kernel, dim3(1024, k), dim3(256), 0, (hipStream_t)stream, t);
+    MAED_CHECK_LAUNCH("ste_block_fwd_twin: cast");
     return MAED_OK;
 }
 

@@ -77,17 +77,62 @@ def bwd_prec(prec):
     return "bf16x3" if prec == "bf16x6" else prec
 
 
+# "bf16": the backward of a compute_dtype = float32 model runs the bf16 MODE's backward on bf16 TWINS of what the forward saved (round 5):
+# the forward keeps fp32 operands (split-bf16 products: the outputs' accuracy), the arena the backward reads holds bf16 copies written behind it.
+_BWD_TWIN = [os.environ.get("MAED_F32_BWD", "") == "bf16"]
+
+
 def set_float32_backward_precision(mode):
     """engine of the BACKWARD matrix products on fp32 tensors: None / "same" = the forward's (bf16x6 -> bf16x3, see bwd_prec), "bf16x1" = ONE bf16 plane per operand,
     one MFMA per product ("bf16x3 forward / bf16 backward", round 4): outputs keep the forward engine's accuracy (1e-3 on SMPL parameters and better), gradients are
     what the bf16 mode computes -- bf16 products, fp32 accumulation -- but from fp32-stored activations.  Process-wide (MAED_OPT_F32_BWD_X1: the fused STE block
-    driver reads it); MAED_F32_BWD=bf16x1 in the environment sets the initial value."""
-    assert mode in (None, "same", "bf16x1"), mode
-    L.set_option(L.OPT_F32_BWD_X1, int(mode == "bf16x1"))
+    driver reads it); MAED_F32_BWD=bf16x1 in the environment sets the initial value.
+    "bf16" (round 5): the backward is the bf16 MODE's, on bf16 twins of the saved activations (STE blocks: maed_ste_block_fwd_twin; backbone: the bf16 autograd graph
+    over fp32 shadow tensors, maed_amd/resnetv2.py) -- bf16 operand traffic and the bf16 kernels instead of one-plane products on fp32 operands; whatever keeps fp32
+    operands in its backward (the few GEMMs outside the blocks and the backbone) uses one plane."""
+    assert mode in (None, "same", "bf16x1", "bf16"), mode
+    L.set_option(L.OPT_F32_BWD_X1, int(mode in ("bf16x1", "bf16")))
+    _BWD_TWIN[0] = mode == "bf16"
 
 
 def get_float32_backward_precision():
-    return "bf16x1" if L.get_option(L.OPT_F32_BWD_X1) else "same"
+    return "bf16" if _BWD_TWIN[0] else "bf16x1" if L.get_option(L.OPT_F32_BWD_X1) else "same"
+
+
+# ---- fp32 shadows of a bf16 autograd graph (the backbone's half of the "bf16" backward mode) ---------------------------------------------------------------
+# The backbone is a chain of per-layer autograd Functions; autograd insists that a gradient has the dtype of the tensor it belongs to.  For a bf16 backward behind an
+# fp32 forward the GRAPH is therefore the bf16 mode's: every tensor autograd sees is the bf16 twin, and the fp32 tensor the forward chain really computes with travels
+# beside it in this registry (data pointer of the twin -> (twin, fp32 shadow); the twin is held too, so its address cannot be recycled while the entry lives).  A
+# Function's forward looks its inputs' shadows up, computes in fp32 (split-bf16 products), registers its output's shadow and SAVES THE TWINS; its backward is the bf16
+# mode's, untouched.  The registry is emptied when the backbone's output has been consumed (HybridEmbed) -- the fp32 activations are transient.
+_SHADOW = {}
+TWIN_FORWARDS = [0]      # twin forwards taken (tests / bench.py assert that the mode they time is the mode that ran)
+
+
+def shadow_put(t16, t32):
+    _SHADOW[t16.data_ptr()] = (t16, t32)
+    return t16
+
+
+def shadow_of(t):
+    if not _SHADOW or t is None or t.dtype != torch.bfloat16:
+        return None
+    e = _SHADOW.get(t.data_ptr())
+    return e[1] if e is not None and e[0].numel() == t.numel() else None
+
+
+def shadow_clear():
+    _SHADOW.clear()
+
+
+def twin_of(y32):
+    """bf16 twin of an fp32 forward result, registered with its shadow (one cast pass; candidates for a second store in the producer's epilogue)"""
+    return shadow_put(y32.to(torch.bfloat16), y32)
+
+
+def bwd_twin():
+    """True: compute_dtype = float32 modules save bf16 twins and run the bf16 mode's backward (needs the split-bf16 forward engine)"""
+    return _BWD_TWIN[0] and f32_split()
 
 
 def mm_code(dtype, prec=None):
@@ -482,12 +527,15 @@ class LinearFn(torch.autograd.Function):
         (wc, wt), = cache.get([weight], x.dtype)
         ctx.save_for_backward(x, weight, bias)
         ctx.wt = wt
+        x32 = shadow_of(x)
+        if x32 is not None:     # bf16 graph over fp32 shadows: the product on the fp32 operands (fp32 master weight, split-bf16 engine), an fp32 result; the backward stays bf16
+            return gemm_nt(_c(x32), _c(weight.detach()), L.EPI_STORE, bias=bias)
         return gemm_nt(_c(x), wc, L.EPI_STORE, bias=bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
-        dy = _c(dy)
+        dy = _c(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         db = torch.zeros_like(bias) if bias is not None else None
         if lib_matmul_dtype(dy.dtype) and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0:
             dW = gemm_tn_wgrad(dy, x, dbias=db)
@@ -560,13 +608,24 @@ class STEBlockFn(ReportingFn):
         lib = L.lib()
         x = _c(x)
         d = L.BlockDims(*dims)
-        pr = block._c_params(x.dtype if False else block.compute_dtype)
-        saved = _aligned_bytes(lib.maed_ste_block_saved_bytes(C.byref(d)), x.device)
         y = torch.empty_like(x)
-        # no backward will follow (torch.no_grad / nothing requires grad): the inference entry point leaves out what only the backward reads
-        entry = lib.maed_ste_block_fwd if ReportingFn.will_run_backward(ctx) else lib.maed_ste_block_infer
-        check(entry(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _stream()), "ste_block_fwd")
-        ctx.block, ctx.dims = block, dims
+        # fp32 forward, bf16 twins for the backward (set_float32_backward_precision("bf16")): the arena has the bf16 block's layout, the backward its dims
+        twin = block.compute_dtype == torch.float32 and bwd_twin() and ReportingFn.will_run_backward(ctx) and dims[7] != L.IMPL_VALU and dims[2] % 8 == 0 and dims[5] % 8 == 0
+        if twin:
+            dims = dims[:6] + (BF16,) + dims[7:]
+            d16 = L.BlockDims(*dims)
+            pr = block._c_params_masters()
+            saved = _aligned_bytes(lib.maed_ste_block_saved_bytes(C.byref(d16)), x.device)
+            work = _scratch(lib.maed_ste_block_twin_work_bytes(C.byref(d)), x.device)
+            check(lib.maed_ste_block_fwd_twin(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _p(work), _stream()), "ste_block_fwd_twin")
+            TWIN_FORWARDS[0] += 1
+        else:
+            pr = block._c_params(block.compute_dtype)
+            saved = _aligned_bytes(lib.maed_ste_block_saved_bytes(C.byref(d)), x.device)
+            # no backward will follow (torch.no_grad / nothing requires grad): the inference entry point leaves out what only the backward reads
+            entry = lib.maed_ste_block_fwd if ReportingFn.will_run_backward(ctx) else lib.maed_ste_block_infer
+            check(entry(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _stream()), "ste_block_fwd")
+        ctx.block, ctx.dims, ctx.bdt = block, dims, (torch.bfloat16 if twin else block.compute_dtype)
         ctx.save_for_backward(x, saved)
         # a hand-off left by the LAST block of an earlier backward pass (nobody consumes block 0's) is stale once a new forward runs: dropping it here frees its tensor
         _TWIN[0], _TWIN[1], _TWIN[2] = None, None, None
@@ -580,13 +639,13 @@ class STEBlockFn(ReportingFn):
         x, saved = ctx.saved_tensors
         block = ctx.block
         d = L.BlockDims(*ctx.dims)
-        pr = block._c_params(block.compute_dtype)
+        cdt = ctx.bdt           # dtype of the backward's operands: the block's compute dtype, or bf16 behind a twin forward
+        pr = block._c_params(cdt, backward=True)
         gr = block._c_grads()
         dy = _c(dy)
         dx = torch.empty_like(dy)
         scratch = _scratch(lib.maed_ste_block_scratch_bytes(C.byref(d)), dy.device)
         # consecutive blocks hand the compute-dtype copy of the residual gradient along (no cast pass in between)
-        cdt = block.compute_dtype
         tw_in = None
         if cdt != torch.float32:
             ref, cand, producer = _TWIN
@@ -752,10 +811,14 @@ class GroupNormFn(torch.autograd.Function):
         its 52 layers instead of one memset per layer and direction).  stats_ready: `sums` already holds the statistics of x (the
         producing convolution's epilogue accumulated them: Conv1x1Fn / Conv3x3Fn gn_sums) -- no statistics pass."""
         N, C_, H, W = x.shape
+        x32 = shadow_of(x)                       # bf16 graph over fp32 shadows (shadow_put): the forward runs on the shadows, the twins are what is saved
+        r32 = shadow_of(residual) if x32 is not None else None
+        assert x32 is None or residual is None or r32 is not None, "GroupNormFn: the residual of a shadowed input has no shadow"
         x = x.contiguous(memory_format=torch.channels_last)
         if residual is not None:
             residual = residual.contiguous(memory_format=torch.channels_last).to(x.dtype)
-        y = torch.empty_like(x, memory_format=torch.channels_last)
+        xin, rin = (x, residual) if x32 is None else (x32.contiguous(memory_format=torch.channels_last), r32)
+        y = torch.empty_like(xin, memory_format=torch.channels_last)
         zeroed = sums is not None
         if sums is None:
             sums = torch.empty(N, 32, 2, dtype=torch.float64, device=x.device)
@@ -763,8 +826,10 @@ class GroupNormFn(torch.autograd.Function):
         # ReLU after a residual add: the backward cannot recompute the mask from x -> 1 bit per element instead of re-reading y
         need_mask = relu and ctx.has_res and (x.requires_grad or residual.requires_grad or gamma.requires_grad)
         mask = torch.empty(N * H * W * (C_ // 8), dtype=torch.uint8, device=x.device) if need_mask else None
-        check(L.lib().maed_groupnorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(sums), _p(mask), N, H * W, C_, eps, int(relu),
-                                         dt_code(x.dtype), 2 if (stats_ready and zeroed) else int(zeroed), _stream()), "groupnorm_fwd")
+        check(L.lib().maed_groupnorm_fwd(_p(xin), _p(rin), _p(gamma), _p(beta), _p(y), _p(sums), _p(mask), N, H * W, C_, eps, int(relu),
+                                         dt_code(xin.dtype), 2 if (stats_ready and zeroed) else int(zeroed), _stream()), "groupnorm_fwd")
+        if x32 is not None:
+            y = twin_of(y)
         ctx.ab = ab
         ctx.sync = sync if ab is not None else None      # N * GN_SYNC_WORDS zero words (any 4-byte dtype): frame_sync of the one-pass backward, single use like ab
         ctx.save_for_backward(x, mask, sums)
@@ -847,11 +912,16 @@ class StemConvFn(torch.autograd.Function):
         assert xp.shape[1] == 4 and xp.shape[2] == H + 5 and xp.shape[3] == W + 6 and xp.dtype == torch.bfloat16 and w.shape[0] == 64 and w.shape[2:] == (7, 7), (xp.shape, w.shape)
         wc = w.permute(0, 2, 3, 1)
         assert wc.is_contiguous() and wc.shape[3] == 3, "stem: the standardised weight must be the channels_last (64, 7, 7, 3) image"
+        ctx.save_for_backward(xp)
+        ctx.dw, ctx.hw = dw, hw
+        x32 = shadow_of(xp)
+        if x32 is not None:     # bf16 graph over fp32 shadows: x32 is the TF-SAME padded fp32 image (stem_input own=False); the vendor's fp32 convolution as in the f32 modes
+            assert sums is None, "stem: the GroupNorm behind a shadowed stem computes its own statistics"
+            w32 = shadow_of(w)
+            return twin_of(torch.nn.functional.conv2d(x32, w32, None, 2, 0))
         y = torch.empty((F_, 64, H // 2, W // 2), dtype=xp.dtype, device=xp.device, memory_format=torch.channels_last)
         wimg = torch.empty(64 * 224, dtype=xp.dtype, device=xp.device)
         check(L.lib().maed_stem7x7s2_fwd(_p(xp), _p(wc), _p(wimg), _p(y), _p(sums), F_, H, W, dt_code(xp.dtype), _stream()), "stem7x7s2_fwd")
-        ctx.save_for_backward(xp)
-        ctx.dw, ctx.hw = dw, hw
         return y
 
     @staticmethod
@@ -873,14 +943,15 @@ class MaxPool3s2SameFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         N, C_, H, W = x.shape
-        x = x.contiguous(memory_format=torch.channels_last)
+        x32 = shadow_of(x)
+        x = (x if x32 is None else x32).contiguous(memory_format=torch.channels_last)
         Ho, Wo = (H + 1) // 2, (W + 1) // 2
         y = torch.empty((N, C_, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         idx = torch.empty(N * Ho * Wo * C_, dtype=torch.uint8, device=x.device)
         check(L.lib().maed_maxpool3s2_same_fwd(_p(x), _p(y), _p(idx), N, H, W, C_, dt_code(x.dtype), _stream()), "maxpool3s2_same_fwd")
         ctx.save_for_backward(idx)
         ctx.geom = (N, C_, H, W)
-        return y
+        return y if x32 is None else twin_of(y)
 
     @staticmethod
     def backward(ctx, dy):
@@ -911,31 +982,47 @@ class Conv1x1Fn(torch.autograd.Function):
         stride=2 (the downsample shortcuts of stages 2 and 3): the pixels the convolution reads are packed first (maed_subsample2_fwd),
         all three GEMMs then run on a quarter of the rows and the input gradient is spread back in one write pass."""
         N, I, H, W = x.shape
+        x32, w32 = shadow_of(x), shadow_of(w)   # bf16 graph over fp32 shadows (shadow_put): the product runs on the fp32 operands, the bf16 operands are what is saved
+        assert (x32 is None) == (w32 is None), "Conv1x1Fn: activation and weight must both (or neither) have fp32 shadows"
         x = x.contiguous(memory_format=torch.channels_last)
         O = w.shape[0]
-        w2 = w.reshape(O, I)
-        w2 = w2 if w2.is_contiguous() else w2.contiguous()
-        Ho, Wo = H, W
-        if stride == 2:
-            assert not fork
-            Ho, Wo = (H + 1) // 2, (W + 1) // 2
-            A = torch.empty(N * Ho * Wo, I, dtype=x.dtype, device=x.device)
-            check(L.lib().maed_subsample2_fwd(_p(x), _p(A), N, H, W, I, dt_code(x.dtype), _stream()), "subsample2_fwd")
-        else:
+        Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
+
+        def rows_of(t):
+            if stride == 2:
+                assert not fork
+                A_ = torch.empty(N * Ho * Wo, I, dtype=t.dtype, device=t.device)
+                check(L.lib().maed_subsample2_fwd(_p(t), _p(A_), N, H, W, I, dt_code(t.dtype), _stream()), "subsample2_fwd")
+                return A_
             assert stride == 1
-            A = x.permute(0, 2, 3, 1).reshape(N * H * W, I)
-        if gn_sums is not None:
-            y = torch.empty(N * Ho * Wo, O, dtype=x.dtype, device=x.device)
-            check(L.lib().maed_conv1x1_fwd(_p(A), A.stride(0), _p(w2), w2.stride(0), N * Ho * Wo, O, I, _p(y), O, Ho * Wo, _p(gn_sums), mm_code(x.dtype, prec),
-                                           _stream()), "conv1x1_fwd")
+            return t.permute(0, 2, 3, 1).reshape(N * H * W, I)
+
+        def product(A_, w_):
+            w2 = w_.reshape(O, I)
+            w2 = w2 if w2.is_contiguous() else w2.contiguous()
+            if gn_sums is not None:
+                y_ = torch.empty(N * Ho * Wo, O, dtype=A_.dtype, device=A_.device)
+                check(L.lib().maed_conv1x1_fwd(_p(A_), A_.stride(0), _p(w2), w2.stride(0), N * Ho * Wo, O, I, _p(y_), O, Ho * Wo, _p(gn_sums), mm_code(A_.dtype, prec),
+                                               _stream()), "conv1x1_fwd")
+                return y_
+            return gemm_nt(A_, w2, L.EPI_STORE, prec=prec)
+
+        A = rows_of(x)
+        if x32 is not None:
+            y32 = product(rows_of(x32.contiguous(memory_format=torch.channels_last)), w32).view(N, Ho, Wo, O).permute(0, 3, 1, 2)
+            y = twin_of(y32)
         else:
-            y = gemm_nt(A, w2, L.EPI_STORE, prec=prec)
+            y = product(A, w).view(N, Ho, Wo, O).permute(0, 3, 1, 2)
         ctx.save_for_backward(A, wt)
         ctx.dw, ctx.geom, ctx.stride, ctx.prec = dw, (N, I, H, W, O, Ho, Wo), stride, prec
         ctx.lazy_short = bool(lazy_short) and fork      # the shortcut's gradient will arrive unmasked, its ReLU bits registered in LAZY_RES
         ctx.set_materialize_grads(False)
-        y = y.view(N, Ho, Wo, O).permute(0, 3, 1, 2)
-        return (y, x.view_as(x)) if fork else y
+        if not fork:
+            return y
+        xa = x.view_as(x)
+        if x32 is not None:
+            shadow_put(xa, x32)     # (same address as x: the entry now holds the alias -- x itself stays alive as long as the alias does)
+        return y, xa
 
     @staticmethod
     def backward(ctx, dy, g_short=None):
@@ -1077,11 +1164,15 @@ class Conv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, stride, wt=None, dw=None, gn_sums=None, prec=None):
+        x32, w32 = shadow_of(x), shadow_of(w)   # bf16 graph over fp32 shadows: see Conv1x1Fn
+        assert (x32 is None) == (w32 is None), "Conv3x3Fn: activation and weight must both (or neither) have fp32 shadows"
         x = x.contiguous(memory_format=torch.channels_last)
-        w_taps = w.permute(0, 2, 3, 1)
-        w_taps = w_taps if w_taps.is_contiguous() else w_taps.contiguous()
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.wt, ctx.dw, ctx.prec = stride, wt, dw, prec
+        w_taps = (w if w32 is None else w32).permute(0, 2, 3, 1)
+        w_taps = w_taps if w_taps.is_contiguous() else w_taps.contiguous()
+        if x32 is not None:
+            return twin_of(conv3x3(x32, w_taps, stride, gn_sums=gn_sums, prec=prec))
         return conv3x3(x, w_taps, stride, gn_sums=gn_sums, prec=prec)
 
     @staticmethod

@@ -152,7 +152,8 @@ class StdConv2dSame(nn.Conv2d):
             # the stem on the library (ops.StemConvFn): x is the 4-channel padded image of ops.stem_input(own=True); statistics of the norm behind from the epilogue
             gn = self._gn_behind[0] if self._gn_behind else None
             sums = None
-            if gn is not None and _FUSE_GN_STATS and gn._sums_buf is not None and gn.num_groups == 32 and self.out_channels == 64:
+            # (a shadowed input -- the "bf16" backward mode's fp32 forward -- runs the vendor's fp32 convolution: the norm behind computes its own statistics)
+            if ops.shadow_of(x) is None and gn is not None and _FUSE_GN_STATS and gn._sums_buf is not None and gn.num_groups == 32 and self.out_channels == 64:
                 gn._stats_ready, sums = True, gn._sums_buf
             return ops.StemConvFn.apply(x, w, self._dw, sums, self._stem_hw)
         if self._prepadded:
@@ -352,6 +353,9 @@ class ResNetV2(nn.Module):
         # out of memory, an unsupported size -- must not leave the stem marked "pre-padded" (the next forward would convolve an unpadded image: silently wrong)
         try:
             return self._forward_features_library(x)
+        except BaseException:
+            ops.shadow_clear()
+            raise
         finally:
             _slots(self.stem.conv, _prepadded=False, _stem_hw=None)
             self._own_stem_now = []
@@ -362,17 +366,33 @@ class ResNetV2(nn.Module):
 
     def _forward_features_library(self, x):
         stem = self.stem.conv
-        if (x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] <= 4 and not x.requires_grad and os.environ.get("MAED_STEM_INPUT", "1") == "1"
-                and stem.dilation == (1, 1) and stem.kernel_size[0] == stem.kernel_size[1]):
+        cdt = self.compute_dtype
+        stem_fused = (x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] <= 4 and not x.requires_grad and os.environ.get("MAED_STEM_INPUT", "1") == "1"
+                      and stem.dilation == (1, 1) and stem.kernel_size[0] == stem.kernel_size[1])
+        own_ok = (os.environ.get("MAED_STEM_OWN", "1") == "1" and stem.kernel_size == (7, 7) and stem.stride == (2, 2)
+                  and stem.in_channels <= 3 and stem.out_channels == 64 and stem.groups == 1 and ops.stem7x7s2_supported(x.shape[2], x.shape[3], x.shape[0]))
+        # "bf16x3 forward / bf16 backward from bf16 twins" (ops.set_float32_backward_precision("bf16")): the autograd graph of this pass is the bf16 mode's -- every
+        # tensor autograd sees is a bf16 twin, the fp32 tensors the forward chain computes with travel beside them as shadows (ops.shadow_put).  Training passes of an
+        # fp32 model only; anything the bf16 graph cannot express here (no fused stem input, a frame size the library's stem does not take) keeps the one-plane backward.
+        # (every convolution must be one of the library's: a layer on the framework's convolution would produce a bf16 tensor without a shadow)
+        twin = (cdt == torch.float32 and ops.bwd_twin() and torch.is_grad_enabled() and stem_fused and own_ok
+                and len(set(self._gemm_convs) | set(self._own3x3) | {0}) == len(self._convs) and any(p.requires_grad for p in self.fused_parameters()))
+        ops.shadow_clear()
+        if twin:
+            cdt = torch.bfloat16
+            ops.TWIN_FORWARDS[0] += 1
+        if stem_fused:
             # cast + channels_last + the stem's TF-SAME padding in one pass (the framework: three); the stem convolution below sees an already padded image
-            own = (self.compute_dtype == torch.bfloat16 and os.environ.get("MAED_STEM_OWN", "1") == "1" and stem.kernel_size == (7, 7) and stem.stride == (2, 2)
-                   and stem.in_channels <= 3 and stem.out_channels == 64 and stem.groups == 1 and ops.stem7x7s2_supported(x.shape[2], x.shape[3], x.shape[0]))
+            own = cdt == torch.bfloat16 and own_ok
             self._own_stem_now = [0] if own else []
             _slots(stem, _prepadded="own" if own else True, _stem_hw=(x.shape[2], x.shape[3]))
-            x = ops.stem_input(x, self.compute_dtype, stem.kernel_size[0], stem.stride[0], own=own)
+            x32p = ops.stem_input(x, torch.float32, stem.kernel_size[0], stem.stride[0], own=False) if twin else None
+            x = ops.stem_input(x, cdt, stem.kernel_size[0], stem.stride[0], own=own)
+            if twin:
+                ops.shadow_put(x, x32p)
         else:
-            x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
-        ws = None if _ws_per_stage() else ops.WeightStdFn.apply(self, self.compute_dtype, self._convs[0].eps, *self.conv_weights())
+            x = x.to(dtype=cdt, memory_format=torch.channels_last)
+        ws = None if _ws_per_stage() else self._standardise(self, cdt, twin)
         # GroupNorm scratch for all layers of this pass: ONE zero-fill each instead of a memset per layer and direction
         N = x.shape[0]
         sums = torch.zeros(len(self._norms), N, 32, 2, dtype=torch.float64, device=x.device)
@@ -396,7 +416,7 @@ class ResNetV2(nn.Module):
         if ws is not None:
             return self.stages(self.stem(x))
         for gi, g in enumerate(self._ws_groups):       # standardise a stage's weights right before it runs: its autograd node
-            wg = ops.WeightStdFn.apply(g, self.compute_dtype, self._convs[0].eps, *g.conv_weights())   # then fires right after its backward
+            wg = self._standardise(g, cdt, twin)                                                       # then fires right after its backward
             for k, (ci, w) in enumerate(zip(g.conv_idx, wg)):
                 c = self._convs[ci]
                 _slots(c, _w_std=w, _w_t=g._w_std_t.get(k), _dw=g._dw_slices.get(k), _prec=self.f32_matmul)
@@ -406,6 +426,20 @@ class ResNetV2(nn.Module):
         for k, g in enumerate(self._ws_groups):
             g._ws_on_side = bool(runs) and g is not runs[0] and g in runs
         return x
+
+    def _standardise(self, owner, cdt, twin):
+        """the batched weight standardisation of `owner` (the backbone or one stage group) in the pass's dtype; twin: + the fp32 images of the same weights for the
+        forward products, registered as the shadows of the bf16 ones (no autograd node, no transposed images, no gradient slices: the backward is the bf16 graph's)"""
+        eps = self._convs[0].eps
+        ws = ops.WeightStdFn.apply(owner, cdt, eps, *owner.conv_weights())
+        if twin:
+            import types
+            with torch.no_grad():
+                ws32 = ops.WeightStdFn.apply(types.SimpleNamespace(_direct_convs=[], f32_matmul=self.f32_matmul, _pending_backwards=0), torch.float32, eps,
+                                             *[w.detach() for w in owner.conv_weights()])
+            for w16, w32 in zip(ws, ws32):
+                ops.shadow_put(w16, w32)
+        return ws
 
     def forward(self, x, seqlen=8):
         return self.forward_features(x)

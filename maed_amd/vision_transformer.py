@@ -150,9 +150,22 @@ class Block(nn.Module):
             self.__dict__["_hot_cache"] = c
         return c
 
-    def _c_params(self, dtype):
+    def _c_params_masters(self):
+        """parameters of a FORWARD on the fp32 masters themselves (no images: the forward reads w_* only) -- the twin forward of ops.STEBlockFn"""
         lin, weights, biases, ln, _ = self._hot()
-        w = self._cache.get(weights, dtype)
+        p = L.BlockParams()
+        p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b = ln[0].data_ptr(), ln[1].data_ptr(), ln[2].data_ptr(), ln[3].data_ptr()
+        for name, b, w in zip(_LIN_FIELDS, biases, weights):
+            assert w.is_contiguous()
+            setattr(p, name[0], w.data_ptr())
+            setattr(p, name[2], b.data_ptr() if b is not None else None)
+        return p
+
+    def _c_params(self, dtype, backward=False):
+        lin, weights, biases, ln, _ = self._hot()
+        # (a backward in another dtype than the forward's -- bf16 twins behind an fp32 forward -- has its own image cache: one cache holds one dtype)
+        cache = self._cache if (not backward or dtype == self.compute_dtype) else self.__dict__.setdefault("_cache_bwd", ops.WeightCache())
+        w = cache.get(weights, dtype)
         self.__dict__["_keep"] = w
         p = L.BlockParams()
         p.ln1_g, p.ln1_b, p.ln2_g, p.ln2_b = ln[0].data_ptr(), ln[1].data_ptr(), ln[2].data_ptr(), ln[3].data_ptr()
@@ -214,7 +227,13 @@ class HybridEmbed(nn.Module):
         f = self.backbone(x)                                      # (F, Cin, h, w) channels_last on GPU
         Fr, Cin, h, w = f.shape
         a = f.permute(0, 2, 3, 1).reshape(Fr * h * w, Cin)         # a view when f is channels_last
-        y = ops.LinearFn.apply(a, self.proj.weight.view(self.proj.out_channels, Cin), self.proj.bias, self._cache)
+        f32 = ops.shadow_of(f)                                     # "bf16" backward mode: f is the bf16 twin autograd sees, its fp32 shadow is the operand
+        if f32 is not None:
+            ops.shadow_put(a, f32.permute(0, 2, 3, 1).reshape(Fr * h * w, Cin))
+        try:
+            y = ops.LinearFn.apply(a, self.proj.weight.view(self.proj.out_channels, Cin), self.proj.bias, self._cache)
+        finally:
+            ops.shadow_clear()                                     # the backbone's fp32 activations were transient: everything behind the projection is fp32 anyway
         return y.view(Fr, h * w, -1)
 
 

@@ -59,7 +59,7 @@ def test_attn_temporal_fwd_bwd(dtype, N, T, P, H):
 
 
 @pytest.mark.parametrize("dtype,f32_mode,rows", [(torch.float32, "exact", 9), (torch.float32, "bf16x3", 20), (torch.float32, "bf16x6", 9), (torch.bfloat16, "exact", 9),
-                                                 (torch.bfloat16, "exact", 20), (torch.float32, "bf16x3+bwd:bf16x1", 20)])
+                                                 (torch.bfloat16, "exact", 20), (torch.float32, "bf16x3+bwd:bf16x1", 20), (torch.float32, "bf16x3+bwd:bf16", 20)])
 def test_ste_block_forward_backward_vs_oracle(dtype, f32_mode, rows):
     """one whole Block through maed_ste_block_fwd/bwd (vision_transformer.py:244-261) incl. every parameter gradient: f32 parity mode (exact VALU
     kernels + transposed copies), f32 on the split-bf16 MFMA kernels (bf16x3 / bf16x6: the bf16 mode's kernel sequence on fp32 operands) and the
@@ -82,13 +82,16 @@ def test_ste_block_forward_backward_vs_oracle(dtype, f32_mode, rows):
     blk.load_state_dict(p)
     xg = x.clone().requires_grad_(True)
     old = ops.get_float32_matmul_precision()
-    f32_mode, _, bwd = f32_mode.partition("+bwd:")          # "bf16x3+bwd:bf16x1" = the mixed mode of round 4: split forward, one-plane backward products
+    f32_mode, _, bwd = f32_mode.partition("+bwd:")          # "bf16x3+bwd:bf16x1" = the mixed mode of round 4: split forward, one-plane backward products;
+                                                            # "+bwd:bf16" (round 5): split forward into an fp32 work buffer, bf16 twins saved, the bf16 mode's backward on them
     try:
         ops.set_float32_matmul_precision(f32_mode)
         ops.set_float32_backward_precision(bwd or None)
+        twins = ops.TWIN_FORWARDS[0]
         with patched():
             y = blk(xg, T)
             y.backward(dy)
+        assert (ops.TWIN_FORWARDS[0] - twins == 1) == (bwd == "bf16")
     finally:
         ops.set_float32_matmul_precision(old)
         ops.set_float32_backward_precision(None)

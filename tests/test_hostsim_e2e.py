@@ -23,9 +23,9 @@ pytestmark = pytest.mark.skipif(os.environ.get("MAED_SLOW_TESTS") != "1", reason
 class TinyMAED(nn.Module):
     """maed_amd.MAED (lib/models/maed.py:52-67) with a (1,1,1) backbone at 32x32 instead of the R50 at 224x224"""
 
-    def __init__(self, dtype):
+    def __init__(self, dtype, channels=(128, 256, 512)):
         super().__init__()
-        bb = ResNetV2(layers=(1, 1, 1), channels=(128, 256, 512), in_chans=3, compute_dtype=dtype)
+        bb = ResNetV2(layers=(1, 1, 1), channels=channels, in_chans=3, compute_dtype=dtype)
         self.encoder = VisionTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, hybrid_backbone=bb, mlp_ratio=4,
                                          qkv_bias=True, representation_size=128, norm_layer=partial(nn.LayerNorm, eps=1e-6),
                                          st_mode="parallel", num_classes=-1, compute_dtype=dtype)
@@ -37,10 +37,29 @@ class TinyMAED(nn.Module):
         return {k: v.reshape(n, t, *v.shape[1:]) for k, v in out.items()}
 
 
-def test_train_steps_end_to_end_on_the_simulator():
+@pytest.mark.parametrize("mode", ["bf16", "f32:bf16x3+bwd:bf16"])
+def test_train_steps_end_to_end_on_the_simulator(mode):
+    """mode "f32:bf16x3+bwd:bf16" (round 5): the accurate mode's forward (fp32 operands, split-bf16 products) with the bf16 mode's backward on bf16 twins --
+    backbone (bf16 autograd graph over fp32 shadows), projection (bf16 input twin, fp32 output) and STE blocks (maed_ste_block_fwd_twin) composed"""
+    from maed_amd import ops
+    twin = mode != "bf16"
+    if twin:
+        ops.set_float32_matmul_precision("bf16x3")
+        ops.set_float32_backward_precision("bf16")
+    try:
+        _train_steps(torch.float32 if twin else torch.bfloat16, twin)
+    finally:
+        ops.set_float32_matmul_precision("exact")
+        ops.set_float32_backward_precision(None)
+
+
+def _train_steps(dtype, twin):
+    from maed_amd import ops
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1)
-    model = TinyMAED(torch.bfloat16).train()
+    # (twin mode needs every convolution on the library's kernels: channel counts that are multiples of 64 from the first bottleneck on)
+    model = TinyMAED(dtype, (256, 512, 1024) if twin else (128, 256, 512)).train()
+    n_twin = ops.TWIN_FORWARDS[0]
     N, T = 2, 2
     clip = torch.randn(N, T, 3, 32, 32, generator=g)
     tgt = dict(images=clip, kp_2d=torch.cat([torch.randn(N, T, 49, 2, generator=g) * 0.3, torch.rand(N, T, 49, 1, generator=g)], -1),
@@ -57,6 +76,8 @@ def test_train_steps_end_to_end_on_the_simulator():
         for _ in range(3):
             total, terms = step(target_3d=tgt)
             totals.append(float(total.detach()))
+    assert ops.TWIN_FORWARDS[0] - n_twin == (3 * 3 if twin else 0)      # per step: the backbone + two STE blocks
+    assert not ops._SHADOW, "fp32 shadows must not outlive the forward"
     assert all(torch.isfinite(torch.tensor(totals))), totals
     assert totals[-1] < totals[0], totals                              # three Adam steps on one batch must reduce its loss
     assert bool(torch.isfinite(arena.flat).all())

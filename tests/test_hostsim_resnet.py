@@ -302,3 +302,49 @@ def test_stem_convolution_on_the_library_when_the_frame_geometry_allows(own, mon
     assert cos(ys.float(), yr.detach()) > 0.999
     for (n, p), q in zip(sim.named_parameters(), ref.parameters()):
         assert p.grad is not None and cos(p.grad, q.grad) > 0.97, (n, cos(p.grad, q.grad))
+
+
+def test_backbone_twin_mode_fp32_forward_on_shadows_bf16_backward_on_twins(monkeypatch):
+    """round 5, ops.set_float32_backward_precision("bf16"): a compute_dtype = float32 backbone in a training pass runs the bf16 mode's AUTOGRAD GRAPH (own stem,
+    GEMM / implicit-GEMM convolutions, fused GroupNorm, bit masks, fp32 dW slices) over bf16 twins while the forward chain computes on fp32 shadows with the
+    split-bf16 products: the output's shadow agrees with the fp32 ATen composition at the split engine's level (the bf16 mode: cosine 0.999), the twin is its bf16
+    rounding, every parameter gradient is what the bf16 mode delivers, and a no-grad pass of the same module stays the plain fp32 path."""
+    from maed_amd import ops
+    torch.manual_seed(5)
+    ref = ResNetV2(layers=(1, 1), channels=(256, 512), in_chans=3, compute_dtype=torch.float32)
+    for m in ref._norms:
+        torch.nn.init.normal_(m.weight, 1.0, 0.2); torch.nn.init.normal_(m.bias, 0.0, 0.2)
+    sim = copy.deepcopy(ref)
+    x = torch.randn(2, 3, 64, 64)
+    yr = ref(x)
+    gout = torch.randn_like(yr)
+    (yr * gout).sum().backward()
+    old = ops.get_float32_matmul_precision()
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    try:
+        ops.set_float32_matmul_precision("bf16x3")
+        ops.set_float32_backward_precision("bf16")
+        with patched():
+            n0 = ops.TWIN_FORWARDS[0]
+            ys = sim(x)
+            assert ops.TWIN_FORWARDS[0] == n0 + 1 and ys.dtype == torch.bfloat16
+            y32 = ops.shadow_of(ys)
+            assert y32 is not None and y32.dtype == torch.float32
+            assert rel(y32, yr.detach()) <= 2e-4, rel(y32, yr.detach())
+            assert torch.equal(ys, y32.to(torch.bfloat16))
+            ops.shadow_clear()
+            (ys.float() * gout).sum().backward()
+            assert sim._own_stem_now == [] and sim.stem.conv._prepadded is False
+            with torch.no_grad():
+                yn = sim(x)
+            assert yn.dtype == torch.float32 and ops.TWIN_FORWARDS[0] == n0 + 1 and rel(yn, yr.detach()) <= 2e-4
+    finally:
+        ops.set_float32_matmul_precision(old)
+        ops.set_float32_backward_precision(None)
+    worst = 1.0
+    for (n, p), q in zip(sim.named_parameters(), ref.parameters()):
+        assert p.grad is not None, n
+        c = cos(p.grad, q.grad)
+        worst = min(worst, c)
+        assert c > 0.97, (n, c)
+    print(f"twin mode: output shadow rel-to-max {rel(y32, yr.detach()):.2e}, worst parameter-gradient cosine {worst:.4f}")
