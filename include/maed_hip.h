@@ -243,9 +243,12 @@ int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, con
  * engine (MAED_OPT_F32_MATMUL; p->w_* = the fp32 master weights, wt_* unused), written to the transient `work_f32` (maed_ste_block_twin_work_bytes).  What the
  * backward reads is saved to `saved_bf16` in the layout of a MAED_BF16 block (maed_ste_block_saved_bytes of the same dims with dtype MAED_BF16): bf16 twins of the
  * activations, the fp32 statistics as they are.  The backward is then maed_ste_block_bwd with dtype MAED_BF16 and bf16 weight images on that arena -- the throughput
- * mode's backward behind the accurate mode's forward.  Same reference lines as maed_ste_block_fwd. */
+ * mode's backward behind the accurate mode's forward.  The cast pass that writes the twins runs on a side stream beside the NEXT block's forward: consecutive calls
+ * alternate work_slot 0 / 1 and give each slot its own work buffer (a slot's buffer is reused only after the cast that read it; maed_ste_block_bwd waits for the
+ * outstanding casts).  Same reference lines as maed_ste_block_fwd. */
 size_t maed_ste_block_twin_work_bytes(const maed_block_dims* d);
-int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved_bf16, void* work_f32, void* stream);
+int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved_bf16, void* work_f32, int work_slot,
+                            void* stream);
 /* the same forward when no backward will follow (inference): `work` = maed_ste_block_saved_bytes of scratch; what only the backward would read
  * (fc1's pre-activation: 103 MB per block at cfg3) is not written.  x_out may alias x_in. */
 int maed_ste_block_infer(const maed_block_dims* d, const maed_block_params* p, const float* x_in,
@@ -399,6 +402,10 @@ int maed_weight_std_bwd(const void* conv_table, int n_convs, int n_filters, int 
  * convolution's epilogue (maed_conv1x1_fwd / maed_conv3x3_fwd gn_sums) -- and the statistics pass over x is skipped. */
 int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
                        uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream);
+/* maed_groupnorm_fwd on fp32 tensors that ALSO writes bf16 twins of its input (twin_x, may be NULL) and of its result (twin_y, may be NULL), same shapes: what a
+ * bf16 backward reads behind an fp32 forward ("bf16x3 forward / bf16 backward from bf16 twins", maed_amd/resnetv2.py).  resnetv2.py:35-49. */
+int maed_groupnorm_fwd_twin(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
+                            uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int sums_zeroed, void* twin_x, void* twin_y, void* stream);
 /* relu_mask (N*HW*C/8 bytes, bit j of byte (n,hw,c/8) = output channel 8*(c/8)+j > 0): written by forward when a residual is
  * added before the ReLU (optional: inference passes NULL), required by backward in that case -- without a residual the mask is
  * recomputed from x.  16x less traffic than re-reading the saved output in both backward passes.

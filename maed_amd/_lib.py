@@ -86,7 +86,7 @@ SIGNATURES = {
     "maed_ste_block_saved_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_scratch_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
     "maed_ste_block_twin_work_bytes": (C.c_size_t, [C.POINTER(BlockDims)]),
-    "maed_ste_block_fwd_twin": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp, vp]),
+    "maed_ste_block_fwd_twin": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp, i32, vp]),
     "maed_ste_block_fwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
     "maed_ste_block_infer": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), vp, vp, vp, vp]),
     "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -117,6 +117,7 @@ SIGNATURES = {
     "maed_weight_std_fwd": (i32, [vp, i32, i32, vp, i32, vp, f32, i32, vp]),
     "maed_weight_std_bwd": (i32, [vp, i32, i32, i32, vp, f32, vp]),
     "maed_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp]),
+    "maed_groupnorm_fwd_twin": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp, vp, vp]),
     "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp, vp, vp]),
     "maed_comm_load": (i32, [C.c_char_p]),
     "maed_comm_unique_id": (i32, [vp]),

@@ -230,7 +230,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 template <typename T, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const double* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
-                                                       uint8_t* __restrict__ mask, int HW, int C, float eps, int rows_per_wg) {
+                                                       uint8_t* __restrict__ mask, int HW, int C, float eps, int rows_per_wg,
+                                                       bf16* __restrict__ twin_x = nullptr, bf16* __restrict__ twin_y = nullptr) {
+    // twin_x / twin_y (maed_groupnorm_fwd_twin, T = float): bf16 copies of the input and of the result for a bf16 backward, written from the registers of this pass
     __shared__ float lmu[GN_G], lrs[GN_G];
     const int n = blockIdx.y;
     if (threadIdx.x < GN_G) {
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (int r = r0 + rsub; r < r1; r += rstep) {
         float v[8], o[8];
         gn_load8(x + base + (int64_t)r * C, v);
+        if (twin_x) st8_nt(twin_x + base + (int64_t)r * C, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = fmaf(v[j], a[j], b[j]);
         if (RES) { float rr[8]; gn_load8(res + base + (int64_t)r * C, rr);
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f); }
         st8(y + base + (int64_t)r * C, o);
+        if (twin_y) st8_nt(twin_y + base + (int64_t)r * C, o);
     }
 }
 
@@ -594,8 +598,8 @@ static int gn_rows_per_wg(int N, int HW, int C, int target_wgs = 2048) {
     return rows < tile ? tile : rows;
 }
 
-extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
-                                  uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream) {
+static int groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
+                         uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* twin_x, void* twin_y, void* stream) {
     MAED_CHECK_ARG(x && gamma && beta && y && sums, MAED_ERR_ARG, "groupnorm_fwd: null pointer");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_fwd"));
     if (N <= 0) return MAED_OK;
@@ -606,13 +610,25 @@ extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const flo
     MAED_DISPATCH_DTYPE(dtype, T, {
         if (sums_zeroed != 2)       // 2: the producing convolution's epilogue accumulated the statistics already (maed_conv1x1_fwd / maed_conv3x3_fwd)
             hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, s, (const T*)x, sums, HW, C, rows);
-        if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
-        else if (residual) hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
-        else if (relu) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
-        else hipLaunchKernelGGL((gn_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows);
+        if (residual && relu) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows, (bf16*)twin_x, (bf16*)twin_y);
+        else if (residual) hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)residual, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows, (bf16*)twin_x, (bf16*)twin_y);
+        else if (relu) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows, (bf16*)twin_x, (bf16*)twin_y);
+        else hipLaunchKernelGGL((gn_apply_kernel<T, false, false>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, sums, gamma, beta, (T*)y, relu_mask, HW, C, eps, rows, (bf16*)twin_x, (bf16*)twin_y);
     });
     MAED_CHECK_LAUNCH("groupnorm_fwd");
     return MAED_OK;
+}
+
+extern "C" int maed_groupnorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
+                                  uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int dtype, int sums_zeroed, void* stream) {
+    return groupnorm_fwd(x, residual, gamma, beta, y, sums, relu_mask, N, HW, C, eps, relu, dtype, sums_zeroed, nullptr, nullptr, stream);
+}
+// the fp32 forward that also leaves bf16 twins of its input and its result ("bf16x3 forward / bf16 backward from bf16 twins": the backward reads x, the next
+// layer's backward reads y -- both as bf16): two more 2-byte stores per element from registers the pass holds anyway, instead of a cast pass per tensor
+extern "C" int maed_groupnorm_fwd_twin(const void* x, const void* residual, const float* gamma, const float* beta, void* y, double* sums,
+                                       uint8_t* relu_mask, int N, int HW, int C, float eps, int relu, int sums_zeroed, void* twin_x, void* twin_y, void* stream) {
+    MAED_CHECK_ARG(is_aligned(twin_x, 16) && is_aligned(twin_y, 16), MAED_ERR_ALIGN, "groupnorm_fwd_twin: 16-B alignment");
+    return groupnorm_fwd(x, residual, gamma, beta, y, sums, relu_mask, N, HW, C, eps, relu, MAED_F32, sums_zeroed, twin_x, twin_y, stream);
 }
 
 extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,

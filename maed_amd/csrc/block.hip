@@ -85,12 +85,17 @@ extern "C" int maed_prof_collect(double* ms_total, int* count) {
 // keep everything on the caller's stream.
 struct SideStream {
     hipStream_t s = nullptr;
+    hipStream_t s2 = nullptr;      // second side stream: the twin forward's cast pass (it feeds only the backward: it runs beside the NEXT block's forward)
     hipEvent_t ev[64];
+    hipEvent_t cast_ev[2];         // "the cast that read work buffer k is done"; cast_pending: recorded and not yet waited for by a backward
+    bool cast_pending[2] = {false, false};
     int next = 0;
     bool ok = false;
     SideStream() {
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return;
         for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return;
+        for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&cast_ev[i], hipEventDisableTiming) != hipSuccess) return;
         ok = true;
     }
     // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void cast_table_kernel(CastTab t) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
         float v[8];
         ld8(src + i * 8, v);
-        st8(dst + i * 8, v);
+        st8_nt(dst + i * 8, v);
     }
 }
 
@@ -312,15 +317,20 @@ extern "C" size_t maed_ste_block_twin_work_bytes(const maed_block_dims* d) {
 }
 
 extern "C" int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved_bf16, void* work_f32,
-                                       void* stream) {
+                                       int work_slot, void* stream) {
     MAED_PROPAGATE(check_dims(d, "ste_block_fwd_twin"));
     MAED_CHECK_ARG(d->dtype == MAED_F32, MAED_ERR_ARG, "ste_block_fwd_twin: dims describe the FORWARD (dtype MAED_F32); the arena is laid out for MAED_BF16");
     MAED_CHECK_ARG(p && x_in && x_out && saved_bf16 && work_f32, MAED_ERR_ARG, "ste_block_fwd_twin: null pointer");
     MAED_CHECK_ARG(is_aligned(saved_bf16, 256) && is_aligned(work_f32, 256), MAED_ERR_ALIGN, "ste_block_fwd_twin: buffers must be 256-B aligned");
     MAED_CHECK_ARG(d->C % 8 == 0 && d->hidden % 8 == 0, MAED_ERR_SHAPE, "ste_block_fwd_twin: C and hidden must be multiples of 8");
+    MAED_CHECK_ARG(work_slot == 0 || work_slot == 1, MAED_ERR_ARG, "ste_block_fwd_twin: work_slot must be 0 or 1");
     maed_block_dims d16 = *d; d16.dtype = MAED_BF16;
     const SavedLayout L32 = saved_layout(*d), L16 = saved_layout(d16);
     char* w = (char*)work_f32; char* sv = (char*)saved_bf16;
+    // the cast pass runs on a side stream of its own, beside the next block's forward (which writes the OTHER work buffer: the caller alternates work_slot 0 / 1 and
+    // hands each slot its own buffer); before this forward overwrites its buffer, the cast that last read it must be done
+    SideStream* ss = side_stream();
+    if (ss && ss->cast_pending[work_slot]) MAED_HIP(hipStreamWaitEvent((hipStream_t)stream, ss->cast_ev[work_slot], 0), "ste_block_fwd_twin: stream wait");
     MAED_PROPAGATE(block_fwd_bufs(d, p, x_in, x_out, fwd_bufs(w, L32, sv, L16), true, stream));
     const long long M = (long long)d->F * d->P, C = d->C, Hd = d->hidden;
     CastTab t{};
@@ -329,8 +339,11 @@ extern "C" int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_bloc
     add(L32.ln1, L16.ln1, M * C); add(L32.qkv, L16.qkv, M * 3 * C); add(L32.xs, L16.xs, M * C); add(L32.xt, L16.xt, M * C);
     add(L32.means, L16.means, (long long)d->F * 2 * C); add(L32.mix, L16.mix, M * C); add(L32.ln2, L16.ln2, M * C);
     add(L32.hpre, L16.hpre, M * Hd); add(L32.hact, L16.hact, M * Hd);
-    hipLaunchKernelGGL(cast_table_kernel, dim3(1024, k), dim3(256), 0, (hipStream_t)stream, t);
+    hipStream_t cs = (hipStream_t)stream;
+    if (ss) { ss->fence((hipStream_t)stream, ss->s2); cs = ss->s2; }
+    hipLaunchKernelGGL(cast_table_kernel, dim3(1024, k), dim3(256), 0, cs, t);
     MAED_CHECK_LAUNCH("ste_block_fwd_twin: cast");
+    if (ss) { MAED_HIP(hipEventRecord(ss->cast_ev[work_slot], ss->s2), "ste_block_fwd_twin: event"); ss->cast_pending[work_slot] = true; }
     return MAED_OK;
 }
 
@@ -352,6 +365,11 @@ extern "C" int maed_ste_block_bwd(const maed_block_dims* d, const maed_block_par
     const SavedLayout L = saved_layout(*d);
     const ScratchLayout S = scratch_layout(*d);
     char* sv = (char*)saved; char* sc = (char*)scratch;
+    if (d->dtype == MAED_BF16) {        // twin forwards leave their cast passes on a side stream: the arena is complete once they are done
+        SideStream* ssc = side_stream();
+        for (int k = 0; ssc && k < 2; ++k)
+            if (ssc->cast_pending[k]) { MAED_HIP(hipStreamWaitEvent((hipStream_t)stream, ssc->cast_ev[k], 0), "ste_block_bwd: stream wait"); ssc->cast_pending[k] = false; }
+    }
     const int64_t M = (int64_t)d->F * d->P, Mp = S.Mp, Fp = S.Fp;
     const int C = d->C, Hd = d->hidden, dt = d->dtype;
     const int gi = d->impl == MAED_IMPL_VALU ? MAED_IMPL_VALU : MAED_IMPL_AUTO;

@@ -157,6 +157,18 @@ __device__ __forceinline__ void st8(bf16* p, const float (&o)[8]) {
                                              pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
 }
 
+// 8 bf16 with a non-temporal store: data nobody reads again in this pass (the bf16 twins an fp32 forward leaves for the backward) should not displace the forward's
+// working set from L2 / the Infinity Cache
+__device__ __forceinline__ void st8_nt(bf16* p, const float (&o)[8]) {
+#ifdef MAED_HOSTSIM
+    st8(p, o);
+#else
+    typedef uint32_t maed_u32x4_nt_t __attribute__((ext_vector_type(4)));
+    const maed_u32x4_nt_t v = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+    __builtin_nontemporal_store(v, reinterpret_cast<maed_u32x4_nt_t*>(p));
+#endif
+}
+
 // ---- wave (64 lanes) reductions -----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -122,12 +122,37 @@ def shadow_of(t):
 
 
 def shadow_clear():
+    assert not (_UNFILLED and _SHADOW) or all(k in _SHADOW for k in _UNFILLED), "an unfilled twin lost its shadow"
+    for k in list(_UNFILLED):       # (twins nobody consumed: fill them before their shadows go)
+        e = _SHADOW.get(k)
+        if e is not None:
+            e[0].copy_(e[1])
+    _UNFILLED.clear()
     _SHADOW.clear()
 
 
 def twin_of(y32):
-    """bf16 twin of an fp32 forward result, registered with its shadow (one cast pass; candidates for a second store in the producer's epilogue)"""
+    """bf16 twin of an fp32 forward result, registered with its shadow (one cast pass)"""
     return shadow_put(y32.to(torch.bfloat16), y32)
+
+
+_UNFILLED = set()    # data pointers of twins whose CONTENT the consumer will write (twin_later)
+
+
+def twin_later(y32):
+    """bf16 twin of a convolution's fp32 result WITHOUT a cast pass: every convolution of the backbone feeds a GroupNorm, whose forward reads the fp32 tensor anyway
+    and writes the twin from its registers (maed_groupnorm_fwd_twin twin_x).  Until then the twin is an identity for autograd and the shadow registry only; a
+    consumer that is not a GroupNorm (none in this backbone) fills it with a cast (twin_fill)."""
+    y16 = torch.empty_like(y32, dtype=torch.bfloat16)
+    _UNFILLED.add(y16.data_ptr())
+    return shadow_put(y16, y32)
+
+
+def twin_fill(t16):
+    """make sure a twin_later twin holds data (consumers other than GroupNormFn)"""
+    if t16 is not None and t16.data_ptr() in _UNFILLED:
+        _UNFILLED.discard(t16.data_ptr())
+        t16.copy_(shadow_of(t16))
 
 
 def bwd_twin():
@@ -506,8 +531,8 @@ def _aligned_bytes(nbytes, device, align=256):
     return buf[off:off + nbytes]
 
 
-def _scratch(nbytes, device):
-    key = (device.index, _stream())
+def _scratch(nbytes, device, tag=None):
+    key = (device.index, _stream(), tag)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _aligned_bytes(nbytes, device)
@@ -616,8 +641,10 @@ class STEBlockFn(ReportingFn):
             d16 = L.BlockDims(*dims)
             pr = block._c_params_masters()
             saved = _aligned_bytes(lib.maed_ste_block_saved_bytes(C.byref(d16)), x.device)
-            work = _scratch(lib.maed_ste_block_twin_work_bytes(C.byref(d)), x.device)
-            check(lib.maed_ste_block_fwd_twin(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _p(work), _stream()), "ste_block_fwd_twin")
+            # two work buffers, alternating: the cast pass of block i (side stream) reads buffer i % 2 while block i + 1 writes the other
+            slot = getattr(block, "_chain_index", 0) & 1
+            work = _scratch(lib.maed_ste_block_twin_work_bytes(C.byref(d)), x.device, tag=("twin", slot))
+            check(lib.maed_ste_block_fwd_twin(C.byref(d), C.byref(pr), _p(x), _p(y), _p(saved), _p(work), slot, _stream()), "ste_block_fwd_twin")
             TWIN_FORWARDS[0] += 1
         else:
             pr = block._c_params(block.compute_dtype)
@@ -826,10 +853,19 @@ class GroupNormFn(torch.autograd.Function):
         # ReLU after a residual add: the backward cannot recompute the mask from x -> 1 bit per element instead of re-reading y
         need_mask = relu and ctx.has_res and (x.requires_grad or residual.requires_grad or gamma.requires_grad)
         mask = torch.empty(N * H * W * (C_ // 8), dtype=torch.uint8, device=x.device) if need_mask else None
-        check(L.lib().maed_groupnorm_fwd(_p(xin), _p(rin), _p(gamma), _p(beta), _p(y), _p(sums), _p(mask), N, H * W, C_, eps, int(relu),
-                                         dt_code(xin.dtype), 2 if (stats_ready and zeroed) else int(zeroed), _stream()), "groupnorm_fwd")
         if x32 is not None:
-            y = twin_of(y)
+            # the pass that reads the fp32 convolution output and writes the fp32 result also writes both bf16 twins: x's (handed out unfilled by the convolution:
+            # twin_later) and its own result's
+            fill_x = x.data_ptr() in _UNFILLED
+            y16 = torch.empty_like(y, dtype=torch.bfloat16)
+            twin_fill(residual)
+            check(L.lib().maed_groupnorm_fwd_twin(_p(xin), _p(rin), _p(gamma), _p(beta), _p(y), _p(sums), _p(mask), N, H * W, C_, eps, int(relu),
+                                                  2 if (stats_ready and zeroed) else int(zeroed), _p(x) if fill_x else None, _p(y16), _stream()), "groupnorm_fwd_twin")
+            _UNFILLED.discard(x.data_ptr())
+            y = shadow_put(y16, y)
+        else:
+            check(L.lib().maed_groupnorm_fwd(_p(xin), _p(rin), _p(gamma), _p(beta), _p(y), _p(sums), _p(mask), N, H * W, C_, eps, int(relu),
+                                             dt_code(xin.dtype), 2 if (stats_ready and zeroed) else int(zeroed), _stream()), "groupnorm_fwd")
         ctx.ab = ab
         ctx.sync = sync if ab is not None else None      # N * GN_SYNC_WORDS zero words (any 4-byte dtype): frame_sync of the one-pass backward, single use like ab
         ctx.save_for_backward(x, mask, sums)
@@ -918,7 +954,7 @@ class StemConvFn(torch.autograd.Function):
         if x32 is not None:     # bf16 graph over fp32 shadows: x32 is the TF-SAME padded fp32 image (stem_input own=False); the vendor's fp32 convolution as in the f32 modes
             assert sums is None, "stem: the GroupNorm behind a shadowed stem computes its own statistics"
             w32 = shadow_of(w)
-            return twin_of(torch.nn.functional.conv2d(x32, w32, None, 2, 0))
+            return twin_later(torch.nn.functional.conv2d(x32, w32, None, 2, 0))
         y = torch.empty((F_, 64, H // 2, W // 2), dtype=xp.dtype, device=xp.device, memory_format=torch.channels_last)
         wimg = torch.empty(64 * 224, dtype=xp.dtype, device=xp.device)
         check(L.lib().maed_stem7x7s2_fwd(_p(xp), _p(wc), _p(wimg), _p(y), _p(sums), F_, H, W, dt_code(xp.dtype), _stream()), "stem7x7s2_fwd")
@@ -1010,7 +1046,7 @@ class Conv1x1Fn(torch.autograd.Function):
         A = rows_of(x)
         if x32 is not None:
             y32 = product(rows_of(x32.contiguous(memory_format=torch.channels_last)), w32).view(N, Ho, Wo, O).permute(0, 3, 1, 2)
-            y = twin_of(y32)
+            y = twin_later(y32)
         else:
             y = product(A, w).view(N, Ho, Wo, O).permute(0, 3, 1, 2)
         ctx.save_for_backward(A, wt)
@@ -1172,7 +1208,7 @@ class Conv3x3Fn(torch.autograd.Function):
         w_taps = (w if w32 is None else w32).permute(0, 2, 3, 1)
         w_taps = w_taps if w_taps.is_contiguous() else w_taps.contiguous()
         if x32 is not None:
-            return twin_of(conv3x3(x32, w_taps, stride, gn_sums=gn_sums, prec=prec))
+            return twin_later(conv3x3(x32, w_taps, stride, gn_sums=gn_sums, prec=prec))
         return conv3x3(x, w_taps, stride, gn_sums=gn_sums, prec=prec)
 
     @staticmethod

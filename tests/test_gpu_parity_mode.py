@@ -112,8 +112,9 @@ def test_cfg3_full_size_mixed_mode_bf16x3_forward_bf16_backward():
     res = {}
     try:
         ops.set_float32_matmul_precision("bf16x3")
-        for bwd in (None, "bf16x1"):
+        for bwd in (None, "bf16x1", "bf16"):
             ops.set_float32_backward_precision(bwd)
+            twins = ops.TWIN_FORWARDS[0]
             m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["H"], embed_dim=C, hidden_dim=CFG["hidden"], img_size=CFG["img"], compute_dtype=torch.float32)
             m.load_state_dict(params, strict=False)
             m = m.to(DEV).train()
@@ -123,23 +124,71 @@ def test_cfg3_full_size_mixed_mode_bf16x3_forward_bf16_backward():
             sum(w * (out[k] ** 2).mean() for k, w in WTS.items()).backward()
             torch.cuda.synchronize()
             res[bwd] = ({k: v.detach().float().cpu() for k, v in out.items()}, {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()})
+            # "bf16" (round 5): the backbone as a bf16 graph over fp32 shadows + every STE block through maed_ste_block_fwd_twin -- and nothing of it in the other modes
+            assert ops.TWIN_FORWARDS[0] - twins == ((1 + CFG["depth"]) if bwd == "bf16" else 0), (bwd, ops.TWIN_FORWARDS[0] - twins)
+            assert not ops._SHADOW
             del m, out
     finally:
         ops.set_float32_matmul_precision(old)
         ops.set_float32_backward_precision(None)
-    for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts"):
-        report(f"mixed mode (f32 storage, bf16x3 forward / bf16x1 backward) cfg3 full size {k} vs fp32 oracle", res["bf16x1"][0][k], o32[k], rtol=0,
-               atol=1e-3 * o32[k].abs().max().item())
-        # same forward kernels in both runs; only the order of fp32 atomics (split-K head GEMMs, token means) differs from run to run
-        assert (res["bf16x1"][0][k] - res[None][0][k]).abs().max() <= 2e-5 * o32[k].abs().max(), f"{k}: the backward engine changed the forward"
-    worst = {}
-    for n, g1 in res["bf16x1"][1].items():
-        g3 = res[None][1][n]
-        cos = float((g1.double() * g3.double()).sum() / (g1.double().norm() * g3.double().norm() + 1e-30))
-        grp = "backbone" if "backbone" in n else "ste+decoder"
-        if grp not in worst or cos < worst[grp][0]:
-            worst[grp] = (cos, n)
-        assert torch.isfinite(g1).all(), n
-    for grp, (cos, n) in sorted(worst.items()):
-        note(f"mixed mode gradients vs all-bf16x3 gradients, {grp}: worst cosine {cos:.5f} ({n})")
-    assert worst["ste+decoder"][0] >= 0.995 and worst["backbone"][0] >= 0.95, worst
+    for bwd, label in (("bf16x1", "bf16x3 forward / bf16x1 backward"), ("bf16", "bf16x3 forward on fp32 shadows / bf16 backward on bf16 twins")):
+        for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts"):
+            report(f"mixed mode (f32 forward storage, {label}) cfg3 full size {k} vs fp32 oracle", res[bwd][0][k], o32[k], rtol=0,
+                   atol=1e-3 * o32[k].abs().max().item())
+            # same forward kernels in all runs; only the order of fp32 atomics (split-K head GEMMs, token means) differs from run to run
+            assert (res[bwd][0][k] - res[None][0][k]).abs().max() <= 2e-5 * o32[k].abs().max(), f"{k}: the backward engine ({bwd}) changed the forward"
+        worst = {}
+        for n, g1 in res[bwd][1].items():
+            g3 = res[None][1][n]
+            cos = float((g1.double() * g3.double()).sum() / (g1.double().norm() * g3.double().norm() + 1e-30))
+            grp = "backbone" if "backbone" in n else "ste+decoder"
+            if grp not in worst or cos < worst[grp][0]:
+                worst[grp] = (cos, n)
+            assert torch.isfinite(g1).all(), n
+        for grp, (cos, n) in sorted(worst.items()):
+            note(f"mixed mode ({bwd} backward) gradients vs all-bf16x3 gradients, {grp}: worst cosine {cos:.5f} ({n})")
+        # the twin mode's gradients are the bf16 MODE's (bf16-rounded saved activations, bf16 gradient stream): inside the backbone that mode sits at cosine
+        # ~0.94 against fp64 on a freshly initialised network; the one-plane mode keeps fp32 saved activations and gradient tensors
+        lo = {"bf16x1": (0.995, 0.95), "bf16": (0.99, 0.90)}[bwd]
+        assert worst["ste+decoder"][0] >= lo[0] and worst["backbone"][0] >= lo[1], (bwd, worst)
+
+
+def test_cfg5_full_size_twin_mode_training_pass_vs_oracle_fixture():
+    """round 5: the mode bench.py promotes to `value_at_1e3` -- bf16x3 forward on fp32 operands, bf16 backward on bf16 twins -- at the LONG-CLIP configuration
+    (BASELINE.json configs[4]: T = 64, 256^2, P = 257, depth 12, dim 768) at full size: the outputs of a TRAINING pass (the pass that takes the twin route: bf16
+    autograd graph over fp32 shadows in the backbone, maed_ste_block_fwd_twin in every block; KTD dropout off) against the oracle fixture g15 within 1e-3 of each
+    output's maximum, and a finite backward through all of it."""
+    import importlib.util
+    import numpy as np
+    import maed_amd
+    from maed_amd import ops
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_golden_cfg5", os.path.join(ROOT, "oracle", "make_golden_cfg5.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "g15_cfg5_full.npz"))
+    params, clip = mk.inputs()
+    c5 = mk.CFG5
+    old = maed_amd.get_float32_matmul_precision()
+    try:
+        maed_amd.set_float32_matmul_precision("bf16x3")
+        maed_amd.set_float32_backward_precision("bf16")
+        m = maed_amd.MAED(num_blocks=c5["depth"], num_heads=c5["H"], embed_dim=c5["C"], hidden_dim=c5["hidden"], img_size=c5["img"], max_seqlen=c5["T"],
+                          compute_dtype=torch.float32)
+        m.load_state_dict(params, strict=False)
+        m = m.to(DEV).train()
+        m.decoder.drop1.p = 0.0
+        m.decoder.drop2.p = 0.0
+        twins = ops.TWIN_FORWARDS[0]
+        out = m(clip.to(DEV))
+        assert ops.TWIN_FORWARDS[0] - twins == 1 + c5["depth"]
+        sum(w * (out[k] ** 2).mean() for k, w in WTS.items()).backward()
+        torch.cuda.synchronize()
+        bad = [n for n, p in m.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+        assert not [n for n in bad if "smpl" not in n], bad
+    finally:
+        maed_amd.set_float32_matmul_precision(old)
+        maed_amd.set_float32_backward_precision(None)
+    out = dict({k: v.detach() for k, v in out.items()}, verts_sample=out["verts"].detach()[:, :, ::53])
+    for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts_sample"):
+        ref = torch.from_numpy(G[k])
+        report(f"cfg5 full size, twin mode training pass {k} vs oracle fixture", out[k], ref, rtol=0, atol=1e-3 * ref.abs().max().item())
