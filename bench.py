@@ -188,6 +188,8 @@ def parity_mode_line(dev, steps=5):
             # fourth (round 5): the same forward on fp32 operands, bf16 TWINS of what the backward reads, the bf16 mode's backward on them
             maed_amd.set_float32_backward_precision({"bf16x3_fwd_bf16_bwd": "bf16x1", "bf16x3_fwd_bf16_twin_bwd": "bf16"}.get(name))
             model = build_model(torch.float32, dev, bb).train()
+            from maed_amd import ops as _ops
+            twins0 = _ops.TWIN_FORWARDS[0]
             arena = ParamArena(model)
             opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=GradBucketer(arena, model))
             criterion = LossVideo(**LOSS_W)
@@ -210,12 +212,21 @@ def parity_mode_line(dev, steps=5):
             torch.cuda.synchronize()
             per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
             ms = per[len(per) // 2] if steps % 2 else 0.5 * (per[steps // 2 - 1] + per[steps // 2])
+            twin_variant = name == "bf16x3_fwd_bf16_twin_bwd"
+            # the mode that was timed is the mode that ran: every step of the twin variant took the twin route in the backbone and in every block
+            assert (_ops.TWIN_FORWARDS[0] - twins0 == (3 + steps) * (1 + CFG["depth"])) if twin_variant else (_ops.TWIN_FORWARDS[0] == twins0), (name, _ops.TWIN_FORWARDS[0] - twins0)
             del model, arena, opt
-            with torch.no_grad():       # forward parity at full module size, one clip, against the fp32 oracle
-                m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["heads"], embed_dim=CFG["dim"], hidden_dim=CFG["hidden"], img_size=CFG["img"],
-                                  max_seqlen=max(16, CFG["T"]), compute_dtype=torch.float32, backbone_f32_matmul=bb)
-                m.load_state_dict(params, strict=False)
-                o = m.to(dev).eval()(one.to(dev))
+            m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["heads"], embed_dim=CFG["dim"], hidden_dim=CFG["hidden"], img_size=CFG["img"],
+                              max_seqlen=max(16, CFG["T"]), compute_dtype=torch.float32, backbone_f32_matmul=bb)
+            m.load_state_dict(params, strict=False)
+            if twin_variant:            # the outputs of a TRAINING pass (the pass that takes the twin route; KTD dropout off), not of the plain fp32 inference path
+                m = m.to(dev).train()
+                m.decoder.drop1.p = m.decoder.drop2.p = 0.0
+                o = {k: v.detach() for k, v in m(one.to(dev)).items()}
+                assert _ops.TWIN_FORWARDS[0] - twins0 == (4 + steps) * (1 + CFG["depth"])
+            else:
+                with torch.no_grad():       # forward parity at full module size, one clip, against the fp32 oracle
+                    o = m.to(dev).eval()(one.to(dev))
             err = {k: float((o[k].float().cpu() - ref[k]).abs().max() / ref[k].abs().max()) for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts")}
             variants[name] = dict(ms_per_step=round(ms, 3), clips_per_sec=round(CFG["clips"] * 1e3 / ms, 2), theta_rel_err=err["theta"], rel_err=err)
             del m
@@ -595,7 +606,8 @@ def main():
         pm = out.get("parity_mode") or {}
         fw = pm.get("fastest_within_1e3")
         out["value_at_1e3"] = (dict(value=fw["clips_per_sec"], unit="video-clips/sec", ms_per_step=fw["ms_per_step"], theta_rel_err=fw["theta_rel_err"], mode=fw["name"],
-                                    note="fp32 storage, split-bf16 matrix products; see parity_mode.variants") if fw else None)
+                                    note="fp32 forward operands, split-bf16 matrix products (3 MFMAs); variant bf16x3_fwd_bf16_twin_bwd: the backward is the bf16 mode's, on bf16 "
+                                         "twins of what the forward saved (DESIGN.md section 4); see parity_mode.variants") if fw else None)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
