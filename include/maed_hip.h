@@ -100,6 +100,8 @@ typedef enum {
                                    * goes to the general TN kernel instead (A/B knob) */
     MAED_OPT_STEM_WGRAD_WGS = 8,   /* workgroups of maed_stem7x7s2_wgrad (default 512) */
     MAED_OPT_LBS_FRAMES = 9,       /* frames per workgroup of the LBS skinning kernel: 0 (default) = 16 for more than 32 frames, else 4; or 4 / 8 / 16 */
+    MAED_OPT_TN_DMA = 10,          /* 1 (default): bf16 weight-gradient GEMMs (maed_gemm_tn_wgrad, M % 32 == 0) on the LDS-DMA + transposing-read kernel (csrc/gemm_tn2.hip);
+                                    * 0: the register-transposing kernel (csrc/gemm_tn.hip) -- A/B knob */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's

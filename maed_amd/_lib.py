@@ -19,7 +19,7 @@ IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
 IMPL_X3, IMPL_X6, IMPL_X1 = 7, 8, 9  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
 (OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS, OPT_F32_BWD_X1, OPT_ST_FUSED, OPT_CONV3X3_ROWS_WGS, OPT_STEM_WGRAD_WGS,
- OPT_LBS_FRAMES) = range(10)   # maed_option (include/maed_hip.h)
+ OPT_LBS_FRAMES, OPT_TN_DMA) = range(11)   # maed_option (include/maed_hip.h)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -199,6 +199,7 @@ _OPTIONS = {
     OPT_CONV3X3_ROWS_WGS: 0 if os.environ.get("MAED_CONV3X3_WGRAD_ROWS", "1") == "0" else int(os.environ.get("MAED_CONV3X3_ROWS_WGS", "256")),
     OPT_STEM_WGRAD_WGS: int(os.environ.get("MAED_STEM_WGS", "512")),
     OPT_LBS_FRAMES: int(os.environ.get("MAED_LBS_FB", "0")),
+    OPT_TN_DMA: int(os.environ.get("MAED_TN_DMA", "1")),                 # A/B knob: 0 = the register-transposing weight-gradient kernel
 }
 
 

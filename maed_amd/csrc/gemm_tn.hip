@@ -28,6 +28,8 @@ int maed_tn_splits(int tiles) {
 }
 static int tn_remap() { return 1; }     // XCD-aware (split, tile) order: -6...8 % and 292 -> 189 MB of HBM traffic per launch (profiles/r02_pmc)
 
+bool maed_gemm_tn_dma_ok(int64_t M, int N, int K, int64_t ldy, int64_t ldx);                                            // gemm_tn2.hip
+int maed_gemm_tn_dma_launch(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw, float* dbias, int which, hipStream_t stream);
 bool maed_conv3x3_wgrad_rows64_ok(int F, int H, int W, int Cin, int Cout);                                            // conv3x3_rows.hip
 int maed_conv3x3_wgrad_rows64_launch(const void* dy, const void* x, float* dW, void* scratch, int F, int H, int W, hipStream_t stream);
 
@@ -255,6 +257,16 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
                    "gemm_tn_wgrad: need N, K, ldy, ldx multiples of 8 (N=%d K=%d)", N, K);
     MAED_CHECK_ARG(is_aligned(Y, 16) && is_aligned(X, 16), MAED_ERR_ALIGN, "gemm_tn_wgrad: Y/X must be 16-B aligned");
     MAED_CHECK_ARG(ldy < (1 << 24) && ldx < (1 << 24), MAED_ERR_SHAPE, "gemm_tn_wgrad: row strides must be < 2^24 elements");
+    // operands copied unchanged by LDS-DMA, fragments by transposing LDS reads (gemm_tn2.hip).  In isolation it wins 2-9 % on the STE's linears and loses 20-30 % on
+    // the backbone's narrow outputs (profiles/r05_tn_dma_micro.txt); IN SITU -- beside the dy -> dx chain on the side stream, where its copies cost no VALU slots --
+    // it is the faster choice for every shape: train step 20.28 / 20.33 -> 20.02 / 20.11 ms same-box (profiles/r05_tn_dma_bench_ab.txt).  Option value 3: its
+    // 256 x 256 tile (rejected: see gemm_tn2.hip), 0: this file's kernel.
+    const int tnd = maed_opt(MAED_OPT_TN_DMA);
+    if (tnd && maed_gemm_tn_dma_ok(M, N, K, ldy, ldx)) {
+        MAED_PROPAGATE(maed_gemm_tn_dma_launch(Y, ldy, X, ldx, M, N, K, dW, ldw, dbias, tnd, (hipStream_t)stream));
+        MAED_CHECK_LAUNCH("gemm_tn_wgrad(dma)");
+        return MAED_OK;
+    }
     const int tn = (N + 127) / 128, tk = (K + 127) / 128;
     const int nmt = (int)((M + TN_BM - 1) / TN_BM);
     int splits = maed_tn_splits(tn * tk);

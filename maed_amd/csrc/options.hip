@@ -17,6 +17,7 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {256},    // MAED_OPT_CONV3X3_ROWS_WGS
     {512},    // MAED_OPT_STEM_WGRAD_WGS
     {0},      // MAED_OPT_LBS_FRAMES: auto
+    {1},      // MAED_OPT_TN_DMA
 };
 
 extern "C" int maed_init(int device) {

@@ -73,15 +73,45 @@ def test_gemm_nt_splitk_atomic():
     assert torch.allclose(out, A.float() @ B.float().t(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 136, 72), (64, 128, 128), (37, 8, 8), (130, 64, 256)])
-def test_gemm_tn_wgrad_and_bias(M, N, K):
+# (M % 32 == 0: the LDS-DMA + transposing-read kernel of round 5, csrc/gemm_tn2.hip -- one tile, exactly the ring depth, more tiles than stages, several M-splits,
+#  column tiles that end inside a 128-block, a second K tile (rotating bias owner); the others: the register-transposing kernel incl. its ragged tile)
+@pytest.mark.parametrize("M,N,K", [(200, 136, 72), (64, 128, 128), (37, 8, 8), (130, 64, 256), (32, 128, 128), (128, 136, 72), (160, 8, 8), (416, 264, 200),
+                                   (2048, 64, 136)])
+@pytest.mark.parametrize("dma", [2, 3, 0])         # 2 / 3: the round-5 kernel's 128 x 128 / 256 x 256 tile forced for every shape, 0: the register-transposing kernel
+def test_gemm_tn_wgrad_and_bias(M, N, K, dma):
+    from _hostsim import option
     Y, X = rnd(M, N, seed=12).bfloat16(), rnd(M, K, seed=13).bfloat16()
     dW0, db0 = rnd(N, K, seed=14), rnd(N, seed=15)
     dW, db = dW0.clone(), db0.clone()
-    with patched():
+    with patched() as lib, option(lib, L.OPT_TN_DMA, dma):
         ops.gemm_tn_wgrad(Y, X, dW=dW, dbias=db)          # ACCUMULATES into dW / dbias
+    # transpose-detecting: Y and X are unrelated random matrices, N != K in most cases
     assert torch.allclose(dW, dW0 + Y.float().t() @ X.float(), rtol=1e-4, atol=1e-3)
     assert torch.allclose(db, db0 + Y.float().sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_tn_dma_strided_operands_and_no_bias():
+    """operands that are column slices of wider matrices (row strides 3C / hidden as in the STE block), no bias gradient"""
+    from _hostsim import option
+    M, N, K = 192, 64, 96
+    Yw, Xw = rnd(M, 3 * N, seed=16).bfloat16(), rnd(M, K + 40, seed=17).bfloat16()
+    Y, X = Yw[:, N:2 * N], Xw[:, 8:8 + K]
+    dW = torch.zeros(N, K)
+    for which in (2, 3):
+        dW.zero_()
+        with patched() as lib, option(lib, L.OPT_TN_DMA, which):
+            ops.gemm_tn_wgrad(Y, X, dW=dW)
+        assert torch.allclose(dW, Y.float().t() @ X.float(), rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_tn_dma_default_dispatch_takes_the_big_tile_for_outputs_of_512_and_more():
+    from _hostsim import option
+    M, N, K = 96, 520, 512
+    Y, X = rnd(M, N, seed=18).bfloat16(), rnd(M, K, seed=19).bfloat16()
+    dW, db = torch.zeros(N, K), torch.zeros(N)
+    with patched() as lib, option(lib, L.OPT_TN_DMA, 1):
+        ops.gemm_tn_wgrad(Y, X, dW=dW, dbias=db)
+    assert torch.allclose(dW, Y.float().t() @ X.float(), rtol=1e-4, atol=1e-3) and torch.allclose(db, Y.float().sum(0), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 264, 128), (256, 256, 192), (70, 512, 320)])
