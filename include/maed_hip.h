@@ -106,7 +106,10 @@ typedef enum {
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's
  * architecture in maed_last_error() -- the host calls it once after loading the library, so that a wrong device fails here and not as an "invalid device
- * function" at the first launch.  The library keeps no per-device state. */
+ * function" at the first launch.  It also creates, here and nowhere else, every runtime object the library owns: two non-blocking side streams, two rings of
+ * timing-less events (fences between the caller's stream and the side streams) and one word of pinned host memory (maed_device_faults); nothing is created at call
+ * time afterwards (a host that never called maed_init gets the same objects on first use; the opt-in communicator has its own maed_comm_init).  One device per
+ * process (one process per GPU, as train.py:166-182 launches them). */
 int maed_init(int device);
 /* Frame-barrier timeouts since the process started (or since maed_device_faults_clear).  The one-pass GroupNorm backward (MAED_OPT_GN_BWD_ONEPASS) and the fused
  * attentive addition (MAED_OPT_ST_FUSED) synchronise the workgroups of one frame INSIDE a launch; that needs them co-resident, which holds on a GPU this process has

@@ -694,13 +694,9 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
             // dgamma / dbeta are read by nobody before the caller joins aux_stream (ops.side_stream_join): the small column-sum kernel leaves the
             // dy -> dx chain and runs beside the apply pass
             hipStream_t sa = s;
-            if (aux_stream) {
-                static hipEvent_t ring[32]; static int next = -1;
-                if (next < 0) { for (int i = 0; i < 32; ++i) MAED_HIP(hipEventCreateWithFlags(&ring[i], hipEventDisableTiming), "groupnorm_bwd: event ring"); next = 0; }
-                hipEvent_t e = ring[next]; next = (next + 1) & 31;
-                MAED_HIP(hipEventRecord(e, s), "groupnorm_bwd: event");
+            if (aux_stream) {      // (the library's one fence ring: maed_init_runtime, block.hip)
+                MAED_PROPAGATE(maed_stream_fence(s, aux_stream));
                 sa = (hipStream_t)aux_stream;
-                MAED_HIP(hipStreamWaitEvent(sa, e, 0), "groupnorm_bwd: stream wait");
             }
             hipLaunchKernelGGL(gn_affine_grad_kernel, dim3((2 * C + 63) / 64, (N + 63) / 64), dim3(256), 0, sa, ab_scratch, dgamma, dbeta, N, C);
         }

@@ -80,9 +80,9 @@ extern "C" int maed_prof_collect(double* ms_total, int* count) {
 // of kernel leave most of the MFMA pipe idle on their own (0.2 / 0.3 of peak) and each kernel's ramp-up and tail fill with the other's
 // workgroups.  Fences: an event per operand hand-over (main -> side), one before the dqkv buffer is re-used and one at the end of the block
 // (side -> main), so everything after maed_ste_block_bwd on the caller's stream -- gradient all-reduce, Adam -- is ordered after the weight
-// gradients.  The only objects the library ever creates besides the opt-in communicator: one non-blocking stream and a ring of
-// timing-less events, made on first use, never destroyed.  MAED_WGRAD_SIDE_STREAM=0, the in-situ profiler (maed_prof_enable) and the f32 parity mode
-// keep everything on the caller's stream.
+// gradients.  The only objects the library ever creates besides the opt-in communicator: two non-blocking streams and two rings of timing-less events -- ALL of
+// them made in ONE place, maed_init_runtime() (called by maed_init; a host that skipped maed_init gets them on first use through the same function), never
+// destroyed.  MAED_WGRAD_SIDE_STREAM=0, the in-situ profiler (maed_prof_enable) and the f32 parity mode keep everything on the caller's stream.
 struct SideStream {
     hipStream_t s = nullptr;
     hipStream_t s2 = nullptr;      // second side stream: the twin forward's cast pass (it feeds only the backward: it runs beside the NEXT block's forward)
@@ -91,13 +91,6 @@ struct SideStream {
     bool cast_pending[2] = {false, false};
     int next = 0;
     bool ok = false;
-    SideStream() {
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
-        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return;
-        for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return;
-        for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&cast_ev[i], hipEventDisableTiming) != hipSuccess) return;
-        ok = true;
-    }
     // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
     void fence(hipStream_t from, hipStream_t to) {
         hipEvent_t e = ev[next]; next = (next + 1) % 62;               // slots 62 / 63 are named fences, outside the ring
@@ -105,27 +98,39 @@ struct SideStream {
         (void)hipStreamWaitEvent(to, e, 0);
     }
 };
+// every stream / event the library owns (this block driver's side streams + fence events, maed_stream_fence's ring): created here and nowhere else
+static SideStream g_side;
+static hipEvent_t g_fence_ring[64];
+static bool g_fence_ok = false;
+static std::once_flag g_runtime_once;
+int maed_init_runtime(void) {
+    std::call_once(g_runtime_once, [] {
+        SideStream& ss = g_side;
+        bool ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 64; ++i) ok = hipEventCreateWithFlags(&ss.ev[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < 2; ++i) ok = hipEventCreateWithFlags(&ss.cast_ev[i], hipEventDisableTiming) == hipSuccess;
+        ss.ok = ok;
+        g_fence_ok = true;
+        for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&g_fence_ring[i], hipEventDisableTiming) != hipSuccess) { g_fence_ok = false; break; }
+        if (!ok || !g_fence_ok) (void)hipGetLastError();
+    });
+    return (g_side.ok && g_fence_ok) ? MAED_OK : MAED_ERR_LAUNCH;
+}
 static SideStream* side_stream() {
-    if (!maed_opt(MAED_OPT_SIDE_STREAM) || g_prof) return nullptr;      // (before the static: with the option off the stream is never created)
-    static SideStream ss;
-    return ss.ok ? &ss : nullptr;
+    if (!maed_opt(MAED_OPT_SIDE_STREAM) || g_prof) return nullptr;
+    (void)maed_init_runtime();
+    return g_side.ok ? &g_side : nullptr;
 }
 
 // "everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on": one event record + one stream wait from a ring of timing-less
 // events the library owns.  For hosts that run single launches on a second stream of their own (maed_amd/ops.py: the backbone's weight-gradient GEMMs): the same
 // fence through the framework costs a Python-level event object, a record and a wait per use.
 extern "C" int maed_stream_fence(void* from_stream, void* to_stream) {
-    static hipEvent_t ring[64];
-    static std::once_flag once;
     static std::atomic<unsigned> next{0};
-    static bool ok = false;
-    std::call_once(once, [] {
-        ok = true;
-        for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) { ok = false; break; }
-    });
-    MAED_CHECK_ARG(ok, MAED_ERR_LAUNCH, "stream_fence: event ring could not be created");
+    (void)maed_init_runtime();
+    MAED_CHECK_ARG(g_fence_ok, MAED_ERR_LAUNCH, "stream_fence: event ring could not be created");
     if (from_stream == to_stream) return MAED_OK;
-    hipEvent_t e = ring[next.fetch_add(1, std::memory_order_relaxed) & 63];
+    hipEvent_t e = g_fence_ring[next.fetch_add(1, std::memory_order_relaxed) & 63];
     MAED_HIP(hipEventRecord(e, (hipStream_t)from_stream), "stream_fence: record");
     MAED_HIP(hipStreamWaitEvent((hipStream_t)to_stream, e, 0), "stream_fence: wait");
     return MAED_OK;

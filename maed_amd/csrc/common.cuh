@@ -90,6 +90,8 @@ void maed_set_error(const char* fmt, ...);
 #define MAED_HIP(expr, name) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
     maed_set_error("%s: %s", name, hipGetErrorString(e__)); return MAED_ERR_LAUNCH; } } while (0)
 
+// the streams and event rings the library owns: all created by this one function (block.hip), which maed_init calls
+int maed_init_runtime(void);
 // process-wide options (csrc/options.hip; maed_set_option in include/maed_hip.h)
 int maed_opt(int key);
 

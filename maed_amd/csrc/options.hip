@@ -32,6 +32,9 @@ extern "C" int maed_init(int device) {
     (void)device;
 #endif
     (void)maed_fault_word();
+#ifndef MAED_HOSTSIM
+    if (maed_init_runtime() != MAED_OK) { maed_set_error("init: could not create the library's side streams / event rings"); return MAED_ERR_LAUNCH; }
+#endif
     return MAED_OK;
 }
 

@@ -59,3 +59,67 @@ def test_no_cpu_fallback():
     from maed_amd import ops, _lib
     with pytest.raises(_lib.MaedHipError):
         ops.layernorm_fwd(torch.zeros(4, 128), torch.ones(128), torch.zeros(128), torch.float32)
+
+
+def _function_spans(path):
+    """(name, first line, last line) of every top-level function body of a kernel source (brace depth from column 0)"""
+    spans, depth, name, start = [], 0, None, 0
+    for i, line in enumerate(open(path), 1):
+        code = line.split("//")[0]
+        if depth == 0 and "(" in code and "{" in code and not code.lstrip().startswith("#"):
+            m = re.search(r"(\w+)\s*\(", code)          # (one-line definitions included; a declaration has no brace)
+            if m:
+                name, start = m.group(1), i
+        elif depth == 0 and "(" in code and not code.rstrip().endswith(";") and not code.lstrip().startswith("#"):
+            m = re.search(r"(\w+)\s*\(", code)          # header of a definition whose parameter list continues on the next lines
+            if m and name is None:
+                name, start = m.group(1), i
+        depth += code.count("{") - code.count("}")
+        if depth == 0 and name is not None and "}" in code:
+            spans.append((name, start, i))
+            name = None
+    return spans
+
+
+def test_runtime_objects_are_created_in_the_init_functions_only():
+    """no allocation / no object creation at call time.  Every stream, event and pinned allocation the library owns is made by maed_init
+    (maed_init_runtime, maed_fault_word) or by the opt-in communicator's maed_comm_init; the in-situ profiler (a diagnostic the host switches on) makes its
+    timing events per measurement.  Checked on the sources: a creation call anywhere else fails here."""
+    csrc = os.path.join(ROOT, "maed_amd", "csrc")
+    allowed = {"maed_init_runtime", "maed_fault_word", "maed_comm_init", "maed_prof_open", "maed_prof_close"}
+    pat = re.compile(r"\bhip(StreamCreate\w*|EventCreate\w*|HostMalloc|Malloc\w*)\s*\(")
+    found = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".cuh", ".h")):
+            continue
+        path = os.path.join(csrc, f)
+        spans = _function_spans(path)
+        for i, line in enumerate(open(path), 1):
+            if pat.search(line.split("//")[0]):
+                owner = next((n for n, a, b in spans if a <= i <= b), None)
+                found.append((f, i, owner))
+    assert found, "the scan found no creation call at all: the pattern is broken"
+    bad = [x for x in found if x[2] not in allowed]
+    assert not bad, bad
+    assert {x[2] for x in found} >= {"maed_init_runtime", "maed_fault_word", "maed_comm_init"}
+
+
+def test_empty_batch_queries_do_not_divide_by_zero(built_lib):
+    """the row-item / stem weight-gradient scratch queries with F = 0 returned through an integer division by the number of rows (SIGFPE)"""
+    lib = ctypes.CDLL(built_lib)
+    assert lib.maed_conv3x3_wgrad_rows64_scratch_floats(0, 56, 56, 64, 64) == 0
+    assert lib.maed_conv3x3_wgrad_rows64_scratch_floats(4, 56, 56, 64, 64) > 0
+    assert lib.maed_stem7x7s2_wgrad_scratch_floats(0, 224, 224) == 0
+
+
+def test_stem_clip_size_limit_is_part_of_the_support_query():
+    """a clip past the stem kernels' 32-bit offsets must take the vendor convolution, not fail with MAED_ERR_SHAPE"""
+    from maed_amd import ops
+    assert ops.stem7x7s2_supported(224, 224, 128)
+    assert not ops.stem7x7s2_supported(224, 224, 2700)       # F * 112 * 112 * 128 B >= 2^32
+    assert not ops.stem7x7s2_supported(224, 224, 0)
+
+
+def test_device_fault_counter_is_exported_and_zero_without_a_gpu(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    assert lib.maed_device_faults() == 0 and lib.maed_device_faults_clear() == 0

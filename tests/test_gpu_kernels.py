@@ -638,3 +638,48 @@ def test_stream_fence_orders_two_streams():
     assert lib.maed_stream_fence(a.cuda_stream, a.cuda_stream) == 0                          # same stream: nothing to do
     note("maed_stream_fence: 20 producer/consumer rounds across two streams in order")
 
+
+
+def test_frame_barrier_timeout_is_reported_and_the_library_falls_back():
+    """the one-pass GroupNorm backward synchronises the workgroups of a frame inside the launch with a bounded spin.  A peer that never arrives --
+    forced here by a frame_sync arrival counter that is NOT zero at launch (the wait is for equality) -- used to end in a silently NaN-poisoned dx.  Now the poisoned
+    call also raises the library's device-fault word: maed_device_faults() > 0, maed_last_error() explains, and from the next call on the two-pass kernels run and
+    give the right answer.  The counter is cleared at the end so that the rest of the suite keeps the one-pass kernels."""
+    ops, L = _ops()
+    lib = L.lib()
+    assert lib.maed_device_faults() == 0, "an earlier test already tripped a frame barrier"
+    N, C, H, W = 2, 256, 56, 56
+    dtype = torch.bfloat16
+    x = q(rnd(N, C, H, W, seed=1) * 1.5 + 0.2, dtype)
+    g, b = 1 + 0.2 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    dy = q(rnd(N, C, H, W, seed=5), dtype)
+    xd = x.double().requires_grad_(True)
+    ref = F.relu(F.group_norm(xd, 32, g.double(), b.double(), 1e-5))
+    ref.backward(dy.double())
+    cl = lambda t: t.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+
+    def run(dirty):
+        xg = cl(x).requires_grad_(True)
+        gg, bg = g.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        ab = torch.zeros(N, C, 2, device=DEV)
+        sync = torch.zeros(N * ops.GN_SYNC_WORDS, dtype=torch.int32, device=DEV)
+        if dirty:
+            sync.view(N, ops.GN_SYNC_WORDS)[:, 0] = 1000        # arrival counters that can never EQUAL the number of workgroups of a frame
+        sums = torch.zeros(N, 32, 2, dtype=torch.float64, device=DEV)
+        y = ops.GroupNormFn.apply(xg, None, gg, bg, 1e-5, True, False, sums, ab, False, False, sync)
+        y.backward(cl(dy))
+        torch.cuda.synchronize()
+        return xg.grad.float().cpu()
+    try:
+        bad = run(dirty=True)
+        assert torch.isnan(bad).any(), "a frame barrier that cannot complete must poison the result (if this shape no longer takes the one-pass kernel, pick one that does)"
+        assert lib.maed_device_faults() > 0
+        good = run(dirty=False)                 # the library has switched to the two-pass kernels
+        assert "frame-barrier timeout" in lib.maed_last_error().decode()
+        report("groupnorm_bwd.dx after a frame-barrier timeout (two-pass fallback)", good, xd.grad, **tol(dtype, 2))
+        assert L.device_faults() > 0
+    finally:
+        lib.maed_device_faults_clear()
+    assert lib.maed_device_faults() == 0
+    again = run(dirty=False)                    # ... and the one-pass kernel is back
+    report("groupnorm_bwd.dx after the fault word was cleared (one-pass kernel again)", again, xd.grad, **tol(dtype, 2))

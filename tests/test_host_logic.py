@@ -398,3 +398,13 @@ def test_weight_initialisation_distributions_follow_the_reference():
         bound = 0.01 * math.sqrt(6.0 / (fan_in + fan_out))                                          # xavier_uniform_(gain=0.01)
         w = lin.weight.detach()
         assert w.abs().max().item() <= bound * (1 + 1e-6) and abs(w.std().item() / (bound / math.sqrt(3.0)) - 1.0) < 0.1
+
+
+def test_rccl_comm_feasibility_check_is_not_collective():
+    """creating the library's communicator is collective (unique-id broadcast + ncclCommInitRank); a rank on which the NCCL-API library cannot even be
+    bound must find that out WITHOUT entering a collective, so that all ranks can agree on the fallback first.  RcclComm.available() touches no process group."""
+    import torch.distributed as dist
+    from maed_amd.ddp import RcclComm
+    assert not (dist.is_available() and dist.is_initialized())
+    ok, why = RcclComm.available(lib_path="/nonexistent/librccl.so")
+    assert ok is False and why

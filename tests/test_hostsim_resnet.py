@@ -348,3 +348,27 @@ def test_backbone_twin_mode_fp32_forward_on_shadows_bf16_backward_on_twins(monke
         worst = min(worst, c)
         assert c > 0.97, (n, c)
     print(f"twin mode: output shadow rel-to-max {rel(y32, yr.detach()):.2e}, worst parameter-gradient cosine {worst:.4f}")
+
+
+def test_a_failing_forward_leaves_no_prepadded_stem_behind(monkeypatch):
+    """forward_features marked the stem "pre-padded" before entering its try/finally; an exception in between (alignment, out of memory, an unsupported size)
+    left the mark set, and the next forward on another route convolved an UNPADDED image -- silently wrong.  Every hand-over slot is now set inside the try."""
+    from maed_amd import ops
+    torch.manual_seed(2)
+    ref = ResNetV2(layers=(1,), channels=(256,), in_chans=3, compute_dtype=torch.float32)
+    sim = copy.deepcopy(ref)
+    sim.compute_dtype = torch.bfloat16
+    x = torch.randn(2, 3, 32, 32)
+    real = ops.WeightStdFn.apply
+
+    def boom(*a, **k):
+        raise RuntimeError("simulated failure after the stem input was prepared")
+    with patched():
+        monkeypatch.setattr(ops.WeightStdFn, "apply", boom)
+        with pytest.raises(RuntimeError, match="simulated failure"):
+            sim(x)
+        monkeypatch.setattr(ops.WeightStdFn, "apply", real)
+    assert sim.stem.conv._prepadded is False and sim.stem.conv._stem_hw is None and sim._own_stem_now == []
+    sim.compute_dtype = torch.float32
+    with torch.no_grad():                      # the ATen route of the same module: a stale mark would skip the TF-SAME padding here
+        assert torch.allclose(sim(x), ref(x), rtol=1e-5, atol=1e-5)
