@@ -162,6 +162,31 @@ class _SimModel(torch.nn.Module):
         return dict(kp_2d=o[..., :98].reshape(N, T, 49, 2), kp_3d=o[..., 98:245].reshape(N, T, 49, 3), theta=o[..., 245:])
 
 
+def ddp_rehearsal(plain_ms, steps=10):
+    """What one GPU can say about the N > 1 step: the contract's own launch line (torch.distributed.run, one process per GPU over RCCL) with ONE rank and every
+    gradient bucket's all-reduce forced (MAED_FORCE_COLLECTIVES=1) plus the per-stage weight standardisation the data-parallel path uses -- process group, parameter
+    broadcast, bucketed all-reduce on the communicator's side stream overlapped with backward, barrier -- against the plain step of this run.  The collectives are
+    device-local copies here (nothing about xGMI); what the number shows is what the overlap machinery itself costs a rank.  A subprocess: this process has no
+    process group and must not get one after its timed region."""
+    import subprocess
+    env = dict(os.environ, MAED_FORCE_COLLECTIVES="1", MAED_WS_PER_STAGE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--no-ddp-rehearsal"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return dict(world1_forced_ms=d["ms_per_step"], plain_ms=round(plain_ms, 3), overhead_ms=round(d["ms_per_step"] - plain_ms, 3), transport=d["ddp"]["transport"],
+                    buckets=len(d["ddp"]["buckets"]), per_stage_weight_std=d["ddp"]["per_stage_weight_std"],
+                    note="the multi-GPU launch line with one rank, every bucket's all-reduce forced (device-local copies on one GPU: says what the overlap machinery "
+                         "costs a rank, nothing about xGMI)")
+    except Exception as e:  # noqa: BLE001
+        return dict(world1_forced_ms=None, note=f"rehearsal failed: {e!r}")
+
+
 def parity_mode_line(dev, steps=5):
     """the fp32-accurate mode beside the headline bf16 line: compute_dtype = float32 with the fp32 matrix products on the split-bf16 MFMA kernels, the SAME cfg3
     train step (8 clips x 16 frames, fwd + bwd + Adam), median of a few steps, and the error of that mode's forward at full module size (one clip) against the
@@ -254,6 +279,7 @@ def main():
     ap.add_argument("--f32-matmul", default=None, choices=["exact", "bf16x3", "bf16x6"],
                     help="--dtype f32 only: engine of the fp32 matrix products (maed_amd.set_float32_matmul_precision); default: MAED_F32_MATMUL or exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ddp-rehearsal", action="store_true", help="skip the one-rank rehearsal of the multi-GPU launch line (ddp.world1_forced_ms)")
     ap.add_argument("--forward-only", action="store_true", help="cfg2: inference forward instead of the train step")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"], help="cfg3 = BASELINE's metric workload (default); cfg5 = long-clip stress")
     ap.add_argument("--simulate", action="store_true",
@@ -535,7 +561,7 @@ def main():
                         for (fl, by), e in sorted(shapes.items(), key=lambda kv: -kv[1][1])]
             launch_bound = dict(frac=round(tb_sum / dur_sum, 4) if dur_sum else None, hbm_bound_launches_per_step=round(n_hbm / nprof, 1),
                                 mfma_bound_launches_per_step=round((len(tn_recs) - n_hbm) / nprof, 1), mfma_ops_per_product=mult, by_shape=by_shape[:12])
-            roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_mfma_bf16_kernel<false, false>") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
+            roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_dma_bf16_kernel<2, 2, 2, 2> (csrc/gemm_tn2.hip; MAED_TN_DMA=0: gemm_tn_mfma_bf16_kernel)") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
                                    "5 per STE block + the backbone's 1x1 convolutions)", bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                             frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=traffic_db.get("gemm_tn"), avg_us=round(us, 2), launches=cnt[TN_ALL] // nprof,
                             ms_per_step=round(ms[TN_ALL] / nprof, 3), algorithmic_bytes=(int(sum(r[2] for r in tn_recs) / len(tn_recs)) if tn_recs else None),
@@ -601,6 +627,8 @@ def main():
             "parity_err_bf16": (cpu or {}).get("parity_probe", {}).get("rel_err", {}).get("bf16") if cpu and (cpu.get("parity_probe") or {}).get("rel_err") else None,
             "parity_mode": (cpu or {}).pop("parity_mode", None) if cpu else None,
         }
+        if world == 1 and not sim and not args.forward_only and not args.no_ddp_rehearsal and not args.no_cpu_baseline and args.dtype == "bf16" and args.workload == "cfg3" and out.get("ddp") is not None:
+            out["ddp"]["rehearsal"] = ddp_rehearsal(ms_per_step)
         # first-class beside `value`: the same train step in the fastest mode whose OUTPUTS meet north_star's 1e-3 on SMPL parameters at full module
         # size -- `value` itself is the bf16 mode's number, at bf16 accuracy
         pm = out.get("parity_mode") or {}

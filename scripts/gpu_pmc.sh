@@ -33,8 +33,8 @@ out = {"source_hash": source_hash(), "dtype": "bf16", "workload": "cfg3",
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (--kernel-trace only) over scripts/attn_micro.py, gemm_micro.py ste, "
                  "wgrad_micro.py (WGRAD_STE=1); bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, averaged over the launches of the kernel family "
                  "(gfx950: FETCH_SIZE reports 1/2 of a wide coalesced stream, MI355X_MICROARCH.md HBM section)", "kernels": {}, "detail": {}}
-for key, tag, pats in (("attn_spatial_fwd", "attn", ["attn_sp_fwd", "attn_long_fwd"]), ("gemm_nt", "gemm", ["gemm_nt_glds", "gemm_nt_256"]), ("gemm_tn_ste_shapes", "wgrad", ["gemm_tn_mfma"]),
-                       ("gemm_tn", "step", ["gemm_tn_mfma_bf16_kernel<false", "gemm_tn_mfma_bf16_kernelILb0"])):   # gemm_tn: every launch inside the train step
+for key, tag, pats in (("attn_spatial_fwd", "attn", ["attn_sp_fwd", "attn_long_fwd"]), ("gemm_nt", "gemm", ["gemm_nt_glds", "gemm_nt_256"]), ("gemm_tn_ste_shapes", "wgrad", ["gemm_tn_mfma", "gemm_tn_dma"]),
+                       ("gemm_tn", "step", ["gemm_tn_mfma_bf16_kernel<false", "gemm_tn_mfma_bf16_kernelILb0", "gemm_tn_dma_bf16_kernel"])):   # gemm_tn: every launch inside the train step
     f, nf = mean(tag, "FETCH_SIZE", pats); w, nw = mean(tag, "WRITE_SIZE", pats)
     out["detail"][key] = {"FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w, "launches": [nf, nw]}
     out["kernels"][key] = None if f is None or w is None else int((2.0 * f + w) * 1024)
