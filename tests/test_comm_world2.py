@@ -50,7 +50,8 @@ def _worker(rank, world, port, fake, out):
             bucketer.broadcast_parameters(0)
             assert len(bucketer.buckets) > 1 and bucketer.collectives
             x, y = _batch()
-            shard = slice(rank * 4, rank * 4 + 4)
+            per = 8 // world
+            shard = slice(rank * per, rank * per + per)
             for _ in range(2):
                 arena.zero_grad()
                 loss = ((model(x[shard]) - y[shard]) ** 2).mean() + 0.5 * ((model(x[shard] * 2) - y[shard]) ** 2).mean()
@@ -68,32 +69,43 @@ def _worker(rank, world, port, fake, out):
             t = torch.full((5,), float(rank + 1))
             comm2.allreduce_async(t)
             comm2.wait()
-            assert torch.equal(t, torch.full((5,), 3.0))
+            assert torch.equal(t, torch.full((5,), world * (world + 1) / 2.0))
             comm2.destroy()
     finally:
         dist.destroy_process_group()
 
 
-def test_library_communicator_two_processes_matches_single_process_gradient():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_library_communicator_two_processes_matches_single_process_gradient(world):
+    """world = 4 (round 5): four ranks through the same communicator code -- rank-ordered reduction, several buckets per backward, bf16 payload"""
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(HERE, "hostsim"))
     import build_sim
     build_sim.build()
     fake = build_sim.build_fakerccl()
-    world, port = 2, 29633 + os.getpid() % 1000
+    port = 29633 + (os.getpid() + 7 * world) % 1000
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, fake, out), nprocs=world, join=True)
-    (g0, p0, s0), (g1, p1, s1) = out[0], out[1]
-    assert torch.equal(p0, p1), "parameters must be identical after the broadcast"
-    assert torch.equal(g0, g1), "every rank must hold the same reduced gradient"
+    (g0, p0, s0) = out[0]
+    for r in range(1, world):
+        g1, p1, s1 = out[r]
+        assert torch.equal(p0, p1), "parameters must be identical after the broadcast"
+        assert torch.equal(g0, g1), "every rank must hold the same reduced gradient"
+        assert s1 == s0
     from maed_amd.ddp import ParamArena
     model = _Toy()
     arena = ParamArena(model, device=torch.device("cpu"))
     x, y = _batch()
     (((model(x) - y) ** 2).mean() + 0.5 * ((model(x * 2) - y) ** 2).mean()).backward()
     torch.testing.assert_close(g0, arena.grad, rtol=1e-5, atol=1e-6)
-    ref = ((torch.arange(700_000, dtype=torch.float32) % 251).bfloat16().float() + (torch.arange(700_000, dtype=torch.float32) % 251 * 2).bfloat16().float()).bfloat16().float().sum().item()
-    assert s0 == s1 == ref
+    base = torch.arange(700_000, dtype=torch.float32) % 251
+    acc = torch.zeros_like(base)
+    for r in range(world):                      # the stand-in sums the ranks' bf16 values in rank order in fp32 and rounds once
+        acc += (base * (r + 1)).bfloat16().float()
+    assert s0 == acc.bfloat16().float().sum().item()
 
 
 def test_comm_load_refuses_a_library_without_the_nccl_api(tmp_path):
