@@ -368,7 +368,19 @@ def main():
                 log(f"MAED_COMM=direct: own RCCL communicator unavailable on rank {rank} ({why}); every rank falls back to torch.distributed")
             ok = torch.tensor([1.0 if ok_here else 0.0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            comm = RcclComm() if ok.item() == 1.0 else None     # (a failure inside the collective constructor now raises on this rank: loud, not a silent fallback)
+            if ok.item() == 1.0:
+                # every rank can bind the library: the collective constructor.  A failure in here (ncclCommInitRank) is, in practice, the same on every rank -- agree
+                # once more and fall back together rather than lose the run; a rank-local failure is what the non-collective check above was for
+                try:
+                    comm = RcclComm()
+                except Exception as e:  # noqa: BLE001
+                    log(f"MAED_COMM=direct: communicator creation failed on rank {rank} ({e}); falling back to torch.distributed")
+                    comm = None
+                ok2 = torch.tensor([1.0 if comm is not None else 0.0], device=dev)
+                dist.all_reduce(ok2, op=dist.ReduceOp.MIN)
+                if ok2.item() == 0.0 and comm is not None:
+                    comm.destroy()
+                    comm = None
         bucketer = GradBucketer(arena, model, comm=comm, force_collectives=force_coll, **(dict(bucket_bytes=16 << 10) if sim else {}))
         bucketer.broadcast_parameters(0)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=bucketer)  # configs/config_stage2.yaml:63-66

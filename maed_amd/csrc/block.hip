@@ -244,7 +244,9 @@ extern "C" size_t maed_ste_block_scratch_bytes(const maed_block_dims* d) { retur
 // where the forward writes what it saves: one pointer per field of SavedLayout.  Plain forward: every field inside `saved`.  Twin forward (maed_ste_block_fwd_twin):
 // the fields in the compute dtype go to an fp32 work buffer (they are the forward chain's operands), the fp32 fields straight into the bf16-layout arena the
 // backward will read.
-struct FwdBufs { char *ln1, *mean1, *rstd1, *qkv, *xs, *xt, *lse_s, *lse_t, *means, *logits, *mix, *xmid, *mean2, *rstd2, *ln2, *hpre, *hact, *st_sync, *st_ex; };
+struct FwdBufs { char *ln1, *mean1, *rstd1, *qkv, *xs, *xt, *lse_s, *lse_t, *means, *logits, *mix, *xmid, *mean2, *rstd2, *ln2, *hpre, *hact, *st_sync, *st_ex;
+                 // twin forward only: bf16 twins written by the producing GEMM's epilogue (no cast pass for them); hpre then holds bf16 (nothing of the forward reads it)
+                 char *tw_qkv = nullptr, *tw_hact = nullptr; bool hpre_bf16 = false; };
 static FwdBufs fwd_bufs(char* act_base, const SavedLayout& A, char* f32_base, const SavedLayout& Fl) {
     FwdBufs b;
     b.ln1 = act_base + A.ln1; b.qkv = act_base + A.qkv; b.xs = act_base + A.xs; b.xt = act_base + A.xt; b.means = act_base + A.means; b.mix = act_base + A.mix;
@@ -254,6 +256,8 @@ static FwdBufs fwd_bufs(char* act_base, const SavedLayout& A, char* f32_base, co
     return b;
 }
 
+int maed_gemm_nt_twin(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype, int epilogue, const float* bias, void* out,
+                      int64_t ldo, void* out2, const void* aux, int64_t ldaux, int splitk, int impl, void* stream, void* twin, bool out2_bf16);      // gemm.hip
 static int block_fwd_bufs(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, const FwdBufs& B, bool for_backward, void* stream) {
     const int64_t M = (int64_t)d->F * d->P;
     const int C = d->C, Hd = d->hidden, dt = d->dtype;
@@ -266,7 +270,7 @@ static int block_fwd_bufs(const maed_block_dims* d, const maed_block_params* p, 
     const bool piggy = stf && maed_opt(MAED_OPT_ST_FUSED) != 2 && (int64_t)d->F * 16 <= 256 * ((M + 31) / 32);       // (the backward LayerNorm's grid is the smaller one; otherwise the fused call clears itself; option value 2: A/B knob -- memset nodes, LayerNorm column sums on the caller's stream)
     MAED_PROPAGATE(maed_layernorm_fwd_ws(x_in, C, p->ln1_g, p->ln1_b, B.ln1, dt, (float*)(B.mean1), (float*)(B.rstd1), M, C, d->eps,
                                          piggy ? (uint32_t*)(B.st_sync) : nullptr, piggy ? d->F * 16 : 0, stream));
-    PROF(PROF_GEMM_QKV, maed_gemm_nt(B.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, B.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream));
+    PROF(PROF_GEMM_QKV, maed_gemm_nt_twin(B.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, B.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream, B.tw_qkv, false));
     {   // the two attention branches read the same qkv and write disjoint outputs: temporal on the side stream beside spatial
         SideStream* ss = (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || maed_x3_planes())) ? side_stream() : nullptr;
         void* tst = ss ? (void*)ss->s : stream;
@@ -285,7 +289,8 @@ static int block_fwd_bufs(const maed_block_dims* d, const maed_block_params* p, 
     }
     PROF(PROF_GEMM_PROJ, maed_gemm_nt(B.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, B.xmid, C, nullptr, x_in, C, 1, gi, stream));
     MAED_PROPAGATE(maed_layernorm_fwd((const float*)(B.xmid), C, p->ln2_g, p->ln2_b, B.ln2, dt, (float*)(B.mean2), (float*)(B.rstd2), M, C, d->eps, stream));
-    PROF(PROF_GEMM_FC1, maed_gemm_nt(B.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, B.hact, Hd, for_backward ? B.hpre : nullptr /* only GELU' reads it */, nullptr, 0, 1, gi, stream));
+    PROF(PROF_GEMM_FC1, maed_gemm_nt_twin(B.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, B.hact, Hd, for_backward ? B.hpre : nullptr /* only GELU' reads it */, nullptr, 0, 1, gi,
+                                          stream, B.tw_hact, B.hpre_bf16));
     PROF(PROF_GEMM_FC2, maed_gemm_nt(B.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, B.xmid, C, 1, gi, stream));
     return MAED_OK;
 }
@@ -336,14 +341,17 @@ extern "C" int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_bloc
     // hands each slot its own buffer); before this forward overwrites its buffer, the cast that last read it must be done
     SideStream* ss = side_stream();
     if (ss && ss->cast_pending[work_slot]) MAED_HIP(hipStreamWaitEvent((hipStream_t)stream, ss->cast_ev[work_slot], 0), "ste_block_fwd_twin: stream wait");
-    MAED_PROPAGATE(block_fwd_bufs(d, p, x_in, x_out, fwd_bufs(w, L32, sv, L16), true, stream));
-    const long long M = (long long)d->F * d->P, C = d->C, Hd = d->hidden;
+    // the three largest fields -- qkv and fc1's pre- / post-activation, 11 of the block's 16 M x C units -- get their twins from the producing GEMM's epilogue
+    // (the pre-activation as bf16 only: the forward never reads it); the cast pass handles the rest
+    FwdBufs fb = fwd_bufs(w, L32, sv, L16);
+    fb.tw_qkv = sv + L16.qkv; fb.tw_hact = sv + L16.hact; fb.hpre = sv + L16.hpre; fb.hpre_bf16 = true;
+    MAED_PROPAGATE(block_fwd_bufs(d, p, x_in, x_out, fb, true, stream));
+    const long long M = (long long)d->F * d->P, C = d->C;
     CastTab t{};
     int k = 0;
     auto add = [&](size_t o32, size_t o16, long long n) { t.src[k] = (const float*)(w + o32); t.dst[k] = (bf16*)(sv + o16); t.n8[k] = n / 8; ++k; };
-    add(L32.ln1, L16.ln1, M * C); add(L32.qkv, L16.qkv, M * 3 * C); add(L32.xs, L16.xs, M * C); add(L32.xt, L16.xt, M * C);
+    add(L32.ln1, L16.ln1, M * C); add(L32.xs, L16.xs, M * C); add(L32.xt, L16.xt, M * C);
     add(L32.means, L16.means, (long long)d->F * 2 * C); add(L32.mix, L16.mix, M * C); add(L32.ln2, L16.ln2, M * C);
-    add(L32.hpre, L16.hpre, M * Hd); add(L32.hact, L16.hact, M * Hd);
     hipStream_t cs = (hipStream_t)stream;
     if (ss) { ss->fence((hipStream_t)stream, ss->s2); cs = ss->s2; }
     hipLaunchKernelGGL(cast_table_kernel, dim3(1024, k), dim3(256), 0, cs, t);

@@ -12,16 +12,24 @@ struct EpiArgs {
     // statistics of the STORED (bf16-rounded) output, sums[n][32][2] (fp64, pre-zeroed by the caller) += (sum x, sum x^2) with n = row / gn_hw,
     // group = column / (N / 32) -- the separate statistics pass over the activation tensor disappears
     double* gn_sums = nullptr; int gn_hw = 0;
+    // fp32 products that leave bf16 twins for a bf16 backward (maed_gemm_nt_twin, block.hip's twin forward; T = float only): `twin` = bf16 copy of what goes to `out`
+    // (STORE: the result; GELU: the activation), same leading dimension; out2_bf16: the GELU pre-activation (out2) is stored as bf16 ONLY -- nothing of the forward
+    // chain reads it
+    void* twin = nullptr; bool out2_bf16 = false;
 };
 
 template <int EPI, typename T>
 __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int64_t c, float acc) {
     if constexpr (EPI == MAED_EPI_STORE) {
-        stf((T*)e.out + r * e.ldo + c, acc + (e.bias ? e.bias[c] : 0.f));
+        const float v = acc + (e.bias ? e.bias[c] : 0.f);
+        stf((T*)e.out + r * e.ldo + c, v);
+        if constexpr (sizeof(T) == 4) { if (e.twin) stf((bf16*)e.twin + r * e.ldo + c, v); }
     } else if constexpr (EPI == MAED_EPI_GELU) {
         const float pre = acc + (e.bias ? e.bias[c] : 0.f);
-        if (e.out2) stf((T*)e.out2 + r * e.ldo + c, pre);          // (out2 = NULL: nobody will ask for GELU', inference)
-        stf((T*)e.out + r * e.ldo + c, gelu_fwd<T>(round_to<T>(pre)));  // activation of the STORED (rounded) pre-activation
+        if (e.out2) { if (sizeof(T) == 4 && e.out2_bf16) stf((bf16*)e.out2 + r * e.ldo + c, pre); else stf((T*)e.out2 + r * e.ldo + c, pre); }   // (out2 = NULL: nobody will ask for GELU', inference)
+        const float a = gelu_fwd<T>(round_to<T>(pre));
+        stf((T*)e.out + r * e.ldo + c, a);  // activation of the STORED (rounded) pre-activation
+        if constexpr (sizeof(T) == 4) { if (e.twin) stf((bf16*)e.twin + r * e.ldo + c, a); }
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         ((float*)e.out)[r * e.ldo + c] = ((const float*)e.aux)[r * e.ldaux + c] + (acc + (e.bias ? e.bias[c] : 0.f));
     } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
@@ -58,11 +66,13 @@ __device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int
     }
     if constexpr (EPI == MAED_EPI_STORE) {
         st4((T*)e.out + r * e.ldo + c0, v);
+        if constexpr (sizeof(T) == 4) { if (e.twin) st4((bf16*)e.twin + r * e.ldo + c0, v); }
     } else if constexpr (EPI == MAED_EPI_GELU) {
-        if (e.out2) st4((T*)e.out2 + r * e.ldo + c0, v);
+        if (e.out2) { if (sizeof(T) == 4 && e.out2_bf16) st4((bf16*)e.out2 + r * e.ldo + c0, v); else st4((T*)e.out2 + r * e.ldo + c0, v); }
         // activation of the STORED (rounded) pre-activation, as the backward sees it -- rounded in registers, not read back
         float a[4] = {gelu_fwd<T>(round_to<T>(v[0])), gelu_fwd<T>(round_to<T>(v[1])), gelu_fwd<T>(round_to<T>(v[2])), gelu_fwd<T>(round_to<T>(v[3]))};
         st4((T*)e.out + r * e.ldo + c0, a);
+        if constexpr (sizeof(T) == 4) { if (e.twin) st4((bf16*)e.twin + r * e.ldo + c0, a); }
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         float x[4]; ld4((const float*)e.aux + r * e.ldaux + c0, x);
         float o[4] = {x[0] + v[0], x[1] + v[1], x[2] + v[2], x[3] + v[3]};
@@ -107,12 +117,14 @@ __device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int
     }
     if constexpr (EPI == MAED_EPI_STORE) {
         st8((T*)e.out + r * e.ldo + c0, v);
+        if constexpr (sizeof(T) == 4) { if (e.twin) st8_nt((bf16*)e.twin + r * e.ldo + c0, v); }
     } else if constexpr (EPI == MAED_EPI_GELU) {
-        if (e.out2) st8((T*)e.out2 + r * e.ldo + c0, v);
+        if (e.out2) { if (sizeof(T) == 4 && e.out2_bf16) st8_nt((bf16*)e.out2 + r * e.ldo + c0, v); else st8((T*)e.out2 + r * e.ldo + c0, v); }
         float a[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = gelu_fwd<T>(round_to<T>(v[j]));   // activation of the STORED (rounded) pre-activation
         st8((T*)e.out + r * e.ldo + c0, a);
+        if constexpr (sizeof(T) == 4) { if (e.twin) st8_nt((bf16*)e.twin + r * e.ldo + c0, a); }
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         float x[8]; ld8((const float*)e.aux + r * e.ldaux + c0, x);
 #pragma unroll
