@@ -71,7 +71,16 @@ bool maed_fault_seen(const char* who) {
                        "NaN-poisoned, the one-pass GroupNorm backward and the fused attentive addition now run as their multi-launch forms", who, *(volatile uint32_t*)w);
     return true;
 }
-extern "C" int maed_device_faults(void) { uint32_t* w = g_fault.load(std::memory_order_acquire); return w ? (int)*(volatile uint32_t*)w : 0; }
+// (maed_last_error is thread-local and the call that noticed the fault may have run on another thread -- autograd's backward worker: a non-zero answer also leaves the
+//  explanation as THIS thread's last error)
+extern "C" int maed_device_faults(void) {
+    uint32_t* w = g_fault.load(std::memory_order_acquire);
+    const int n = w ? (int)*(volatile uint32_t*)w : 0;
+    if (n > 0)
+        maed_set_error("%d frame-barrier timeout(s) on this device (workgroups of a frame were not co-resident: shared GPU / preemption); the affected results were "
+                       "NaN-poisoned, the one-pass GroupNorm backward and the fused attentive addition run as their multi-launch forms from the next call on", n);
+    return n;
+}
 extern "C" int maed_device_faults_clear(void) { uint32_t* w = g_fault.load(std::memory_order_acquire); if (w) *(volatile uint32_t*)w = 0; g_fault_told.store(0); return MAED_OK; }
 
 extern "C" int maed_set_option(int key, int value) {
