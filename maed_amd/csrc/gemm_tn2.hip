@@ -165,7 +165,10 @@ int maed_gemm_tn_dma_launch(const void* Y, int64_t ldy, const void* X, int64_t l
     const int tn = (N + T - 1) / T, tk = (K + T - 1) / T;
     const int nmt = (int)(M / T2_BM);
     // 128 x 128: two workgroups per CU (gemm_tn.hip's sweep: 512 workgroups for large outputs, ~256 for small ones); 256 x 256: one per CU
-    int splits = big ? (256 + tn * tk - 1) / (tn * tk) : maed_tn_splits(tn * tk);
+    // split sweep of THIS kernel (profiles/r05_tn_split_sweep.txt): the round-3 heuristic holds except for outputs of 32 .. 63 tiles, which want ~384 workgroups
+    // instead of 512 (qkv, 48 tiles: 8 splits 56.8 us, 10 splits 63.9; stage-3 strided 3x3 shortcut, 32 tiles: 12 splits 47.3, 16 splits 51.9) -- fewer closing atomics
+    const int tiles = tn * tk;
+    int splits = big ? (256 + tiles - 1) / tiles : (maed_opt(MAED_OPT_TN_TARGET_WGS) == 0 && tiles >= 32 && tiles < 64) ? 384 / tiles : maed_tn_splits(tiles);
     if (big && tn * tk * splits > 256 && splits > 1) --splits;          // never a second residency round
     if (splits > (nmt + 7) / 8) splits = (nmt + 7) / 8;                 // at least 8 M-tiles (256 rows) per workgroup
     if (splits < 1) splits = 1;

@@ -224,6 +224,108 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(maed_smpl_params sp, cons
     }
 }
 
+// ---- K12 on the matrix cores (round 5) --------------------------------------------------------------------------------------------
+// v_posed = v_template + shapedirs . beta + posedirs^T . (R[1:] - I) is ONE product per frame group: [frames x 218] . [218 x 20670] with the feature row
+// (207 pose features | 10 betas | 1) -- on v_mfma_f32_32x32x2_f32 (exact fp32: an fmaf chain in k order; 157 TF/s) instead of 207 rolled VALU iterations per vertex
+// thread with one wave per SIMD (lbs_skin_kernel: 140-150 us at 128 frames).  A wave owns one 32-column tile of the 20670 columns for up to 128 frames (four
+// accumulators); its B operand -- posedirs rows, the transposed shape directions, the template -- is streamed ONCE per frame group (17 MB for the whole launch) as
+// 128-byte row pieces, its A operand is read straight from the rotation matrices (k-th pose feature of frame f = rotmat[f][9 + k] minus the identity's diagonal).
+// The skinning itself (24 x 12 blend per vertex and frame) follows as a streaming kernel over v_posed.
+#define LB_KF 224                          // feature rows: 207 pose features, 10 betas, 1 (template), 6 zero rows (whole groups of 8 k-pairs)
+#define LB_FG 64                           // frames per workgroup (two 32-frame MFMA tiles per wave): 58 KB of LDS, two workgroups per CU
+#define LB_LD (LB_FG + 1)                  // LDS row stride of the [k][frame] feature image (floats): staging writes walk k, fragment reads walk the frame
+__global__ __launch_bounds__(256) void lbs_blend_mfma_kernel(maed_smpl_params sp, const float* __restrict__ betas, const float* __restrict__ rotmat,
+                                                            float* __restrict__ v_posed, int F) {
+    MAED_DYN_SHARED(float, s_feat);        // [LB_KF][LB_LD]: feature k of frame f0 + f.  (First version: A operands straight from rotmat -- 32 cache lines per load
+                                           // instruction, 416 of them per wave: 158 us against the VALU kernel's 137; second: one dependent B load per k-pair,
+                                           // nothing in flight behind it: 122 us.  Now eight B loads are issued ahead of the 16 MFMAs that consume them.)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int f0 = blockIdx.y * LB_FG, nf = min(LB_FG, F - f0);
+    // staging: thread -> (frame tid >> 2, k = (tid & 3) + 4 q): no integer division in the loop; frames past F stage a duplicate of the last frame (their results
+    // are never stored), so every load is unconditional -- a predicate made hipcc branch around each load and wait for it (52 serial round trips per thread)
+    {
+        const int f = tid >> 2, kq = tid & 3;
+        const float* rrow = rotmat + (int64_t)min(f0 + f, F - 1) * (NJ * 9) + 9;
+        float v[52];
+#pragma unroll
+        for (int q = 0; q < 52; ++q) { const int k = kq + 4 * q; v[q] = rrow[k < 207 ? k : 206]; }
+#pragma unroll
+        for (int q = 0; q < 52; ++q) {
+            const int k = kq + 4 * q, m9 = k % 9;
+            if (k < 207) s_feat[k * LB_LD + f] = v[q] - ((m9 == 0 || m9 == 4 || m9 == 8) ? 1.f : 0.f);
+        }
+    }
+    for (int i = tid; i < LB_FG * (LB_KF - 207); i += 256) {
+        const int f = i / (LB_KF - 207), l = i - f * (LB_KF - 207);
+        s_feat[(207 + l) * LB_LD + f] = l < 10 ? betas[(int64_t)min(f0 + f, F - 1) * 10 + l] : l == 10 ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const int c0 = (blockIdx.x * 4 + wave) * 32;
+    if (c0 >= NV * 3) return;
+    const int col = min(c0 + l31, NV * 3 - 1);
+    f32x16_t acc[LB_FG / 32];
+#pragma unroll
+    for (int t = 0; t < LB_FG / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // B operand: groups of eight k-pairs, the NEXT group's loads issued before this group's 16 MFMAs (two register sets, named: no runtime-indexed arrays);
+    // every frame tile is computed (a partial frame group multiplies duplicates): no branch between the MFMAs
+#define LB_LOAD(dst_, kk0_) _Pragma("unroll") for (int u = 0; u < 8; ++u) { const int k = 2 * ((kk0_) + u) + hi; \
+        const float* src__ = k < 207 ? sp.posedirs + (int64_t)k * (NV * 3) + col : k < 217 ? sp.shapedirs + (int64_t)col * 10 + (k - 207) : sp.v_template + col; \
+        dst_[u] = *src__; }     /* (k > 217: feature 0) */
+#define LB_MMA(src_, kk0_) _Pragma("unroll") for (int u = 0; u < 8; ++u) { const float* fa = s_feat + (2 * ((kk0_) + u) + hi) * LB_LD + l31; \
+        _Pragma("unroll") for (int t = 0; t < LB_FG / 32; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[32 * t], src_[u], acc[t], 0, 0, 0); }
+    float b0[8], b1[8];
+    LB_LOAD(b0, 0)
+    for (int kk0 = 0; kk0 < LB_KF / 2; kk0 += 16) {          // LB_KF / 2 = 112 = 7 x 16
+        LB_LOAD(b1, kk0 + 8)
+        LB_MMA(b0, kk0)
+        if (kk0 + 16 < LB_KF / 2) LB_LOAD(b0, kk0 + 16)
+        LB_MMA(b1, kk0 + 8)
+    }
+#undef LB_LOAD
+#undef LB_MMA
+    if (c0 + l31 >= NV * 3) return;
+#pragma unroll
+    for (int t = 0; t < LB_FG / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (f < nf) v_posed[(int64_t)(f0 + f) * (NV * 3) + c0 + l31] = acc[t][r];
+        }
+}
+
+// verts[f][v] = (sum_j w[v][j] A[f][j]) . [v_posed[f][v]; 1]: thread per vertex, FB frames per workgroup (the weights of a vertex are read once per FB frames).
+// v_posed may alias verts (inference: the blend is written into the output buffer and skinned in place -- a thread reads its own three values before it writes them).
+template <int FB>
+__global__ __launch_bounds__(256) void lbs_skin_posed_kernel(maed_smpl_params sp, const float* __restrict__ A, const float* v_posed, float* verts, int F) {
+    __shared__ float s_A[FB][NJ * 12];
+    const int f0 = blockIdx.y * FB;
+    for (int i = threadIdx.x; i < FB * NJ * 12; i += 256) {
+        const int fb = i / (NJ * 12), k = i % (NJ * 12);
+        s_A[fb][k] = A[(int64_t)min(f0 + fb, F - 1) * NJ * 12 + k];
+    }
+    __syncthreads();
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= NV) return;
+    float w[NJ];
+    for (int j = 0; j < NJ; ++j) w[j] = sp.lbs_weights[v * NJ + j];
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) {
+        if (f0 + fb >= F) break;
+        const float* q = v_posed + ((int64_t)(f0 + fb) * NV + v) * 3;
+        const float x = q[0], y = q[1], z = q[2];
+        float T[12];
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int j = 0; j < NJ; ++j)
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], s_A[fb][j * 12 + e], T[e]);
+        float* o = verts + ((int64_t)(f0 + fb) * NV + v) * 3;
+        o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+        o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+        o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    }
+}
+
 extern "C" int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas, const float* rotmat, float* verts,
                                  float* joints24, float* scratch_A, float* v_posed, int F, void* stream) {
     MAED_CHECK_ARG(sp && betas && rotmat && verts && joints24 && scratch_A, MAED_ERR_ARG, "smpl_lbs_fwd: null pointer");
@@ -232,7 +334,17 @@ extern "C" int maed_smpl_lbs_fwd(const maed_smpl_params* sp, const float* betas,
     if (F <= 0) return MAED_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lbs_chain_par_kernel, dim3((F + LC_FPB - 1) / LC_FPB), dim3(64), 0, s, *sp, betas, rotmat, joints24, scratch_A, F);
-    const int fb = maed_opt(MAED_OPT_LBS_FRAMES) ? maed_opt(MAED_OPT_LBS_FRAMES) : (F > 32 ? 16 : 4);     // frames per workgroup (4 / 8 / 16 = 157 / 183 / 138 us per forward at 128 frames)
+    if (maed_opt(MAED_OPT_LBS_FRAMES) == 0) {      // default (round 5): the blend on the fp32 matrix cores, then the skinning pass (MAED_OPT_LBS_FRAMES = 4 / 8 / 16: the VALU kernel)
+        float* vp = v_posed ? v_posed : verts;      // inference: blend into the output buffer, skinned in place
+        constexpr size_t lds = (size_t)LB_KF * LB_LD * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)lbs_blend_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL(lbs_blend_mfma_kernel, dim3((NV * 3 + 127) / 128, (F + LB_FG - 1) / LB_FG), dim3(256), lds, s, *sp, betas, rotmat, vp, F);
+        hipLaunchKernelGGL(lbs_skin_posed_kernel<4>, dim3((NV + 255) / 256, (F + 3) / 4), dim3(256), 0, s, *sp, scratch_A, vp, verts, F);
+        MAED_CHECK_LAUNCH("smpl_lbs_fwd");
+        return MAED_OK;
+    }
+    const int fb = maed_opt(MAED_OPT_LBS_FRAMES);     // frames per workgroup (4 / 8 / 16 = 157 / 183 / 138 us per forward at 128 frames)
     if (fb == 8) hipLaunchKernelGGL(lbs_skin_kernel<8>, dim3((NV + 255) / 256, (F + 7) / 8), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
     else if (fb == 4) hipLaunchKernelGGL(lbs_skin_kernel<4>, dim3((NV + 255) / 256, (F + 3) / 4), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
     else hipLaunchKernelGGL(lbs_skin_kernel<16>, dim3((NV + 255) / 256, (F + 15) / 16), dim3(256), 0, s, *sp, betas, rotmat, scratch_A, verts, v_posed, F);
