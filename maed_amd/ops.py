@@ -131,6 +131,19 @@ def shadow_clear():
     _SHADOW.clear()
 
 
+def shadow_keep_only(t16):
+    """drop every shadow but `t16`'s: the backbone calls it on its result -- the fp32 activations of its layers are dead once the last layer has run; only the output's
+    shadow has a consumer left (the projection GEMM of HybridEmbed, which clears the registry)"""
+    e = _SHADOW.get(t16.data_ptr()) if t16 is not None else None
+    for k in list(_UNFILLED):
+        if k in _SHADOW:
+            _SHADOW[k][0].copy_(_SHADOW[k][1])
+    _UNFILLED.clear()
+    _SHADOW.clear()
+    if e is not None:
+        _SHADOW[t16.data_ptr()] = e
+
+
 def twin_of(y32):
     """bf16 twin of an fp32 forward result, registered with its shadow (one cast pass)"""
     return shadow_put(y32.to(torch.bfloat16), y32)

@@ -352,7 +352,9 @@ class ResNetV2(nn.Module):
         # every per-pass hand-over slot (pre-padded stem input, standardised weights, GroupNorm scratch) is set INSIDE the try: an exception anywhere -- alignment,
         # out of memory, an unsupported size -- must not leave the stem marked "pre-padded" (the next forward would convolve an unpadded image: silently wrong)
         try:
-            return self._forward_features_library(x)
+            y = self._forward_features_library(x)
+            ops.shadow_keep_only(y)          # twin mode: the layers' fp32 activations are dead now; only the output's shadow has a consumer (HybridEmbed's projection)
+            return y
         except BaseException:
             ops.shadow_clear()
             raise
