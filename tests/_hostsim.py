@@ -20,6 +20,10 @@ def load():
             fn.restype, fn.argtypes = res, args
     assert h.maed_version() < 0, "this must be the simulator, not the product library"
     L.apply_options(h)          # the host's option values (fp32 matmul mode, side stream ...) as the product library would get them
+    # the LBS blend on the fp32 matrix cores (round 5) costs the simulator ~150 k emulated MFMA rendezvous per call: the suites that merely pass through the decoder
+    # tail run the VALU kernel (identical interface); tests/test_hostsim_tail.py::test_lbs_blend_on_the_matrix_cores_matches_the_valu_kernel covers the MFMA path
+    if "MAED_LBS_FB" not in os.environ:
+        h.maed_set_option(L.OPT_LBS_FRAMES, 4)
     return h
 
 

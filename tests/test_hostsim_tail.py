@@ -232,3 +232,37 @@ def test_regressor_csr_cache_follows_the_tensor_not_its_address():
     b = torch.zeros(2, 6890); b[0, 1] = 1.0          # (often lands on the freed storage)
     c3 = smpl.regressor_csr(b)
     assert c3[1].tolist() == [1], (ptr == b.data_ptr(), c3[1].tolist())
+
+
+def test_lbs_blend_on_the_matrix_cores_matches_the_valu_kernel():
+    """round 5: maed_smpl_lbs_fwd's default route -- v_posed = [pose features | betas | 1] . [posedirs; shapedirs^T; v_template] on v_mfma_f32_32x32x2_f32 (a wave
+    per 32-column tile and 64 frames; the last column tile is partial: 20670 = 645 * 32 + 30) followed by the streaming skinning pass -- against the VALU kernel
+    (MAED_OPT_LBS_FRAMES = 4) and the fp64 ATen composition: a partial frame group (3 of 64 frames), in place (inference: no v_posed buffer) and with the buffer
+    the training path keeps for the backward."""
+    import ctypes as C
+    from _hostsim import option
+    from maed_amd import _lib as L, ops
+    from maed_amd.smpl import SMPL
+    torch.manual_seed(4)
+    smpl = SMPL()
+    Fr = 3
+    betas = torch.randn(Fr, 10)
+    from maed_amd.geometry import rot6d_to_rotmat
+    rot = rot6d_to_rotmat(torch.randn(Fr * 24, 6)).reshape(Fr, 24, 3, 3).contiguous()
+    res = {}
+    with patched() as lib:
+        for mode in (4, 0):
+            with option(lib, L.OPT_LBS_FRAMES, mode):
+                res[mode] = [t.clone() for t in smpl.lbs_hip(betas, rot)]
+        with option(lib, L.OPT_LBS_FRAMES, 0):      # with the v_posed buffer (training)
+            verts = torch.empty(Fr, 6890, 3); j24 = torch.empty(Fr, 24, 3); A = torch.empty(Fr, 24, 12); vp = torch.empty(Fr, 6890, 3)
+            sp = smpl._c_params()
+            ops.check(lib.maed_smpl_lbs_fwd(C.byref(sp), ops._p(betas), ops._p(rot), ops._p(verts), ops._p(j24), ops._p(A), ops._p(vp), Fr, None), "smpl_lbs_fwd")
+    scale = res[4][0].abs().max()
+    assert (res[0][0] - res[4][0]).abs().max() <= 2e-6 * scale        # same fp32 products, another summation order
+    assert torch.equal(res[0][1], res[4][1])
+    assert torch.equal(verts, res[0][0])
+    # v_posed itself against the closed form in fp64
+    feat = (rot[:, 1:] - torch.eye(3)).reshape(Fr, 207).double()
+    vp_ref = (smpl.v_template.double().reshape(1, -1) + betas.double() @ smpl.shapedirs.double().reshape(-1, 10).t() + feat @ smpl.posedirs.double()).reshape(Fr, 6890, 3)
+    assert (vp.double() - vp_ref).abs().max() <= 2e-6 * vp_ref.abs().max()
