@@ -853,6 +853,8 @@ class GroupNormFn(torch.autograd.Function):
         N, C_, H, W = x.shape
         x32 = shadow_of(x)                       # bf16 graph over fp32 shadows (shadow_put): the forward runs on the shadows, the twins are what is saved
         r32 = shadow_of(residual) if x32 is not None else None
+        if x32 is not None and not x.is_contiguous(memory_format=torch.channels_last):
+            twin_fill(x)                         # an unfilled twin in another layout would be COPIED below, unfilled: fill it first (the kernel then need not)
         assert x32 is None or residual is None or r32 is not None, "GroupNormFn: the residual of a shadowed input has no shadow"
         x = x.contiguous(memory_format=torch.channels_last)
         if residual is not None:
@@ -967,7 +969,8 @@ class StemConvFn(torch.autograd.Function):
         if x32 is not None:     # bf16 graph over fp32 shadows: x32 is the TF-SAME padded fp32 image (stem_input own=False); the vendor's fp32 convolution as in the f32 modes
             assert sums is None, "stem: the GroupNorm behind a shadowed stem computes its own statistics"
             w32 = shadow_of(w)
-            return twin_later(torch.nn.functional.conv2d(x32, w32, None, 2, 0))
+            # (channels_last whatever the vendor solver returns: the GroupNorm behind writes this tensor's twin in place, by address)
+            return twin_later(torch.nn.functional.conv2d(x32, w32, None, 2, 0).contiguous(memory_format=torch.channels_last))
         y = torch.empty((F_, 64, H // 2, W // 2), dtype=xp.dtype, device=xp.device, memory_format=torch.channels_last)
         wimg = torch.empty(64 * 224, dtype=xp.dtype, device=xp.device)
         check(L.lib().maed_stem7x7s2_fwd(_p(xp), _p(wc), _p(wimg), _p(y), _p(sums), F_, H, W, dt_code(xp.dtype), _stream()), "stem7x7s2_fwd")
