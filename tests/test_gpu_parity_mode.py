@@ -192,3 +192,57 @@ def test_cfg5_full_size_twin_mode_training_pass_vs_oracle_fixture():
     for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts_sample"):
         ref = torch.from_numpy(G[k])
         report(f"cfg5 full size, twin mode training pass {k} vs oracle fixture", out[k], ref, rtol=0, atol=1e-3 * ref.abs().max().item())
+
+
+def test_cfg3_twin_mode_train_steps_track_the_all_bf16x3_mode():
+    """What a trainer cares about: the accurate mode's loss trajectory with the bf16 backward on twins.  Six FusedAdam steps on one fixed 2-clip batch at cfg3
+    dimensions with the reference's own objective (LossVideo), from the same seeded parameters, KTD dropout off: all-bf16x3 (forward and backward on split products)
+    against the twin mode.  The first loss is the same forward (to the order of its fp32 atomics); the later ones follow it although every update came from bf16-level
+    gradients -- within 1e-3 of each other's value, both decreasing."""
+    import maed_amd
+    from maed_amd import ops
+    from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+    from maed_amd.loss import LossVideo
+    C, P = 64 * CFG["H"], (CFG["img"] // 16) ** 2 + 1
+    params = R.make_params(embed_dim=C, depth=CFG["depth"], hidden_dim=CFG["hidden"], n_tokens=P, seed=7)
+    g = torch.Generator().manual_seed(5)
+    N, T = 2, CFG["T"]
+    clip = torch.randn(N, T, 3, CFG["img"], CFG["img"], generator=g).to(DEV)
+    r = lambda *s: torch.randn(*s, generator=g)
+    tgt = {k: v.to(DEV) for k, v in dict(kp_2d=torch.cat([r(N, T, 49, 2) * 0.3, torch.rand(N, T, 49, 1, generator=g)], -1),
+                                         kp_3d=torch.cat([r(N, T, 49, 3) * 0.3, torch.ones(N, T, 49, 1)], -1),
+                                         theta=torch.cat([r(N, T, 3) * 0.1, r(N, T, 72) * 0.2, r(N, T, 10)], -1), w_smpl=torch.ones(N, T)).items()}
+    crit = LossVideo(e_loss_weight=300.0, e_3d_loss_weight=600.0, e_pose_loss_weight=60.0, e_shape_loss_weight=0.06, e_smpl_norm_loss=1.0, e_smpl_accl_loss=0.0)
+    old = ops.get_float32_matmul_precision()
+    curves = {}
+    try:
+        ops.set_float32_matmul_precision("bf16x3")
+        for bwd in (None, "bf16"):
+            ops.set_float32_backward_precision(bwd)
+            m = maed_amd.MAED(num_blocks=CFG["depth"], num_heads=CFG["H"], embed_dim=C, hidden_dim=CFG["hidden"], img_size=CFG["img"], compute_dtype=torch.float32)
+            m.load_state_dict(params, strict=False)
+            m = m.to(DEV).train()
+            m.decoder.drop1.p = m.decoder.drop2.p = 0.0
+            arena = ParamArena(m)
+            opt = FusedAdam(arena, lr=1e-4, bucketer=GradBucketer(arena, m))
+            twins = ops.TWIN_FORWARDS[0]
+            losses = []
+            for _ in range(6):
+                opt.zero_grad()
+                loss, _ = crit(m(clip), tgt, None)
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach())
+            torch.cuda.synchronize()
+            assert ops.TWIN_FORWARDS[0] - twins == (6 * (1 + CFG["depth"]) if bwd == "bf16" else 0)
+            curves[bwd] = torch.stack(losses).float().cpu()
+            del m, arena, opt
+    finally:
+        ops.set_float32_matmul_precision(old)
+        ops.set_float32_backward_precision(None)
+    a, b = curves[None], curves["bf16"]
+    note(f"six train steps at cfg3 dims, LossVideo: all-bf16x3 {[round(float(v), 5) for v in a]}  twin mode {[round(float(v), 5) for v in b]}")
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert abs(float(a[0] - b[0])) <= 1e-5 * abs(float(a[0])), (a[0], b[0])
+    assert ((a - b).abs() <= 1e-3 * a.abs()).all(), (a, b)
+    assert a[-1] < a[0] and b[-1] < b[0]

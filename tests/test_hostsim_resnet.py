@@ -304,12 +304,15 @@ def test_stem_convolution_on_the_library_when_the_frame_geometry_allows(own, mon
         assert p.grad is not None and cos(p.grad, q.grad) > 0.97, (n, cos(p.grad, q.grad))
 
 
-def test_backbone_twin_mode_fp32_forward_on_shadows_bf16_backward_on_twins(monkeypatch):
+@pytest.mark.parametrize("per_stage", [False, True])
+def test_backbone_twin_mode_fp32_forward_on_shadows_bf16_backward_on_twins(per_stage, monkeypatch):
     """round 5, ops.set_float32_backward_precision("bf16"): a compute_dtype = float32 backbone in a training pass runs the bf16 mode's AUTOGRAD GRAPH (own stem,
     GEMM / implicit-GEMM convolutions, fused GroupNorm, bit masks, fp32 dW slices) over bf16 twins while the forward chain computes on fp32 shadows with the
     split-bf16 products: the output's shadow agrees with the fp32 ATen composition at the split engine's level (the bf16 mode: cosine 0.999), the twin is its bf16
     rounding, every parameter gradient is what the bf16 mode delivers, and a no-grad pass of the same module stays the plain fp32 path."""
     from maed_amd import ops
+    # per_stage: the data-parallel path's weight standardisation per backbone stage (resnetv2._WS_PER_STAGE) -- one bf16 autograd node + one fp32 shadow image set per stage
+    monkeypatch.setattr(resnetv2, "_WS_PER_STAGE", per_stage)
     torch.manual_seed(5)
     ref = ResNetV2(layers=(1, 1), channels=(256, 512), in_chans=3, compute_dtype=torch.float32)
     for m in ref._norms:
