@@ -102,6 +102,12 @@ typedef enum {
     MAED_OPT_LBS_FRAMES = 9,       /* frames per workgroup of the LBS skinning kernel: 0 (default) = 16 for more than 32 frames, else 4; or 4 / 8 / 16 */
     MAED_OPT_TN_DMA = 10,          /* 1 (default): bf16 weight-gradient GEMMs (maed_gemm_tn_wgrad, M % 32 == 0) on the LDS-DMA + transposing-read kernel (csrc/gemm_tn2.hip);
                                     * 0: the register-transposing kernel (csrc/gemm_tn.hip) -- A/B knob */
+    MAED_OPT_X3_PLANES = 11,       /* maed_ste_block_fwd_twin: fc1's activation is stored as (hi, lo) bf16 planes -- hi is the backward's twin, 4 bytes per element instead of
+                                    * fp32 + twin = 6 -- and fc2 runs on maed_gemm_nt_planes' kernel variant of this value: 6 (default) = 256 x 256 tiles, 2 / 4 = 128 x 128 with a
+                                    * ring of 2 / 4 stages, 5 = 256 x 128, 7 = 128 x 128 with K tiles of 64; 0 = fp32 activation + twin, fc2 on the fp32-operand kernel (A/B knob) */
+    MAED_OPT_X3_PLANES_LN = 12,    /* with MAED_OPT_X3_PLANES != 0: 1 = the block's two LayerNorm outputs are stored as planes too (hi straight into the bf16 arena: no cast pass
+                                    * for them) and qkv / fc1 run on the 128 x 128 plane kernel; 0 (default) = fp32 LayerNorm outputs, fp32-operand kernel.  Measured neutral
+                                    * in the cfg3 train step (28.83 vs 28.80 ms): kept as an A/B knob */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's
@@ -140,6 +146,22 @@ int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb,
                  int64_t M, int64_t N, int64_t K, int dtype, int epilogue,
                  const float* bias, void* out, int64_t ldo, void* out2,
                  const void* aux, int64_t ldaux, int splitk, int impl, void* stream);
+
+/* The same product in the accurate mode's arithmetic ("bf16x3": 16 significand bits per operand, three bf16 MFMAs per product, fp32 accumulators) on operands that are
+ * STORED as two bf16 planes, x = hi + lo with hi = bf16(x) (round to nearest even), lo = bf16(x - hi) (round 5; csrc/gemm_x3p.hip):
+ *     out[f32](M, ldo) = epi((a_hi + a_lo)[M,K] (b_hi + b_lo)[N,K]^T)          both planes of an operand share its leading dimension (elements)
+ * bit for bit what maed_gemm_nt computes with dtype MAED_F32X3 on the fp32 operand the planes were split from; the planes move the same 4 bytes per element but reach
+ * LDS by LDS-DMA (no register staging, no VALU split), and the hi plane doubles as the bf16 twin a bf16 backward reads (maed_ste_block_fwd_twin).
+ * epilogue: MAED_EPI_STORE (+ bias), MAED_EPI_GELU (+ bias; out2_bf16 = the pre-activation as bf16, or NULL), MAED_EPI_RESID_F32 (out = aux[f32] + product + bias).
+ * out_hi / out_lo (STORE, GELU; leading dimension ldo): the result as planes for the next product of the chain; `out` may be NULL when out_hi is given.
+ * variant: 0 = the one MAED_OPT_X3_PLANES names; 2 / 4 = 128 x 128 tiles with a copy ring of 2 / 4 stages, 5 = 256 x 128 (3 stages), 6 = 256 x 256 (2 stages),
+ * 7 = 128 x 128 with K tiles of 64 on eight waves -- all bit-identical (profiles/r05_x3p_micro.txt).  K % 32 == 0, lda / ldb % 8 == 0, planes 16-byte aligned and < 4 GB each.
+ * Reference: the nn.Linear calls of vision_transformer.py:98-111,124-128 in fp32. */
+int maed_gemm_nt_planes(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                        int epilogue, const float* bias, void* out, int64_t ldo, void* out2_bf16, const void* aux, int64_t ldaux, void* out_hi, void* out_lo,
+                        int variant, void* stream);
+/* hi[bf16](n), lo[bf16](n) = the two planes of x[f32](n) (n % 8 == 0, 16-byte aligned): what maed_gemm_nt_planes takes for a tensor that exists as fp32 (weights) */
+int maed_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream);
 
 /* weight gradient dW[N,K] += Y[M,N]^T X[M,K] and (optional) bias gradient dbias[N] += colsum(Y), bf16 operands,
  * fp32 atomics (split over M).  No transposed copies: 8x8 blocks are transposed in registers while staging. */

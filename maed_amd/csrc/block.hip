@@ -194,7 +194,7 @@ int maed_layernorm_bwd_ws(const void* dy, int dtype, const float* x, int64_t x_r
                           void* stream, bool finish = true, uint32_t* clear = nullptr, int clear_words = 0);
 int maed_layernorm_affine_finish(const float* partials, int64_t rows, int C, float* dgamma, float* dbeta, void* stream);
 int maed_layernorm_fwd_ws(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y, int dtype, float* mean, float* rstd, int64_t rows,
-                          int C, float eps, uint32_t* clear, int clear_words, void* stream);
+                          int C, float eps, uint32_t* clear, int clear_words, void* stream, void* y_lo = nullptr);
 int maed_st_fused_fwd_ws(const void* x_s, const void* x_t, const void* w_ts, const float* b_ts, void* means, float* logits, void* mix,
                          uint32_t* sync, float* ex, int F, int P, int C, int dtype, bool clear_sync, uint32_t arrive_base, void* stream);
 int maed_st_fused_bwd_ws(const void* dmix, const void* x_s, const void* x_t, const float* logits, const void* wt_ts, void* dlogits, void* dx_s,
@@ -246,7 +246,12 @@ extern "C" size_t maed_ste_block_scratch_bytes(const maed_block_dims* d) { retur
 // backward will read.
 struct FwdBufs { char *ln1, *mean1, *rstd1, *qkv, *xs, *xt, *lse_s, *lse_t, *means, *logits, *mix, *xmid, *mean2, *rstd2, *ln2, *hpre, *hact, *st_sync, *st_ex;
                  // twin forward only: bf16 twins written by the producing GEMM's epilogue (no cast pass for them); hpre then holds bf16 (nothing of the forward reads it)
-                 char *tw_qkv = nullptr, *tw_hact = nullptr; bool hpre_bf16 = false; };
+                 char *tw_qkv = nullptr, *tw_hact = nullptr; bool hpre_bf16 = false;
+                 // ... with plane storage of fc1's activation (MAED_OPT_X3_PLANES): its lo plane and the planes of fc2's weight, in the work buffer's (unused) fp32 field
+                 char *hact_lo = nullptr, *wfc2_hi = nullptr, *wfc2_lo = nullptr; int planes_variant = 0;
+                 // ... and of the two LayerNorm outputs (MAED_OPT_X3_PLANES_LN): hi planes straight into the bf16 arena (they ARE the twins), lo planes + the planes of
+                 // the qkv / fc1 weights in the work buffer; qkv and fc1 then run on the plane kernel too
+                 char *ln1_hi = nullptr, *ln1_lo = nullptr, *ln2_hi = nullptr, *ln2_lo = nullptr, *wqkv_hi = nullptr, *wqkv_lo = nullptr, *wfc1_hi = nullptr, *wfc1_lo = nullptr; };
 static FwdBufs fwd_bufs(char* act_base, const SavedLayout& A, char* f32_base, const SavedLayout& Fl) {
     FwdBufs b;
     b.ln1 = act_base + A.ln1; b.qkv = act_base + A.qkv; b.xs = act_base + A.xs; b.xt = act_base + A.xt; b.means = act_base + A.means; b.mix = act_base + A.mix;
@@ -257,7 +262,7 @@ static FwdBufs fwd_bufs(char* act_base, const SavedLayout& A, char* f32_base, co
 }
 
 int maed_gemm_nt_twin(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype, int epilogue, const float* bias, void* out,
-                      int64_t ldo, void* out2, const void* aux, int64_t ldaux, int splitk, int impl, void* stream, void* twin, bool out2_bf16);      // gemm.hip
+                      int64_t ldo, void* out2, const void* aux, int64_t ldaux, int splitk, int impl, void* stream, void* twin, bool out2_bf16, void* lo);      // gemm.hip
 static int block_fwd_bufs(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, const FwdBufs& B, bool for_backward, void* stream) {
     const int64_t M = (int64_t)d->F * d->P;
     const int C = d->C, Hd = d->hidden, dt = d->dtype;
@@ -268,9 +273,24 @@ static int block_fwd_bufs(const maed_block_dims* d, const maed_block_params* p, 
     // (the LayerNorm kernel also zeroes the per-frame arrival counters of the fused attentive addition further down: no memset launch of their own)
     const bool stf = st_fused(*d);
     const bool piggy = stf && maed_opt(MAED_OPT_ST_FUSED) != 2 && (int64_t)d->F * 16 <= 256 * ((M + 31) / 32);       // (the backward LayerNorm's grid is the smaller one; otherwise the fused call clears itself; option value 2: A/B knob -- memset nodes, LayerNorm column sums on the caller's stream)
+    if (B.ln1_lo) {
+        // weights of the block's plane products, split once per call: [fc2 | qkv | fc1]
+        const float* wsrc[3] = {(const float*)p->w_fc2, (const float*)p->w_qkv, (const float*)p->w_fc1};
+        void* wh[3] = {B.wfc2_hi, B.wqkv_hi, B.wfc1_hi}; void* wl[3] = {B.wfc2_lo, B.wqkv_lo, B.wfc1_lo};
+        const int64_t wn[3] = {(int64_t)C * Hd, (int64_t)3 * C * C, (int64_t)C * Hd};
+        MAED_PROPAGATE(maed_split_planes_launch(3, wsrc, wh, wl, wn, (hipStream_t)stream));
+        MAED_CHECK_LAUNCH("ste_block_fwd_twin: weight planes");
+        MAED_PROPAGATE(maed_layernorm_fwd_ws(x_in, C, p->ln1_g, p->ln1_b, B.ln1_hi, MAED_BF16, (float*)(B.mean1), (float*)(B.rstd1), M, C, d->eps,
+                                             piggy ? (uint32_t*)(B.st_sync) : nullptr, piggy ? d->F * 16 : 0, stream, B.ln1_lo));
+        EpiArgs eq{};
+        eq.bias = p->b_qkv; eq.out = B.qkv; eq.ldo = 3 * C; eq.twin = B.tw_qkv;
+        PROF(PROF_GEMM_QKV, maed_gemm_nt_x3p_launch(MAED_EPI_STORE, 2, B.ln1_hi, B.ln1_lo, C, B.wqkv_hi, B.wqkv_lo, C, M, 3 * C, C, eq, (hipStream_t)stream));
+        MAED_CHECK_LAUNCH("ste_block_fwd_twin: qkv on planes");
+    } else {
     MAED_PROPAGATE(maed_layernorm_fwd_ws(x_in, C, p->ln1_g, p->ln1_b, B.ln1, dt, (float*)(B.mean1), (float*)(B.rstd1), M, C, d->eps,
                                          piggy ? (uint32_t*)(B.st_sync) : nullptr, piggy ? d->F * 16 : 0, stream));
-    PROF(PROF_GEMM_QKV, maed_gemm_nt_twin(B.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, B.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream, B.tw_qkv, false));
+    PROF(PROF_GEMM_QKV, maed_gemm_nt_twin(B.ln1, C, p->w_qkv, C, M, 3 * C, C, dt, MAED_EPI_STORE, p->b_qkv, B.qkv, 3 * C, nullptr, nullptr, 0, 1, gi, stream, B.tw_qkv, false, nullptr));
+    }
     {   // the two attention branches read the same qkv and write disjoint outputs: temporal on the side stream beside spatial
         SideStream* ss = (d->impl != MAED_IMPL_VALU && (dt == MAED_BF16 || maed_x3_planes())) ? side_stream() : nullptr;
         void* tst = ss ? (void*)ss->s : stream;
@@ -288,9 +308,33 @@ static int block_fwd_bufs(const maed_block_dims* d, const maed_block_params* p, 
         MAED_PROPAGATE(maed_st_mix_fwd(B.xs, B.xt, logits, B.mix, d->F, d->P, C, dt, stream));
     }
     PROF(PROF_GEMM_PROJ, maed_gemm_nt(B.mix, C, p->w_proj, C, M, C, C, dt, MAED_EPI_RESID_F32, p->b_proj, B.xmid, C, nullptr, x_in, C, 1, gi, stream));
-    MAED_PROPAGATE(maed_layernorm_fwd((const float*)(B.xmid), C, p->ln2_g, p->ln2_b, B.ln2, dt, (float*)(B.mean2), (float*)(B.rstd2), M, C, d->eps, stream));
+    if (B.ln2_lo) MAED_PROPAGATE(maed_layernorm_fwd_ws((const float*)(B.xmid), C, p->ln2_g, p->ln2_b, B.ln2_hi, MAED_BF16, (float*)(B.mean2), (float*)(B.rstd2), M, C, d->eps,
+                                                       nullptr, 0, stream, B.ln2_lo));
+    else MAED_PROPAGATE(maed_layernorm_fwd((const float*)(B.xmid), C, p->ln2_g, p->ln2_b, B.ln2, dt, (float*)(B.mean2), (float*)(B.rstd2), M, C, d->eps, stream));
+    if (B.hact_lo) {
+        // twin forward with plane storage (MAED_OPT_X3_PLANES): fc1's epilogue leaves the activation as (hi, lo) bf16 planes only -- hi IS the backward's twin, 4 bytes
+        // per element instead of fp32 + twin = 6 -- and fc2 multiplies the planes (csrc/gemm_x3p.hip: the same three products per K step, bit for bit); its weight is
+        // split once per call (1 M elements)
+        if (!B.ln1_lo) {
+            const float* wsrc[1] = {(const float*)p->w_fc2}; void* wh[1] = {B.wfc2_hi}; void* wl[1] = {B.wfc2_lo}; const int64_t wn[1] = {(int64_t)C * Hd};
+            MAED_PROPAGATE(maed_split_planes_launch(1, wsrc, wh, wl, wn, (hipStream_t)stream));
+            MAED_CHECK_LAUNCH("ste_block_fwd_twin: weight planes");
+        }
+        if (B.ln2_lo) {
+            EpiArgs e1{};
+            e1.bias = p->b_fc1; e1.ldo = Hd; e1.out2 = B.hpre; e1.out2_bf16 = true; e1.twin = B.tw_hact; e1.lo = B.hact_lo;
+            PROF(PROF_GEMM_FC1, maed_gemm_nt_x3p_launch(MAED_EPI_GELU, 2, B.ln2_hi, B.ln2_lo, C, B.wfc1_hi, B.wfc1_lo, C, M, Hd, C, e1, (hipStream_t)stream));
+            MAED_CHECK_LAUNCH("ste_block_fwd_twin: fc1 on planes");
+        } else
+        PROF(PROF_GEMM_FC1, maed_gemm_nt_twin(B.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, nullptr, Hd, B.hpre, nullptr, 0, 1, gi, stream, B.tw_hact, true, B.hact_lo));
+        EpiArgs e2{};
+        e2.bias = p->b_fc2; e2.out = x_out; e2.ldo = C; e2.aux = B.xmid; e2.ldaux = C;
+        PROF(PROF_GEMM_FC2, maed_gemm_nt_x3p_launch(MAED_EPI_RESID_F32, B.planes_variant, B.tw_hact, B.hact_lo, Hd, B.wfc2_hi, B.wfc2_lo, Hd, M, C, Hd, e2, (hipStream_t)stream));
+        MAED_CHECK_LAUNCH("ste_block_fwd_twin: fc2 on planes");
+        return MAED_OK;
+    }
     PROF(PROF_GEMM_FC1, maed_gemm_nt_twin(B.ln2, C, p->w_fc1, C, M, Hd, C, dt, MAED_EPI_GELU, p->b_fc1, B.hact, Hd, for_backward ? B.hpre : nullptr /* only GELU' reads it */, nullptr, 0, 1, gi,
-                                          stream, B.tw_hact, B.hpre_bf16));
+                                          stream, B.tw_hact, B.hpre_bf16, nullptr));
     PROF(PROF_GEMM_FC2, maed_gemm_nt(B.hact, Hd, p->w_fc2, Hd, M, C, Hd, dt, MAED_EPI_RESID_F32, p->b_fc2, x_out, C, nullptr, B.xmid, C, 1, gi, stream));
     return MAED_OK;
 }
@@ -323,7 +367,7 @@ __global__ __launch_bounds__(256) void cast_table_kernel(CastTab t) {
 extern "C" size_t maed_ste_block_twin_work_bytes(const maed_block_dims* d) {
     if (!d) return 0;
     maed_block_dims d32 = *d; d32.dtype = MAED_F32;
-    return saved_layout(d32).total;
+    return saved_layout(d32).total + ((size_t)2 * d->C * d->hidden + (size_t)3 * d->C * d->C) * 4;       // + the bf16 planes of the fc2, qkv and fc1 weights (MAED_OPT_X3_PLANES / _LN)
 }
 
 extern "C" int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved_bf16, void* work_f32,
@@ -345,13 +389,27 @@ extern "C" int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_bloc
     // (the pre-activation as bf16 only: the forward never reads it); the cast pass handles the rest
     FwdBufs fb = fwd_bufs(w, L32, sv, L16);
     fb.tw_qkv = sv + L16.qkv; fb.tw_hact = sv + L16.hact; fb.hpre = sv + L16.hpre; fb.hpre_bf16 = true;
+    const int pv = maed_opt(MAED_OPT_X3_PLANES);
+    char* const wpl = w + L32.total;                                       // (fields are 256-byte aligned, so is the total)
+    if (pv && maed_x3_planes() == 2 && d->impl != MAED_IMPL_VALU
+        && maed_x3p_shape_ok(fb.tw_hact, w + L32.hact, d->hidden, wpl, wpl + (size_t)d->C * d->hidden * 2, d->hidden, (int64_t)d->F * d->P, d->C, d->hidden)) {
+        // the fp32 field of fc1's activation holds its lo plane (half of it); the planes of fc2's weight sit behind the fp32 layout
+        fb.hact_lo = w + L32.hact; fb.wfc2_hi = wpl; fb.wfc2_lo = wpl + (size_t)d->C * d->hidden * 2; fb.planes_variant = pv;
+        if (maed_opt(MAED_OPT_X3_PLANES_LN) && d->C % 32 == 0) {
+            const size_t CH2 = (size_t)d->C * d->hidden * 2, CC2 = (size_t)3 * d->C * d->C * 2;
+            fb.ln1_hi = sv + L16.ln1; fb.ln1_lo = w + L32.ln1; fb.ln2_hi = sv + L16.ln2; fb.ln2_lo = w + L32.ln2;
+            fb.wqkv_hi = wpl + 2 * CH2; fb.wqkv_lo = fb.wqkv_hi + CC2; fb.wfc1_hi = fb.wqkv_lo + CC2; fb.wfc1_lo = fb.wfc1_hi + CH2;
+        }
+    }
     MAED_PROPAGATE(block_fwd_bufs(d, p, x_in, x_out, fb, true, stream));
     const long long M = (long long)d->F * d->P, C = d->C;
     CastTab t{};
     int k = 0;
     auto add = [&](size_t o32, size_t o16, long long n) { t.src[k] = (const float*)(w + o32); t.dst[k] = (bf16*)(sv + o16); t.n8[k] = n / 8; ++k; };
-    add(L32.ln1, L16.ln1, M * C); add(L32.xs, L16.xs, M * C); add(L32.xt, L16.xt, M * C);
-    add(L32.means, L16.means, (long long)d->F * 2 * C); add(L32.mix, L16.mix, M * C); add(L32.ln2, L16.ln2, M * C);
+    if (!fb.ln1_lo) add(L32.ln1, L16.ln1, M * C);
+    add(L32.xs, L16.xs, M * C); add(L32.xt, L16.xt, M * C);
+    add(L32.means, L16.means, (long long)d->F * 2 * C); add(L32.mix, L16.mix, M * C);
+    if (!fb.ln2_lo) add(L32.ln2, L16.ln2, M * C);
     hipStream_t cs = (hipStream_t)stream;
     if (ss) { ss->fence((hipStream_t)stream, ss->s2); cs = ss->s2; }
     hipLaunchKernelGGL(cast_table_kernel, dim3(1024, k), dim3(256), 0, cs, t);

@@ -764,16 +764,18 @@ extern "C" int maed_conv1x1_fwd(const void* x, int64_t ldx, const void* w, int64
 // maed_gemm_nt with the twin outputs of EpiArgs (fp32 operands on the split kernels, STORE / GELU epilogues): block.hip's twin forward
 int maed_gemm_nt_twin(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       int dtype, int epilogue, const float* bias, void* out, int64_t ldo, void* out2,
-                      const void* aux, int64_t ldaux, int splitk, int impl, void* stream, void* twin, bool out2_bf16);
+                      const void* aux, int64_t ldaux, int splitk, int impl, void* stream, void* twin, bool out2_bf16, void* lo);
 extern "C" int maed_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                             int dtype, int epilogue, const float* bias, void* out, int64_t ldo, void* out2,
                             const void* aux, int64_t ldaux, int splitk, int impl, void* stream) {
-    return maed_gemm_nt_twin(A, lda, B, ldb, M, N, K, dtype, epilogue, bias, out, ldo, out2, aux, ldaux, splitk, impl, stream, nullptr, false);
+    return maed_gemm_nt_twin(A, lda, B, ldb, M, N, K, dtype, epilogue, bias, out, ldo, out2, aux, ldaux, splitk, impl, stream, nullptr, false, nullptr);
 }
 int maed_gemm_nt_twin(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       int dtype, int epilogue, const float* bias, void* out, int64_t ldo, void* out2,
-                      const void* aux, int64_t ldaux, int splitk, int impl, void* stream, void* twin, bool out2_bf16) {
-    MAED_CHECK_ARG(A && B && out, MAED_ERR_ARG, "gemm_nt: null pointer");
+                      const void* aux, int64_t ldaux, int splitk, int impl, void* stream, void* twin, bool out2_bf16, void* lo) {
+    // (twin + lo: the result as (hi, lo) bf16 planes for maed_gemm_nt_planes -- the fp32 form `out` may then be NULL)
+    MAED_CHECK_ARG(A && B && (out || (twin && lo)), MAED_ERR_ARG, "gemm_nt: null pointer");
+    MAED_CHECK_ARG(!lo || (twin && is_aligned(lo, 16)), MAED_ERR_ARG, "gemm_nt: a lo plane goes with the twin (hi) plane, 16-byte aligned");
     {   // MAED_F32X3 / MAED_F32X6: fp32 storage with an explicit engine = MAED_F32 + impl MAED_IMPL_X3 / _X6
         const int np_call = maed_x3_take_dtype(dtype);
         if (np_call && impl == MAED_IMPL_AUTO) impl = np_call == 2 ? MAED_IMPL_X3 : np_call == 1 ? MAED_IMPL_X1 : MAED_IMPL_X6;
@@ -787,7 +789,7 @@ int maed_gemm_nt_twin(const void* A, int64_t lda, const void* B, int64_t ldb, in
                                            && is_aligned(twin, 16) && (!out2_bf16 || is_aligned(out2, 16))),
                    MAED_ERR_ARG, "gemm_nt: twin outputs go with fp32 operands, the STORE / GELU epilogues, N and ldo multiples of 8 and 16-byte aligned buffers");
     EpiArgs e{bias, out, ldo, out2, aux, ldaux};
-    e.twin = twin; e.out2_bf16 = out2_bf16;
+    e.twin = twin; e.out2_bf16 = out2_bf16; e.lo = lo;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (epilogue) {

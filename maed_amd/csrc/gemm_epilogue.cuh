@@ -16,20 +16,32 @@ struct EpiArgs {
     // (STORE: the result; GELU: the activation), same leading dimension; out2_bf16: the GELU pre-activation (out2) is stored as bf16 ONLY -- nothing of the forward
     // chain reads it
     void* twin = nullptr; bool out2_bf16 = false;
+    // plane storage of the same output (csrc/gemm_x3p.hip; T = float only): `twin` is the hi plane, `lo` = bf16(value - hi) with the twin's leading dimension -- the next
+    // split product reads (twin, lo) instead of fp32; `out` may then be NULL (nothing else reads the fp32 form)
+    void* lo = nullptr;
 };
+
+// the (hi, lo) bf16 planes of eight fp32 values: hi = bf16(v) (round to nearest even), lo = bf16(v - hi) -- gemm_x3.h's split4<2>
+__device__ __forceinline__ void epi_store_planes8(bf16* hi, bf16* lo, const float (&v)[8]) {
+    float l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = v[j] - round_to<bf16>(v[j]);
+    st8_nt(hi, v);
+    if (lo) st8_nt(lo, l);
+}
 
 template <int EPI, typename T>
 __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int64_t r, int64_t c, float acc) {
     if constexpr (EPI == MAED_EPI_STORE) {
         const float v = acc + (e.bias ? e.bias[c] : 0.f);
-        stf((T*)e.out + r * e.ldo + c, v);
-        if constexpr (sizeof(T) == 4) { if (e.twin) stf((bf16*)e.twin + r * e.ldo + c, v); }
+        if (sizeof(T) != 4 || e.out) stf((T*)e.out + r * e.ldo + c, v);
+        if constexpr (sizeof(T) == 4) { if (e.twin) stf((bf16*)e.twin + r * e.ldo + c, v); if (e.lo) stf((bf16*)e.lo + r * e.ldo + c, v - round_to<bf16>(v)); }
     } else if constexpr (EPI == MAED_EPI_GELU) {
         const float pre = acc + (e.bias ? e.bias[c] : 0.f);
         if (e.out2) { if (sizeof(T) == 4 && e.out2_bf16) stf((bf16*)e.out2 + r * e.ldo + c, pre); else stf((T*)e.out2 + r * e.ldo + c, pre); }   // (out2 = NULL: nobody will ask for GELU', inference)
         const float a = gelu_fwd<T>(round_to<T>(pre));
-        stf((T*)e.out + r * e.ldo + c, a);  // activation of the STORED (rounded) pre-activation
-        if constexpr (sizeof(T) == 4) { if (e.twin) stf((bf16*)e.twin + r * e.ldo + c, a); }
+        if (sizeof(T) != 4 || e.out) stf((T*)e.out + r * e.ldo + c, a);  // activation of the STORED (rounded) pre-activation
+        if constexpr (sizeof(T) == 4) { if (e.twin) stf((bf16*)e.twin + r * e.ldo + c, a); if (e.lo) stf((bf16*)e.lo + r * e.ldo + c, a - round_to<bf16>(a)); }
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         ((float*)e.out)[r * e.ldo + c] = ((const float*)e.aux)[r * e.ldaux + c] + (acc + (e.bias ? e.bias[c] : 0.f));
     } else if constexpr (EPI == MAED_EPI_MUL_DGELU) {
@@ -65,13 +77,13 @@ __device__ __forceinline__ void epilogue_store4(const EpiArgs& e, int64_t r, int
         if (e.bias) { float b[4]; ld4(e.bias + c0, b); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
     }
     if constexpr (EPI == MAED_EPI_STORE) {
-        st4((T*)e.out + r * e.ldo + c0, v);
+        if (sizeof(T) != 4 || e.out) st4((T*)e.out + r * e.ldo + c0, v);
         if constexpr (sizeof(T) == 4) { if (e.twin) st4((bf16*)e.twin + r * e.ldo + c0, v); }
     } else if constexpr (EPI == MAED_EPI_GELU) {
         if (e.out2) { if (sizeof(T) == 4 && e.out2_bf16) st4((bf16*)e.out2 + r * e.ldo + c0, v); else st4((T*)e.out2 + r * e.ldo + c0, v); }
         // activation of the STORED (rounded) pre-activation, as the backward sees it -- rounded in registers, not read back
         float a[4] = {gelu_fwd<T>(round_to<T>(v[0])), gelu_fwd<T>(round_to<T>(v[1])), gelu_fwd<T>(round_to<T>(v[2])), gelu_fwd<T>(round_to<T>(v[3]))};
-        st4((T*)e.out + r * e.ldo + c0, a);
+        if (sizeof(T) != 4 || e.out) st4((T*)e.out + r * e.ldo + c0, a);
         if constexpr (sizeof(T) == 4) { if (e.twin) st4((bf16*)e.twin + r * e.ldo + c0, a); }
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         float x[4]; ld4((const float*)e.aux + r * e.ldaux + c0, x);
@@ -116,15 +128,15 @@ __device__ __forceinline__ void epilogue_store8(const EpiArgs& e, int64_t r, int
             for (int j = 0; j < 8; ++j) v[j] += b[j]; }
     }
     if constexpr (EPI == MAED_EPI_STORE) {
-        st8((T*)e.out + r * e.ldo + c0, v);
-        if constexpr (sizeof(T) == 4) { if (e.twin) st8_nt((bf16*)e.twin + r * e.ldo + c0, v); }
+        if (sizeof(T) != 4 || e.out) st8((T*)e.out + r * e.ldo + c0, v);
+        if constexpr (sizeof(T) == 4) { if (e.twin) epi_store_planes8((bf16*)e.twin + r * e.ldo + c0, e.lo ? (bf16*)e.lo + r * e.ldo + c0 : nullptr, v); }
     } else if constexpr (EPI == MAED_EPI_GELU) {
         if (e.out2) { if (sizeof(T) == 4 && e.out2_bf16) st8_nt((bf16*)e.out2 + r * e.ldo + c0, v); else st8((T*)e.out2 + r * e.ldo + c0, v); }
         float a[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = gelu_fwd<T>(round_to<T>(v[j]));   // activation of the STORED (rounded) pre-activation
-        st8((T*)e.out + r * e.ldo + c0, a);
-        if constexpr (sizeof(T) == 4) { if (e.twin) st8_nt((bf16*)e.twin + r * e.ldo + c0, a); }
+        if (sizeof(T) != 4 || e.out) st8((T*)e.out + r * e.ldo + c0, a);
+        if constexpr (sizeof(T) == 4) { if (e.twin) epi_store_planes8((bf16*)e.twin + r * e.ldo + c0, e.lo ? (bf16*)e.lo + r * e.ldo + c0 : nullptr, a); }
     } else if constexpr (EPI == MAED_EPI_RESID_F32) {
         float x[8]; ld8((const float*)e.aux + r * e.ldaux + c0, x);
 #pragma unroll

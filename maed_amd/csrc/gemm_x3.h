@@ -74,3 +74,9 @@ bool maed_attn_tm_x3_bwd_launch(int np, const void* qkv, const void* o, const vo
                                 float scale, hipStream_t s);
 int maed_gemm_tn_x3_launch(int np, const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw, float* dbias,
                            const X3TnConv* conv, int target_wgs, hipStream_t s);
+
+// csrc/gemm_x3p.hip: the two-plane NT product on operands stored as (hi, lo) bf16 planes; variant 0 = MAED_OPT_X3_PLANES's ring, 2 / 4 = stages
+bool maed_x3p_shape_ok(const void* Ah, const void* Al, int64_t lda, const void* Bh, const void* Bl, int64_t ldb, int64_t M, int64_t N, int64_t K);
+int maed_gemm_nt_x3p_launch(int epilogue, int variant, const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb, int64_t M,
+                            int64_t N, int64_t K, const EpiArgs& e, hipStream_t s);
+int maed_split_planes_launch(int count, const float* const* src, void* const* hi, void* const* lo, const int64_t* n, hipStream_t s);   // count <= 8

@@ -10,7 +10,10 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t xs,
                                                      const float* __restrict__ g, const float* __restrict__ b,
                                                      T* __restrict__ y, float* __restrict__ mean_o,
-                                                     float* __restrict__ rstd_o, int64_t rows, int C, float eps, uint32_t* __restrict__ clear, int clear_words) {
+                                                     float* __restrict__ rstd_o, int64_t rows, int C, float eps, uint32_t* __restrict__ clear, int clear_words,
+                                                     bf16* __restrict__ y_lo) {
+    // y_lo (T = bf16 only): the output as (hi, lo) bf16 planes for the split products of the accurate mode -- y = bf16(o) is the hi plane (and the bf16 backward's twin),
+    // y_lo = bf16(o - hi) (csrc/gemm_x3p.hip)
     // (piggy-backed scratch clear of the fused STE block: the arrival counters its attentive-addition kernel polls later in the same call -- a memset node of
     //  its own was a launch per block and direction on the dependent chain)
     if (clear) { const int64_t ci = (int64_t)blockIdx.x * 256 + threadIdx.x; if (ci < clear_words) clear[ci] = 0u; }
@@ -48,6 +51,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
             st4(yr + c4 * 4, o);
+            if constexpr (sizeof(T) == 2) {
+                if (y_lo) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] -= round_to<bf16>(o[j]);
+                    st4(y_lo + row * (int64_t)C + c4 * 4, o);
+                }
+            }
         }
     }
 }
@@ -145,21 +155,22 @@ __global__ __launch_bounds__(256) void ln_affine_finish_kernel(const float* __re
 
 // internal (block.hip): the forward that also zeroes `clear_words` 4-byte words at `clear` (clear_words <= 256 * ceil(rows / 4))
 int maed_layernorm_fwd_ws(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y, int dtype, float* mean, float* rstd, int64_t rows,
-                          int C, float eps, uint32_t* clear, int clear_words, void* stream);
+                          int C, float eps, uint32_t* clear, int clear_words, void* stream, void* y_lo = nullptr);
 extern "C" int maed_layernorm_fwd(const float* x, int64_t x_row_stride, const float* gamma, const float* beta,
                                   void* y, int dtype, float* mean, float* rstd, int64_t rows, int C, float eps,
                                   void* stream) {
     return maed_layernorm_fwd_ws(x, x_row_stride, gamma, beta, y, dtype, mean, rstd, rows, C, eps, nullptr, 0, stream);
 }
 int maed_layernorm_fwd_ws(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, void* y, int dtype, float* mean, float* rstd, int64_t rows,
-                          int C, float eps, uint32_t* clear, int clear_words, void* stream) {
+                          int C, float eps, uint32_t* clear, int clear_words, void* stream, void* y_lo) {
     MAED_CHECK_ARG(x && gamma && beta && y, MAED_ERR_ARG, "layernorm_fwd: null pointer");
+    MAED_CHECK_ARG(!y_lo || (dtype == MAED_BF16 && is_aligned(y_lo, 8)), MAED_ERR_ARG, "layernorm_fwd: a lo plane goes with a bf16 (hi plane) output");
     MAED_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXV, MAED_ERR_SHAPE, "layernorm_fwd: C=%d must be a multiple of 4, <= %d", C, 64 * 4 * LN_MAXV);
     MAED_CHECK_ARG(x_row_stride % 4 == 0 && is_aligned(x, 16) && is_aligned(y, 8), MAED_ERR_ALIGN, "layernorm_fwd: x/y/stride alignment");
     if (rows == 0) return MAED_OK;
     dim3 grid((unsigned)((rows + 3) / 4));
     MAED_CHECK_ARG(!clear || (int64_t)clear_words <= (int64_t)grid.x * 256, MAED_ERR_SHAPE, "layernorm_fwd: %d words to clear exceed the grid", clear_words);
-#define LN_FWD(NV_) hipLaunchKernelGGL((ln_fwd_kernel<T, NV_>), grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, gamma, beta, (T*)y, mean, rstd, rows, C, eps, clear, clear_words)
+#define LN_FWD(NV_) hipLaunchKernelGGL((ln_fwd_kernel<T, NV_>), grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, gamma, beta, (T*)y, mean, rstd, rows, C, eps, clear, clear_words, (bf16*)y_lo)
     MAED_DISPATCH_DTYPE(dtype, T, { if (C <= 512) LN_FWD(2); else if (C <= 768) LN_FWD(3); else if (C <= 1024) LN_FWD(4); else LN_FWD(8); });
 #undef LN_FWD
     MAED_CHECK_LAUNCH("layernorm_fwd");

@@ -379,6 +379,33 @@ def gemm_nt(A, B, epilogue=L.EPI_STORE, bias=None, out=None, out2=None, aux=None
     return (out, out2) if epilogue == L.EPI_GELU else out
 
 
+def split_planes(x):
+    """(hi, lo) bf16 planes of an fp32 tensor: hi = bf16(x), lo = bf16(x - hi) -- the operand format of gemm_nt_planes (csrc/gemm_x3p.hip)"""
+    x = _c(x)
+    assert x.dtype == torch.float32 and x.numel() % 8 == 0
+    hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
+    check(L.lib().maed_split_planes(_p(x), _p(hi), _p(lo), x.numel(), _stream()), "split_planes")
+    return hi, lo
+
+
+def gemm_nt_planes(A, B, epilogue=L.EPI_STORE, bias=None, aux=None, want_f32=True, want_planes=False, want_pre=False, variant=0):
+    """epilogue((A_hi + A_lo)[M,K] @ (B_hi + B_lo)[N,K]^T) in the bf16x3 arithmetic on plane operands; A, B = (hi, lo) pairs of 2-D bf16 tensors.
+    Returns (out fp32 | None, (hi, lo) | None, pre-activation bf16 | None)."""
+    (Ah, Al), (Bh, Bl) = A, B
+    assert Ah.dtype == Al.dtype == Bh.dtype == Bl.dtype == torch.bfloat16 and Ah.shape == Al.shape and Bh.shape == Bl.shape
+    assert Ah.stride() == Al.stride() and Bh.stride() == Bl.stride() and Ah.stride(1) == 1 and Bh.stride(1) == 1
+    M, K = Ah.shape
+    N = Bh.shape[0]
+    dev = Ah.device
+    out = torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None
+    oh = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if want_planes else None
+    ol = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if want_planes else None
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if (want_pre and epilogue == L.EPI_GELU) else None
+    check(L.lib().maed_gemm_nt_planes(_p(Ah), _p(Al), Ah.stride(0), _p(Bh), _p(Bl), Bh.stride(0), M, N, K, epilogue, _p(bias), _p(out), N, _p(pre), _p(aux),
+                                      aux.stride(0) if aux is not None else 0, _p(oh), _p(ol), variant, _stream()), "gemm_nt_planes")
+    return out, ((oh, ol) if want_planes else None), pre
+
+
 def transpose_cast(x, out_dtype, want_t=True, want_c=False, colsum=None, pad_to=64):
     """x (M,N) f32/bf16 -> (x^T (N, Mp) zero-padded, cast copy (M,N)) in out_dtype; colsum[N] += sum_m."""
     assert x.dim() == 2 and x.stride(1) == 1

@@ -59,7 +59,8 @@ def test_attn_temporal_fwd_bwd(dtype, N, T, P, H):
 
 
 @pytest.mark.parametrize("dtype,f32_mode,rows", [(torch.float32, "exact", 9), (torch.float32, "bf16x3", 20), (torch.float32, "bf16x6", 9), (torch.bfloat16, "exact", 9),
-                                                 (torch.bfloat16, "exact", 20), (torch.float32, "bf16x3+bwd:bf16x1", 20), (torch.float32, "bf16x3+bwd:bf16", 20)])
+                                                 (torch.bfloat16, "exact", 20), (torch.float32, "bf16x3+bwd:bf16x1", 20), (torch.float32, "bf16x3+bwd:bf16", 20),
+                                                 (torch.float32, "bf16x3+bwd:bf16/fp32 operands", 20)])
 def test_ste_block_forward_backward_vs_oracle(dtype, f32_mode, rows):
     """one whole Block through maed_ste_block_fwd/bwd (vision_transformer.py:244-261) incl. every parameter gradient: f32 parity mode (exact VALU
     kernels + transposed copies), f32 on the split-bf16 MFMA kernels (bf16x3 / bf16x6: the bf16 mode's kernel sequence on fp32 operands) and the
@@ -84,13 +85,21 @@ def test_ste_block_forward_backward_vs_oracle(dtype, f32_mode, rows):
     old = ops.get_float32_matmul_precision()
     f32_mode, _, bwd = f32_mode.partition("+bwd:")          # "bf16x3+bwd:bf16x1" = the mixed mode of round 4: split forward, one-plane backward products;
                                                             # "+bwd:bf16" (round 5): split forward into an fp32 work buffer, bf16 twins saved, the bf16 mode's backward on them
+    bwd, _, no_planes = bwd.partition("/")                  # default: fc1's activation stored as (hi, lo) planes, fc2 on the plane
+                                                            # kernel (MAED_OPT_X3_PLANES); "/fp32 operands": the fp32-operand kernels + a cast pass for every twin
     try:
         ops.set_float32_matmul_precision(f32_mode)
         ops.set_float32_backward_precision(bwd or None)
         twins = ops.TWIN_FORWARDS[0]
-        with patched():
-            y = blk(xg, T)
-            y.backward(dy)
+        with patched() as lib:
+            old_planes = lib.maed_get_option(L.OPT_X3_PLANES)
+            if no_planes:
+                lib.maed_set_option(L.OPT_X3_PLANES, 0)
+            try:
+                y = blk(xg, T)
+                y.backward(dy)
+            finally:
+                lib.maed_set_option(L.OPT_X3_PLANES, old_planes)
         assert (ops.TWIN_FORWARDS[0] - twins == 1) == (bwd == "bf16")
     finally:
         ops.set_float32_matmul_precision(old)
@@ -106,6 +115,50 @@ def test_ste_block_forward_backward_vs_oracle(dtype, f32_mode, rows):
         scale = max(ref.abs().max().item(), 1e-3)
         assert prm.grad is not None, name
         close(prm.grad, ref, rtol=1e-3 if f32 else 5e-2, atol=(1e-4 if f32 else 3e-2) * scale)
+
+
+def test_twin_forward_with_plane_storage_of_fc1s_activation_changes_no_bit():
+    """MAED_OPT_X3_PLANES (round 5): fc1's activation stored as (hi, lo) bf16 planes + fc2 on the plane kernel (csrc/gemm_x3p.hip, every tile variant) against the fp32
+    activation + twin + fp32-operand kernel: the same output, and the input gradient and every parameter gradient bit for bit"""
+    from functools import partial
+    import torch.nn as nn
+    from maed_amd.vision_transformer import Block
+    from _hostsim import option
+    C, H, T, P = 128, 2, 2, 20
+    torch.manual_seed(5)
+    blk = Block(C, H, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", compute_dtype=torch.float32, impl=0)
+    x, dy = rnd(T, P, C, seed=1), rnd(T, P, C, seed=2)
+    old = ops.get_float32_matmul_precision()
+    res = {}
+    try:
+        ops.set_float32_matmul_precision("bf16x3")
+        ops.set_float32_backward_precision("bf16")
+        with patched() as lib:
+            for variant, ln in ((0, 0), (2, 0), (6, 0), (5, 1), (6, 1)):       # (fc2's kernel variant, LayerNorm outputs as planes + qkv / fc1 on the plane kernel)
+                with option(lib, L.OPT_X3_PLANES, variant), option(lib, L.OPT_X3_PLANES_LN, ln):
+                    blk.zero_grad()
+                    xg = x.clone().requires_grad_(True)
+                    y = blk(xg, T)
+                    y.backward(dy)
+                    res[variant, ln] = [y.detach().clone(), xg.grad.clone()] + [prm.grad.clone() for prm in blk.parameters()]
+    finally:
+        ops.set_float32_matmul_precision(old)
+        ops.set_float32_backward_precision(None)
+    base = res[0, 0]
+    for key, got in res.items():
+        # the output: same products, but at this size (one or two output tiles, K up to 512) the fp32-operand route may split K over workgroups -- another summation
+        # order (tests/test_hostsim_gemm.py holds the two kernels to bit equality where both run unsplit)
+        assert (base[0] - got[0]).abs().max() <= 2e-6 * base[0].abs().max(), key
+        if key[1] == 0:
+            for a, b in zip(base[1:], got[1:]):      # fc2 only: the backward reads the hi plane = the twin and fc1's bf16 pre-activation: the same bits
+                assert torch.equal(a, b), key
+        else:
+            # qkv / fc1 on the plane kernel: their results feed what the backward reads (qkv, the attention outputs, fc1's pre-activation).  At 40 rows the
+            # fp32-operand route is not the split kernel the plane kernel mirrors, so a sum differs in its last bit here and there and the bf16 twin of it by one
+            # ulp: gradients agree to a few 1e-3 (measured 2.8e-3 at most), far inside what test_ste_block_forward_backward_vs_oracle allows either path
+            for a, b in zip(base[1:], got[1:]):
+                assert (a - b).abs().max() <= 6e-3 * a.abs().max() + 1e-6, key
+    assert torch.equal(res[5, 1][0], res[6, 1][0]) and all(torch.equal(a, b) for a, b in zip(res[5, 1], res[6, 1]))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -167,3 +167,57 @@ def test_gemm_nt_add_epilogue_masks_aux_by_bits(impl):
         out_plain = ops.gemm_nt(A, B, L.EPI_ADD, aux=aux, impl=impl)
     assert torch.allclose(out.float(), ref, rtol=2e-2, atol=2e-2)
     assert torch.allclose(out_plain.float(), A.float() @ B.float().t() + aux.float(), rtol=2e-2, atol=2e-2)
+
+
+# ---- round 5: the split product on operands stored as (hi, lo) bf16 planes (csrc/gemm_x3p.hip) -------------------------------------------------------------------
+def _planes_ref(x):
+    hi = x.bfloat16()
+    return hi, (x - hi.float()).bfloat16()
+
+
+@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7])  # 128 x 128 tiles with 2 / 4 stages, 256 x 128 (3 stages), 256 x 256 (2 stages), 128 x 128 with K tiles of 64
+@pytest.mark.parametrize("M,N,K", [(130, 136, 96), (128, 128, 32), (64, 264, 160), (257, 72, 64), (300, 392, 64)])      # ragged tiles, one K tile, fewer tiles than stages, more
+def test_gemm_nt_planes_is_the_split_product_bit_for_bit(M, N, K, variant):
+    A, B, bias = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33)
+    with patched():
+        Ap, Bp = ops.split_planes(A), ops.split_planes(B)
+        for got, want in zip(Ap + Bp, _planes_ref(A) + _planes_ref(B)):
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+        out, planes, _ = ops.gemm_nt_planes(Ap, Bp, L.EPI_STORE, bias=bias, want_planes=True, variant=variant)
+        x3 = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias, prec="bf16x3")
+    assert torch.equal(out, x3)                                                   # same K order, same product order as the register-staged kernel
+    ref = A.double() @ B.double().t() + bias.double()
+    assert (out.double() - ref).abs().max() <= 2 ** -14 * (A.abs().double() @ B.abs().double().t()).max()
+    oh, ol = _planes_ref(out)
+    assert torch.equal(planes[0].view(torch.int16), oh.view(torch.int16)) and torch.equal(planes[1].view(torch.int16), ol.view(torch.int16))
+
+
+def test_gemm_nt_planes_epilogues_and_strided_operands():
+    M, N, K = 96, 200, 128
+    Abig, B, bias, res = rnd(M, 2 * K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43), rnd(M, N, seed=44)
+    A = Abig[:, K:]                                                                # a column window: leading dimension 2 K
+    with patched():
+        Ahb, Alb = ops.split_planes(Abig)
+        Ap, Bp = (Ahb[:, K:], Alb[:, K:]), ops.split_planes(B)
+        act, planes, pre = ops.gemm_nt_planes(Ap, Bp, L.EPI_GELU, bias=bias, want_f32=False, want_planes=True, want_pre=True)
+        assert act is None
+        a3, p3 = ops.gemm_nt(A.contiguous(), B, L.EPI_GELU, bias=bias, prec="bf16x3")
+        resid, _, _ = ops.gemm_nt_planes(Ap, Bp, L.EPI_RESID_F32, bias=bias, aux=res)
+        r3 = ops.gemm_nt(A.contiguous(), B, L.EPI_RESID_F32, bias=bias, aux=res, prec="bf16x3")
+    hi, lo = _planes_ref(a3)
+    assert torch.equal(planes[0].view(torch.int16), hi.view(torch.int16)) and torch.equal(planes[1].view(torch.int16), lo.view(torch.int16))
+    assert torch.equal(pre.view(torch.int16), p3.bfloat16().view(torch.int16))
+    assert torch.equal(resid, r3)
+
+
+def test_gemm_nt_planes_rejects_what_it_cannot_do():
+    A, B = rnd(32, 48, seed=51), rnd(32, 48, seed=52)
+    with patched() as lib:
+        Ap, Bp = ops.split_planes(A), ops.split_planes(B)
+        with pytest.raises(Exception, match="K %"):
+            ops.gemm_nt_planes(Ap, Bp)                                            # K = 48 is not a multiple of 32
+        A2, B2 = ops.split_planes(rnd(32, 64, seed=53)), ops.split_planes(rnd(32, 64, seed=54))
+        with pytest.raises(Exception, match="epilogue"):
+            ops.gemm_nt_planes(A2, B2, L.EPI_TANH)
+        with pytest.raises(Exception, match="no output"):
+            ops.gemm_nt_planes(A2, B2, want_f32=False)
