@@ -135,8 +135,10 @@ def test_cfg3_full_size_mixed_mode_bf16x3_forward_bf16_backward():
         for k in ("theta", "kp_3d", "kp_2d", "rotmat", "verts"):
             report(f"mixed mode (f32 forward storage, {label}) cfg3 full size {k} vs fp32 oracle", res[bwd][0][k], o32[k], rtol=0,
                    atol=1e-3 * o32[k].abs().max().item())
-            # same forward kernels in all runs; only the order of fp32 atomics (split-K head GEMMs, token means) differs from run to run
-            assert (res[bwd][0][k] - res[None][0][k]).abs().max() <= 2e-5 * o32[k].abs().max(), f"{k}: the backward engine ({bwd}) changed the forward"
+            # same forward arithmetic in all runs; only the order of fp32 atomics (split-K head GEMMs, token means) differs from run to run -- which moves the
+            # outputs by up to 1.8e-5 of their maximum between two runs of ONE setting (scripts/x3p_forward_noise.py, profiles/r05_x3p_micro.txt: the first
+            # bound of 2e-5 sat inside that noise and tripped at 2.1e-5)
+            assert (res[bwd][0][k] - res[None][0][k]).abs().max() <= 5e-5 * o32[k].abs().max(), f"{k}: the backward engine ({bwd}) changed the forward"
         worst = {}
         for n, g1 in res[bwd][1].items():
             g3 = res[None][1][n]
