@@ -124,7 +124,7 @@ def test_twin_forward_with_plane_storage_of_fc1s_activation_changes_no_bit():
     import torch.nn as nn
     from maed_amd.vision_transformer import Block
     from _hostsim import option
-    C, H, T, P = 128, 2, 2, 20
+    C, H, T, P = 128, 2, 2, 12
     torch.manual_seed(5)
     blk = Block(C, H, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", compute_dtype=torch.float32, impl=0)
     x, dy = rnd(T, P, C, seed=1), rnd(T, P, C, seed=2)
@@ -134,7 +134,8 @@ def test_twin_forward_with_plane_storage_of_fc1s_activation_changes_no_bit():
         ops.set_float32_matmul_precision("bf16x3")
         ops.set_float32_backward_precision("bf16")
         with patched() as lib:
-            for variant, ln in ((0, 0), (2, 0), (6, 0), (5, 1), (6, 1)):       # (fc2's kernel variant, LayerNorm outputs as planes + qkv / fc1 on the plane kernel)
+            for variant, ln in ((0, 0), (6, 0), (5, 1)):       # (fc2's kernel variant, LayerNorm outputs as planes + qkv / fc1 on the plane kernel); the other tile
+                                                                # variants are held to bit equality per product in tests/test_hostsim_gemm.py
                 with option(lib, L.OPT_X3_PLANES, variant), option(lib, L.OPT_X3_PLANES_LN, ln):
                     blk.zero_grad()
                     xg = x.clone().requires_grad_(True)
@@ -158,7 +159,6 @@ def test_twin_forward_with_plane_storage_of_fc1s_activation_changes_no_bit():
             # ulp: gradients agree to a few 1e-3 (measured 2.8e-3 at most), far inside what test_ste_block_forward_backward_vs_oracle allows either path
             for a, b in zip(base[1:], got[1:]):
                 assert (a - b).abs().max() <= 6e-3 * a.abs().max() + 1e-6, key
-    assert torch.equal(res[5, 1][0], res[6, 1][0]) and all(torch.equal(a, b) for a, b in zip(res[5, 1], res[6, 1]))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
