@@ -1,42 +1,70 @@
-// What does the matrix pipe sustain?  Back-to-back v_mfma_f32_32x32x16_bf16 on registers only (no LDS, no memory), 4 independent accumulators per wave,
-// 1 / 2 / 4 waves per SIMD on every CU, long enough (~1 ms, ~10 ms) for the clock to settle.  Prints TFLOP/s against the 2.5 PFLOP/s figure of 2.4 GHz x 256 CUs.
+// What does the matrix pipe sustain?  Back-to-back v_mfma_f32_32x32x16_bf16, 4 independent accumulators per wave, 1 / 2 / 4 waves per SIMD on every CU, ~10 ms per run:
+//   registers only, constant operand bits | registers only, random operand bits | random bits re-read from LDS at a GEMM's rate (16 ds_read_b128 per 24 MFMAs)
+// Prints TFLOP/s (against the 2.5 PFLOP/s of 2.4 GHz x 256 CUs) and the shader clock during the run (s_memtime ticks per wall second).
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/peak/mfma_peak scripts/peak/mfma_peak.hip   (build container)   ->   run on the GPU box
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float seed, const bf16x8_t* rnd) {
-    bf16x8_t a, b;
-    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + threadIdx.x * 1e-3f); b[i] = (__bf16)(seed - i * 1e-3f); }
-    if (rnd) { a = rnd[threadIdx.x]; b = rnd[256 + threadIdx.x]; }        // random operand bits: what the multipliers toggle on real data
+template <bool LDS>
+__global__ __launch_bounds__(256) void mfma_loop(float* out, unsigned long long* ticks, int iters, const bf16x8_t* rnd) {
+    __shared__ bf16x8_t tile[2048];                                        // 32 KB of operand bits
+    bf16x8_t a = {}, b = {};
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(1.f + threadIdx.x * 1e-3f); b[i] = (__bf16)(1.f - i * 1e-3f); }
+    if (rnd) { a = rnd[threadIdx.x]; b = rnd[256 + threadIdx.x]; }
+    for (int i = threadIdx.x; i < 2048; i += 256) tile[i] = rnd ? rnd[i & 511] : a;
+    __syncthreads();
     f32x16_t c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = 0; i < iters; ++i) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+        if constexpr (LDS) {
+            // 6 MFMAs per 4 fragment reads = 24 per 16; fragment addresses walk the tile (conflict-free: consecutive lanes, consecutive 16-byte words)
+            const bf16x8_t a0 = tile[((i * 4 + 0) * 64 + l + w * 256) & 2047], a1 = tile[((i * 4 + 1) * 64 + l + w * 256) & 2047];
+            const bf16x8_t b0 = tile[((i * 4 + 2) * 64 + l + w * 256) & 2047], b1 = tile[((i * 4 + 3) * 64 + l + w * 256) & 2047];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c1, 0, 0, 0);
+        } else {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+        }
     }
+    const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
     if (s == 12345.678f) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
 }
 int main() {
-    float* out; hipMalloc(&out, 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    float* out; (void)hipMalloc(&out, 4);
+    unsigned long long* ticks; (void)hipMalloc(&ticks, 8);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     printf("%s, %d CUs, clockRate %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
     unsigned short h[512 * 8];
     unsigned x = 12345u;
     for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(((x >> 16) & 0x807f) | (0x3f00 + ((x >> 9) & 0x0080))); }     // bf16 in +-[0.5, 2)
-    bf16x8_t* rnd; hipMalloc(&rnd, sizeof(h)); hipMemcpy(rnd, h, sizeof(h), hipMemcpyHostToDevice);
-    for (const bf16x8_t* r : {(const bf16x8_t*)nullptr, (const bf16x8_t*)rnd}) for (int wps : {1, 2, 4}) for (int iters : {20000, 100000}) {
-        const int grid = p.multiProcessorCount * wps;      // 256-thread workgroups = 4 waves = one per SIMD
-        mfma_loop<<<grid, 256>>>(out, 100, 1.f, r); hipDeviceSynchronize();
-        hipEventRecord(e0); mfma_loop<<<grid, 256>>>(out, iters, 1.f, r); hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        const double flop = (double)grid * 4 * iters * 4 * 32768.0;
-        printf("%s operands, waves per SIMD %d, %6d x 4 MFMAs per wave: %8.3f ms  %7.0f TFLOP/s  (%.0f cycles of a 2.4 GHz clock per MFMA and SIMD)\n", r ? "random  " : "constant", wps, iters, ms, flop / ms / 1e9,
-               ms * 1e-3 * 2.4e9 / ((double)wps * iters * 4));
+    bf16x8_t* rnd; (void)hipMalloc(&rnd, sizeof(h)); (void)hipMemcpy(rnd, h, sizeof(h), hipMemcpyHostToDevice);
+    for (int mode = 0; mode < 3; ++mode) for (int wps : {1, 2, 4}) {
+        const int iters = 60000, grid = p.multiProcessorCount * wps;      // 256-thread workgroups = 4 waves = one per SIMD
+        const bf16x8_t* r = mode ? rnd : nullptr;
+        auto run = [&](int n) { if (mode == 2) mfma_loop<true><<<grid, 256>>>(out, ticks, n, r); else mfma_loop<false><<<grid, 256>>>(out, ticks, n, r); };
+        run(100); (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0); run(iters); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long t; (void)hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+        const double flop = (double)grid * 4 * iters * 6 * 32768.0;
+        printf("%-44s waves per SIMD %d: %7.3f ms  %5.0f TFLOP/s   s_memtime %.3f G ticks/s\n",
+               mode == 0 ? "registers, constant operand bits" : mode == 1 ? "registers, random operand bits" : "random bits from LDS, 16 reads per 24 MFMAs", wps, ms, flop / ms / 1e9,
+               (double)t / ms / 1e6);
     }
     return 0;
 }
