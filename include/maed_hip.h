@@ -70,6 +70,7 @@ typedef enum { MAED_IMPL_AUTO = 0, MAED_IMPL_VALU = 1, MAED_IMPL_MFMA = 2,
                MAED_IMPL_MFMA_LONG = 5, /* attn_spatial only: K/V-tiled long-sequence kernels (chosen automatically past 512 / 320 tokens) */
                MAED_IMPL_MFMA_256 = 6, /* gemm_nt only: 256x256 tiles, counted-vmcnt LDS-DMA pipeline (csrc/gemm256.hip) */
                MAED_IMPL_X1 = 9, /* gemm_nt only: fp32 operands, ONE bf16 plane (what dtype MAED_F32X1 selects) */
+               MAED_IMPL_MFMA_SK = 10, /* gemm_nt only: the persistent K-stream kernel (csrc/gemm_sk.hip), K cuts per MAED_OPT_SK (1 and 3: allowed) */
                MAED_IMPL_X3 = 7, MAED_IMPL_X6 = 8 /* MAED_F32 matrix products on the bf16 matrix cores: every fp32 operand split into 2 / 3 bf16
                                                    * terms, 3 / 6 MFMAs per product, fp32 accumulation (csrc/gemm_x3.hip): |error| ~2^-16 / ~2^-23
                                                    * of |a||b| instead of bf16's 2^-8.  MAED_IMPL_AUTO takes them when MAED_OPT_F32_MATMUL says so. */
@@ -99,7 +100,8 @@ typedef enum {
     MAED_OPT_CONV3X3_ROWS_WGS = 7, /* row-item 3x3 weight gradient at 64 -> 64 channels (maed_conv3x3_wgrad_rows64): workgroups per launch (default 256); 0: the shape
                                    * goes to the general TN kernel instead (A/B knob) */
     MAED_OPT_STEM_WGRAD_WGS = 8,   /* workgroups of maed_stem7x7s2_wgrad (default 512) */
-    MAED_OPT_LBS_FRAMES = 9,       /* frames per workgroup of the LBS skinning kernel: 0 (default) = 16 for more than 32 frames, else 4; or 4 / 8 / 16 */
+    MAED_OPT_LBS_FRAMES = 9,       /* SMPL linear blend skinning: 0 (default) = the pose-corrective blend on the fp32 matrix cores + a streaming skinning pass (smpl.hip,
+                                    * round 5); 4 / 8 / 16 = the VALU kernel with that many frames per workgroup (A/B knob; what the host simulator runs) */
     MAED_OPT_TN_DMA = 10,          /* 1 (default): bf16 weight-gradient GEMMs (maed_gemm_tn_wgrad, M % 32 == 0) on the LDS-DMA + transposing-read kernel (csrc/gemm_tn2.hip);
                                     * 0: the register-transposing kernel (csrc/gemm_tn.hip) -- A/B knob */
     MAED_OPT_X3_PLANES = 11,       /* maed_ste_block_fwd_twin: fc1's activation is stored as (hi, lo) bf16 planes -- hi is the backward's twin, 4 bytes per element instead of
@@ -108,6 +110,11 @@ typedef enum {
     MAED_OPT_X3_PLANES_LN = 12,    /* with MAED_OPT_X3_PLANES != 0: 1 = the block's two LayerNorm outputs are stored as planes too (hi straight into the bf16 arena: no cast pass
                                     * for them) and qkv / fc1 run on the 128 x 128 plane kernel; 0 (default) = fp32 LayerNorm outputs, fp32-operand kernel.  Measured neutral
                                     * in the cfg3 train step (28.83 vs 28.80 ms): kept as an A/B knob */
+    MAED_OPT_SK = 13,              /* bf16 maed_gemm_nt on the persistent K-stream kernel (csrc/gemm_sk.hip: one workgroup per CU walks 256 x 256 tiles as one continuous
+                                    * stream of K tiles; tiles that do not fill a round of the grid are cut along K, "stream-K") where the shape allows (K % 128 == 0,
+                                    * M, N >= 256) and the dispatcher's heuristic picks it: 1 (default) = heuristic, 0 = never (the per-tile kernels of rounds 1-5),
+                                    * 2 = wherever the shape allows without K cuts, 3 = wherever the shape allows, K cuts whenever the tiles do not fill whole rounds */
+    MAED_OPT_SK_GRID = 14,         /* workgroups of that kernel: 0 (default) = one per CU; a smaller grid is a test / sweep knob */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's
@@ -163,8 +170,10 @@ int maed_gemm_nt_planes(const void* a_hi, const void* a_lo, int64_t lda, const v
 /* hi[bf16](n), lo[bf16](n) = the two planes of x[f32](n) (n % 8 == 0, 16-byte aligned): what maed_gemm_nt_planes takes for a tensor that exists as fp32 (weights) */
 int maed_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream);
 
-/* weight gradient dW[N,K] += Y[M,N]^T X[M,K] and (optional) bias gradient dbias[N] += colsum(Y), bf16 operands,
- * fp32 atomics (split over M).  No transposed copies: 8x8 blocks are transposed in registers while staging. */
+/* weight gradient dW[N,K] += Y[M,N]^T X[M,K] and (optional) bias gradient dbias[N] += colsum(Y), bf16 operands, fp32 atomics (split over M).  No transposed
+ * copies in memory.  Default for M % 32 == 0 (MAED_OPT_TN_DMA = 1): csrc/gemm_tn2.hip -- both operands copied unchanged into LDS by LDS-DMA, fragments by
+ * ds_read_b64_tr_b16, the bias gradient as one more MFMA against a ones operand; otherwise, or with MAED_OPT_TN_DMA = 0: csrc/gemm_tn.hip -- 8x8 blocks transposed in
+ * registers while staging.  Replaces autograd's backward of nn.Linear / the 1x1 convolutions (vision_transformer.py:98-111,124-128; resnetv2.py:91-93). */
 int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K,
                        float* dW, int64_t ldw, float* dbias, int dtype, void* stream);
 
@@ -276,6 +285,10 @@ int maed_ste_block_fwd(const maed_block_dims* d, const maed_block_params* p, con
 size_t maed_ste_block_twin_work_bytes(const maed_block_dims* d);
 int maed_ste_block_fwd_twin(const maed_block_dims* d, const maed_block_params* p, const float* x_in, float* x_out, void* saved_bf16, void* work_f32, int work_slot,
                             void* stream);
+/* `stream` waits for the cast passes of earlier maed_ste_block_fwd_twin calls that are still pending on the library's side stream.  maed_ste_block_bwd does this by
+ * itself; a host calls it when NO backward will follow a twin forward (the arenas are about to be freed) and before it frees or re-sizes a work buffer.  No reference
+ * counterpart (scheduling only). */
+int maed_ste_block_twin_join(void* stream);
 /* the same forward when no backward will follow (inference): `work` = maed_ste_block_saved_bytes of scratch; what only the backward would read
  * (fc1's pre-activation: 103 MB per block at cfg3) is not written.  x_out may alias x_in. */
 int maed_ste_block_infer(const maed_block_dims* d, const maed_block_params* p, const float* x_in,

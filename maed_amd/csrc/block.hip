@@ -103,6 +103,7 @@ static SideStream g_side;
 static hipEvent_t g_fence_ring[64];
 static bool g_fence_ok = false;
 static std::once_flag g_runtime_once;
+int maed_sk_init(void);
 int maed_init_runtime(void) {
     std::call_once(g_runtime_once, [] {
         SideStream& ss = g_side;
@@ -113,6 +114,7 @@ int maed_init_runtime(void) {
         g_fence_ok = true;
         for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&g_fence_ring[i], hipEventDisableTiming) != hipSuccess) { g_fence_ok = false; break; }
         if (!ok || !g_fence_ok) (void)hipGetLastError();
+        (void)maed_sk_init();        // slabs + flags of the persistent K-stream GEMM's hand-offs (csrc/gemm_sk.hip): the one device allocation the library owns
     });
     return (g_side.ok && g_fence_ok) ? MAED_OK : MAED_ERR_LAUNCH;
 }
@@ -125,6 +127,17 @@ static SideStream* side_stream() {
 // "everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on": one event record + one stream wait from a ring of timing-less
 // events the library owns.  For hosts that run single launches on a second stream of their own (maed_amd/ops.py: the backbone's weight-gradient GEMMs): the same
 // fence through the framework costs a Python-level event object, a record and a wait per use.
+// The cast passes of twin forwards run on a library stream and write the CALLER's arenas (maed_ste_block_fwd_twin): a backward joins them by itself, a host that
+// drops the graph without a backward -- or frees / re-sizes a work buffer -- joins them here first: `stream` waits for every cast still pending.
+extern "C" int maed_ste_block_twin_join(void* stream) {
+    (void)maed_init_runtime();
+    SideStream& ss = g_side;
+    if (!ss.ok) return MAED_OK;
+    for (int k = 0; k < 2; ++k)
+        if (ss.cast_pending[k]) { MAED_HIP(hipStreamWaitEvent((hipStream_t)stream, ss.cast_ev[k], 0), "ste_block_twin_join: stream wait"); ss.cast_pending[k] = false; }
+    return MAED_OK;
+}
+
 extern "C" int maed_stream_fence(void* from_stream, void* to_stream) {
     static std::atomic<unsigned> next{0};
     (void)maed_init_runtime();

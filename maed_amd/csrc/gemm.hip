@@ -637,6 +637,12 @@ static int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, i
 bool maed_gemm_nt_256_launch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e,
                              hipStream_t s);
 
+// csrc/gemm_sk.hip: persistent K-stream kernel (256x256 tiles, one workgroup per CU, stream-K cuts)
+bool maed_gemm_nt_sk_shape_ok(int64_t M, int64_t N, int64_t K);
+bool maed_gemm_nt_sk_launch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e,
+                            int mode, int grid_opt, hipStream_t s);
+int maed_sk_cus(void);
+
 template <int EPI>
 static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype,
                     const EpiArgs& e, int splitk, int impl, hipStream_t s) {
@@ -652,7 +658,8 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
             if constexpr (EPI == MAED_EPI_STORE || EPI == MAED_EPI_STORE_F32) {
                 // an EXPLICIT split engine on a GEMM with few output tiles and a long K (the decoder head in the bf16 mode, round 4: 128 frames x 1024 x 512 is 8 tiles
                 // of 128 x 128): the split-K route of the exact kernel below, on the matrix cores -- bias fill, then K slices that meet with fp32 atomics
-                if (ok && impl != MAED_IMPL_AUTO && splitk == 1 && tiles128 < 48 && K >= 256 && e.ldo >= N) {
+                // (never for a call that also leaves bf16 twins / planes: the atomic epilogue of the K slices writes the fp32 result only -- ADVICE r5)
+                if (ok && impl != MAED_IMPL_AUTO && splitk == 1 && tiles128 < 48 && K >= 256 && e.ldo >= N && !e.twin && !e.lo && !e.out2_bf16) {
                     int sk = (int)(256 / tiles128);
                     if (sk > K / 32) sk = (int)(K / 32);
                     if (sk > 1) {
@@ -670,7 +677,7 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         // K over the chip -- the fp32 output starts as the bias and the K slices accumulate with fp32 atomics (15 us)
         if constexpr (EPI == MAED_EPI_STORE || EPI == MAED_EPI_STORE_F32) {
             const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
-            if (splitk == 1 && tiles < 96 && K >= 256) {
+            if (splitk == 1 && tiles < 96 && K >= 256 && !e.twin && !e.lo && !e.out2_bf16) {
                 // more K slices would hide more load latency, but every slice adds an output tile of fp32 atomics: ~256 workgroups measured best (128 x 1024 x 2136: 50.7 / 55.4 / 69.3 us
                 // at 256 / 512 / 1024)
                 constexpr int target = 256;
@@ -707,6 +714,14 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         maed_gemm_nt_256_launch(EPI, A, lda, B, ldb, M, N, K, e, s);
         return MAED_OK;
     }
+    // persistent K-stream kernel (gemm_sk.hip): explicitly, or by the heuristic below
+    const bool oksk = ok256 && maed_gemm_nt_sk_shape_ok(M, N, K) && !e.gn_sums;
+    if (impl == MAED_IMPL_MFMA_SK) {
+        const int mode = maed_opt(MAED_OPT_SK);
+        MAED_CHECK_ARG(oksk && maed_gemm_nt_sk_launch(EPI, A, lda, B, ldb, M, N, K, e, mode == 0 ? 1 : mode, maed_opt(MAED_OPT_SK_GRID), s), MAED_ERR_ALIGN,
+                       "gemm_nt(sk): need K%%128==0 (K=%lld), M, N >= 256, lda/ldb%%8==0, 16-B aligned A/B, no split-K, the library's slab allocation", (long long)K);
+        return MAED_OK;
+    }
     if (impl == MAED_IMPL_MFMA) {
         MAED_CHECK_ARG(mfma_ok, MAED_ERR_ALIGN, "gemm_nt(mfma): need K%%64==0 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B", (long long)K);
         return launch_mfma<EPI>(A, lda, B, ldb, M, N, K, e, splitk, s);
@@ -722,6 +737,11 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
     // Never when the 256x256 grid would leave most CUs idle (stage-3 1x1 convolutions: 98 tiles).
     if constexpr (EPI != MAED_EPI_ATOMIC_F32) {
         const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+        // the persistent kernel wherever the 256x256 tiles can occupy most of the chip (stream-K spreads any tile count >= ~0.7 rounds over all CUs)
+        const int skmode = maed_opt(MAED_OPT_SK);
+        if (oksk && skmode != 0 && tiles256 * 10 >= (int64_t)maed_sk_cus() * 7 &&
+            maed_gemm_nt_sk_launch(EPI, A, lda, B, ldb, M, N, K, e, skmode, maed_opt(MAED_OPT_SK_GRID), s))
+            return MAED_OK;
         if (ok256 && N >= 256 && tiles256 >= 180 && (K >= 1024 || tiles256 <= 256)) {
             maed_gemm_nt_256_launch(EPI, A, lda, B, ldb, M, N, K, e, s);
             return MAED_OK;

@@ -242,6 +242,9 @@ extern "C" int maed_gemm_nt_planes(const void* a_hi, const void* a_lo, int64_t l
     MAED_CHECK_ARG(!out_lo || out_hi, MAED_ERR_ARG, "gemm_nt_planes: out_lo without out_hi");
     MAED_CHECK_ARG(ldo >= N, MAED_ERR_SHAPE, "gemm_nt_planes: ldo < N");
     if (epilogue == MAED_EPI_RESID_F32) MAED_CHECK_ARG(aux && ldaux >= N && !out_hi, MAED_ERR_ARG, "gemm_nt_planes: MAED_EPI_RESID_F32 needs aux (fp32) and writes fp32 only");
+    // (the epilogues store / load 16 and 32 bytes per lane whenever ldo % 8 == 0 and ldaux % 8 == 0: a misaligned output from a C host must be an error, not a fault)
+    MAED_CHECK_ARG(is_aligned(out, 16) && is_aligned(out_hi, 16) && is_aligned(out_lo, 16) && is_aligned(out2_bf16, 16) && is_aligned(aux, 16) && is_aligned(bias, 16),
+                   MAED_ERR_ALIGN, "gemm_nt_planes: out, out_hi, out_lo, out2_bf16, aux and bias must be 16-byte aligned");
     EpiArgs e{};
     e.bias = bias; e.out = out; e.ldo = ldo; e.out2 = out2_bf16; e.aux = aux; e.ldaux = ldaux; e.twin = out_hi; e.lo = out_lo; e.out2_bf16 = true;
     MAED_PROPAGATE(maed_gemm_nt_x3p_launch(epilogue, variant, a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, e, (hipStream_t)stream));

@@ -571,10 +571,18 @@ def _aligned_bytes(nbytes, device, align=256):
     return buf[off:off + nbytes]
 
 
+def twin_join():
+    """the current stream waits for the cast passes twin forwards left on the library's side stream (maed_ste_block_twin_join): called where no backward is
+    guaranteed to do it -- at the end of a chain of blocks, before a work buffer is replaced"""
+    check(L.lib().maed_ste_block_twin_join(_stream()), "ste_block_twin_join")
+
+
 def _scratch(nbytes, device, tag=None):
     key = (device.index, _stream(), tag)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and isinstance(tag, tuple) and tag and tag[0] == "twin":
+            twin_join()         # a pending cast pass may still read the buffer this one replaces
         buf = _aligned_bytes(nbytes, device)
         _SCRATCH[key] = buf
     return buf

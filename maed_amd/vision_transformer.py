@@ -299,8 +299,14 @@ class VisionTransformer(nn.Module):
             tok = ops.EmbedAddFn.apply(patch, self.cls_token, self.pos_embed, self.temp_embed, seqlen)
         else:
             tok = ops.EmbedAddFn.apply(patch, self.cls_token, self.pos_embed, self._no_temp_embed, 1)
+        twins = ops.TWIN_FORWARDS[0]
         for blk in self.blocks:
             tok = blk(tok, seqlen)
+        if ops.TWIN_FORWARDS[0] != twins:
+            # twin forwards leave cast passes on a library stream that write the blocks' saved arenas: joined here, once per chain, so that a graph that is dropped
+            # without a backward (or an exception further down) can never hand an arena back to the allocator while a cast still writes it (costs the
+            # overlap of the LAST block's cast pass only)
+            ops.twin_join()
         return tok
 
     def forward_features(self, x, seqlen=1):

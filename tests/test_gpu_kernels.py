@@ -683,3 +683,75 @@ def test_frame_barrier_timeout_is_reported_and_the_library_falls_back():
     assert lib.maed_device_faults() == 0
     again = run(dirty=False)                    # ... and the one-pass kernel is back
     report("groupnorm_bwd.dx after the fault word was cleared (one-pass kernel again)", again, xd.grad, **tol(dtype, 2))
+
+
+# ---- round 6: the persistent K-stream GEMM (csrc/gemm_sk.hip) -----------------------------------------------------------------------------
+class _sk_mode:
+    """MAED_OPT_SK for the duration of a block (2 = whole tiles only, 3 = stream-K cuts whenever the tiles do not fill whole rounds of the grid)"""
+
+    def __init__(self, mode, grid=0):
+        self.mode, self.grid = mode, grid
+
+    def __enter__(self):
+        _, L = _ops()
+        self.lib = L.lib()
+        self.old = (self.lib.maed_get_option(L.OPT_SK), self.lib.maed_get_option(L.OPT_SK_GRID))
+        assert self.lib.maed_set_option(L.OPT_SK, self.mode) == 0 and self.lib.maed_set_option(L.OPT_SK_GRID, self.grid) == 0
+
+    def __exit__(self, *a):
+        _, L = _ops()
+        self.lib.maed_set_option(L.OPT_SK, self.old[0])
+        self.lib.maed_set_option(L.OPT_SK_GRID, self.old[1])
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (197 * 8, 512, 256), (1000, 1536, 512), (777, 256, 2048), (25216, 512, 512), (32896, 768, 3072)])
+def test_gemm_persistent_kstream(M, N, K):
+    """csrc/gemm_sk.hip against the fp64 oracle on the bf16-rounded operands -- whole tiles only (mode 2: bitwise equal to the 128x128 kernel, same k order), stream-K
+    cuts on the full grid (mode 3) and on grids of 7 / 96 workgroups (several items per workgroup, tiles cut two and three ways, empty ranges), every epilogue the
+    STE uses; ragged M / N edges; cfg3's proj and cfg5's fc2 at full size."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    A, B = q(rnd(M, K, seed=21), dtype), q(rnd(N, K, seed=22, scale=K ** -0.5), dtype)
+    bias = rnd(N, seed=23)
+    Ad, Bd, bd = A.to(DEV).to(dtype), B.to(DEV).to(dtype), bias.to(DEV)
+    ref = (Ad.double() @ Bd.double().t()).cpu()
+    t = tol(dtype, 2)
+    res, pre_in = rnd(M, N, seed=24), q(rnd(M, N, seed=25), dtype)
+    xg = pre_in.double().requires_grad_(True)
+    R.gelu(xg).sum().backward()
+    for mode, grid in [(2, 0), (3, 0), (3, 7), (3, 96)]:
+        with _sk_mode(mode, grid):
+            tag = f"gemm_sk[mode {mode} grid {grid},{M}x{N}x{K}]"
+            out = ops.gemm_nt(Ad, Bd, L.EPI_STORE, bias=bd, impl=L.IMPL_MFMA_SK)
+            report(tag + "[STORE]", out.float(), ref + bias.double(), **t)
+            if mode == 2:
+                assert torch.equal(out, ops.gemm_nt(Ad, Bd, L.EPI_STORE, bias=bd, impl=3))
+            out = ops.gemm_nt(Ad, Bd, L.EPI_RESID_F32, bias=bd, aux=res.to(DEV), impl=L.IMPL_MFMA_SK)
+            report(tag + "[RESID_F32]", out, ref + bias.double() + res.double(), rtol=2e-5, atol=1e-4)
+            act, pre = ops.gemm_nt(Ad, Bd, L.EPI_GELU, bias=bd, impl=L.IMPL_MFMA_SK)
+            report(tag + "[GELU.pre]", pre.float(), ref + bias.double(), **t)
+            report(tag + "[GELU.act]", act.float(), R.gelu(pre.float().cpu().double()), **t)
+            out = ops.gemm_nt(Ad, Bd, L.EPI_MUL_DGELU, aux=pre_in.to(DEV).to(dtype), impl=L.IMPL_MFMA_SK)
+            report(tag + "[MUL_DGELU]", out.float(), ref * xg.grad, **t)
+    assert L.lib().maed_device_faults() == 0
+
+
+def test_gemm_persistent_kstream_race_screen():
+    """the benchmarked shapes, 25 back-to-back launches per mode into NaN-filled outputs, every one bit-identical to the first and NaN-free: a copy landing late, a
+    ring slot re-targeted early, a stale or half-written slab shows up as a differing launch.  A screen, not a proof -- the reads are placed by the vmcnt / barrier
+    count and the hand-off by the release / acquire protocol (gemm_sk.hip header)."""
+    ops, L = _ops()
+    for M, N, K in [(25216, 512, 2048), (25216, 1536, 512), (25216, 2048, 512), (32896, 768, 3072)]:
+        A = (torch.randn(M, K, device=DEV, generator=torch.Generator(device=DEV).manual_seed(K + N))).bfloat16()
+        B = (torch.randn(N, K, device=DEV, generator=torch.Generator(device=DEV).manual_seed(N)) * K ** -0.5).bfloat16()
+        for mode in (2, 3):
+            with _sk_mode(mode):
+                want = ops.gemm_nt(A, B, L.EPI_STORE, impl=L.IMPL_MFMA_SK)
+                assert not torch.isnan(want.float()).any()
+                bad = 0
+                for _ in range(25):
+                    out = torch.full_like(want, float("nan"))
+                    ops.gemm_nt(A, B, L.EPI_STORE, out=out, impl=L.IMPL_MFMA_SK)
+                    bad += int(not torch.equal(out, want))
+                assert bad == 0, f"{bad}/25 launches of the persistent kernel (mode {mode}) differ at {M}x{N}x{K}"
+    assert L.lib().maed_device_faults() == 0

@@ -316,3 +316,48 @@ def test_attn_long_exact_valu_kernels(dtype, impl):
     close(lse, lse_ref.detach(), rtol=1e-4, atol=1e-3 if dtype == torch.float32 else 2e-2)
     close(dqkv.float(), x.grad, **tol(dtype, 0.5))
     close(acc.float(), 2 * x.grad, **tol(dtype, 1.0))
+
+
+def test_twin_forward_at_256_channels_and_few_rows_leaves_no_twin_unwritten(monkeypatch):
+    """with C >= 256 and a few dozen rows the fp32 STORE products used to take a split-K route whose atomic epilogue writes the fp32 result only -- the qkv
+    twin the bf16 backward reads stayed uninitialised.  Every arena / work buffer is handed out NaN-filled here: a field nobody wrote shows up as a NaN gradient."""
+    from functools import partial
+    import torch.nn as nn
+    from maed_amd.vision_transformer import Block
+    C, H, T, P = 256, 4, 2, 12
+    torch.manual_seed(7)
+    blk = Block(C, H, mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), st_mode="parallel", compute_dtype=torch.float32, impl=0)
+    x, dy = rnd(T, P, C, seed=1), rnd(T, P, C, seed=2)
+    real = ops._aligned_bytes
+
+    def poisoned(nbytes, device, align=256):
+        buf = real(nbytes, device, align) if align != 256 else real(nbytes, device)
+        buf.fill_(0xFF)                   # 0xFFFF = a bf16 NaN, 0xFFFFFFFF = an fp32 NaN
+        return buf
+
+    monkeypatch.setattr(ops, "_aligned_bytes", poisoned)
+    monkeypatch.setattr(ops, "_SCRATCH", {})
+    old = ops.get_float32_matmul_precision()
+    try:
+        ops.set_float32_matmul_precision("bf16x3")
+        ops.set_float32_backward_precision("bf16")
+        twins = ops.TWIN_FORWARDS[0]
+        with patched():
+            xg = x.clone().requires_grad_(True)
+            y = blk(xg, T)
+            y.backward(dy)
+        assert ops.TWIN_FORWARDS[0] - twins == 1
+    finally:
+        ops.set_float32_matmul_precision(old)
+        ops.set_float32_backward_precision(None)
+    assert torch.isfinite(y).all() and torch.isfinite(xg.grad).all()
+    for name, prm in blk.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+    # and the gradients are the oracle's, to the bf16 backward's tolerance
+    pd = {k: v.detach().double().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    R.block(xr, pd, "", H, T).backward(dy.double())
+    close(xg.grad, xr.grad, rtol=3e-2, atol=3e-2)
+    for name, prm in blk.named_parameters():
+        ref = pd[name].grad
+        close(prm.grad, ref, rtol=5e-2, atol=3e-2 * max(ref.abs().max().item(), 1e-3))

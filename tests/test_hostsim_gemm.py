@@ -8,7 +8,7 @@ import torch
 from maed_amd import _lib as L
 from maed_amd import ops
 
-from _hostsim import patched
+from _hostsim import option, patched
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -221,3 +221,46 @@ def test_gemm_nt_planes_rejects_what_it_cannot_do():
             ops.gemm_nt_planes(A2, B2, L.EPI_TANH)
         with pytest.raises(Exception, match="no output"):
             ops.gemm_nt_planes(A2, B2, want_f32=False)
+
+
+# ---- round 6: the persistent K-stream kernel (csrc/gemm_sk.hip) --------------------------------------------------------------------------------------
+# MAED_OPT_SK_GRID shrinks the grid so that a few workgroups of the simulator see every kind of item: several whole tiles per workgroup (the copy stream
+# running through an epilogue), a part whose slab is handed on, a tile finished from one / two slabs, empty ranges.
+@pytest.mark.parametrize("M,N,K,grid,mode", [
+    (300, 520, 256, 2, 2),      # 2 x 3 tiles (ragged M and N), two workgroups, no K cuts: three whole tiles each, the stream crosses two epilogues
+    (300, 520, 256, 4, 3),      # 6 tiles on 4 workgroups: one round whole + two tiles cut... (rounds - 1) * G = 0 whole: all six tiles cut into 4 ranges of 3 pairs
+    (256, 512, 384, 3, 3),      # 2 tiles x 3 pairs on 3 workgroups: ranges of 2 pairs: head / (tail + head) / tail
+    (256, 256, 512, 3, 3),      # ONE tile cut three ways: the finisher adds two slabs (a middle part)
+    (256, 256, 128, 4, 3),      # one pair on four workgroups: three empty ranges
+])
+def test_gemm_nt_persistent_kstream(M, N, K, grid, mode):
+    A, B, bias = rnd(M, K, seed=31).bfloat16(), rnd(N, K, seed=32, scale=K ** -0.5).bfloat16(), rnd(N, seed=33)
+    ref = A.float() @ B.float().t() + bias
+    with patched() as lib, option(lib, L.OPT_SK, mode), option(lib, L.OPT_SK_GRID, grid):
+        out = ops.gemm_nt(A, B, L.EPI_STORE_F32, bias=bias, impl=L.IMPL_MFMA_SK)
+        assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4), (out - ref).abs().max()
+        again = ops.gemm_nt(A, B, L.EPI_STORE_F32, bias=bias, impl=L.IMPL_MFMA_SK)          # second launch: the flags carry the next epoch
+        assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("epi", ["gelu", "resid", "dgelu", "store"])
+def test_gemm_nt_persistent_kstream_epilogues(epi):
+    M, N, K = 264, 264, 256                     # 2 x 2 tiles with 8 valid rows / columns in the edge tiles; 3 workgroups, K cuts
+    A, B, bias = rnd(M, K, seed=34).bfloat16(), rnd(N, K, seed=35, scale=K ** -0.5).bfloat16(), rnd(N, seed=36)
+    acc = A.float() @ B.float().t()
+    with patched() as lib, option(lib, L.OPT_SK, 3), option(lib, L.OPT_SK_GRID, 3):
+        if epi == "gelu":
+            out, pre = ops.gemm_nt(A, B, L.EPI_GELU, bias=bias, impl=L.IMPL_MFMA_SK)
+            assert torch.allclose(pre.float(), (acc + bias).bfloat16().float(), atol=2e-2)
+            assert torch.allclose(out.float(), gelu(pre.float()), rtol=2e-2, atol=2e-2)
+        elif epi == "resid":
+            aux = rnd(M, N, seed=37)
+            out = ops.gemm_nt(A, B, L.EPI_RESID_F32, bias=bias, aux=aux, impl=L.IMPL_MFMA_SK)
+            assert torch.allclose(out, aux + acc + bias, rtol=1e-4, atol=1e-4)
+        elif epi == "dgelu":
+            aux = rnd(M, N, seed=38).bfloat16()
+            out = ops.gemm_nt(A, B, L.EPI_MUL_DGELU, aux=aux, impl=L.IMPL_MFMA_SK)
+            assert torch.allclose(out.float(), acc * dgelu(aux.float()), rtol=3e-2, atol=3e-2)
+        else:
+            out = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias, impl=L.IMPL_MFMA_SK)
+            assert (out.float() - (acc + bias).bfloat16().float()).abs().max() <= 2 * 2 ** -8 * (acc + bias).abs().max()
