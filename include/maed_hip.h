@@ -459,6 +459,11 @@ int maed_groupnorm_fwd_twin(const void* x, const void* residual, const float* ga
 int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                        void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
                        int relu, int dtype, int ab_zeroed, uint32_t* frame_sync, void* aux_stream, void* stream);
+/* dgamma == NULL and dbeta == NULL: the closing column sum over the frames is left to the caller -- ab_scratch then holds, per frame and channel, the (dbeta, dgamma)
+ * partials of this layer, and ONE maed_gn_affine_grad_batch call folds the partials of many layers (a backbone pass: 52) into their gradients: one launch instead of
+ * one per layer (round 6: 52 x 6 us of launch granularity per step).  items: HOST array; dgamma[c] += sum_n ab[n][c][1], dbeta[c] += sum_n ab[n][c][0]. */
+typedef struct { const float* ab; float* dgamma; float* dbeta; int N; int C; } maed_gn_affine_item;
+int maed_gn_affine_grad_batch(const maed_gn_affine_item* items, int count, void* stream);
 /* aux_stream (optional): a second stream of the caller's on which the closing dgamma/dbeta column sum is enqueued (fenced after the reduction
  * pass on `stream`); the caller joins it before anybody reads dgamma/dbeta.  NULL: everything on `stream`. */
 

@@ -25,6 +25,11 @@ IMPL_X3, IMPL_X6, IMPL_X1 = 7, 8, 9  # MAED_F32 matrix products on the bf16 matr
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
 
+class GnAffineItem(C.Structure):
+    """maed_gn_affine_item (include/maed_hip.h): one layer of maed_gn_affine_grad_batch"""
+    _fields_ = [("ab", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("N", C.c_int), ("C", C.c_int)]
+
+
 class BlockDims(C.Structure):
     _fields_ = [("F", i32), ("P", i32), ("C", i32), ("H", i32), ("T", i32), ("hidden", i32),
                 ("dtype", i32), ("impl", i32), ("eps", f32)]
@@ -123,6 +128,7 @@ SIGNATURES = {
     "maed_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp]),
     "maed_groupnorm_fwd_twin": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp, vp, vp]),
     "maed_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, i32, vp, vp, vp]),
+    "maed_gn_affine_grad_batch": (i32, [vp, i32, vp]),
     "maed_comm_load": (i32, [C.c_char_p]),
     "maed_comm_unique_id": (i32, [vp]),
     "maed_comm_init": (i32, [i32, i32, vp]),

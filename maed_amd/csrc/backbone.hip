@@ -358,6 +358,50 @@ __global__ __launch_bounds__(256) void gn_affine_grad_kernel(const float* __rest
     colsum_add(ab, N, 2 * C, [=](int i) { return ((i & 1) ? dgamma : dbeta) + (i >> 1); });      // ab[n][c][0|1] = (dbeta, dgamma) partials
 }
 
+// The same closing sum for MANY layers in one launch (maed_gn_affine_grad_batch): workgroup b -> (layer, block of 64 columns of its (N, 2C) partial matrix) through
+// a prefix table that travels in the kernel arguments with the layers' pointers; 64 columns x 4 row lanes per workgroup over all N rows, one LDS fold, plain += (the
+// only writer of these gradients in the pass).
+#define GN_BATCH_MAX 64
+struct GnAffineBatch {
+    maed_gn_affine_item it[GN_BATCH_MAX];
+    int first[GN_BATCH_MAX + 1];           // first workgroup of layer i; first[count] = grid size
+    int count;
+};
+__global__ __launch_bounds__(256) void gn_affine_grad_batch_kernel(GnAffineBatch t) {
+    __shared__ float fold[4][64];
+    int i = 0;
+    while (i + 1 < t.count && (int)blockIdx.x >= t.first[i + 1]) ++i;
+    const maed_gn_affine_item it = t.it[i];
+    const int cols = 2 * it.C, c = ((int)blockIdx.x - t.first[i]) * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = rl; r < it.N; r += 4) s += it.ab[(int64_t)r * cols + c];
+    fold[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        float* const dst = ((c & 1) ? it.dgamma : it.dbeta) + (c >> 1);
+        *dst += (fold[0][threadIdx.x] + fold[1][threadIdx.x]) + (fold[2][threadIdx.x] + fold[3][threadIdx.x]);
+    }
+}
+extern "C" int maed_gn_affine_grad_batch(const maed_gn_affine_item* items, int count, void* stream) {
+    MAED_CHECK_ARG(count >= 0 && (items || count == 0), MAED_ERR_ARG, "gn_affine_grad_batch: null table");
+    for (int base = 0; base < count; base += GN_BATCH_MAX) {
+        GnAffineBatch t;
+        t.count = count - base < GN_BATCH_MAX ? count - base : GN_BATCH_MAX;
+        int wg = 0;
+        for (int i = 0; i < t.count; ++i) {
+            const maed_gn_affine_item& it = items[base + i];
+            MAED_CHECK_ARG(it.ab && it.dgamma && it.dbeta && it.N > 0 && it.C > 0, MAED_ERR_ARG, "gn_affine_grad_batch: item %d: null pointer or empty extent", base + i);
+            t.it[i] = it; t.first[i] = wg;
+            wg += (2 * it.C + 63) / 64;
+        }
+        t.first[t.count] = wg;
+        hipLaunchKernelGGL(gn_affine_grad_batch_kernel, dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, t);
+    }
+    MAED_CHECK_LAUNCH("gn_affine_grad_batch");
+    return MAED_OK;
+}
+
 // ---- backward pass 2: dx = rstd * (gamma*dy_eff - m1 - xhat*m2); optional d_res = dy_eff ------------------------
 template <typename T, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask, const T* __restrict__ dy,
@@ -634,7 +678,8 @@ extern "C" int maed_groupnorm_fwd_twin(const void* x, const void* residual, cons
 extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const void* dy, const double* sums, const float* gamma, const float* beta,
                                   void* dx, void* dres, float* dgamma, float* dbeta, float* ab_scratch, int N, int HW, int C, float eps,
                                   int relu, int dtype, int ab_zeroed, uint32_t* frame_sync, void* aux_stream, void* stream) {
-    MAED_CHECK_ARG(x && dy && sums && gamma && beta && dx && dgamma && dbeta && ab_scratch, MAED_ERR_ARG, "groupnorm_bwd: null pointer");
+    MAED_CHECK_ARG(x && dy && sums && gamma && beta && dx && ab_scratch, MAED_ERR_ARG, "groupnorm_bwd: null pointer");
+    MAED_CHECK_ARG((dgamma != nullptr) == (dbeta != nullptr), MAED_ERR_ARG, "groupnorm_bwd: dgamma and dbeta go together (both NULL: the caller folds ab_scratch with maed_gn_affine_grad_batch)");
     MAED_CHECK_ARG(!(relu && dres) || relu_mask, MAED_ERR_ARG, "groupnorm_bwd: the forward's relu_mask is needed when a residual was added before the ReLU");
     MAED_PROPAGATE(gn_check(C, HW, "groupnorm_bwd"));
     if (N <= 0) return MAED_OK;
@@ -690,7 +735,7 @@ extern "C" int maed_groupnorm_bwd(const void* x, const uint8_t* relu_mask, const
             GN_ONE(0);
 #endif
         } else if (!relu) GN_RED(false, false); else if (ymask) GN_RED(true, true); else GN_RED(true, false);
-        if (defer) {
+        if (defer && dgamma) {
             // dgamma / dbeta are read by nobody before the caller joins aux_stream (ops.side_stream_join): the small column-sum kernel leaves the
             // dy -> dx chain and runs beside the apply pass
             hipStream_t sa = s;

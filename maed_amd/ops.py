@@ -829,6 +829,7 @@ class WeightStdFn(ReportingFn):
         their kernel AND their readiness report on the side stream itself, behind that stage's weight gradients, so the caller's stream -- the
         dy -> dx chain of the next stage -- never waits for them; the last group's join covers them."""
         dev = ctx.weights[0].device
+        gn_affine_flush(dev)        # the GroupNorm layers' deferred dgamma / dbeta sums: on the caller's stream, before anything below hands the gradients on
         st = _SIDE.get(dev) if (_side_on() and getattr(ctx.owner, "_ws_on_side", False)) else None
         if st is None or not st[1]:
             side_stream_join(dev)
@@ -873,6 +874,32 @@ LAZY_RES = {}
 
 
 GN_SYNC_WORDS = 80      # MAED_GN_SYNC_WORDS (include/maed_hip.h): 4-byte words per frame of maed_groupnorm_bwd's frame_sync scratch
+GN_DEFER_AFFINE = os.environ.get("MAED_GN_DEFER_AFFINE", "1") == "1"      # A/B knob: 0 = one closing kernel per GroupNorm layer (rounds 2-5)
+_GN_DEFERRED = {}       # device -> [(ab, dgamma, dbeta, N, C)]: GroupNorm backward partials whose column sums are still to be folded into the gradients
+
+
+def gn_affine_defer(device, ab, dgamma, dbeta, N, C_):
+    pend = _GN_DEFERRED.setdefault(device, [])
+    if not pend:
+        # safety net: a pass whose weight standardisation has no backward (frozen convolutions) still folds its partials when the engine finishes
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: gn_affine_flush(device))
+        except RuntimeError:        # not inside a backward pass (a Function called by hand): the caller flushes
+            pass
+    pend.append((ab, dgamma, dbeta, N, C_))
+
+
+def gn_affine_flush(device):
+    """fold the deferred GroupNorm partials of `device` into dgamma / dbeta: one launch on the CURRENT stream (which is the stream the GroupNorm backward kernels ran
+    on, or one ordered behind it)"""
+    pend = _GN_DEFERRED.get(device)
+    if not pend:
+        return
+    items = (L.GnAffineItem * len(pend))()
+    for i, (ab, dg, db, N, C_) in enumerate(pend):
+        items[i].ab, items[i].dgamma, items[i].dbeta, items[i].N, items[i].C = _p(ab), _p(dg), _p(db), N, C_
+    check(L.lib().maed_gn_affine_grad_batch(C.cast(items, C.c_void_p), len(pend), _stream()), "gn_affine_grad_batch")
+    pend.clear()
 
 
 class GroupNormFn(torch.autograd.Function):
@@ -949,10 +976,17 @@ class GroupNormFn(torch.autograd.Function):
             ab = torch.empty(N, C_, 2, dtype=torch.float32, device=x.device)
         if sync is None:
             sync = torch.zeros(N * GN_SYNC_WORDS, dtype=torch.int32, device=x.device)
-        # kernel-written dgamma / dbeta are read only after WeightStdFn.backward's side_stream_join: their closing column sum goes to the side stream
-        aux = side_stream_handle(x.device, ab) if ctx.direct else None
-        check(L.lib().maed_groupnorm_bwd(_p(x), _p(mask), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ab),
-                                         N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), _p(sync), aux, _stream()), "groupnorm_bwd")
+        # kernel-written dgamma / dbeta are read only after WeightStdFn.backward: with the pass's scratch arena (ab_zeroed) the closing column sum over the frames is
+        # DEFERRED -- the layer's partials stay in `ab` and ONE maed_gn_affine_grad_batch launch folds every layer of the pass (gn_affine_flush, called by
+        # WeightStdFn.backward and by the engine's end-of-pass callback): 52 launches of 6 us and 52 stream fences per step less (round 6).  Without the arena:
+        # the per-layer closing kernel on the side stream, as before.
+        defer = ctx.direct and ab_zeroed and GN_DEFER_AFFINE
+        aux = side_stream_handle(x.device, ab) if (ctx.direct and not defer) else None
+        check(L.lib().maed_groupnorm_bwd(_p(x), _p(mask), _p(dy), _p(sums), _p(gamma), _p(beta), _p(dx), _p(dres), None if defer else _p(dgamma),
+                                         None if defer else _p(dbeta), _p(ab), N, H * W, C_, ctx.eps, int(ctx.relu), dt_code(x.dtype), int(ab_zeroed), _p(sync), aux,
+                                         _stream()), "groupnorm_bwd")
+        if defer:
+            gn_affine_defer(x.device, ab, dgamma, dbeta, N, C_)
         if ctx.lazy_res:
             for k in [k for k, (r, _) in LAZY_RES.items() if r() is None]:      # announcements whose consumer never ran (an interrupted backward)
                 del LAZY_RES[k]

@@ -755,3 +755,52 @@ def test_gemm_persistent_kstream_race_screen():
                     bad += int(not torch.equal(out, want))
                 assert bad == 0, f"{bad}/25 launches of the persistent kernel (mode {mode}) differ at {M}x{N}x{K}"
     assert L.lib().maed_device_faults() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_groupnorm_affine_gradients_deferred_to_one_batched_launch(dtype):
+    """round 6: with the pass's pre-zeroed scratch arena the GroupNorm backward leaves its per-frame (dbeta, dgamma) partials in `ab`; ONE maed_gn_affine_grad_batch
+    launch (ops.gn_affine_flush) folds every layer into gamma.grad / beta.grad.  Three layers of different widths and frame counts -- one of them twice (+= onto the
+    first result) -- against the fp64 oracle, and bit-for-bit against the per-layer closing kernel (MAED_GN_DEFER_AFFINE=0: same partials, same fold order per column)."""
+    ops, _ = _ops()
+    layers = [(3, 64, 9, 7), (5, 256, 14, 14), (2, 1024, 5, 5), (5, 256, 14, 14)]
+    cl = lambda t: t.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    params = {}
+    res = {}
+    for defer in (True, False):
+        ops.GN_DEFER_AFFINE = defer
+        grads = {}
+        try:
+            for li, (N, C, H, W) in enumerate(layers):
+                key = (C,)
+                if key not in grads:
+                    g, b = 1 + 0.2 * rnd(C, seed=3 + C), 0.1 * rnd(C, seed=4 + C)
+                    params[key] = (g, b)
+                    grads[key] = (g.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True))
+                gg, bg = grads[key]
+                x, dy = q(rnd(N, C, H, W, seed=10 + li) * 1.5 + 0.2, dtype), q(rnd(N, C, H, W, seed=20 + li), dtype)
+                ab = torch.zeros(N, C, 2, dtype=torch.float32, device=DEV)
+                sums = torch.zeros(N, 32, 2, dtype=torch.float64, device=DEV)
+                sync = torch.zeros(N * ops.GN_SYNC_WORDS, dtype=torch.int32, device=DEV)
+                xg = cl(x).requires_grad_(True)
+                y = ops.GroupNormFn.apply(xg, None, gg, bg, 1e-5, True, True, sums, ab, False, False, sync)
+                y.backward(cl(dy))
+            ops.gn_affine_flush(torch.device(DEV))        # (the engine's end-of-pass callback has done it already: this must be a no-op then)
+            torch.cuda.synchronize()
+            res[defer] = {k: (a.grad.clone(), b.grad.clone()) for k, (a, b) in grads.items()}
+        finally:
+            ops.GN_DEFER_AFFINE = True
+    for k in res[True]:
+        assert torch.equal(res[True][k][0], res[False][k][0]) and torch.equal(res[True][k][1], res[False][k][1]), k
+    # the oracle
+    for key, (g, b) in params.items():
+        gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+        for li, (N, C, H, W) in enumerate(layers):
+            if (C,) != key:
+                continue
+            x, dy = q(rnd(N, C, H, W, seed=10 + li) * 1.5 + 0.2, dtype), q(rnd(N, C, H, W, seed=20 + li), dtype)
+            F.relu(F.group_norm(x.double(), 32, gd, bd, 1e-5)).backward(dy.double())
+        scale = max(1.0, gd.grad.abs().max().item())
+        f32 = dtype == torch.float32
+        report(f"groupnorm_bwd.dgamma[deferred,{dtype},C={key[0]}]", res[True][key][0], gd.grad, rtol=1e-4 if f32 else 2e-2, atol=(1e-4 if f32 else 3e-2) * scale)
+        report(f"groupnorm_bwd.dbeta[deferred,{dtype},C={key[0]}]", res[True][key][1], bd.grad, rtol=1e-4 if f32 else 2e-2, atol=(1e-4 if f32 else 3e-2) * scale)
