@@ -359,8 +359,8 @@ __global__ __launch_bounds__(256) void gn_affine_grad_kernel(const float* __rest
 }
 
 // The same closing sum for MANY layers in one launch (maed_gn_affine_grad_batch): workgroup b -> (layer, block of 64 columns of its (N, 2C) partial matrix) through
-// a prefix table that travels in the kernel arguments with the layers' pointers; 64 columns x 4 row lanes per workgroup over all N rows, one LDS fold, plain += (the
-// only writer of these gradients in the pass).
+// a prefix table that travels in the kernel arguments with the layers' pointers; 64 columns x 4 row lanes per workgroup over all N rows, one LDS fold, one atomic
+// per column and layer.
 #define GN_BATCH_MAX 64
 struct GnAffineBatch {
     maed_gn_affine_item it[GN_BATCH_MAX];
@@ -379,8 +379,8 @@ __global__ __launch_bounds__(256) void gn_affine_grad_batch_kernel(GnAffineBatch
     fold[rl][threadIdx.x & 63] = s;
     __syncthreads();
     if (rl == 0 && c < cols) {
-        float* const dst = ((c & 1) ? it.dgamma : it.dbeta) + (c >> 1);
-        *dst += (fold[0][threadIdx.x] + fold[1][threadIdx.x]) + (fold[2][threadIdx.x] + fold[3][threadIdx.x]);
+        // (an atomic: two layers of one launch may share their parameters -- a norm module applied twice in a pass)
+        atomicAdd(((c & 1) ? it.dgamma : it.dbeta) + (c >> 1), (fold[0][threadIdx.x] + fold[1][threadIdx.x]) + (fold[2][threadIdx.x] + fold[3][threadIdx.x]));
     }
 }
 extern "C" int maed_gn_affine_grad_batch(const maed_gn_affine_item* items, int count, void* stream) {

@@ -261,7 +261,10 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     // the backbone's narrow outputs (profiles/r05_tn_dma_micro.txt); IN SITU -- beside the dy -> dx chain on the side stream, where its copies cost no VALU slots --
     // it is the faster choice for every shape: train step 20.28 / 20.33 -> 20.02 / 20.11 ms same-box (profiles/r05_tn_dma_bench_ab.txt).  Option value 3: its
     // 256 x 256 tile (rejected: see gemm_tn2.hip), 0: this file's kernel.
-    const int tnd = maed_opt(MAED_OPT_TN_DMA);
+    // Option value 4 (round 6): by shape -- this file's kernel for the backbone's long-and-narrow products (M >= 65536 rows onto at most
+    // 65536 outputs: stage 1 / 2's 1x1 convolutions, where it is 7-19 us faster per launch in isolation, profiles/r05_tn_micro.txt), the LDS-DMA kernel elsewhere.
+    int tnd = maed_opt(MAED_OPT_TN_DMA);
+    if (tnd == 4) tnd = (M >= 65536 && (int64_t)N * K <= 65536) ? 0 : 1;
     if (tnd && maed_gemm_tn_dma_ok(M, N, K, ldy, ldx)) {
         MAED_PROPAGATE(maed_gemm_tn_dma_launch(Y, ldy, X, ldx, M, N, K, dW, ldw, dbias, tnd, (hipStream_t)stream));
         MAED_CHECK_LAUNCH("gemm_tn_wgrad(dma)");

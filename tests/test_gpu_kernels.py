@@ -761,7 +761,7 @@ def test_gemm_persistent_kstream_race_screen():
 def test_groupnorm_affine_gradients_deferred_to_one_batched_launch(dtype):
     """round 6: with the pass's pre-zeroed scratch arena the GroupNorm backward leaves its per-frame (dbeta, dgamma) partials in `ab`; ONE maed_gn_affine_grad_batch
     launch (ops.gn_affine_flush) folds every layer into gamma.grad / beta.grad.  Three layers of different widths and frame counts -- one of them twice (+= onto the
-    first result) -- against the fp64 oracle, and bit-for-bit against the per-layer closing kernel (MAED_GN_DEFER_AFFINE=0: same partials, same fold order per column)."""
+    first result) -- against the fp64 oracle, and against the per-layer closing kernel (MAED_GN_DEFER_AFFINE=0: same fold order per column)."""
     ops, _ = _ops()
     layers = [(3, 64, 9, 7), (5, 256, 14, 14), (2, 1024, 5, 5), (5, 256, 14, 14)]
     cl = lambda t: t.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
@@ -791,7 +791,10 @@ def test_groupnorm_affine_gradients_deferred_to_one_batched_launch(dtype):
         finally:
             ops.GN_DEFER_AFFINE = True
     for k in res[True]:
-        assert torch.equal(res[True][k][0], res[False][k][0]) and torch.equal(res[True][k][1], res[False][k][1]), k
+        # (same fold per column; the PARTIALS are atomically accumulated by the frame's workgroups in the one-pass backward -- up to four per frame in fp32 -- so two
+        #  runs agree to the last bits, not bit for bit; scripts/r6/gn_defer_diag.py shows equality where the partials are equal)
+        for a, b in zip(res[True][k], res[False][k]):
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), k
     # the oracle
     for key, (g, b) in params.items():
         gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
