@@ -391,6 +391,7 @@ def main():
             loss, _ = criterion(model(clip), tgt, None)
             loss.backward()
             opt.step()
+            return loss
 
     def fence():
         cuda_sync()
@@ -401,8 +402,11 @@ def main():
     # setup, not a benchmark step: the first pass through the model makes MIOpen search its convolution algorithms (~20 s) and
     # loads every code object; it is kept out of the W warm-up steps so that a small --warmup cannot put it next to the timed region
     t1 = time.perf_counter()
-    step()
+    first_loss = step()
     cuda_sync()
+    # the objective of the very first step (seeded parameters, seeded batch, before any update): equal -- to the order of fp32 atomics -- whatever the launch line,
+    # the transport of the gradient all-reduce or the number of ranks' worth of machinery around it (tests/test_gpu_model.py compares the two launch lines)
+    first_loss = None if first_loss is None else float(first_loss.detach().float().item())
     log(f"setup pass (MIOpen algorithm search, code-object loading): {time.perf_counter() - t1:.3f}s")
     for i in range(args.warmup):
         t1 = time.perf_counter()
@@ -627,7 +631,7 @@ def main():
                        "smpl": "synthetic SMPL-shaped parameters (licensed model file unavailable)",
                        "input": "one synthetic clip batch resident in HBM, reused by every step: no host-to-device copy in the timed region (DESIGN.md section 5: a 77 MB fp32 "
                                 "batch is ~1.4 ms over PCIe Gen5 when not overlapped)"},
-            "step_time": step_stats, "host_enqueue_ms": host_enqueue_ms,
+            "step_time": step_stats, "host_enqueue_ms": host_enqueue_ms, "first_step_loss": first_loss,
             # data-parallel diagnostics (N > 1 or forced collectives): transport, ranks, gradient buckets and when each was launched in the last backward
             "ddp": (None if args.forward_only else dict(transport="maed_comm (own RCCL communicator)" if comm is not None else ("torch.distributed/" + (dist.get_backend() if dist.is_initialized() else "none")),
                                                      rccl_ranks=world, collectives=bool(bucketer.collectives), gradient_dtype="f32",

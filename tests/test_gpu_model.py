@@ -678,3 +678,37 @@ def test_cfg3_full_size_block_bf16_fwd_bwd_vs_fp64_oracle():
     for name, prm in blk.named_parameters():
         ref = pd[name].grad
         report(f"cfg3 Block.backward.d[{name}] bf16", prm.grad, ref, rtol=5e-2, atol=3e-2 * max(ref.abs().max().item(), 1e-3))
+
+
+def test_contract_launch_line_with_one_rank_and_forced_collectives_matches_the_plain_run():
+    """the driver's multi-GPU line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...` -- end to end as a subprocess with N = 1 and every gradient bucket's all-reduce forced (MAED_FORCE_COLLECTIVES=1, per-stage weight standardisation
+    as with N > 1): it must come up on the library's own RCCL communicator, cut the gradient arena into the seven buckets of DESIGN.md section 6, launch them in
+    backward order, and compute the SAME first-step objective as the plain single-process run (seeded parameters and batch; fp32 atomics order is the only noise).
+    What one GPU can pin down about `bench.py --gpus 8` before it meets xGMI."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-ddp-rehearsal"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+    def run(cmd, extra):
+        r = subprocess.run(cmd, env=dict(env, **extra), capture_output=True, text=True, timeout=600, cwd=root)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and lines, (r.returncode, r.stderr[-2000:])
+        return json.loads(lines[-1])
+
+    plain = run([sys.executable] + base, {})
+    port = 29500 + (os.getpid() % 400)
+    ddp = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)] + base,
+              {"MAED_FORCE_COLLECTIVES": "1", "MAED_WS_PER_STAGE": "1"})
+    d = ddp["ddp"]
+    assert d["transport"].startswith("maed_comm"), d["transport"]
+    assert d["rccl_ranks"] == 1 and d["collectives"] is True and d["per_stage_weight_std"] is True, d
+    assert len(d["buckets"]) == 7, d["buckets"]
+    assert sorted(d["bucket_launch_order"]) == list(range(7)) and d["bucket_launch_order"][0] == 6, d["bucket_launch_order"]     # backward order: the last bucket first
+    assert plain["ddp"]["collectives"] is False
+    a, b = plain["first_step_loss"], ddp["first_step_loss"]
+    note(f"contract launch line, one rank, forced collectives: first-step loss {b!r} vs plain {a!r}; {ddp['ms_per_step']} vs {plain['ms_per_step']} ms/step")
+    assert a is not None and b is not None and abs(a - b) <= 2e-4 * abs(a), (a, b)
