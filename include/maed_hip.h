@@ -115,6 +115,9 @@ typedef enum {
                                     * M, N >= 256) and the dispatcher's heuristic picks it: 1 (default) = heuristic, 0 = never (the per-tile kernels of rounds 1-5),
                                     * 2 = wherever the shape allows without K cuts, 3 = wherever the shape allows, K cuts whenever the tiles do not fill whole rounds */
     MAED_OPT_SK_GRID = 14,         /* workgroups of that kernel: 0 (default) = one per CU; a smaller grid is a test / sweep knob */
+    MAED_OPT_TN_SK = 15,           /* bf16 maed_gemm_tn_wgrad on the persistent K-stream kernel (csrc/gemm_tn_sk.hip: 256 x 256 tiles, the reduction rows dealt to one workgroup
+                                    * per CU, partial tiles in slabs, a second launch adds them in a fixed order -- no atomics) where the shape allows (M % 128 == 0; N, K >= 256
+                                    * and multiples of 128; at most one tile per two CUs): 1 (default) = yes, 0 = the split-M kernels with closing atomics (gemm_tn2.hip / gemm_tn.hip) */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's

@@ -458,7 +458,7 @@ struct SkState {
     std::mutex mu;
 };
 SkState g_sk;
-size_t sk_slot_bytes(int ncu) { return 4096 + (size_t)ncu * SK_SLAB_FLOATS * sizeof(float); }
+size_t sk_slot_bytes(int ncu) { return 4096 + (size_t)ncu * (SK_SLAB_FLOATS + 256) * sizeof(float); }      // (+ 256: the weight-gradient kernel's column sums, gemm_tn_sk.hip)
 }  // namespace
 
 // called once from maed_init_runtime (the one place that creates what the library owns); safe to call again
@@ -494,6 +494,16 @@ static int sk_take_slot(hipStream_t s, uint32_t* epoch) {
     const int i = g_sk.nslots++;
     g_sk.slot[i].stream = (void*)s; g_sk.slot[i].epoch = 1; *epoch = 1;
     return i;
+}
+
+// the slab set of `s` for the weight-gradient kernel (gemm_tn_sk.hip: one slab per workgroup, no flags); NULL: no allocation / more streams than sets
+float* maed_sk_slab_set(hipStream_t s, size_t* bytes, int* ncu) {
+    if (!g_sk.base && maed_sk_init() != MAED_OK) return nullptr;
+    uint32_t epoch = 0;
+    const int slot = sk_take_slot(s, &epoch);
+    if (slot < 0) return nullptr;
+    *bytes = sk_slot_bytes(g_sk.ncu) - 4096; *ncu = g_sk.ncu;
+    return (float*)(g_sk.base + (size_t)slot * sk_slot_bytes(g_sk.ncu) + 4096);
 }
 
 template <int EPI>

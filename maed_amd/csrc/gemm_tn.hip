@@ -28,6 +28,9 @@ int maed_tn_splits(int tiles) {
 }
 static int tn_remap() { return 1; }     // XCD-aware (split, tile) order: -6...8 % and 292 -> 189 MB of HBM traffic per launch (profiles/r02_pmc)
 
+bool maed_gemm_tn_sk_ok(int64_t M, int N, int K, int64_t ldy, int64_t ldx, int64_t ldw, const void* Y, const void* X, const void* dW);      // gemm_tn_sk.hip
+int maed_gemm_tn_sk_launch(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw, float* dbias, int grid_opt, hipStream_t s);
+int maed_sk_cus(void);                                                                                                          // gemm_sk.hip
 bool maed_gemm_tn_dma_ok(int64_t M, int N, int K, int64_t ldy, int64_t ldx);                                            // gemm_tn2.hip
 int maed_gemm_tn_dma_launch(const void* Y, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, float* dW, int64_t ldw, float* dbias, int which, hipStream_t stream);
 bool maed_conv3x3_wgrad_rows64_ok(int F, int H, int W, int Cin, int Cout);                                            // conv3x3_rows.hip
@@ -263,6 +266,11 @@ extern "C" int maed_gemm_tn_wgrad(const void* Y, int64_t ldy, const void* X, int
     // 256 x 256 tile (rejected: see gemm_tn2.hip), 0: this file's kernel.
     // Option value 4 (round 6): by shape -- this file's kernel for the backbone's long-and-narrow products (M >= 65536 rows onto at most
     // 65536 outputs: stage 1 / 2's 1x1 convolutions, where it is 7-19 us faster per launch in isolation, profiles/r05_tn_micro.txt), the LDS-DMA kernel elsewhere.
+    // persistent K-stream kernel (gemm_tn_sk.hip, round 6): 256 x 256 tiles, the reduction dealt to one workgroup per CU, slabs + a fixed-order reduce launch
+    if (maed_opt(MAED_OPT_TN_SK) && maed_gemm_tn_sk_ok(M, N, K, ldy, ldx, ldw, Y, X, dW) && ((N + 255) / 256) * ((K + 255) / 256) * 2 <= maed_sk_cus()) {
+        const int rc = maed_gemm_tn_sk_launch(Y, ldy, X, ldx, M, N, K, dW, ldw, dbias, maed_opt(MAED_OPT_SK_GRID), (hipStream_t)stream);
+        if (rc == MAED_OK) { MAED_CHECK_LAUNCH("gemm_tn_wgrad(sk)"); return MAED_OK; }
+    }
     int tnd = maed_opt(MAED_OPT_TN_DMA);
     if (tnd == 4) tnd = (M >= 65536 && (int64_t)N * K <= 65536) ? 0 : 1;
     if (tnd && maed_gemm_tn_dma_ok(M, N, K, ldy, ldx)) {

@@ -22,6 +22,7 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {0},      // MAED_OPT_X3_PLANES_LN: measured neutral in the train step (profiles/r05_x3p_micro.txt)
     {1},      // MAED_OPT_SK: heuristic
     {0},      // MAED_OPT_SK_GRID: one workgroup per CU
+    {1},      // MAED_OPT_TN_SK
 };
 
 extern "C" int maed_init(int device) {
@@ -95,6 +96,7 @@ extern "C" int maed_set_option(int key, int value) {
     if (key == MAED_OPT_LBS_FRAMES) MAED_CHECK_ARG(value == 0 || value == 4 || value == 8 || value == 16, MAED_ERR_ARG, "set_option: MAED_OPT_LBS_FRAMES takes 0 (auto), 4, 8 or 16");
     if (key == MAED_OPT_X3_PLANES) MAED_CHECK_ARG(value == 0 || (value >= 2 && value <= 7 && value != 3), MAED_ERR_ARG, "set_option: MAED_OPT_X3_PLANES takes 0 (fp32 operands) or a kernel variant 2, 4, 5, 6, 7");
     if (key == MAED_OPT_SK) MAED_CHECK_ARG(value >= 0 && value <= 3, MAED_ERR_ARG, "set_option: MAED_OPT_SK takes 0 (off), 1 (heuristic), 2 (no K cuts) or 3 (always)");
+    if (key == MAED_OPT_TN_SK) MAED_CHECK_ARG(value == 0 || value == 1, MAED_ERR_ARG, "set_option: MAED_OPT_TN_SK takes 0 or 1");
     if (key == MAED_OPT_SK_GRID) MAED_CHECK_ARG(value >= 0 && value <= 512, MAED_ERR_ARG, "set_option: MAED_OPT_SK_GRID takes 0 (one workgroup per CU) or a workgroup count <= 512");
     g_opt[key].store(value, std::memory_order_relaxed);
     return MAED_OK;

@@ -807,3 +807,35 @@ def test_groupnorm_affine_gradients_deferred_to_one_batched_launch(dtype):
         f32 = dtype == torch.float32
         report(f"groupnorm_bwd.dgamma[deferred,{dtype},C={key[0]}]", res[True][key][0], gd.grad, rtol=1e-4 if f32 else 2e-2, atol=(1e-4 if f32 else 3e-2) * scale)
         report(f"groupnorm_bwd.dbeta[deferred,{dtype},C={key[0]}]", res[True][key][1], bd.grad, rtol=1e-4 if f32 else 2e-2, atol=(1e-4 if f32 else 3e-2) * scale)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(25216, 1536, 512, True), (25216, 512, 2048, True), (32896, 768, 3072, True), (1280, 264, 392, False), (25088, 1024, 256, False)])
+def test_gemm_tn_persistent_kstream(M, N, K, bias):
+    """csrc/gemm_tn_sk.hip (weight gradient dW += Y^T X, dbias += colsum Y on 256 x 256 tiles, one workgroup per CU, slabs + fixed-order reduce launch) against fp64 at
+    the STE's shapes of cfg3 / cfg5, a ragged shape and a stage-3 convolution: fp32-accumulation accuracy, `+=` onto existing gradients, and -- no atomics -- bit-identical
+    results over repeated launches (the split-M kernels differ from run to run)."""
+    ops, L = _ops()
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    Y = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    X = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    dW0, db0 = torch.randn(N, K, device=DEV, generator=g), torch.randn(N, device=DEV, generator=g)
+    ref = dW0.double() + Y.double().t() @ X.double()
+    refb = db0.double() + Y.double().sum(0)
+    old = (lib.maed_get_option(L.OPT_TN_SK), lib.maed_get_option(L.OPT_SK_GRID))
+    try:
+        for grid in (255, 96):           # (an explicit grid takes the kernel whatever the heuristic says: 255 ~ one workgroup per CU, 96: longer items, other tile shares)
+            lib.maed_set_option(L.OPT_TN_SK, 1); lib.maed_set_option(L.OPT_SK_GRID, grid)
+            outs = []
+            for _ in range(4):
+                dW, db = dW0.clone(), (db0.clone() if bias else None)
+                ops.gemm_tn_wgrad(Y, X, dW=dW, dbias=db)
+                outs.append((dW, db))
+            scale = ref.abs().max().item()
+            report(f"gemm_tn_sk[{M}x{N}x{K},grid {grid}] dW", outs[0][0], ref, rtol=0, atol=2e-6 * scale)
+            if bias:
+                report(f"gemm_tn_sk[{M}x{N}x{K},grid {grid}] dbias", outs[0][1], refb, rtol=0, atol=2e-6 * refb.abs().max().item())
+            for dW, db in outs[1:]:
+                assert torch.equal(dW, outs[0][0]) and (not bias or torch.equal(db, outs[0][1])), "the persistent weight-gradient kernel must be deterministic"
+    finally:
+        lib.maed_set_option(L.OPT_TN_SK, old[0]); lib.maed_set_option(L.OPT_SK_GRID, old[1])

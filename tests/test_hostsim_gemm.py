@@ -264,3 +264,23 @@ def test_gemm_nt_persistent_kstream_epilogues(epi):
         else:
             out = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias, impl=L.IMPL_MFMA_SK)
             assert (out.float() - (acc + bias).bfloat16().float()).abs().max() <= 2 * 2 ** -8 * (acc + bias).abs().max()
+
+
+# ---- round 6: the persistent K-stream weight-gradient kernel (csrc/gemm_tn_sk.hip) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,grid,bias", [
+    (256, 256, 256, 1, True),        # one tile, one workgroup, two pairs
+    (640, 512, 256, 3, True),        # two tiles on three workgroups (2 + 1): five pairs shared 3 / 2 in the first tile; the bias owners are the tiles of column 0
+    (384, 264, 392, 8, False),       # 2 x 2 tiles with ragged N / K (8 and 136 valid columns in the edge tiles), two workgroups per tile, three pairs
+    (128, 256, 256, 4, True),        # one pair on four workgroups: three zero slabs
+])
+def test_gemm_tn_persistent_kstream(M, N, K, grid, bias):
+    Y, X = rnd(M, N, seed=41).bfloat16(), rnd(M, K, seed=42).bfloat16()
+    dW0 = rnd(N, K, seed=43)
+    db0 = rnd(N, seed=44)
+    with patched() as lib, option(lib, L.OPT_TN_SK, 1), option(lib, L.OPT_SK_GRID, grid):
+        dW, db = dW0.clone(), (db0.clone() if bias else None)
+        ops.gemm_tn_wgrad(Y, X, dW=dW, dbias=db)
+    ref = dW0.double() + Y.double().t() @ X.double()
+    assert torch.allclose(dW.double(), ref, rtol=1e-5, atol=1e-4), (dW.double() - ref).abs().max()
+    if bias:
+        assert torch.allclose(db.double(), db0.double() + Y.double().sum(0), rtol=1e-5, atol=1e-4)
