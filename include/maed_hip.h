@@ -118,6 +118,9 @@ typedef enum {
     MAED_OPT_TN_SK = 15,           /* bf16 maed_gemm_tn_wgrad on the persistent K-stream kernel (csrc/gemm_tn_sk.hip: 256 x 256 tiles, the reduction rows dealt to one workgroup
                                     * per CU, partial tiles in slabs, a second launch adds them in a fixed order -- no atomics) where the shape allows (M % 128 == 0; N, K >= 256
                                     * and multiples of 128; at most one tile per two CUs): 1 (default) = yes, 0 = the split-M kernels with closing atomics (gemm_tn2.hip / gemm_tn.hip) */
+    MAED_OPT_CONV3X3_NARROW_WGS = 16, /* maed_conv3x3_fwd (bf16): when the 128 x 128 tiling of the output gives fewer workgroups than this, the 128 x 64 tile is used
+                                    * instead (twice the workgroups: the stage-3 convolutions of the R50 run at 1.5 workgroups per CU on 128 x 128 tiles and are
+                                    * latency-bound for it).  0 = 128 x 64 only for Cout <= 64 (rounds 2-5). */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's

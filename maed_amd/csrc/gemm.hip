@@ -515,8 +515,11 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
     MAED_CHECK_ARG(is_aligned(x, 16) && is_aligned(w_taps, 16) && is_aligned(zero_page, 16) && is_aligned(y, 16), MAED_ERR_ALIGN, "conv3x3_fwd: 16-B alignment");
     if (F == 0) return MAED_OK;
     const int64_t M = (int64_t)F * Ho * Wo, N = Cout;
-    const bool narrow = N <= 64;
-    const int tm = (int)((M + GM_BM - 1) / GM_BM), tn = narrow ? 1 : (int)((N + GM_BN - 1) / GM_BN);
+    const int tm = (int)((M + GM_BM - 1) / GM_BM);
+    // 128 x 64 output tiles for Cout <= 64, and (MAED_OPT_CONV3X3_NARROW_WGS) wherever 128 x 128 tiles would leave the chip with too few workgroups to hide the
+    // single-buffered loop's copy latency (stage 3 of the R50: 392 workgroups = 1.5 per CU)
+    const bool narrow = N <= 64 || (int64_t)tm * ((N + GM_BN - 1) / GM_BN) < maed_opt(MAED_OPT_CONV3X3_NARROW_WGS);
+    const int tn = narrow ? (int)((N + 63) / 64) : (int)((N + GM_BN - 1) / GM_BN);
     // layout 0: w_taps[co][tap][ci].  layout 1 (input gradient from the forward weight's transposed image Wt[tap_f][c_f][o_f], as
     // maed_weight_std_fwd writes it next to the forward image): here Cin = O_f, Cout = I_f, and element (n = c_f, tap, c = o_f) is
     // Wt[(8 - tap)][n][c] -- the tap flip is a negative tap stride, nothing is copied.
