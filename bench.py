@@ -577,7 +577,7 @@ def main():
                         for (fl, by), e in sorted(shapes.items(), key=lambda kv: -kv[1][1])]
             launch_bound = dict(frac=round(tb_sum / dur_sum, 4) if dur_sum else None, hbm_bound_launches_per_step=round(n_hbm / nprof, 1),
                                 mfma_bound_launches_per_step=round((len(tn_recs) - n_hbm) / nprof, 1), mfma_ops_per_product=mult, by_shape=by_shape[:12])
-            roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_dma_bf16_kernel<2, 2, 2, 2> (csrc/gemm_tn2.hip; MAED_TN_DMA=0: gemm_tn_mfma_bf16_kernel)") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
+            roofline = dict(kernel=("gemm_tn_x3_kernel" if args.dtype == "f32" else "gemm_tn_dma_bf16_kernel<2, 2, 2, 2> (csrc/gemm_tn2.hip; MAED_TN_DMA=0: gemm_tn_mfma_bf16_kernel; from 32 K-tile pairs per workgroup -- cfg5's MLP shapes -- gemm_tn_sk_bf16_kernel + its reduce launch, csrc/gemm_tn_sk.hip)") + " (weight-gradient GEMM dW += Y^T X: every launch of the step -- "
                                    "5 per STE block + the backbone's 1x1 convolutions)", bound="mfma", achieved=round(tf, 2), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                             frac=round(tf / MFMA_BF16_PEAK_TF, 4), traffic=traffic_db.get("gemm_tn"), avg_us=round(us, 2), launches=cnt[TN_ALL] // nprof,
                             ms_per_step=round(ms[TN_ALL] / nprof, 3), algorithmic_bytes=(int(sum(r[2] for r in tn_recs) / len(tn_recs)) if tn_recs else None),
