@@ -70,7 +70,6 @@ typedef enum { MAED_IMPL_AUTO = 0, MAED_IMPL_VALU = 1, MAED_IMPL_MFMA = 2,
                MAED_IMPL_MFMA_LONG = 5, /* attn_spatial only: K/V-tiled long-sequence kernels (chosen automatically past 512 / 320 tokens) */
                MAED_IMPL_MFMA_256 = 6, /* gemm_nt only: 256x256 tiles, counted-vmcnt LDS-DMA pipeline (csrc/gemm256.hip) */
                MAED_IMPL_X1 = 9, /* gemm_nt only: fp32 operands, ONE bf16 plane (what dtype MAED_F32X1 selects) */
-               MAED_IMPL_MFMA_2W = 11, /* gemm_nt only: 256x128 tiles on 4 waves, two workgroups per CU, three-stage LDS-DMA ring (csrc/gemm2w.hip) */
                MAED_IMPL_MFMA_SK = 10, /* gemm_nt only: the persistent K-stream kernel (csrc/gemm_sk.hip), K cuts per MAED_OPT_SK (1 and 3: allowed) */
                MAED_IMPL_X3 = 7, MAED_IMPL_X6 = 8 /* MAED_F32 matrix products on the bf16 matrix cores: every fp32 operand split into 2 / 3 bf16
                                                    * terms, 3 / 6 MFMAs per product, fp32 accumulation (csrc/gemm_x3.hip): |error| ~2^-16 / ~2^-23

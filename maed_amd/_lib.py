@@ -18,7 +18,6 @@ IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 IMPL_MFMA_256 = 6       # gemm_nt only: 256x256 pipelined tiles
 IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
 IMPL_MFMA_SK = 10      # gemm_nt only: persistent K-stream kernel (csrc/gemm_sk.hip)
-IMPL_MFMA_2W = 11      # gemm_nt only: 256x128 tiles, two 4-wave workgroups per CU (csrc/gemm2w.hip)
 IMPL_X3, IMPL_X6, IMPL_X1 = 7, 8, 9  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
 (OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS, OPT_F32_BWD_X1, OPT_ST_FUSED, OPT_CONV3X3_ROWS_WGS, OPT_STEM_WGRAD_WGS,
  OPT_LBS_FRAMES, OPT_TN_DMA, OPT_X3_PLANES, OPT_X3_PLANES_LN, OPT_SK, OPT_SK_GRID, OPT_TN_SK, OPT_CONV3X3_NARROW_WGS) = range(17)   # maed_option (include/maed_hip.h)

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmaed_hip.so")
-SOURCES = ["layernorm.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "elementwise.hip", "block.hip", "smpl.hip", "backbone.hip", "tail_bwd.hip", "loss.hip", "comm.hip", "eval_metrics.hip", "attn_long.hip", "gemm_x3.hip", "options.hip", "attn_x3.hip", "stem.hip", "conv3x3_rows.hip", "gemm_tn2.hip", "gemm_x3p.hip", "gemm_sk.hip", "gemm_tn_sk.hip", "gemm2w.hip"]
+SOURCES = ["layernorm.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "elementwise.hip", "block.hip", "smpl.hip", "backbone.hip", "tail_bwd.hip", "loss.hip", "comm.hip", "eval_metrics.hip", "attn_long.hip", "gemm_x3.hip", "options.hip", "attn_x3.hip", "stem.hip", "conv3x3_rows.hip", "gemm_tn2.hip", "gemm_x3p.hip", "gemm_sk.hip", "gemm_tn_sk.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 

@@ -645,8 +645,6 @@ bool maed_gemm_nt_sk_shape_ok(int64_t M, int64_t N, int64_t K);
 bool maed_gemm_nt_sk_launch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e,
                             int mode, int grid_opt, hipStream_t s);
 int maed_sk_cus(void);
-// csrc/gemm2w.hip: 256x128 tiles on 4 waves, two workgroups per CU
-bool maed_gemm_nt_2w_launch(int epilogue, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const EpiArgs& e, hipStream_t s);
 
 template <int EPI>
 static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int dtype,
@@ -725,13 +723,6 @@ static int dispatch(const void* A, int64_t lda, const void* B, int64_t ldb, int6
         const int mode = maed_opt(MAED_OPT_SK);
         MAED_CHECK_ARG(oksk && maed_gemm_nt_sk_launch(EPI, A, lda, B, ldb, M, N, K, e, mode == 0 ? 1 : mode, maed_opt(MAED_OPT_SK_GRID), s), MAED_ERR_ALIGN,
                        "gemm_nt(sk): need K%%128==0 (K=%lld), M, N >= 256, lda/ldb%%8==0, 16-B aligned A/B, no split-K, the library's slab allocation", (long long)K);
-        return MAED_OK;
-    }
-    const bool ok2w = (K % 32 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && is_aligned(A, 16) && is_aligned(B, 16) && fits32 && K >= 64 && splitk == 1 &&
-                      EPI != MAED_EPI_ATOMIC_F32 && !e.gn_sums && !e.twin && !e.lo;
-    if (impl == MAED_IMPL_MFMA_2W) {
-        MAED_CHECK_ARG(ok2w && maed_gemm_nt_2w_launch(EPI, A, lda, B, ldb, M, N, K, e, s), MAED_ERR_ALIGN,
-                       "gemm_nt(2w): need K%%32==0, K>=64 (K=%lld), lda/ldb%%8==0, 16-B aligned A/B, no split-K, one of the STORE / GELU / RESID_F32 / MUL_DGELU / STORE_F32 epilogues", (long long)K);
         return MAED_OK;
     }
     if (impl == MAED_IMPL_MFMA) {

@@ -22,7 +22,7 @@ ASAN = os.environ.get("MAED_SIM_ASAN", "0") not in ("", "0")
 SAN = ["-fsanitize=thread"] if TSAN else ["-fsanitize=address"] if ASAN else []
 OUT_DIR = os.path.join(HERE, "_build_tsan" if TSAN else "_build_asan" if ASAN else "_build")
 OUT = os.path.join(OUT_DIR, "libmaed_hostsim.so")
-SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip", "attn_long.hip", "gemm_x3.hip", "options.hip", "attn_x3.hip", "stem.hip", "conv3x3_rows.hip", "gemm_tn2.hip", "gemm_x3p.hip", "gemm_sk.hip", "gemm_tn_sk.hip", "gemm2w.hip",
+SOURCES = ["smpl.hip", "tail_bwd.hip", "loss.hip", "elementwise.hip", "layernorm.hip", "backbone.hip", "gemm.hip", "gemm256.hip", "gemm_tn.hip", "attn_spatial.hip", "attn_temporal.hip", "block.hip", "eval_metrics.hip", "attn_long.hip", "gemm_x3.hip", "options.hip", "attn_x3.hip", "stem.hip", "conv3x3_rows.hip", "gemm_tn2.hip", "gemm_x3p.hip", "gemm_sk.hip", "gemm_tn_sk.hip",
            "comm.hip"]      # (the RCCL wrapper against tests/hostsim/rccl/rccl.h: streams / events are no-ops here, the NCCL entry points come from whatever library the test names)
 CLANG = os.environ.get("MAED_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 

@@ -284,21 +284,3 @@ def test_gemm_tn_persistent_kstream(M, N, K, grid, bias):
     assert torch.allclose(dW.double(), ref, rtol=1e-5, atol=1e-4), (dW.double() - ref).abs().max()
     if bias:
         assert torch.allclose(db.double(), db0.double() + Y.double().sum(0), rtol=1e-5, atol=1e-4)
-
-
-# ---- round 6: 256 x 128 tiles on four waves, two workgroups per CU (csrc/gemm2w.hip) ------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(300, 136, 64), (256, 128, 96), (520, 264, 160), (130, 72, 256)])      # ragged tiles, 2 / 3 / 5 / 8 K steps (every ring drain)
-def test_gemm_nt_256x128_two_workgroups_per_cu(M, N, K):
-    A, B, bias = rnd(M, K, seed=61).bfloat16(), rnd(N, K, seed=62, scale=K ** -0.5).bfloat16(), rnd(N, seed=63)
-    ref = A.float() @ B.float().t() + bias
-    with patched():
-        out = ops.gemm_nt(A, B, L.EPI_STORE_F32, bias=bias, impl=L.IMPL_MFMA_2W)
-        assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4), (out - ref).abs().max()
-        o16 = ops.gemm_nt(A, B, L.EPI_STORE, bias=bias, impl=L.IMPL_MFMA_2W)
-        if K % 64 == 0:
-            assert torch.equal(o16, ops.gemm_nt(A, B, L.EPI_STORE, bias=bias, impl=3))          # same k order as the 128 x 128 kernel: the same bits
-        aux = rnd(M, N, seed=64)
-        r = ops.gemm_nt(A, B, L.EPI_RESID_F32, bias=bias, aux=aux, impl=L.IMPL_MFMA_2W)
-        assert torch.allclose(r, aux + ref, rtol=1e-4, atol=1e-4)
-        act, pre = ops.gemm_nt(A, B, L.EPI_GELU, bias=bias, impl=L.IMPL_MFMA_2W)
-        assert torch.allclose(pre.float(), ref.bfloat16().float(), atol=2e-2) and torch.allclose(act.float(), gelu(pre.float()), rtol=2e-2, atol=2e-2)
