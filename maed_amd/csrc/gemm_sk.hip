@@ -453,6 +453,7 @@ struct SkSlot { void* stream; uint32_t epoch; };
 struct SkState {
     char* base = nullptr;                 // SK_SLOTS x (flags: SK_MAX_GRID x 4 B, padded to 4 KB ; slabs: ncu x 256 KB)
     int ncu = 0;
+    int dev = -1;                         // the device the slabs live on (the one that was current at maed_init): launches on another device take the per-tile kernels
     int nslots = 0;
     SkSlot slot[SK_SLOTS];
     std::mutex mu;
@@ -474,6 +475,7 @@ int maed_sk_init(void) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return MAED_ERR_LAUNCH; }
     g_sk.ncu = prop.multiProcessorCount;
+    g_sk.dev = dev;
     if (g_sk.ncu < 8 || g_sk.ncu > SK_MAX_GRID) return MAED_ERR_UNSUPPORTED;
     void* p = nullptr;
     if (hipMalloc(&p, SK_SLOTS * sk_slot_bytes(g_sk.ncu)) != hipSuccess || !p) { (void)hipGetLastError(); return MAED_ERR_LAUNCH; }
@@ -485,8 +487,12 @@ int maed_sk_init(void) {
 }
 int maed_sk_cus(void) { return g_sk.ncu; }
 
-// the slab set of a stream (assigned on first use) and the next epoch of that set; -1: table full
+// the slab set of a stream (assigned on first use) and the next epoch of that set; -1: table full, or the calling thread's device is not the slabs'
 static int sk_take_slot(hipStream_t s, uint32_t* epoch) {
+#ifndef MAED_HOSTSIM
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != g_sk.dev) { (void)hipGetLastError(); return -1; }
+#endif
     std::lock_guard<std::mutex> lk(g_sk.mu);
     for (int i = 0; i < g_sk.nslots; ++i)
         if (g_sk.slot[i].stream == (void*)s) { *epoch = ++g_sk.slot[i].epoch; if (*epoch == 0) *epoch = ++g_sk.slot[i].epoch; return i; }
