@@ -187,6 +187,84 @@ def ddp_rehearsal(plain_ms, steps=10):
         return dict(world1_forced_ms=None, note=f"rehearsal failed: {e!r}")
 
 
+def graph_leg_main(args):
+    """`bench.py --graph-leg` (a subprocess of the default run: a failed capture must not cost the run its JSON line): the SAME cfg3 bf16 train step captured once as a
+    hipGraph and replayed (maed_amd/graphed.py) -- ms per step, host time per replay, and the loss trajectory against the eager step that takes the same entry points
+    (learning rate / bias corrections / Dropout seed from the device record), same seeds, same initial parameters."""
+    import maed_amd
+    from maed_amd.ddp import FusedAdam, GradBucketer, ParamArena
+    from maed_amd.graphed import GraphedTrainStep
+    from maed_amd.loss import LossVideo
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(1000)
+    clip = torch.randn(CFG["clips"], CFG["T"], 3, CFG["img"], CFG["img"], generator=gen).to(dev)
+    tgt = make_targets(CFG["clips"], CFG["T"], dev, gen)
+    ncmp = 6
+
+    def arm(eager):
+        model = build_model(torch.bfloat16, dev)
+        model.train()
+        arena = ParamArena(model)
+        opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=GradBucketer(arena, model))
+        torch.manual_seed(4321)
+        step = GraphedTrainStep(model, LossVideo(**LOSS_W), opt, clip, tgt, warmup=2, eager=eager)
+        n0 = 0 if eager else 2          # the graph arm's warm-up steps ARE its first two steps
+        losses = [float(step().detach().float().item()) for _ in range(ncmp - n0)]
+        return step, losses
+
+    e_step, e_losses = arm(True)
+    torch.cuda.synchronize()
+    t1, c1 = time.perf_counter(), time.process_time()
+    for _ in range(args.steps):
+        e_step()
+    eager_cpu_ms = 1e3 * (time.process_time() - c1) / args.steps
+    torch.cuda.synchronize()
+    eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+    e_step.close()
+    del e_step
+    g_step, g_losses = arm(False)
+    for _ in range(args.warmup):
+        g_step()
+    torch.cuda.synchronize()
+    one = []
+    for _ in range(5):                  # host time of ONE replay into an idle queue (what bench.py's host_enqueue_ms is for the eager step)
+        t1 = time.perf_counter()
+        g_step()
+        one.append(1e3 * (time.perf_counter() - t1))
+        torch.cuda.synchronize()
+    t0, c0 = time.perf_counter(), time.process_time()
+    for _ in range(args.steps):
+        g_step()
+    t_host, c_host = time.perf_counter() - t0, time.process_time() - c0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tail = e_losses[2:]
+    rel = max(abs(a - b) / max(abs(a), 1e-30) for a, b in zip(tail, g_losses))
+    print(json.dumps({"graph": dict(ms_per_step=round(1e3 * dt / args.steps, 3), eager_same_entry_points_ms_per_step=round(eager_ms, 3), host_ms_per_step=round(1e3 * t_host / args.steps, 3), host_ms_one_replay_idle_queue=round(sorted(one)[2], 3),
+                                    process_cpu_ms_per_step=round(1e3 * c_host / args.steps, 3), eager_process_cpu_ms_per_step=round(eager_cpu_ms, 3),
+                                    steps=args.steps,
+                                    losses_eager_same_entry_points=tail, losses_graph=g_losses, max_rel_loss_diff=rel,
+                                    note="whole train step (zero_grad, forward, loss, backward, Adam; three streams) replayed as ONE hipGraph; lr / Adam bias corrections / Dropout "
+                                         "seed come from a 32-byte device record rewritten before every replay; host_ms_one_replay_idle_queue is the host's cost of a step "
+                                         "(bench.py's host_enqueue_ms for the eager step); back to back (host_ms_per_step) a launch of the same executable graph waits for "
+                                         "the previous one on this runtime; losses: steps 3.. of both arms from the same seeds (they differ by "
+                                         "the order of the weight gradients' fp32 atomics only)")}), flush=True)
+
+
+def graph_leg(steps=20):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-leg", "--steps", str(steps), "--warmup", "3"], env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)["graph"]
+    except Exception as e:  # noqa: BLE001
+        return dict(ms_per_step=None, note=f"graph leg failed: {e!r}")
+
+
 def parity_mode_line(dev, steps=5):
     """the fp32-accurate mode beside the headline bf16 line: compute_dtype = float32 with the fp32 matrix products on the split-bf16 MFMA kernels, the SAME cfg3
     train step (8 clips x 16 frames, fwd + bwd + Adam), median of a few steps, and the error of that mode's forward at full module size (one clip) against the
@@ -282,6 +360,8 @@ def main():
     ap.add_argument("--no-ddp-rehearsal", action="store_true", help="skip the one-rank rehearsal of the multi-GPU launch line (ddp.world1_forced_ms)")
     ap.add_argument("--forward-only", action="store_true", help="cfg2: inference forward instead of the train step")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"], help="cfg3 = BASELINE's metric workload (default); cfg5 = long-clip stress")
+    ap.add_argument("--graph-leg", action="store_true", help="(subprocess of the default run) the train step captured as one hipGraph: prints {\"graph\": ...}")
+    ap.add_argument("--no-graph-leg", action="store_true")
     ap.add_argument("--simulate", action="store_true",
                     help="TEST ONLY (tests/test_bench_world2.py): the whole driver -- process group, broadcast, bucketed all-reduce overlapped with backward, "
                          "extra profiling steps, barriers, JSON -- on CPU tensors with the kernels on the host simulator and the gloo backend, tiny workload; "
@@ -291,6 +371,8 @@ def main():
     ap.add_argument("--backbone-f32-matmul", default=None, choices=["bf16x3", "bf16x6"],
                     help="--dtype f32 only: the backbone's own engine (MAED(backbone_f32_matmul=...)); default: the process-wide mode")
     args = ap.parse_args()
+    if args.graph_leg:
+        return graph_leg_main(args)
     # stdout carries ONE line, the JSON: native libraries print there too (RCCL writes a five-line version banner to stdout when a communicator is created), so
     # file descriptor 1 points at stderr until the line is printed
     sys.stdout.flush()
@@ -645,6 +727,8 @@ def main():
         }
         if world == 1 and not sim and not args.forward_only and not args.no_ddp_rehearsal and not args.no_cpu_baseline and args.dtype == "bf16" and args.workload == "cfg3" and out.get("ddp") is not None:
             out["ddp"]["rehearsal"] = ddp_rehearsal(ms_per_step)
+        if world == 1 and not sim and not args.forward_only and not args.no_graph_leg and not args.no_cpu_baseline and args.dtype == "bf16" and args.workload == "cfg3":
+            out["graph"] = graph_leg()      # the same step replayed as one hipGraph (host time per step)
         # first-class beside `value`: the same train step in the fastest mode whose OUTPUTS meet north_star's 1e-3 on SMPL parameters at full module
         # size -- `value` itself is the bf16 mode's number, at bf16 accuracy
         pm = out.get("parity_mode") or {}

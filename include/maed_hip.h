@@ -248,6 +248,14 @@ int maed_embed_add_bwd(const float* dtokens, void* dpatch, int dtype, float* dpo
 /* nn.Dropout(p) in training (ktd.py:54,56): y[f32] = keep ? x / (1 - p) : 0 with keep = hash(seed, index) >= p; the same call with the
  * same seed applied to dy is the backward (nothing is stored).  x == y (in place) is allowed. */
 int maed_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* Per-step scalars of a training step kept in DEVICE memory (round 6: hipGraph capture of the whole step, maed_amd/graphed.py).  A captured launch replays with
+ * the arguments it was recorded with: whatever changes from step to step -- the learning rate the host's scheduler chose (train.py:123-127), Adam's bias
+ * corrections 1 - beta^t, the seed of the Dropout masks (ktd.py:54,56) -- is read from this caller-owned 32-byte record instead, which the host rewrites
+ * (one small copy on the same stream) before every replay.  The eager step takes the same entry points when it is handed a record, so both forms run the
+ * same arithmetic. */
+typedef struct { float lr, bias_corr1, bias_corr2, reserved0; uint64_t seed; uint64_t reserved1; } maed_train_state;
+/* maed_dropout with seed = state->seed + call_id * 0x9E3779B97F4A7C15 (call_id: which Dropout layer of the step; its backward passes the same value) */
+int maed_dropout_dev(const float* x, float* y, int64_t n, float p, const maed_train_state* state, uint64_t call_id, void* stream);
 /* backward of the GEMM's TANH epilogue (pre_logits, vision_transformer.py:350-353): dx[T] = dy[f32] * (1 - y[T]^2) */
 int maed_tanh_bwd(const float* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 
@@ -525,6 +533,9 @@ int maed_weight_refresh(const void* table, int n_entries, int n_tiles, int dtype
 int maed_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    float bias_corr1, float bias_corr2, float gscale, void* stream);
+/* the same with lr, bias_corr1, bias_corr2 read from the device record `state` when the kernel runs (see maed_train_state) */
+int maed_adam_step_dev(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const maed_train_state* state,
+                       float beta1, float beta2, float eps, float weight_decay, float gscale, void* stream);
 
 /* ---- gradient all-reduce: RCCL over xGMI on a side HIP stream (train.py:113,182 DDP/NCCL) ----------------------- */
 /* One communicator per process.  RCCL is bound at run time from the library the host names (NULL = "librccl.so.1");

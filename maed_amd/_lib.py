@@ -101,6 +101,7 @@ SIGNATURES = {
     "maed_ste_block_bwd": (i32, [C.POINTER(BlockDims), C.POINTER(BlockParams), C.POINTER(BlockGrads), vp, vp, vp, vp, vp, vp, vp, vp]),
     "maed_loss_accl_fwd_bwd": (i32, [vp, vp, i32, i32, f32, vp, vp, vp]),
     "maed_dropout": (i32, [vp, vp, i64, f32, C.c_uint64, vp]),
+    "maed_dropout_dev": (i32, [vp, vp, i64, f32, vp, C.c_uint64, vp]),
     "maed_tanh_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
     "maed_stream_fence": (i32, [vp, vp]),
     "maed_prof_enable": (i32, [i32]),
@@ -160,6 +161,7 @@ SIGNATURES = {
     "maed_subsample2_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "maed_weight_refresh": (i32, [vp, i32, i32, i32, vp]),
     "maed_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
+    "maed_adam_step_dev": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, vp]),
 }
 
 _lib = None

@@ -609,6 +609,26 @@ extern "C" int maed_dropout(const float* x, float* y, int64_t n, float p, uint64
     return MAED_OK;
 }
 
+// the same with the seed in DEVICE memory (maed_train_state, round 6): a captured hipGraph replays with fresh masks -- the host refreshes the state before every replay,
+// the launch arguments never change.  call_id separates the Dropout layers of one step (and ties a layer's backward to its forward).
+__global__ __launch_bounds__(256) void dropout_dev_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, const maed_train_state* __restrict__ st,
+                                                          uint64_t call_id, uint32_t thresh24, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t seed = st->seed + call_id * 0x9E3779B97F4A7C15ull;
+    if (i < n) y[i] = dropout_keep(seed, (uint64_t)i, thresh24) ? x[i] * scale : 0.f;
+}
+
+extern "C" int maed_dropout_dev(const float* x, float* y, int64_t n, float p, const maed_train_state* state, uint64_t call_id, void* stream) {
+    MAED_CHECK_ARG(x && y && state, MAED_ERR_ARG, "dropout_dev: null pointer");
+    MAED_CHECK_ARG(n >= 0 && p >= 0.f && p < 1.f, MAED_ERR_ARG, "dropout_dev: need 0 <= p < 1 (p=%f)", (double)p);
+    MAED_CHECK_ARG(is_aligned(state, 8), MAED_ERR_ALIGN, "dropout_dev: state must be 8-B aligned");
+    if (n == 0) return MAED_OK;
+    const uint32_t thresh = (uint32_t)((double)p * 16777216.0);
+    hipLaunchKernelGGL(dropout_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, state, call_id, thresh, 1.0f / (1.0f - p));
+    MAED_CHECK_LAUNCH("dropout_dev");
+    return MAED_OK;
+}
+
 // dx = dy * (1 - y^2)   (y = tanh(.) as the GEMM's TANH epilogue stored it; T = its storage type)
 template <typename T>
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, int64_t n) {
@@ -696,11 +716,14 @@ extern "C" int maed_weight_refresh(const void* table, int n_entries, int n_tiles
 // ---------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam semantics: L2 weight decay folded into the gradient)
 // ---------------------------------------------------------------------------------------------------
+// st != NULL (maed_adam_step_dev): learning rate and bias corrections come from DEVICE memory, written by the host before the launch runs -- the launch arguments of a
+// captured step never change
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    bf16* __restrict__ shadow, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                                                   float bc1, float bc2, float gscale) {
+                                                   float bc1, float bc2, float gscale, const maed_train_state* __restrict__ st) {
     const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= n) return;
+    if (st) { lr = st->lr; bc1 = st->bias_corr1; bc2 = st->bias_corr2; }
     const float step = lr / bc1, rbc2 = rsqrtf(bc2);
     if (i4 + 4 <= n) {
         float pp[4], gg[4], mm[4], vv[4];
@@ -734,7 +757,20 @@ extern "C" int maed_adam_step(float* p, const float* g, float* m, float* v, void
     if (n == 0) return MAED_OK;
     const int64_t nthr = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n, lr,
-                       beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, gscale);
+                       beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, gscale, (const maed_train_state*)nullptr);
     MAED_CHECK_LAUNCH("adam_step");
+    return MAED_OK;
+}
+
+extern "C" int maed_adam_step_dev(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const maed_train_state* state, float beta1,
+                                  float beta2, float eps, float weight_decay, float gscale, void* stream) {
+    MAED_CHECK_ARG(p && g && m && v && state, MAED_ERR_ARG, "adam_step_dev: null pointer");
+    MAED_CHECK_ARG(is_aligned(p, 16) && is_aligned(g, 16) && is_aligned(m, 16) && is_aligned(v, 16) && (!shadow_bf16 || is_aligned(shadow_bf16, 8)) && is_aligned(state, 8),
+                   MAED_ERR_ALIGN, "adam_step_dev: arenas must be 16-B aligned, the state 8-B");
+    if (n == 0) return MAED_OK;
+    const int64_t nthr = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n, 0.f,
+                       beta1, beta2, eps, weight_decay, 1.f, 1.f, gscale, state);
+    MAED_CHECK_LAUNCH("adam_step_dev");
     return MAED_OK;
 }

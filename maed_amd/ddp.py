@@ -285,6 +285,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(arena.flat)
         self.exp_avg_sq = torch.zeros_like(arena.flat)
         self.step_count = 0
+        self.device_state = None    # ops.DeviceTrainState: lr and bias corrections are then read from device memory (graphed.GraphedTrainStep; uniform groups only)
         self._stepped = set()       # arena indices that have received at least one update (torch.optim.Adam keeps no state for the others)
 
     # kept as attributes for callers that read them
@@ -329,10 +330,22 @@ class FusedAdam(torch.optim.Optimizer):
                         start = a.offsets[i]
                     if i + 1 == len(a.params) and start is not None:
                         runs.append((start, end_i))
+            st = self.device_state
+            if st is not None:
+                # the record is uploaded here unless the step is being captured: a replay's record is written by the replaying host code (graphed.py)
+                st.set_hyper(g["lr"], 1.0 - g["betas"][0] ** self.step_count, 1.0 - g["betas"][1] ** self.step_count)
+                if not (a.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    st.upload()
             for lo, hi in runs:
-                ops.adam_step(a.flat[lo:hi], a.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], None, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                              g["weight_decay"], self.step_count, gscale=1.0 / world)
+                if st is not None:
+                    ops.adam_step_dev(a.flat[lo:hi], a.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], None, st.dev, g["betas"][0], g["betas"][1],
+                                      g["eps"], g["weight_decay"], gscale=1.0 / world)
+                else:
+                    ops.adam_step(a.flat[lo:hi], a.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], None, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                  g["weight_decay"], self.step_count, gscale=1.0 / world)
         else:                   # per-group hyper-parameters: one launch per tensor
+            if self.device_state is not None:
+                raise RuntimeError("FusedAdam.device_state needs one schedule for every parameter group (the reference's case)")
             for g, i in zip(self.param_groups, self._order):
                 if i in skip:
                     continue

@@ -310,14 +310,36 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_TABLES = {}            # (device, table bytes) -> device copy: the pointer tables of a step are the same from step to step (parameters, gradients and arenas do not move)
+_CAPTURE_KEEP = None    # list owned by a capturing graphed.GraphedTrainStep: what a captured launch / copy node reads must outlive the graph
+
+
 def _upload_table(tab, dev):
     """small host-built pointer table -> device WITHOUT a host/device synchronisation point: staged in pinned memory and copied
     asynchronously on the current stream (a pageable .to(device) blocks the host until the stream has drained, so the GPU
-    idled ~1 ms per step at three such uploads); the caching host allocator keeps the pinned block alive until the copy ran"""
+    idled ~1 ms per step at three such uploads); the caching host allocator keeps the pinned block alive until the copy ran.
+    Round 6: a table with the same bytes as an earlier one re-uses that one's device copy (immutable once uploaded) -- in steady state no step uploads anything."""
     host = torch.from_numpy(tab.view(_np.uint8))
     if dev.type != "cuda":
         return host.clone()
-    return host.pin_memory().to(dev, non_blocking=True)
+    key = (dev, host.numpy().tobytes())
+    capturing = torch.cuda.is_current_stream_capturing()
+    hit = _TABLES.get(key)
+    if hit is not None:
+        if capturing and _CAPTURE_KEEP is not None:
+            _CAPTURE_KEEP.append(hit)
+        return hit
+    if capturing:
+        # a host -> device copy inside a capture would have to come out of the framework's pinned-memory cache, whose bookkeeping (an event per block, queried at the
+        # next allocation) does not survive events recorded in a capturing stream (hipErrorCapturedEvent): the tables of a replayable step must be the ones its eager
+        # warm-up steps uploaded -- they are, as long as no table row points at a per-step temporary (WeightStdFn keeps its fp32 dW arena for this reason)
+        raise RuntimeError("maed_amd: a pointer table changed between the eager warm-up steps and the capture (a row points at a per-step temporary)")
+    pinned = host.pin_memory()
+    out = pinned.to(dev, non_blocking=True)
+    if len(_TABLES) >= 64:
+        _TABLES.pop(next(iter(_TABLES)))        # oldest entry: its device copy is freed in stream order behind the launches that read it
+    _TABLES[key] = out
+    return out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -491,6 +513,43 @@ def adam_step(p, g, m, v, shadow, lr, beta1, beta2, eps, wd, step, gscale=1.0):
     bc2 = 1.0 - beta2 ** step
     check(L.lib().maed_adam_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2, gscale, _stream()),
           "adam_step")
+
+
+def adam_step_dev(p, g, m, v, shadow, state, beta1, beta2, eps, wd, gscale=1.0):
+    """maed_adam_step with lr / bias corrections read from the device record `state` (DeviceTrainState.dev) when the kernel runs"""
+    check(L.lib().maed_adam_step_dev(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(state), beta1, beta2, eps, wd, gscale, _stream()), "adam_step_dev")
+
+
+class DeviceTrainState:
+    """include/maed_hip.h `maed_train_state`: the per-step scalars of a training step (learning rate, Adam's bias corrections, the Dropout seed) in a 32-byte
+    device record, so that the launches of a step carry no argument that changes from step to step -- the precondition of replaying the step as a hipGraph
+    (maed_amd/graphed.py).  The host fills the mirror and uploads it (one 32-byte copy on the launch stream) before the step's kernels are enqueued / replayed."""
+
+    def __init__(self, device):
+        self.dev = torch.zeros(32, dtype=torch.uint8, device=device)
+        self._host = _np.zeros(32, dtype=_np.uint8)
+        self.calls = 0          # Dropout layers seen so far in the running step (call_id of maed_dropout_dev)
+
+    def set_hyper(self, lr, bias_corr1, bias_corr2):
+        self._host[:12].view(_np.float32)[:] = (lr, bias_corr1, bias_corr2)
+
+    def begin_step(self, seed=None):
+        """new Dropout seed (from torch's CPU generator unless given: torch.manual_seed reproduces a run), Dropout call counter back to zero"""
+        self.calls = 0
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        self._host[16:24].view(_np.uint64)[0] = seed
+
+    def upload(self):
+        # a fresh pinned block per upload: the host runs steps ahead of the GPU, a re-used staging buffer would be overwritten before its copy has run
+        self.dev.copy_(torch.from_numpy(self._host.copy()).pin_memory(), non_blocking=True)
+
+    def next_call_id(self):
+        self.calls += 1
+        return self.calls
+
+
+DEVICE_STATE = None      # DeviceTrainState of the running training loop (graphed.GraphedTrainStep sets it): Dropout then takes its seed from the device record
 
 
 # ----------------------------------------------------------------------------------------------
@@ -814,7 +873,16 @@ class WeightStdFn(ReportingFn):
         owner._dw_arena, owner._dw_slices = None, {}
         if gemm and ReportingFn.will_run_backward(ctx):
             n = sum(weights[i].numel() for i in gemm)
-            owner._dw_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+            # ONE arena per owner, re-used from step to step (zero-filled here, behind the previous step's weight_std_bwd in stream order): the table of
+            # maed_weight_std_bwd then holds the same pointers every step (no upload, ops._upload_table; a captured step replays it).  A second forward before the
+            # first one's backward (trainer.py's two-forward step) gets an arena of its own, as before.
+            keep = getattr(owner, "_dw_arena_persist", None)
+            if owner._pending_backwards == 1 and keep is not None and keep.numel() == n and keep.device == dev:
+                owner._dw_arena = keep.zero_()
+            else:
+                owner._dw_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+                if owner._pending_backwards == 1:
+                    owner._dw_arena_persist = owner._dw_arena
             o = 0
             for i in sorted(gemm):
                 owner._dw_slices[i] = owner._dw_arena[o:o + weights[i].numel()].view(weights[i].shape[0], -1)     # (O, I) / (O, 9*I)

@@ -222,10 +222,32 @@ class DropoutFn(torch.autograd.Function):
         return dx, None, None
 
 
+class DropoutDevFn(torch.autograd.Function):
+    """DropoutFn with the seed read from the device record of the running step (ops.DeviceTrainState): the launch arguments do not change from step to step"""
+
+    @staticmethod
+    def forward(ctx, x, p, state, call_id):
+        x = _as(x, torch.float32)
+        y = torch.empty_like(x)
+        L.check(L.lib().maed_dropout_dev(ops._p(x), ops._p(y), x.numel(), p, ops._p(state), call_id, ops._stream()), "dropout_dev")
+        ctx.p, ctx.state, ctx.call_id = p, state, call_id
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _as(dy, torch.float32)
+        dx = torch.empty_like(dy)
+        L.check(L.lib().maed_dropout_dev(ops._p(dy), ops._p(dx), dy.numel(), ctx.p, ops._p(ctx.state), ctx.call_id, ops._stream()), "dropout_dev(bwd)")
+        return dx, None, None, None
+
+
 def dropout(x, p, training):
     """F.dropout on the library: identity in eval / p = 0; the seed comes from torch's CPU generator (torch.manual_seed reproduces a run)"""
     if not training or p == 0.0:
         return x
+    st = ops.DEVICE_STATE
+    if st is not None and st.dev.device == x.device:
+        return DropoutDevFn.apply(x, float(p), st.dev, st.next_call_id())
     seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
     return DropoutFn.apply(x, float(p), seed)
 
