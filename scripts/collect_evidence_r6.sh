@@ -6,6 +6,7 @@ R=r06; F=gpurun_out/final
 cp $F/bench_train_with_traffic.json profiles/${R}_bench_train.json
 for f in bench_forward bench_train_f32_bf16x3 bench_train_f32_bf16x3_fwd_bf16x1_bwd bench_train_f32_bf16x3_fwd_bf16_twin_bwd bench_cfg5 bench_cfg5_twin; do cp $F/$f.json profiles/${R}_$f.json; done
 for f in gemm_micro gemm_vs_vendor tn_micro attn_long_micro sk_micro tn_sk_micro vendor_kernels; do cp $F/$f.txt profiles/${R}_$f.txt; done
+cp $F/graph_leg.json profiles/${R}_graph_leg.json; cp $F/test_gpu_graph.log profiles/${R}_test_gpu_graph.log; cp $F/stress_r6_kernels.txt profiles/${R}_stress_kernels.txt 2>/dev/null || true
 cp $F/parity_report_gpu.txt profiles/${R}_parity_report_gpu.txt; cp $F/pytest_gpu.log profiles/${R}_pytest_gpu.log; cp $F/smoke.log profiles/${R}_smoke.log
 cp $F/rocprofv3_steady_state_kernels.csv profiles/${R}_rocprofv3_steady_state_kernels.csv
 cp $F/rocprofv3_steady_state_kernels_single_stream.csv profiles/${R}_rocprofv3_steady_state_kernels_single_stream.csv

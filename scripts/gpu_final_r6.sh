@@ -19,6 +19,9 @@ timeout 600 python bench.py --steps 10 --warmup 2 --dtype f32 --f32-matmul bf16x
 timeout 600 python bench.py --steps 10 --warmup 2 --dtype f32 --f32-matmul bf16x3 --f32-backward bf16 --no-cpu-baseline > $O/bench_train_f32_bf16x3_fwd_bf16_twin_bwd.json 2>/dev/null; cut -c1-200 $O/bench_train_f32_bf16x3_fwd_bf16_twin_bwd.json
 timeout 600 python bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg5.json 2>/dev/null; cut -c1-200 $O/bench_cfg5.json
 timeout 600 python bench.py --workload cfg5 --steps 5 --warmup 2 --dtype f32 --f32-matmul bf16x3 --f32-backward bf16 --no-cpu-baseline > $O/bench_cfg5_twin.json 2>/dev/null; cut -c1-200 $O/bench_cfg5_twin.json
+timeout 400 python bench.py --graph-leg --steps 20 --warmup 3 > $O/graph_leg.json 2> $O/graph_leg.err; cut -c1-400 $O/graph_leg.json
+timeout 300 python -m pytest tests/test_gpu_graph.py -m gpu -q -s -p no:cacheprovider > $O/test_gpu_graph.log 2>&1; tail -n 3 $O/test_gpu_graph.log
+timeout 600 python scripts/stress_r6_kernels.py 60 > $O/stress_r6_kernels.txt 2>&1; tail -n 4 $O/stress_r6_kernels.txt | cut -c1-200
 timeout 300 python scripts/gemm_vs_vendor.py 30 > $O/gemm_vs_vendor.txt 2>&1; tail -3 $O/gemm_vs_vendor.txt | cut -c1-200
 timeout 300 python scripts/gemm_micro.py 30 all 0 > $O/gemm_micro.txt 2>&1; grep "gemm " $O/gemm_micro.txt | cut -c1-110
 timeout 300 python scripts/tn_micro.py 20 3 > $O/tn_micro.txt 2>&1; tail -15 $O/tn_micro.txt | cut -c1-200
