@@ -542,7 +542,8 @@ class DeviceTrainState:
 
     def upload(self):
         # a fresh pinned block per upload: the host runs steps ahead of the GPU, a re-used staging buffer would be overwritten before its copy has run
-        self.dev.copy_(torch.from_numpy(self._host.copy()).pin_memory(), non_blocking=True)
+        src = torch.from_numpy(self._host.copy())
+        self.dev.copy_(src.pin_memory() if self.dev.is_cuda else src, non_blocking=True)
 
     def next_call_id(self):
         self.calls += 1

@@ -97,3 +97,33 @@ def test_graph_replay_draws_fresh_dropout_masks_and_costs_the_host_little():
     assert not torch.equal(arena.flat, p1)
     assert torch.isfinite(step.loss).all() and a > 0
     step.close()
+
+
+def test_device_record_entry_points_equal_the_scalar_ones_bit_for_bit():
+    """maed_adam_step_dev / maed_dropout_dev against maed_adam_step / maed_dropout with the same scalars as launch arguments"""
+    import numpy as np
+    from maed_amd import ops, _lib as L
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    n = 1000003
+    p0, gr = torch.randn(n, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    m0, v0 = torch.rand(n, generator=g).to(dev) * 0.1, torch.rand(n, generator=g).to(dev) * 0.01
+    lr, b1, b2, eps, wd, step = 3e-4, 0.9, 0.999, 1e-8, 1e-5, 7
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    ops.adam_step(pa, gr, ma, va, None, lr, b1, b2, eps, wd, step, gscale=0.5)
+    st = ops.DeviceTrainState(dev)
+    st.set_hyper(lr, 1.0 - b1 ** step, 1.0 - b2 ** step)
+    st.begin_step(4242)
+    st.upload()
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    ops.adam_step_dev(pb, gr, mb, vb, None, st.dev, b1, b2, eps, wd, gscale=0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    x = torch.randn(257, 1024, generator=g).to(dev)
+    ya, yb = torch.empty_like(x), torch.empty_like(x)
+    call_id = 3
+    seed = (4242 + call_id * 0x9E3779B97F4A7C15) % (1 << 64)
+    L.check(L.lib().maed_dropout(ops._p(x), ops._p(ya), x.numel(), 0.5, seed, ops._stream()), "dropout")
+    L.check(L.lib().maed_dropout_dev(ops._p(x), ops._p(yb), x.numel(), 0.5, ops._p(st.dev), call_id, ops._stream()), "dropout_dev")
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb) and 0.45 < (ya != 0).float().mean().item() < 0.55

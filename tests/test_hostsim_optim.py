@@ -179,3 +179,49 @@ def test_fused_adam_skips_parameters_without_a_gradient_like_torch_adam_and_orde
     for (n, p), (_, q) in zip(model.named_parameters(), fresh.named_parameters()):
         if "spare" in n:
             assert torch.equal(p, q), f"{n} must not have been touched (weight decay 0.1 would have shrunk it)"
+
+
+def test_fused_adam_with_device_record_equals_host_scalars_and_follows_the_schedule():
+    """maed_adam_step_dev (round 6: learning rate and bias corrections read from the 32-byte device record, include/maed_hip.h maed_train_state -- what lets a captured
+    step be replayed) against maed_adam_step with the same scalars as launch arguments: bit-identical parameters over six steps under a LambdaLR schedule"""
+    from maed_amd import ops
+    torch.manual_seed(1)
+    m_host = Tiny()
+    m_dev = copy.deepcopy(m_host)
+    x, y = torch.randn(16, 6), torch.randn(16, 5)
+    warm = lambda epoch: (epoch + 1) * 0.25 if epoch < 3 else 0.5
+    with patched():
+        opts = []
+        for m, with_state in ((m_host, False), (m_dev, True)):
+            arena = ParamArena(m)
+            opt = FusedAdam(arena, lr=1e-2, weight_decay=1e-3, model=m)
+            if with_state:
+                opt.device_state = ops.DeviceTrainState(torch.device("cpu"))
+            opts.append((m, opt, torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=warm)))
+        for epoch in range(6):
+            for m, opt, sched in opts:
+                opt.zero_grad()
+                ((m(x) - y) ** 2).mean().backward()
+                opt.step()
+                sched.step()
+        for p, q in zip(m_host.parameters(), m_dev.parameters()):
+            assert torch.equal(p, q)
+        # the record holds what the last step used
+        st = opts[1][1].device_state
+        import numpy as np
+        lr, bc1, bc2 = st.dev.numpy()[:12].view(np.float32)
+        assert abs(lr - 1e-2 * warm(5)) < 1e-9 and abs(bc1 - (1 - 0.9 ** 6)) < 1e-6 and abs(bc2 - (1 - 0.999 ** 6)) < 1e-6
+
+
+def test_fused_adam_with_device_record_refuses_per_group_schedules():
+    import pytest
+    from maed_amd import ops
+    m = Tiny()
+    with patched():
+        opt = FusedAdam(ParamArena(m), lr=1e-2, model=m)
+        opt.device_state = ops.DeviceTrainState(torch.device("cpu"))
+        opt.param_groups[1]["lr"] = 5e-3
+        opt.zero_grad()
+        m(torch.randn(4, 6)).sum().backward()
+        with pytest.raises(RuntimeError):
+            opt.step()

@@ -109,6 +109,35 @@ def test_dropout_kernel_distribution_scaling_and_backward_mask():
     assert kept.float().mean(0).std().item() < 0.08 and kept.float().mean(1).std().item() < 0.03
 
 
+def test_dropout_with_the_seed_in_the_device_record():
+    """maed_dropout_dev (round 6): the mask of Dropout layer `call_id` is maed_dropout's with seed + call_id * 0x9E3779B97F4A7C15; the backward re-draws the forward's
+    mask; a new step (begin_step) draws new masks, the same seed the same ones"""
+    from maed_amd import _lib as L
+    x = torch.ones(32, 512)
+    st = ops.DeviceTrainState(torch.device("cpu"))
+    prev = ops.DEVICE_STATE
+    with patched() as lib:
+        try:
+            ops.DEVICE_STATE = st
+            st.begin_step(1234); st.upload()
+            xg = x.clone().requires_grad_(True)
+            y1 = ste_modes.dropout(xg, 0.5, True)          # call_id 1
+            y2 = ste_modes.dropout(x, 0.5, True)           # call_id 2
+            y1.sum().backward()
+            st.begin_step(1234); st.upload()
+            y1_again = ste_modes.dropout(x, 0.5, True)
+            st.begin_step(99); st.upload()
+            y1_other = ste_modes.dropout(x, 0.5, True)
+        finally:
+            ops.DEVICE_STATE = prev
+        ref = torch.empty_like(x)
+        seed = (1234 + 1 * 0x9E3779B97F4A7C15) % (1 << 64)
+        L.check(lib.maed_dropout(x.data_ptr(), ref.data_ptr(), x.numel(), 0.5, seed, None), "dropout")
+    assert torch.equal(y1.detach(), ref) and torch.equal(xg.grad, ref)
+    assert torch.equal(y1.detach(), y1_again) and not torch.equal(y1.detach(), y2) and not torch.equal(y1.detach(), y1_other)
+    assert abs((y2 != 0).float().mean().item() - 0.5) < 0.02
+
+
 def test_smpl_forward_with_gradients_runs_on_the_library():
     """SMPL.forward (lib/models/smpl.py:94-106) with grad: tail.SmplLbsFn against the module's ATen composition (CPU path)"""
     from maed_amd.smpl import SMPL, synthetic_smpl_arrays
