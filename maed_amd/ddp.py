@@ -186,11 +186,12 @@ class GradBucketer:
         for p in arena.params:
             if id(p) not in self._fused:
                 p.register_post_accumulate_grad_hook(self._param_ready)
+                p._maed_ready = self._param_ready       # a backward kernel that accumulates into .grad itself (ops.direct_grad_slot) reports through this
 
     # ---- readiness -------------------------------------------------------------------------------
     def _mark(self, p):
         i = self.arena.index.get(id(p))
-        if i is None:
+        if i is None or self._seen[i]:      # (a parameter is final once per step, whoever says so first)
             return
         self._seen[i] = True
         self._finished = False
@@ -247,6 +248,9 @@ class GradBucketer:
                 m._grad_forward_seen = False
         self.unmarked = [i for i, seen in enumerate(self._seen) if not seen]
         self._seen = [False] * len(self._seen)
+        for p in self.arena.params:         # forwards counted in by ops.direct_grad_begin whose backward never ran must not hold the next step's report back
+            if getattr(p, "_maed_direct", 0):
+                p._maed_direct = 0
         for m in self._fused_modules:       # a backward that never ran (an exception, a detached output) must not poison the next step
             m._pending_backwards = 0
             for g in getattr(m, "_ws_groups", ()):      # per-stage weight standardisation: the stage owners count their own backwards

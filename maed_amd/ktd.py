@@ -80,8 +80,8 @@ class KTD(nn.Module):
         from . import ste_modes
         x = x.float()
         hm = self.head_matmul
-        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc1.weight, self.fc1.bias, self._fc_cache, True, hm), self.drop1.p, self.drop1.training)
-        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc2.weight, self.fc2.bias, self._fc_cache2, True, hm), self.drop2.p, self.drop2.training)
+        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc1.weight, self.fc1.bias, self._fc_cache, True, hm, True), self.drop1.p, self.drop1.training)
+        x = ste_modes.dropout(ste_modes.LinearTokFn.apply(x, self.fc2.weight, self.fc2.bias, self._fc_cache2, True, hm, True), self.drop2.p, self.drop2.training)
         return tail.KtdChainFn.apply(x, self, *self.fused_parameters())
 
     # ---- ATen composition for host tensors (the CPU suite's comparison arm; a library device takes _head_hip / _head_train) ----

@@ -656,10 +656,15 @@ class LinearFn(torch.autograd.Function):
     W, b fp32 masters.  Returns y in the compute dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache):
+    def forward(ctx, x, weight, bias, cache, direct_w=None, direct_b=None):
+        """direct_w / direct_b: the Parameters behind weight / bias (weight may be a view of direct_w) when this is their only use per forward: see direct_grad_slot"""
         (wc, wt), = cache.get([weight], x.dtype)
         ctx.save_for_backward(x, weight, bias)
         ctx.wt = wt
+        ctx.direct = None
+        if direct_w is not None and LinearFn._grad_at_apply and any(ctx.needs_input_grad[1:3]):
+            ctx.direct = (direct_w, direct_b)
+            direct_grad_begin(direct_w, direct_b)
         x32 = shadow_of(x)
         if x32 is not None:     # bf16 graph over fp32 shadows: the product on the fp32 operands (fp32 master weight, split-bf16 engine), an fp32 result; the backward stays bf16
             return gemm_nt(_c(x32), _c(weight.detach()), L.EPI_STORE, bias=bias)
@@ -669,17 +674,35 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
         dy = _c(dy if dy.dtype == x.dtype else dy.to(x.dtype))
-        db = torch.zeros_like(bias) if bias is not None else None
         if lib_matmul_dtype(dy.dtype) and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0:
+            if ctx.direct is not None:
+                gw, gb = direct_grad_slot(ctx.direct[0]), direct_grad_slot(ctx.direct[1])
+                if gw is not None and (bias is None or gb is not None):
+                    gemm_tn_wgrad(dy, x, dW=gw.view(weight.shape), dbias=gb)
+                    dx = gemm_nt(dy, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
+                    direct_grad_done(*ctx.direct)
+                    return dx, None, None, None, None, None
+                direct_grad_cancel(*ctx.direct)     # (counted in, taken by autograd after all: AccumulateGrad's own hook reports it)
+            db = torch.zeros_like(bias) if bias is not None else None
             dW = gemm_tn_wgrad(dy, x, dbias=db)
             dx = gemm_nt(dy, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
-            return dx, dW, db, None
+            return dx, dW, db, None, None, None
+        if ctx.direct is not None:
+            direct_grad_cancel(*ctx.direct)
+        db = torch.zeros_like(bias) if bias is not None else None
         dyt, _ = transpose_cast(dy, dy.dtype, colsum=db)
         xt, _ = transpose_cast(x, x.dtype)
         tiles = max(1, (weight.shape[0] // 128) * (weight.shape[1] // 128))
         dW = gemm_nt(dyt, xt, L.EPI_ATOMIC_F32, splitk=max(1, min(dyt.shape[1] // 256, 1024 // tiles)))
         dx = gemm_nt(dy, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
-        return dx, dW, db, None
+        return dx, dW, db, None, None, None
+
+    _grad_at_apply = True
+
+    @classmethod
+    def apply(cls, *args):
+        LinearFn._grad_at_apply = torch.is_grad_enabled()
+        return super().apply(*args)
 
 
 class EmbedAddFn(torch.autograd.Function):
@@ -713,6 +736,50 @@ class EmbedAddFn(torch.autograd.Function):
 _TWIN = [None, None, None]      # [weakref to dx, its compute-dtype copy, chain index of the block that left it (Block._chain_index, None if unknown)]
 TWIN_HITS = [0, 0]   # [hits, misses] -- diagnostics
 _TWIN_WARNED = [False]
+
+
+# ---- parameter gradients written straight into .grad by a backward kernel, without autograd's AccumulateGrad ------------------------------------------------
+# An autograd Function that returns dW costs, per parameter and step, a zero-fill (the kernels accumulate with fp32 atomics), the kernel, and AccumulateGrad's add
+# into .grad: 4 tiny framework launches per nn.Linear (54 framework launches per step).  At call sites where the parameter has ONE use per forward
+# (the decoder head's fc1 / fc2, pre_logits, the encoder's final LayerNorm, the patch projection) the backward accumulates into .grad itself -- when there is an fp32
+# .grad to accumulate into (ParamArena's views, or any optimizer that keeps gradients allocated) -- and tells the data-parallel bucketer through the hook the bucketer
+# left on the parameter.  A forward counts itself in (two forwards before one backward: trainer.py:253-262), the last backward reports.
+DIRECT_GRADS = os.environ.get("MAED_DIRECT_GRADS", "1") == "1"
+
+
+def direct_grad_slot(p):
+    """the fp32 tensor a backward kernel may ACCUMULATE p's gradient into, or None (autograd's way)"""
+    if not DIRECT_GRADS or p is None or not p.is_leaf:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.shape != p.shape or g.device != p.device or not g.is_contiguous():
+        return None
+    return g
+
+
+def direct_grad_begin(*params):
+    for p in params:
+        if p is not None:
+            p._maed_direct = getattr(p, "_maed_direct", 0) + 1
+
+
+def direct_grad_cancel(*params):
+    """counted in, but the gradient goes through autograd after all (no .grad to accumulate into): AccumulateGrad's own hook reports it"""
+    for p in params:
+        if p is not None:
+            p._maed_direct = max(getattr(p, "_maed_direct", 1) - 1, 0)
+
+
+def direct_grad_done(*params):
+    """the backward that was counted in by direct_grad_begin has written its share: the parameter's last one reports it final"""
+    for p in params:
+        if p is None:
+            continue
+        n = getattr(p, "_maed_direct", 1) - 1
+        p._maed_direct = max(n, 0)
+        hook = getattr(p, "_maed_ready", None)
+        if n <= 0 and hook is not None:
+            hook(p)
 
 
 class ReportingFn(torch.autograd.Function):

@@ -38,48 +38,94 @@ def _wgrad(dy, x, need_bias, prec=None):
     return dW, db
 
 
+class _ApplyGradMode:
+    """grad mode at apply() time (inside Function.forward it is always off; ctx.needs_input_grad ignores torch.no_grad())"""
+    on = True
+
+
+def _direct_begin(ctx, direct, idx, *params):
+    """(params) if this forward's backward will run and may write their gradients into .grad itself, else None; counts the forward in"""
+    if not direct or not _ApplyGradMode.on or not all(ctx.needs_input_grad[i] for i in idx if params[idx.index(i)] is not None):
+        return None
+    ops.direct_grad_begin(*params)
+    return params
+
+
 def _as(t, dtype):
     """contiguous copy-free view of t in `dtype` (casts only when needed)"""
     t = t if t.dtype == dtype else t.to(dtype)
     return t if t.is_contiguous() else t.contiguous()
 
 
-class LayerNormFn(torch.autograd.Function):
+def _wgrad_direct(dy, x, params, prec=None):
+    """dW / db of y = x W^T + b accumulated straight into the parameters' .grad (True), or nothing done (False: the caller takes autograd's way)"""
+    w, b = params
+    N, K = dy.shape[1], x.shape[1]
+    gw, gb = ops.direct_grad_slot(w), ops.direct_grad_slot(b)
+    if gw is None or (b is not None and gb is None) or not (ops.lib_matmul_dtype(dy.dtype, prec) and N % 8 == 0 and K % 8 == 0):
+        ops.direct_grad_cancel(*params)
+        return False
+    ops.gemm_tn_wgrad(dy, x, gw.view(N, K), gb, prec=prec)
+    ops.direct_grad_done(*params)
+    return True
+
+
+class _ApplyMixin:
+    @classmethod
+    def apply(cls, *args):
+        _ApplyGradMode.on = torch.is_grad_enabled()
+        return super().apply(*args)
+
+
+class LayerNormFn(_ApplyMixin, torch.autograd.Function):
     """fp32 rows (R,C) -> LayerNorm rows in `out_dtype` (vision_transformer.py:259-260 norm1/norm2)"""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_dtype):
+    def forward(ctx, x, gamma, beta, eps, out_dtype, direct=False):
+        """direct: gamma / beta have this ONE use per forward -- their gradients may be accumulated straight into .grad (ops.direct_grad_slot)"""
         x = _as(x, torch.float32)
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, out_dtype, eps=eps)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.direct = _direct_begin(ctx, direct, (1, 2), gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
+        if ctx.direct is not None:
+            gg, gb = ops.direct_grad_slot(ctx.direct[0]), ops.direct_grad_slot(ctx.direct[1])
+            if gg is not None and gb is not None:
+                dx, _, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=gg, dbeta=gb)
+                ops.direct_grad_done(*ctx.direct)
+                return dx.view_as(x), None, None, None, None, None
+            ops.direct_grad_cancel(*ctx.direct)
         dx, dgamma, dbeta = ops.layernorm_bwd(dy, x, gamma, mean, rstd)
-        return dx.view_as(x), dgamma, dbeta, None, None
+        return dx.view_as(x), dgamma, dbeta, None, None, None
 
 
-class LinearTokFn(torch.autograd.Function):
+class LinearTokFn(_ApplyMixin, torch.autograd.Function):
     """y = x W^T + b on (M,K) rows in the compute dtype; `out_f32` writes fp32 (the branch outputs that join the residual)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache, out_f32, prec=None):
-        """prec: fp32 rows only -- the caller's own matrix-product engine ("bf16x3": the decoder head of a bf16-mode model, KTD.head_matmul)"""
+    def forward(ctx, x, weight, bias, cache, out_f32, prec=None, direct=False):
+        """prec: fp32 rows only -- the caller's own matrix-product engine ("bf16x3": the decoder head of a bf16-mode model, KTD.head_matmul);
+        direct: weight / bias have this ONE use per forward -- their gradients may be accumulated straight into .grad (ops.direct_grad_slot)"""
         (wc, wt), = cache.get([weight], x.dtype)
         x = _as(x, x.dtype)
         ctx.save_for_backward(x)
         ctx.wt, ctx.has_bias, ctx.prec = wt, bias is not None, prec
+        ctx.direct = _direct_begin(ctx, direct, (1, 2), weight, bias)
         return ops.gemm_nt(x, wc, L.EPI_STORE_F32 if out_f32 else L.EPI_STORE, bias=bias, prec=prec)
 
     @staticmethod
     def backward(ctx, dy):
         x, = ctx.saved_tensors
         dy = _as(dy, x.dtype)
-        dW, db = _wgrad(dy, x, ctx.has_bias, ctx.prec) if ctx.needs_input_grad[1] else (None, None)
         dx = ops.gemm_nt(dy, ctx.wt, L.EPI_STORE, prec=ctx.prec) if ctx.needs_input_grad[0] else None
-        return dx, dW, db, None, None, None
+        if ctx.direct is not None and _wgrad_direct(dy, x, ctx.direct, ctx.prec):
+            return dx, None, None, None, None, None, None
+        dW, db = _wgrad(dy, x, ctx.has_bias, ctx.prec) if ctx.needs_input_grad[1] else (None, None)
+        return dx, dW, db, None, None, None, None
 
 
 class MlpFn(torch.autograd.Function):
@@ -180,16 +226,17 @@ class StMixFn(torch.autograd.Function):
         return dx_s, dx_t, dW, db, None
 
 
-class TanhLinearFn(torch.autograd.Function):
+class TanhLinearFn(_ApplyMixin, torch.autograd.Function):
     """tanh(x W^T + b) (pre_logits, vision_transformer.py:350-353): the GEMM's TANH epilogue forward, maed_tanh_bwd + the two GEMMs backward"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache):
+    def forward(ctx, x, weight, bias, cache, direct=False):
         (wc, wt), = cache.get([weight], x.dtype)
         x = _as(x, x.dtype)
         y = ops.gemm_nt(x, wc, L.EPI_TANH, bias=bias)
         ctx.save_for_backward(x, y)
         ctx.wt = wt
+        ctx.direct = _direct_begin(ctx, direct, (1, 2), weight, bias)
         return y
 
     @staticmethod
@@ -198,9 +245,11 @@ class TanhLinearFn(torch.autograd.Function):
         g = torch.empty_like(y)
         dy32 = _as(dy, torch.float32)        # (a named temporary: its storage must outlive the call that reads it)
         L.check(L.lib().maed_tanh_bwd(ops._p(dy32), ops._p(y), ops._p(g), y.numel(), ops.dt_code(y.dtype), ops._stream()), "tanh_bwd")
-        dW, db = _wgrad(g, x, True)
         dx = ops.gemm_nt(g, ctx.wt, L.EPI_STORE) if ctx.needs_input_grad[0] else None
-        return dx, dW, db, None
+        if ctx.direct is not None and _wgrad_direct(g, x, ctx.direct):
+            return dx, None, None, None, None
+        dW, db = _wgrad(g, x, True)
+        return dx, dW, db, None, None
 
 
 class DropoutFn(torch.autograd.Function):

@@ -231,7 +231,7 @@ class HybridEmbed(nn.Module):
         if f32 is not None:
             ops.shadow_put(a, f32.permute(0, 2, 3, 1).reshape(Fr * h * w, Cin))
         try:
-            y = ops.LinearFn.apply(a, self.proj.weight.view(self.proj.out_channels, Cin), self.proj.bias, self._cache)
+            y = ops.LinearFn.apply(a, self.proj.weight.view(self.proj.out_channels, Cin), self.proj.bias, self._cache, self.proj.weight, self.proj.bias)
         finally:
             ops.shadow_clear()                                     # the backbone's fp32 activations were transient: everything behind the projection is fp32 anyway
         return y.view(Fr, h * w, -1)
@@ -316,8 +316,8 @@ class VisionTransformer(nn.Module):
         if _needs_grad(tok, self.norm.weight):
             # tail of the training graph ((F,C) cls rows): the same library kernels behind autograd Functions (LayerNorm fwd/bwd, GEMM with
             # the tanh epilogue, maed_tanh_bwd, weight-gradient GEMMs); autograd's slice backward puts the row gradients back into (F,P,C)
-            y = ste_modes.LayerNormFn.apply(tok[:, 0], self.norm.weight, self.norm.bias, self.norm.eps, self.compute_dtype if fc is not None else torch.float32)
-            return ste_modes.TanhLinearFn.apply(y, fc.weight, fc.bias, self._cache).float() if fc is not None else y
+            y = ste_modes.LayerNormFn.apply(tok[:, 0], self.norm.weight, self.norm.bias, self.norm.eps, self.compute_dtype if fc is not None else torch.float32, True)
+            return ste_modes.TanhLinearFn.apply(y, fc.weight, fc.bias, self._cache, True).float() if fc is not None else y
         # inference: LayerNorm only the cls rows (row stride P*C), pre_logits GEMM with fused tanh
         y, _, _ = ops.layernorm_fwd(tok, self.norm.weight, self.norm.bias, self.compute_dtype if fc is not None else torch.float32,
                                     eps=self.norm.eps, row_stride=P * C_, rows=Fr)

@@ -173,3 +173,48 @@ def test_ktd_refuses_a_differentiable_graph_with_an_evaluation_regressor():
         with torch.no_grad():
             out = ktd.eval()(x, 1, J_regressor=torch.rand(17, 6890))
     assert out["kp_3d"].shape == (2, 17, 3)
+
+
+def test_parameter_gradients_written_straight_into_grad_equal_autograds():
+    """ops.direct_grad_slot (round 6): at the single-use call sites (KTD fc1 / fc2, pre_logits, the encoder's final LayerNorm) the backward kernels accumulate into
+    an existing fp32 .grad themselves -- no zero-fill, no AccumulateGrad add -- and report through the hook the bucketer left on the parameter.  Same numbers as
+    autograd's way (MAED_DIRECT_GRADS = 0), accumulation into a non-zero .grad, two forwards before one backward report once, after the second backward."""
+    from maed_amd.ste_modes import LinearTokFn, LayerNormFn, TanhLinearFn
+    from maed_amd.ops import WeightCache
+    torch.manual_seed(0)
+    lin, lin2, ln = torch.nn.Linear(64, 32), torch.nn.Linear(32, 16), torch.nn.LayerNorm(64, eps=1e-6)
+    x1, x2 = torch.randn(40, 64), torch.randn(24, 64)
+    params = list(lin.parameters()) + list(lin2.parameters()) + list(ln.parameters())
+    reported = []
+
+    def run(direct, preset):
+        for p in params:
+            p.grad = torch.full_like(p, preset) if preset is not None else None
+            p._maed_ready = reported.append
+            p._maed_direct = 0
+        reported.clear()
+        c1, c2 = WeightCache(), WeightCache()
+        out = 0
+        for x in (x1, x2):          # two forwards, one backward (trainer.py:253-262)
+            h = LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, torch.float32, True)
+            h = LinearTokFn.apply(h, lin.weight, lin.bias, c1, False, "bf16x3", True)          # fp32 rows on the split-bf16 engine (the decoder head's mode)
+            out = out + TanhLinearFn.apply(h.bfloat16(), lin2.weight, lin2.bias, c2, True).float().square().sum()
+        out.backward()
+        return [p.grad.clone() for p in params], list(reported)
+
+    with patched():
+        old = ops.DIRECT_GRADS
+        try:
+            ops.DIRECT_GRADS = False
+            ref, rep0 = run(False, 0.25)
+            ops.DIRECT_GRADS = True
+            got, rep1 = run(True, 0.25)
+            none_grads, rep2 = run(True, None)          # no .grad to accumulate into: autograd's way, nothing reported by the kernels
+        finally:
+            ops.DIRECT_GRADS = old
+    assert rep0 == [] and rep2 == []
+    assert len(rep1) == len(params) and {id(p) for p in rep1} == {id(p) for p in params}      # each parameter once, after its LAST backward
+    for a, b, c in zip(ref, got, none_grads):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-4)
+        assert torch.allclose(a - 0.25, c, rtol=1e-5, atol=1e-4)
+    assert all(getattr(p, "_maed_direct", 0) == 0 for p in params)
