@@ -37,23 +37,25 @@ class TinyMAED(nn.Module):
         return {k: v.reshape(n, t, *v.shape[1:]) for k, v in out.items()}
 
 
-@pytest.mark.parametrize("mode", ["bf16", "f32:bf16x3+bwd:bf16"])
+@pytest.mark.parametrize("mode", ["bf16", "f32:bf16x3+bwd:bf16", "bf16+device_record"])
 def test_train_steps_end_to_end_on_the_simulator(mode):
     """mode "f32:bf16x3+bwd:bf16" (round 5): the accurate mode's forward (fp32 operands, split-bf16 products) with the bf16 mode's backward on bf16 twins --
     backbone (bf16 autograd graph over fp32 shadows), projection (bf16 input twin, fp32 output) and STE blocks (maed_ste_block_fwd_twin) composed"""
     from maed_amd import ops
-    twin = mode != "bf16"
+    twin = mode.startswith("f32")
     if twin:
         ops.set_float32_matmul_precision("bf16x3")
         ops.set_float32_backward_precision("bf16")
     try:
-        _train_steps(torch.float32 if twin else torch.bfloat16, twin)
+        _train_steps(torch.float32 if twin else torch.bfloat16, twin, device_record=mode.endswith("device_record"))
     finally:
         ops.set_float32_matmul_precision("exact")
         ops.set_float32_backward_precision(None)
 
 
-def _train_steps(dtype, twin):
+def _train_steps(dtype, twin, device_record=False):
+    """device_record (round 6): learning rate, Adam's bias corrections and the Dropout seed come from the 32-byte record (maed_adam_step_dev / maed_dropout_dev) --
+    the entry points a captured step is replayed with (maed_amd/graphed.py), here in the eager loop"""
     from maed_amd import ops
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1)
@@ -73,9 +75,21 @@ def _train_steps(dtype, twin):
         step = TrainStep(model, Loss(e_loss_weight=300.0, e_3d_loss_weight=600.0, e_pose_loss_weight=60.0, e_shape_loss_weight=0.06,
                                      e_smpl_norm_loss=1.0, e_smpl_accl_loss=0.0, device="cpu"), opt)
         totals = []
-        for _ in range(3):
-            total, terms = step(target_3d=tgt)
-            totals.append(float(total.detach()))
+        st = ops.DeviceTrainState(torch.device("cpu")) if device_record else None
+        prev = ops.DEVICE_STATE
+        try:
+            if st is not None:
+                opt.device_state, ops.DEVICE_STATE = st, st
+            for i in range(3):
+                if st is not None:
+                    st.begin_step(100 + i)
+                    st.upload()
+                total, terms = step(target_3d=tgt)
+                totals.append(float(total.detach()))
+            if st is not None:
+                assert st.calls == 2                                   # the decoder head's two Dropout layers took their seeds from the record
+        finally:
+            ops.DEVICE_STATE = prev
     assert ops.TWIN_FORWARDS[0] - n_twin == (3 * 3 if twin else 0)      # per step: the backbone + two STE blocks
     assert not ops._SHADOW, "fp32 shadows must not outlive the forward"
     assert all(torch.isfinite(torch.tensor(totals))), totals
