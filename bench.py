@@ -208,7 +208,7 @@ def graph_leg_main(args):
         arena = ParamArena(model)
         opt = FusedAdam(arena, lr=1e-4, weight_decay=1e-5, bucketer=GradBucketer(arena, model))
         torch.manual_seed(4321)
-        step = GraphedTrainStep(model, LossVideo(**LOSS_W), opt, clip, tgt, warmup=2, eager=eager)
+        step = GraphedTrainStep(model, LossVideo(**LOSS_W), opt, clip, tgt, warmup=2, eager=eager, n_graphs=int(os.environ.get("MAED_GRAPHS", "1")))
         n0 = 0 if eager else 2          # the graph arm's warm-up steps ARE its first two steps
         losses = [float(step().detach().float().item()) for _ in range(ncmp - n0)]
         return step, losses
@@ -247,8 +247,9 @@ def graph_leg_main(args):
                                     losses_eager_same_entry_points=tail, losses_graph=g_losses, max_rel_loss_diff=rel,
                                     note="whole train step (zero_grad, forward, loss, backward, Adam; three streams) replayed as ONE hipGraph; lr / Adam bias corrections / Dropout "
                                          "seed come from a 32-byte device record rewritten before every replay; host_ms_one_replay_idle_queue is the host's cost of a step "
-                                         "(bench.py's host_enqueue_ms for the eager step); back to back (host_ms_per_step) a launch of the same executable graph waits for "
-                                         "the previous one on this runtime; losses: steps 3.. of both arms from the same seeds (they differ by "
+                                         "(bench.py's host_enqueue_ms for the eager step); back to back the runtime throttles the launching thread (host_ms_per_step; "
+                                         "process CPU time beside it) and leaves the GPU idle for ~1 ms between replays (profiles/r06_graph_overlap.txt: the replay itself keeps the "
+                                         "three-stream concurrency); losses: steps 3.. of both arms from the same seeds (they differ by "
                                          "the order of the weight gradients' fp32 atomics only)")}), flush=True)
 
 

@@ -21,7 +21,10 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, criterion, optimizer, clip, target, warmup=2, eager=False):
+    def __init__(self, model, criterion, optimizer, clip, target, warmup=2, eager=False, n_graphs=1):
+        """n_graphs: executable graphs captured (identical steps over the same parameters, optimizer state and static inputs; each with its own activation pool) and
+        replayed in turn.  Measured (profiles/r06_graph_overlap.txt): a replayed step keeps the three-stream concurrency but leaves the GPU idle for ~1 ms between
+        replays on this runtime, and two or three graphs replayed in turn change nothing about that (21.0 ms against 20.0 eager, same box) -- the default is one."""
         dev = clip.device
         if getattr(optimizer, "bucketer", None) is not None and optimizer.bucketer.collectives:
             raise RuntimeError("GraphedTrainStep: gradient all-reduces are not captured (one rank only)")
@@ -36,6 +39,7 @@ class GraphedTrainStep:
         L.set_option(L.OPT_SK, 0)
         L.set_option(L.OPT_TN_SK, 0)
         self.graph, self.loss = None, None
+        self._graphs, self._losses, self._turn = [], [], 0
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         if eager or dev.type != "cuda":
             return
@@ -47,19 +51,23 @@ class GraphedTrainStep:
                 self._body()
         torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        self._keep = []                      # pointer tables (and their pinned sources) the captured launches read
-        ops._CAPTURE_KEEP = self._keep
-        self._prepare(seed=0)                # (nothing executes during the capture; no draw from the host generator: the eager arm of a comparison makes none here)
-        try:
-            # "relaxed": pinned staging blocks may be allocated while capturing (hipHostMalloc is one of the calls the stricter modes refuse)
-            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
-                self.state.calls = 0
-                self.loss = self._body()
-        finally:
-            ops._CAPTURE_KEEP = None
-        # the capture advanced the optimizer's host-side step counter once without running a step
-        self.opt.step_count -= 1
+        self._keep = []                      # pointer tables the captured launches read
+        for _ in range(max(1, n_graphs)):
+            g = torch.cuda.CUDAGraph()
+            ops._CAPTURE_KEEP = self._keep
+            self._prepare(seed=0)            # (nothing executes during the capture; no draw from the host generator: the eager arm of a comparison makes none here)
+            try:
+                # "relaxed": pinned staging blocks may be allocated while capturing (hipHostMalloc is one of the calls the stricter modes refuse)
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="relaxed"):
+                    self.state.calls = 0
+                    loss = self._body()
+            finally:
+                ops._CAPTURE_KEEP = None
+            # the capture advanced the optimizer's host-side step counter once without running a step
+            self.opt.step_count -= 1
+            self._graphs.append(g)
+            self._losses.append(loss)
+        self.graph, self.loss = self._graphs[0], self._losses[0]
 
     # ---- one step ---------------------------------------------------------------------------------------------------------------------------------------
     def _prepare(self, seed=None):
@@ -88,9 +96,12 @@ class GraphedTrainStep:
         self._prepare()
         if self.graph is None:
             return self._body()
-        self.graph.replay()
+        k = self._turn % len(self._graphs)
+        self._turn += 1
+        self._graphs[k].replay()
         self.opt.step_count += 1
         ops.bump_weight_epoch()          # the parameters changed behind the host's back: an eager forward after this must refresh its compute-dtype weight copies
+        self.loss = self._losses[k]
         return self.loss
 
     def close(self):
@@ -100,3 +111,4 @@ class GraphedTrainStep:
         L.set_option(L.OPT_SK, self._opts[0])
         L.set_option(L.OPT_TN_SK, self._opts[1])
         self.graph = None
+        self._graphs, self._losses = [], []
