@@ -121,6 +121,9 @@ typedef enum {
     MAED_OPT_CONV3X3_NARROW_WGS = 16, /* maed_conv3x3_fwd (bf16): when the 128 x 128 tiling of the output gives fewer workgroups than this, the 128 x 64 tile is used
                                     * instead (twice the workgroups: the stage-3 convolutions of the R50 run at 1.5 workgroups per CU on 128 x 128 tiles and are
                                     * latency-bound for it).  0 = 128 x 64 only for Cout <= 64 (rounds 2-5). */
+    MAED_OPT_CONV3X3_FRAME = 17,   /* maed_conv3x3_fwd (bf16, round 6): feature maps of 129 .. 256 pixels whose frames fill the chip (stage 3 of the R50: 14 x 14, 128 frames x
+                                    * 2 column tiles) run on ONE FRAME x 128 channels per workgroup with a three-stage copy ring (one workgroup per CU, no imbalance, the
+                                    * weight rows shared by a whole frame): 1 (default); 0 = the 128 x 128 tiles of rounds 2-5 (A/B knob); 2 = whenever the shape allows, however few frames (tests) */
     MAED_OPT_COUNT
 } maed_option;
 /* Check that `device` (a HIP device ordinal) is one this library was built for (gfx950: MI355X).  MAED_OK, or MAED_ERR_UNSUPPORTED with the device's

@@ -20,7 +20,7 @@ IMPL_MFMA_LONG = 5      # attention only: K/V-tiled long-sequence kernels
 IMPL_MFMA_SK = 10      # gemm_nt only: persistent K-stream kernel (csrc/gemm_sk.hip)
 IMPL_X3, IMPL_X6, IMPL_X1 = 7, 8, 9  # MAED_F32 matrix products on the bf16 matrix cores (split-bf16: 3 / 6 MFMAs per product), csrc/gemm_x3.hip
 (OPT_F32_MATMUL, OPT_SIDE_STREAM, OPT_TN_TARGET_WGS, OPT_ABLATE, OPT_GN_BWD_ONEPASS, OPT_F32_BWD_X1, OPT_ST_FUSED, OPT_CONV3X3_ROWS_WGS, OPT_STEM_WGRAD_WGS,
- OPT_LBS_FRAMES, OPT_TN_DMA, OPT_X3_PLANES, OPT_X3_PLANES_LN, OPT_SK, OPT_SK_GRID, OPT_TN_SK, OPT_CONV3X3_NARROW_WGS) = range(17)   # maed_option (include/maed_hip.h)
+ OPT_LBS_FRAMES, OPT_TN_DMA, OPT_X3_PLANES, OPT_X3_PLANES_LN, OPT_SK, OPT_SK_GRID, OPT_TN_SK, OPT_CONV3X3_NARROW_WGS, OPT_CONV3X3_FRAME) = range(18)   # maed_option (include/maed_hip.h)
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -215,6 +215,7 @@ _OPTIONS = {
     OPT_X3_PLANES: int(os.environ.get("MAED_X3_PLANES", "6")),           # twin forward of the STE block: fc1's activation stored as (hi, lo) planes, fc2 on maed_gemm_nt_planes' variant 2 / 4 / 5 / 6 / 7; 0 = fp32 activation + twin
     OPT_SK: int(os.environ.get("MAED_SK", "1")),                         # A/B knob: 0 = bf16 NT GEMMs on the per-tile kernels of rounds 1-5; 1 = persistent K-stream kernel by heuristic; 2 / 3 = forced
     OPT_SK_GRID: int(os.environ.get("MAED_SK_GRID", "0")),
+    OPT_CONV3X3_FRAME: int(os.environ.get("MAED_CONV3X3_FRAME", "1")),              # 0: the stage-3 3x3 convolutions on 128 x 128 tiles (A/B knob)
     OPT_CONV3X3_NARROW_WGS: int(os.environ.get("MAED_CONV3X3_NARROW_WGS", "0")),   # 3x3 convolutions whose 128 x 128 grid is smaller than this take 128 x 64 tiles
     OPT_TN_SK: int(os.environ.get("MAED_TN_SK", "1")),                   # A/B knob: 0 = weight-gradient GEMMs on the split-M kernels with closing atomics (rounds 1-5)               # workgroups of the persistent kernel (0 = one per CU)
     OPT_X3_PLANES_LN: int(os.environ.get("MAED_X3_PLANES_LN", "0")),     # 1: ... and the two LayerNorm outputs as planes, qkv / fc1 on the plane kernel (measured neutral); 0 = fc2 only

@@ -15,6 +15,7 @@
 #define MAED_WAIT_VMCNT(n) do { } while (0)
 #define MAED_WAIT_LGKMCNT0() do { } while (0)
 #define MAED_LDS_DMA16(base_, voff_, lds_ptr_) __builtin_amdgcn_global_load_lds((const char*)(base_) + (voff_), (void*)(lds_ptr_), 16, 0, 0)
+#define MAED_LDS_DMA16_PTR(gptr_, lds_ptr_) __builtin_amdgcn_global_load_lds((const void*)(gptr_), (void*)(lds_ptr_), 16, 0, 0)
 typedef void maed_lds_void_t;
 typedef const void maed_glb_void_t;
 #define MAED_DS_READ_TR16(p_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((hostsim_v4i16*)(p_))
@@ -33,6 +34,12 @@ typedef const void maed_glb_void_t;
 #define MAED_LDS_DMA16(base_, voff_, lds_ptr_)                                                                                   \
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"                                                 \
                  :: "v"((uint32_t)(voff_)), "s"((uint32_t)(uintptr_t)(lds_ptr_)), "s"((const char*)(base_)) : "memory")
+// the same with a 64-bit source pointer PER LANE (gathers whose lanes point into different allocations: a tensor and the page of zeros): two VGPRs of address per copy,
+// otherwise as above -- uncounted by hipcc, so a ring of several tiles stays in flight across __syncthreads() (the builtin's copies are pending LDS writes to the
+// compiler: its barrier fence drains them with vmcnt(0))
+#define MAED_LDS_DMA16_PTR(gptr_, lds_ptr_)                                                                                      \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                                               \
+                 :: "v"((const char*)(gptr_)), "s"((uint32_t)(uintptr_t)(lds_ptr_)) : "memory")
 typedef __attribute__((address_space(3))) void maed_lds_void_t;
 typedef const __attribute__((address_space(1))) void maed_glb_void_t;
 // ds_read_b64_tr_b16: every lane reads 8 bytes at its own LDS address; inside each 16-lane group the 16 x 4 elements come back transposed

@@ -493,6 +493,140 @@ __global__ __launch_bounds__(256, 4) void conv3x3_glds_bf16_kernel(const bf16* _
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 6 (second session): the same implicit GEMM on ONE FRAME x 128 output channels per workgroup, for feature maps of at most 256 pixels (stage 3 of the R50:
+// 14 x 14 = 196; cfg5: 16 x 16).  Why: at stage 3 the 128 x 128 tiling gives 392 workgroups -- 1.5 per CU.  Its single-buffered loop costs a workgroup one exposed copy
+// round trip per K tile (36 of them: ~45 us whoever shares the CU), and the CUs that got two workgroups move 2.3 MB through the LDS-DMA path in that time, which is what
+// that path gives a CU (~50 GB/s): latency-bound and fill-bound at once, more workgroups of the same kind re-read more (r06_conv3x3_narrow_tiles_rejected.txt).  A frame
+// tile has NO imbalance (128 frames x 2 column tiles = 256 workgroups = one per CU), moves 1.6 MB per CU (a frame's 196 rows + 128 weight rows per K tile: the weight
+// rows are shared by twice the pixels) and, alone on its CU, can afford a ring: three stages of 48 KB, copies two K tiles ahead, ONE barrier per K tile.
+// Eight waves: wave w owns pixel rows 32 w .. 32 w + 31 of the frame (rows past the frame: nothing to copy, nothing to multiply) against all 128 columns
+// (four 32 x 32 accumulators); GroupNorm statistics as in the 128-row kernel (a tile is one frame: the table's second frame stays empty).
+// ------------------------------------------------------------------------------------------------
+#define CF_STAGES 3
+#define CF_A_ELEMS (256 * GM_BK)
+#define CF_STAGE_ELEMS (CF_A_ELEMS + 128 * GM_BK)          // 48 KB
+template <int EPI, bool GN>
+__global__ __launch_bounds__(512, 2) void conv3x3_frame_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt, const bf16* __restrict__ zero_page,
+                                                                    Conv3x3Dims d, int64_t M, int64_t N, int tiles_n, EpiArgs e) {
+    MAED_DYN_SHARED(unsigned short, lds);                     // CF_STAGES x [A: 256 x 64][B: 128 x 64] (+ the GroupNorm-statistics table)
+    double* const gn_tab = reinterpret_cast<double*>(lds + CF_STAGES * CF_STAGE_ELEMS);
+    if (GN && threadIdx.x < GN_TAB_FLOATS / 2) gn_tab[threadIdx.x] = 0.0;          // (published by the main loop's barriers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int HW = d.Ho * d.Wo;
+    const int f = id / tiles_n;
+    const int64_t m0 = (int64_t)f * HW, n0 = (int64_t)(id % tiles_n) * 128;
+    const bool active = wave * 32 < HW;                       // wave-uniform: this wave has pixel rows
+    const int nkt = 9 * d.Cin / GM_BK;
+    // copies: round j of A = this wave's rows 8 j .. 8 j + 7 (one 1 KB instruction), round j of B = weight rows 16 wave + 8 j ..; the 16-byte chunk a lane copies
+    // undoes the fragment reads' swizzle: slot (lane & 7) of row r holds chunk slot ^ ((r >> 1) & 7), and (r >> 1) & 7 = (4 j + (lane >> 4)) & 7 for both operands
+    int iy[4], ix[4]; int64_t aoff[4]; const bf16* gbp[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sch = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7);
+        int p = wave * 32 + 8 * j + (lane >> 3);
+        if (p > HW - 1) p = HW - 1;
+        const int ox = p % d.Wo, oy = p / d.Wo;
+        iy[j] = oy * d.stride - d.pad_top; ix[j] = ox * d.stride - d.pad_left;
+        aoff[j] = (((int64_t)f * d.H + iy[j]) * d.W + ix[j]) * (int64_t)d.Cin + sch * 8;
+        if (j < 2) {
+            const int64_t br = n0 + 16 * wave + 8 * j + (lane >> 3);
+            gbp[j] = Wt + d.b_base + (br < N ? br : N - 1) * d.b_row + sch * 8;
+        }
+    }
+    const int zch = ((lane & 7)) * 8;                         // any chunk of the zero page
+#define CF_ISSUE(stage_, ty_, tx_, toff_, k0_) {                                                                                          \
+        unsigned short* const sa__ = lds + (stage_) * CF_STAGE_ELEMS;                                                                     \
+        if (active) {                                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                               \
+                const bool ok = (unsigned)(iy[j] + (ty_)) < (unsigned)d.H && (unsigned)(ix[j] + (tx_)) < (unsigned)d.W;                   \
+                const bf16* src = ok ? X + aoff[j] + (toff_) : zero_page + zch;                                                           \
+                MAED_LDS_DMA16_PTR(src, sa__ + (32 * wave + 8 * j) * GM_BK);                                                              \
+            }                                                                                                                             \
+        }                                                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                                     \
+            MAED_LDS_DMA16_PTR(gbp[j] + (k0_), sa__ + CF_A_ELEMS + (16 * wave + 8 * j) * GM_BK);                                          \
+    }
+    f32x16_t acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    const int fsw = (l31 >> 1) & 7;
+    // the copy stream runs two K tiles ahead of the products: its own (tap, channel chunk) counters
+    int ity = 0, itx = 0, ic0 = 0;
+#define CF_ISSUE_NEXT(stage_) {                                                                                                           \
+        const int64_t k0__ = (int64_t)(ity * 3 + itx) * d.b_tap + ic0;                                                                    \
+        const int64_t toff__ = ((int64_t)ity * d.W + itx) * d.Cin + ic0;                                                                  \
+        CF_ISSUE(stage_, ity, itx, toff__, k0__)                                                                                          \
+        ic0 += GM_BK;                                                                                                                     \
+        if (ic0 == d.Cin) { ic0 = 0; if (++itx == 3) { itx = 0; ++ity; } }                                                                \
+    }
+    CF_ISSUE_NEXT(0)
+    CF_ISSUE_NEXT(1)                                            // (nkt >= 9)
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tile kt has landed once at most the younger tile's copies (6 per active wave, 2 per idle one) are outstanding
+        if (kt + 1 < nkt) { if (active) { MAED_WAIT_VMCNT(6); } else { MAED_WAIT_VMCNT(2); } } else { MAED_WAIT_VMCNT0(); }
+        __syncthreads();                                        // ... for every wave; and every wave is done with tile kt - 1: its stage is free
+        if (kt + 2 < nkt) CF_ISSUE_NEXT((kt + 2) % CF_STAGES)
+        if (active) {
+            const unsigned short* const st = lds + (kt % CF_STAGES) * CF_STAGE_ELEMS;
+            const unsigned short* As = st + (wave * 32 + l31) * GM_BK;
+            const unsigned short* Bs = st + CF_A_ELEMS + l31 * GM_BK;
+#pragma unroll
+            for (int kk = 0; kk < GM_BK / 16; ++kk) {
+                const int co = ((kk * 2 + hi) ^ fsw) * 8;
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(As + co);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(Bs + nb * 32 * GM_BK + co);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a0, acc[nb], 0, 0, 0);      // transposed tiles: lane = output row (pixel)
+                }
+            }
+        }
+    }
+#undef CF_ISSUE_NEXT
+#undef CF_ISSUE
+    // LDS-shuffled epilogue as in the 128-row kernels: a wave's 32 x 64 half through its private staging area, rows out as 8-column pieces
+    const bool vec_ok = (e.ldo % 8 == 0) && (e.ldaux % 8 == 0);
+    float* stg = reinterpret_cast<float*>(lds) + wave * 32 * GL_ST;
+    const int rr = lane >> 3, cc = (lane & 7) * 8;
+    const GnTile gnt = GN ? gn_tile(gn_tab, m0, n0, N, HW) : GnTile{nullptr, 0, 0, 0};
+    GnRegs gnr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();                                        // the ring (first pass) / this wave's staging rows (second pass) are no longer read
+        if constexpr (GN) gn_zero(gnr);
+        if (active) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(stg + l31 * GL_ST + 8 * g + 4 * hi) = make_float4(acc[2 * h][4 * g], acc[2 * h][4 * g + 1], acc[2 * h][4 * g + 2], acc[2 * h][4 * g + 3]);
+                *reinterpret_cast<float4*>(stg + l31 * GL_ST + 32 + 8 * g + 4 * hi) = make_float4(acc[2 * h + 1][4 * g], acc[2 * h + 1][4 * g + 1], acc[2 * h + 1][4 * g + 2], acc[2 * h + 1][4 * g + 3]);
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int lr = ps * 8 + rr;
+                const int pr = wave * 32 + lr;
+                const int64_t row = m0 + pr, c0 = n0 + h * 64 + cc;
+                float v8[8];
+                ld8(stg + lr * GL_ST + cc, v8);
+                if (pr < HW && c0 < N) epilogue_store8<EPI, bf16>(e, row, c0, N, v8, vec_ok);
+                if constexpr (GN) { if (pr < HW && c0 < N) gn_acc8(gnr, gnt, v8, row); }
+            }
+            if constexpr (GN) gn_commit(gnr, gnt, lane, n0 + h * 64 + cc, N);
+        }
+    }
+    if constexpr (GN) {
+        __syncthreads();
+        gn_flush(gnt, e.gn_sums, m0, M, HW, 128, tid, 512);
+    }
+}
+
 static bool gn_stats_shape_ok(int64_t channels, int64_t hw) {          // 32 groups of 2^k channels; a 128-row tile spans at most two frames
     const int64_t cpg = channels / 32;
     return channels % 32 == 0 && cpg >= 2 && (cpg & (cpg - 1)) == 0 && hw >= 128;
@@ -531,6 +665,26 @@ extern "C" int maed_conv3x3_fwd(const void* x, const void* w_taps, const void* z
         const X3ConvDims xd{d.F, d.H, d.W, d.Cin, d.Ho, d.Wo, d.stride, d.pad_top, d.pad_left, d.b_row, d.b_tap, d.b_base};
         MAED_PROPAGATE(maed_conv3x3_x3_launch(x3np, x, w_taps, xd, M, Cout, e, add != nullptr, gn_sums != nullptr, (hipStream_t)stream));
         MAED_CHECK_LAUNCH("conv3x3_fwd(x3)");
+        return MAED_OK;
+    }
+    // one frame x 128 channels per workgroup where a frame is at most 256 pixels and the frames fill the chip (stage 3 of the R50)
+    const int fhw = Ho * Wo;
+    const int fopt = maed_opt(MAED_OPT_CONV3X3_FRAME);     // 2: whenever the shape allows (tests)
+    if (fopt && fhw <= 256 && fhw > 128 && N % 8 == 0 && ((int64_t)F * ((N + 127) / 128) >= 192 || fopt == 2) && (!gn_sums || gn_stats_shape_ok(Cout, fhw))) {
+        const int ftn = (int)((N + 127) / 128);
+        constexpr size_t lds_bytes = (size_t)CF_STAGES * CF_STAGE_ELEMS * 2 + GN_TAB_FLOATS * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_frame_bf16_kernel<MAED_EPI_ADD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            (void)hipFuncSetAttribute((const void*)conv3x3_frame_bf16_kernel<MAED_EPI_STORE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            (void)hipFuncSetAttribute((const void*)conv3x3_frame_bf16_kernel<MAED_EPI_STORE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            attr_set = true;
+        }
+#define CF_LAUNCH(EPI_, GN_) hipLaunchKernelGGL((conv3x3_frame_bf16_kernel<EPI_, GN_>), dim3((unsigned)(F * ftn)), dim3(512), lds_bytes, (hipStream_t)stream, (const bf16*)x, \
+                                                (const bf16*)w_taps, (const bf16*)zero_page, d, M, N, ftn, e)
+        if (add) CF_LAUNCH(MAED_EPI_ADD, false); else if (gn_sums) CF_LAUNCH(MAED_EPI_STORE, true); else CF_LAUNCH(MAED_EPI_STORE, false);
+#undef CF_LAUNCH
+        MAED_CHECK_LAUNCH("conv3x3_fwd(frame)");
         return MAED_OK;
     }
     const dim3 grid((unsigned)(tm * tn));

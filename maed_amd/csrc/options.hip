@@ -24,6 +24,7 @@ static std::atomic<int> g_opt[MAED_OPT_COUNT] = {
     {0},      // MAED_OPT_SK_GRID: one workgroup per CU
     {1},      // MAED_OPT_TN_SK
     {0},      // MAED_OPT_CONV3X3_NARROW_WGS
+    {1},      // MAED_OPT_CONV3X3_FRAME
 };
 
 extern "C" int maed_init(int device) {

@@ -490,3 +490,35 @@ def test_conv3x3_weight_gradient_row_items_64_channels(N, H, W, wgs):
         ops.conv3x3_wgrad(cl(dy), cl(x), out=dW)
     got = (dW - dW0).permute(0, 3, 1, 2).double()
     assert (got - wr.grad).abs().max() <= 2e-3 * wr.grad.abs().max(), ((got - wr.grad).abs().max() / wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("NF,H,W,Cin,Cout", [(2, 14, 14, 64, 128), (1, 16, 16, 128, 136), (2, 11, 13, 64, 64)])
+def test_conv3x3_one_frame_per_workgroup_is_bit_identical_to_the_128_row_tiles(NF, H, W, Cin, Cout):
+    """round 6 (second session): conv3x3_frame_bf16_kernel -- one frame x 128 channels per workgroup, three-stage copy ring, eight waves of 32 pixel rows (the last
+    ones partly or wholly past the frame), for feature maps of 129 .. 256 pixels -- against the 128 x 128 tiles (MAED_OPT_CONV3X3_FRAME = 0): same K order, same
+    MFMA shape, so the SAME bits; forward with GroupNorm statistics, with an `add` operand, and as the input gradient (transposed weight image, flipped taps);
+    a ragged last column tile (Cout = 136) and a 64-column one"""
+    torch.manual_seed(7)
+    x = torch.randn(NF, Cin, H, W).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(Cout, 3, 3, Cin) * (9 * Cin) ** -0.5).bfloat16()
+    dy = torch.randn(NF, Cout, H, W).bfloat16().contiguous(memory_format=torch.channels_last)
+    wimg = wt.permute(1, 2, 3, 0).contiguous()             # (3, 3, Cin, Cout): the transposed image maed_weight_std_fwd writes beside the forward weight
+    addt = torch.randn(NF, Cout, H, W).bfloat16().contiguous(memory_format=torch.channels_last)
+    cpg = Cout // 32
+    gn_ok = Cout % 32 == 0 and cpg >= 2 and (cpg & (cpg - 1)) == 0
+    out = {}
+    with patched() as lib:
+        for mode in (0, 2):
+            with option(lib, L.OPT_CONV3X3_FRAME, mode):
+                sums = torch.zeros(NF, 32, 2, dtype=torch.float64)
+                y = ops.conv3x3(x, wt, 1, gn_sums=sums if gn_ok else None)
+                ya = ops.conv3x3(x, wt, 1, add=addt)
+                dx = ops.conv3x3(dy, wimg, 1, w_layout=1) if Cout % 64 == 0 else y
+                out[mode] = (y, ya, dx, sums)
+    for a, b in zip(out[0][:3], out[2][:3]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.allclose(out[0][3], out[2][3], rtol=1e-6, atol=1e-4)       # (fp32 partial sums per lane over other row sets: the statistics agree to fp32 rounding)
+    ref = F.conv2d(x.double(), wt.permute(0, 3, 1, 2).double(), padding=1)
+    assert torch.allclose(out[2][0].double(), ref, rtol=2e-2, atol=2e-2)
+    if Cout % 64 == 0:
+        assert out[2][2].shape == (NF, Cin, H, W)
