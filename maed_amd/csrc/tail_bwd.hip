@@ -431,27 +431,31 @@ __global__ __launch_bounds__(64) void ktd_chain_bwd_par_kernel(const float* __re
     if (l < 3) o[154 + l] = d_cam ? d_cam[(int64_t)f * 3 + l] : 0.f;
 }
 
-// thread per ancestor-weight element: dW_j[o][6*slot+i] = sum_f d_base[f][6j+o] pose[f][6*anc+i]; the last 157 threads
-// produce the bias gradient (column sums of d_out)
-__global__ void ktd_wanc_bwd_kernel(const float* __restrict__ pose, const float* __restrict__ d_out, int64_t ld, float* __restrict__ d_w_anc,
-                                    float* __restrict__ d_b_feat, int F) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= MAED_KTD_W_ANC + KTD_OUT) return;
-    if (e >= MAED_KTD_W_ANC) {
-        const int c = e - MAED_KTD_W_ANC;
-        float s = 0.f;
-        for (int f = 0; f < F; ++f) s += d_out[(int64_t)f * ld + c];
-        d_b_feat[c] = s;
-        return;
-    }
-    int j = 1;
-    while (36 * c_anc_start[j + 1] <= e) ++j;
-    const int na = c_anc_cnt[j], t = e - 36 * c_anc_start[j];
-    const int o = t / (6 * na), col = t % (6 * na);
-    const int a = c_anc[c_anc_start[j] + col / 6], i = col % 6;
+// EIGHT lanes per ancestor-weight element: dW_j[o][6*slot+i] = sum_f d_base[f][6j+o] pose[f][6*anc+i], every lane over every eighth frame, folded with three
+// shuffles; the last 157 elements are the bias gradient (column sums of d_out).  (One thread per element walked all F frames in one dependent chain of strided
+// loads: 55 us for 128 frames, the longest kernel of the decoder's backward.)
+#define KW_LANES 8
+__global__ __launch_bounds__(128) void ktd_wanc_bwd_kernel(const float* __restrict__ pose, const float* __restrict__ d_out, int64_t ld, float* __restrict__ d_w_anc,
+                                                           float* __restrict__ d_b_feat, int F) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t / KW_LANES, part = t % KW_LANES;
+    const bool live = e < MAED_KTD_W_ANC + KTD_OUT;          // (the lanes of a dead element still take part in the shuffles)
     float s = 0.f;
-    for (int f = 0; f < F; ++f) s = fmaf(d_out[(int64_t)f * ld + j * 6 + o], pose[(int64_t)f * NJ * 6 + a * 6 + i], s);
-    d_w_anc[e] = s;
+    if (live && e >= MAED_KTD_W_ANC) {
+        const int c = e - MAED_KTD_W_ANC;
+        for (int f = part; f < F; f += KW_LANES) s += d_out[(int64_t)f * ld + c];
+    } else if (live) {
+        int j = 1;
+        while (36 * c_anc_start[j + 1] <= e) ++j;
+        const int na = c_anc_cnt[j], tt = e - 36 * c_anc_start[j];
+        const int o = tt / (6 * na), col = tt % (6 * na);
+        const int a = c_anc[c_anc_start[j] + col / 6], i = col % 6;
+        for (int f = part; f < F; f += KW_LANES) s = fmaf(d_out[(int64_t)f * ld + j * 6 + o], pose[(int64_t)f * NJ * 6 + a * 6 + i], s);
+    }
+#pragma unroll
+    for (int m = 1; m < KW_LANES; m <<= 1) s += __shfl_xor(s, m);
+    if (!live || part != 0) return;
+    if (e >= MAED_KTD_W_ANC) d_b_feat[e - MAED_KTD_W_ANC] = s; else d_w_anc[e] = s;
 }
 
 extern "C" int maed_ktd_chain_bwd(const float* pose, const float* w_anc, const float* d_pose, const float* d_shape, const float* d_cam,
@@ -461,7 +465,7 @@ extern "C" int maed_ktd_chain_bwd(const float* pose, const float* w_anc, const f
     hipStream_t s = (hipStream_t)stream;
     if (F > 0)
         hipLaunchKernelGGL(ktd_chain_bwd_par_kernel, dim3((F + KB_FPB - 1) / KB_FPB), dim3(64), 0, s, w_anc, d_pose, d_shape, d_cam, d_out, ld_out, F);
-    hipLaunchKernelGGL(ktd_wanc_bwd_kernel, dim3((MAED_KTD_W_ANC + KTD_OUT + 127) / 128), dim3(128), 0, s, pose, d_out, ld_out, d_w_anc, d_b_feat, F);
+    hipLaunchKernelGGL(ktd_wanc_bwd_kernel, dim3(((MAED_KTD_W_ANC + KTD_OUT) * KW_LANES + 127) / 128), dim3(128), 0, s, pose, d_out, ld_out, d_w_anc, d_b_feat, F);
     MAED_CHECK_LAUNCH("ktd_chain_bwd");
     return MAED_OK;
 }
